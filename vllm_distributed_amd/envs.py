@@ -1,0 +1,154 @@
+"""Process-level switches read lazily from the environment.
+
+Every knob is declared once in ``_REGISTRY`` as ``name -> (parser, default)``.
+Attribute access (``envs.VLLM_LOGGING_LEVEL``) parses ``os.environ`` at the
+moment of the read, so tests can monkeypatch the environment freely.
+
+The ``VLLM_*`` spelling is kept for the knobs that have the same meaning as in
+the reference (reference: vllm/envs.py:198-970) so that deployment scripts
+keep working; knobs that only exist here use the ``VDA_*`` prefix.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import tempfile
+from typing import Any, Callable
+
+
+def _bool(v: str) -> bool:
+    return v.strip().lower() in ("1", "true", "yes", "on")
+
+
+def _opt_int(v: str):
+    return int(v) if v not in ("", "None", "none") else None
+
+
+def _path(v: str) -> str:
+    return os.path.abspath(os.path.expanduser(v))
+
+
+def _csv(v: str) -> list[str]:
+    return [x.strip() for x in v.split(",") if x.strip()]
+
+
+# name -> (parser, default-as-python-value)
+_REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
+    # ---- logging / debugging
+    "VLLM_CONFIGURE_LOGGING": (_bool, True),
+    "VLLM_LOGGING_LEVEL": (str.upper, "INFO"),
+    "VLLM_LOGGING_CONFIG_PATH": (str, None),
+    "VLLM_LOGGING_PREFIX": (str, ""),
+    "VLLM_TRACE_FUNCTION": (_bool, False),
+    "VLLM_LOG_BATCHSIZE_INTERVAL": (float, -1.0),
+    "VLLM_COMPUTE_NANS_IN_LOGITS": (_bool, False),
+    "VLLM_TORCH_PROFILER_DIR": (_path, None),
+    "VLLM_DEBUG_DUMP_PATH": (_path, None),
+    # ---- engine / process topology
+    "VLLM_ENABLE_V1_MULTIPROCESSING": (_bool, True),
+    "VLLM_WORKER_MULTIPROC_METHOD": (str, "spawn"),
+    "VLLM_EXECUTE_MODEL_TIMEOUT_SECONDS": (int, 300),
+    "VLLM_ENGINE_ITERATION_TIMEOUT_S": (int, 60),
+    "VLLM_V1_OUTPUT_PROC_CHUNK_SIZE": (int, 128),
+    "VLLM_RPC_BASE_PATH": (_path, tempfile.gettempdir()),
+    "VLLM_HOST_IP": (str, ""),
+    "VLLM_PORT": (_opt_int, None),
+    "VLLM_RINGBUFFER_WARNING_INTERVAL": (int, 60),
+    "VLLM_SLEEP_WHEN_IDLE": (_bool, False),
+    "VLLM_MQ_MAX_CHUNK_BYTES_MB": (int, 16),
+    "VLLM_KEEP_ALIVE_ON_ENGINE_DEATH": (_bool, False),
+    # ---- data parallel
+    "VLLM_DP_RANK": (int, 0),
+    "VLLM_DP_RANK_LOCAL": (int, -1),
+    "VLLM_DP_SIZE": (int, 1),
+    "VLLM_DP_MASTER_IP": (str, "127.0.0.1"),
+    "VLLM_DP_MASTER_PORT": (int, 0),
+    # ---- pipeline parallel
+    "VLLM_PP_LAYER_PARTITION": (str, None),
+    # ---- kernels / device
+    "VDA_OPS_LIBRARY": (_path, None),            # override path of libvda_ops.so
+    "VDA_COMM_LIBRARY": (_path, None),           # override path of libvda_comm.so
+    "VDA_FORCE_TORCH_OPS": (_bool, False),       # CPU/reference ops even on GPU (debug)
+    "VDA_DECODE_SPLIT_TARGET_WGS": (int, 1024),  # split-KV until grid has this many WGs
+    "VDA_SKINNY_GEMM_MAX_M": (int, 8),
+    "VDA_DISABLE_SKINNY_GEMM": (_bool, False),
+    "VLLM_FUSED_MOE_CHUNK_SIZE": (int, 32768),
+    "VLLM_MOE_DP_CHUNK_SIZE": (int, 256),
+    "VLLM_ROCM_FP8_PADDING": (_bool, False),
+    # ---- collectives
+    "VLLM_DISABLE_CUSTOM_ALL_REDUCE": (_bool, False),
+    "VDA_CUSTOM_AR_MAX_BYTES": (int, 16 * 1024 * 1024),
+    "VDA_CUSTOM_AR_ONESHOT_BYTES": (int, 512 * 1024),
+    "VDA_COMM_SPIN_TIMEOUT_MS": (int, 20000),
+    "VLLM_ROCM_QUICK_REDUCE_QUANTIZATION": (str.upper, "NONE"),
+    "VLLM_ROCM_QUICK_REDUCE_CAST_BF16_TO_FP16": (_bool, False),
+    "VLLM_ROCM_QUICK_REDUCE_MAX_SIZE_BYTES_MB": (_opt_int, None),
+    "VLLM_ALL2ALL_BACKEND": (str, "xgmi"),
+    "VDA_RCCL_SO_PATH": (str, None),
+    # ---- KV transfer
+    "VLLM_NIXL_SIDE_CHANNEL_HOST": (str, "127.0.0.1"),
+    "VLLM_NIXL_SIDE_CHANNEL_PORT": (int, 5557),
+    "VLLM_NIXL_ABORT_REQUEST_TIMEOUT": (int, 120),
+    "VDA_KV_SIDE_CHANNEL_HOST": (str, "127.0.0.1"),
+    "VDA_KV_SIDE_CHANNEL_PORT": (int, 5600),
+    # ---- serving
+    "VLLM_API_KEY": (str, None),
+    "VLLM_HTTP_TIMEOUT_KEEP_ALIVE": (int, 5),
+    "VLLM_SERVER_DEV_MODE": (_bool, False),
+    "VLLM_ALLOW_LONG_MAX_MODEL_LEN": (_bool, False),
+    "VLLM_ALLOW_RUNTIME_LORA_UPDATING": (_bool, False),
+    "VLLM_USE_MODELSCOPE": (_bool, False),
+    "VLLM_NO_USAGE_STATS": (_bool, True),
+    "VLLM_DO_NOT_TRACK": (_bool, True),
+    "VLLM_USAGE_SOURCE": (str, "production"),
+    "VLLM_CACHE_ROOT": (_path, os.path.join(os.path.expanduser("~"), ".cache", "vda")),
+    "VLLM_PLUGINS": (_csv, None),
+    "VLLM_USE_V1": (_bool, True),
+    "OTEL_EXPORTER_OTLP_TRACES_PROTOCOL": (str, "grpc"),
+    # ---- torch.distributed launch variables (read-only convenience)
+    "RANK": (int, 0),
+    "LOCAL_RANK": (int, 0),
+    "WORLD_SIZE": (int, 1),
+    "MASTER_ADDR": (str, "127.0.0.1"),
+    "MASTER_PORT": (int, 29500),
+}
+
+# Knobs that change numerics or graph shape: part of the config fingerprint.
+_HASHED = (
+    "VDA_FORCE_TORCH_OPS", "VDA_SKINNY_GEMM_MAX_M", "VDA_DISABLE_SKINNY_GEMM",
+    "VLLM_ROCM_QUICK_REDUCE_QUANTIZATION", "VLLM_DISABLE_CUSTOM_ALL_REDUCE",
+    "VLLM_FUSED_MOE_CHUNK_SIZE",
+)
+
+
+def __getattr__(name: str) -> Any:
+    try:
+        parser, default = _REGISTRY[name]
+    except KeyError:
+        raise AttributeError(f"unknown environment knob {name!r}") from None
+    raw = os.environ.get(name)
+    if raw is None:
+        return default
+    return parser(raw)
+
+
+def __dir__() -> list[str]:
+    return sorted(_REGISTRY)
+
+
+def is_set(name: str) -> bool:
+    if name not in _REGISTRY:
+        raise AttributeError(f"unknown environment knob {name!r}")
+    return name in os.environ
+
+
+def snapshot() -> dict[str, Any]:
+    """All knobs with their current values (for logs and engine dumps)."""
+    return {k: __getattr__(k) for k in _REGISTRY}
+
+
+def compute_hash() -> str:
+    h = hashlib.sha256()
+    for k in _HASHED:
+        h.update(f"{k}={__getattr__(k)!r};".encode())
+    return h.hexdigest()[:16]
