@@ -1,0 +1,343 @@
+"""HIP kernels vs the plain PyTorch fp32 references (ops/reference.py), in the
+style of the reference's tests/kernels/*: dtype x shape grids, fixed seeds."""
+import math
+
+import pytest
+import torch
+
+from vllm_distributed_amd import ops
+from vllm_distributed_amd.ops import reference as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+def tol(dt):
+    return dict(atol=2e-2, rtol=2e-2) if dt == torch.bfloat16 else dict(atol=4e-3, rtol=4e-3)
+
+
+@pytest.fixture(autouse=True)
+def _seed():
+    torch.manual_seed(0)
+
+
+def test_native_library_is_loaded():
+    from vllm_distributed_amd.ops import native
+    assert native.is_available(), "libvda_ops.so must be built in-tree"
+    native.lib()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,H", [(1, 4096), (7, 8192), (83, 768), (5, 5120), (3, 16384)])
+@pytest.mark.parametrize("add", [False, True])
+def test_rms_norm(dt, T, H, add):
+    x = torch.randn(T, H, device=DEV, dtype=dt)
+    w = (torch.randn(H, device=DEV, dtype=dt) * 0.1 + 1)
+    res = torch.randn(T, H, device=DEV, dtype=dt) if add else None
+    res_ref = res.clone() if add else None
+    y = ops.rms_norm(x, w, 1e-5, res)
+    y_ref = R.rms_norm(x, w, 1e-5, res_ref)
+    torch.testing.assert_close(y.float(), y_ref.float(), **tol(dt))
+    if add:
+        torch.testing.assert_close(res.float(), res_ref.float(), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_rms_norm_fp8_dynamic_and_static(dt):
+    x = torch.randn(33, 4096, device=DEV, dtype=dt)
+    w = torch.ones(4096, device=DEV, dtype=dt)
+    q, s = ops.rms_norm_fp8(x, w, 1e-6)
+    y = R.rms_norm(x, w, 1e-6)
+    qr, sr = R.per_token_fp8_quant(y)
+    torch.testing.assert_close(s.view(-1), sr.view(-1), rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(q.float() * s, qr.float() * sr, atol=0.15, rtol=0.07)
+    st = torch.tensor([0.02], device=DEV)
+    q2, _ = ops.rms_norm_fp8(x, w, 1e-6, static_scale=st)
+    torch.testing.assert_close(q2.float() * st, y.float().clamp(-448 * 0.02, 448 * 0.02), atol=0.1, rtol=0.07)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layer_norm(dt):
+    x = torch.randn(19, 768, device=DEV, dtype=dt)
+    w, b = torch.randn(768, device=DEV, dtype=dt), torch.randn(768, device=DEV, dtype=dt)
+    torch.testing.assert_close(ops.layer_norm(x, w, b, 1e-5).float(), R.layer_norm(x, w, b, 1e-5).float(), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("kind", ["silu", "gelu", "gelu_tanh", "fatrelu"])
+def test_act_and_mul(dt, kind):
+    x = torch.randn(37, 2 * 1536, device=DEV, dtype=dt)
+    torch.testing.assert_close(ops.act_and_mul(x, kind, threshold=0.1).float(),
+                               R.act_and_mul(x, kind, threshold=0.1).float(), **tol(dt))
+    torch.testing.assert_close(ops.act_and_mul(x, "silu", act_first=False).float(),
+                               R.act_and_mul(x, "silu", act_first=False).float(), **tol(dt))
+
+
+@pytest.mark.parametrize("kind", ["gelu_new", "gelu_fast", "quick_gelu", "relu", "relu2"])
+def test_plain_activation(kind):
+    x = torch.randn(64, 3072, device=DEV, dtype=torch.float16)
+    torch.testing.assert_close(ops.activation(x, kind).float(), R.activation(x, kind).float(), atol=4e-3, rtol=4e-3)
+
+
+def _cos_sin(max_pos, rot, base=10000.0):
+    inv = 1.0 / (base ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+    f = torch.outer(torch.arange(max_pos, dtype=torch.float32), inv)
+    return torch.cat((f.cos(), f.sin()), dim=-1).to(DEV)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("neox", [True, False])
+@pytest.mark.parametrize("D,rot", [(128, 128), (64, 64), (128, 64)])
+def test_rotary(dt, neox, D, rot):
+    T, Hq, Hkv = 45, 8, 2
+    cs = _cos_sin(512, rot)
+    pos = torch.randint(0, 512, (T,), device=DEV)
+    q = torch.randn(T, Hq * D, device=DEV, dtype=dt)
+    k = torch.randn(T, Hkv * D, device=DEV, dtype=dt)
+    qr, kr = q.clone(), k.clone()
+    ops.rotary_embedding(pos, q, k, cs, rot, D, neox)
+    R.rotary_embedding(pos, qr, kr, cs, rot, D, neox)
+    torch.testing.assert_close(q.float(), qr.float(), **tol(dt))
+    torch.testing.assert_close(k.float(), kr.float(), **tol(dt))
+
+
+def _make_cache(nblk, Hkv, bs, D, dt):
+    kc = torch.zeros(nblk, Hkv, bs, D, device=DEV, dtype=dt)
+    vc = torch.zeros(nblk, Hkv, D, bs, device=DEV, dtype=dt)
+    return kc, vc
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("bs", [16, 32, 64])
+def test_reshape_and_cache_and_gather(dt, bs):
+    T, Hkv, D, nblk = 70, 4, 128, 20
+    kc, vc = _make_cache(nblk, Hkv, bs, D, dt)
+    kr, vr = kc.clone(), vc.clone()
+    k = torch.randn(T, Hkv, D, device=DEV, dtype=dt)
+    v = torch.randn(T, Hkv, D, device=DEV, dtype=dt)
+    slots = torch.randperm(nblk * bs, device=DEV)[:T]
+    slots[3] = -1
+    ops.reshape_and_cache(k, v, kc, vc, slots)
+    R.reshape_and_cache(k, v, kr, vr, slots)
+    assert torch.equal(kc, kr) and torch.equal(vc, vr)
+    good = slots[slots >= 0]
+    kg, vg = ops.gather_cache(kc, vc, good)
+    assert torch.equal(kg, k[slots >= 0]) and torch.equal(vg, v[slots >= 0])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_rope_and_cache_fused(dt):
+    T, Hq, Hkv, D, bs, nblk = 50, 8, 2, 128, 16, 8
+    cs = _cos_sin(256, D)
+    pos = torch.randint(0, 256, (T,), device=DEV)
+    qkv = torch.randn(T, (Hq + 2 * Hkv) * D, device=DEV, dtype=dt)
+    ref = qkv.clone()
+    kc, vc = _make_cache(nblk, Hkv, bs, D, dt)
+    kr, vr = kc.clone(), vc.clone()
+    slots = torch.randperm(nblk * bs, device=DEV)[:T]
+    ops.rope_and_cache(pos, qkv, cs, kc, vc, slots, D, D, Hq, Hkv, True)
+    q, k, v = ref[:, :Hq * D], ref[:, Hq * D:(Hq + Hkv) * D], ref[:, (Hq + Hkv) * D:]
+    R.rotary_embedding(pos, q, k, cs, D, D, True)
+    R.reshape_and_cache(k.reshape(T, Hkv, D), v.reshape(T, Hkv, D), kr, vr, slots)
+    torch.testing.assert_close(qkv[:, :Hq * D].float(), q.float(), **tol(dt))
+    torch.testing.assert_close(kc.float(), kr.float(), **tol(dt))
+    assert torch.equal(vc, vr)
+
+
+def _paged_problem(seq_lens, q_lens, Hq, Hkv, D, bs, dt, scale_in=1.0):
+    S = len(seq_lens)
+    maxb = max((s + bs - 1) // bs for s in seq_lens) + 1
+    nblk = sum((s + bs - 1) // bs for s in seq_lens) + 4
+    kc = (torch.randn(nblk, Hkv, bs, D, device=DEV, dtype=dt) * scale_in)
+    vc = torch.randn(nblk, Hkv, D, bs, device=DEV, dtype=dt)
+    perm = torch.randperm(nblk - 1, device=DEV) + 1
+    bt = torch.zeros(S, maxb, dtype=torch.int32, device=DEV)
+    o = 0
+    for i, s in enumerate(seq_lens):
+        n = (s + bs - 1) // bs
+        bt[i, :n] = perm[o:o + n].int()
+        o += n
+    T = sum(q_lens)
+    q = torch.randn(T, Hq, D, device=DEV, dtype=dt) * scale_in
+    qsl = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    sl = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+    return q, kc, vc, bt, sl, qsl
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (12, 12, 64), (28, 4, 128), (16, 2, 256)])
+@pytest.mark.parametrize("bs", [16, 32, 64])
+@pytest.mark.parametrize("nsplit", [1, 4])
+def test_paged_attention_decode(dt, Hq, Hkv, D, bs, nsplit):
+    seq_lens = [1, 17, 300, 1025, 64, 33]
+    q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, [1] * len(seq_lens), Hq, Hkv, D, bs, dt)
+    scale = 1.0 / math.sqrt(D)
+    out = torch.empty_like(q)
+    ops.paged_attention_decode(out, q, kc, vc, bt, sl, qsl, scale, num_splits=nsplit)
+    ref = R.paged_attention(q, kc, vc, bt, sl, qsl, scale)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_paged_attention_decode_window_softcap_alibi_multiq(dt):
+    Hq, Hkv, D, bs = 8, 2, 128, 16
+    seq_lens, q_lens = [40, 700, 130], [3, 4, 1]
+    q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, q_lens, Hq, Hkv, D, bs, dt)
+    scale = 1.0 / math.sqrt(D)
+    alibi = torch.tensor([2 ** (-(i + 1)) for i in range(Hq)], device=DEV, dtype=torch.float32)
+    for kw in (dict(window=100), dict(softcap=30.0), dict(alibi=alibi), dict()):
+        out = torch.empty_like(q)
+        ops.paged_attention_decode(out, q, kc, vc, bt, sl, qsl, scale, num_splits=2, max_q_len=4, **kw)
+        ref = R.paged_attention(q, kc, vc, bt, sl, qsl, scale, **kw)
+        torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (12, 12, 64), (28, 4, 128)])
+@pytest.mark.parametrize("bs", [16, 32])
+def test_paged_attention_prefill(dt, Hq, Hkv, D, bs):
+    # mix of full prefills, chunked prefills with cached context, and single-token rows
+    seq_lens = [5, 130, 300, 77, 1, 257]
+    q_lens = [5, 130, 44, 77, 1, 100]
+    q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, q_lens, Hq, Hkv, D, bs, dt)
+    scale = 1.0 / math.sqrt(D)
+    out = torch.full_like(q, float("nan"))
+    ops.paged_attention_prefill(out, q, kc, vc, bt, sl, qsl, scale)
+    ref = R.paged_attention(q, kc, vc, bt, sl, qsl, scale)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
+def test_paged_attention_prefill_window():
+    dt, Hq, Hkv, D, bs = torch.bfloat16, 8, 2, 128, 16
+    q, kc, vc, bt, sl, qsl = _paged_problem([400, 90], [400, 30], Hq, Hkv, D, bs, dt)
+    out = torch.empty_like(q)
+    ops.paged_attention_prefill(out, q, kc, vc, bt, sl, qsl, 0.09, window=64)
+    ref = R.paged_attention(q, kc, vc, bt, sl, qsl, 0.09, window=64)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
+def test_attention_online_softmax_rescale_path():
+    """One key far larger than the rest late in the sequence forces the running-max rescale."""
+    dt, Hq, Hkv, D, bs = torch.bfloat16, 8, 2, 128, 16
+    q, kc, vc, bt, sl, qsl = _paged_problem([513], [1], Hq, Hkv, D, bs, dt)
+    blk, off = int(bt[0, 480 // bs]), 480 % bs
+    kc[blk, :, off, :] = q[0, ::4, :] * 6.0
+    out = torch.empty_like(q)
+    ops.paged_attention_decode(out, q, kc, vc, bt, sl, qsl, 0.1)
+    ref = R.paged_attention(q, kc, vc, bt, sl, qsl, 0.1)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
+def test_merge_attn_states():
+    T, H, D = 33, 8, 128
+    a = torch.randn(T, H, D, device=DEV, dtype=torch.bfloat16)
+    b = torch.randn(T, H, D, device=DEV, dtype=torch.bfloat16)
+    la, lb = torch.randn(H, T, device=DEV), torch.randn(H, T, device=DEV)
+    lb[0, 0] = float("-inf")
+    o, l = ops.merge_attn_states(a, la, b, lb, return_lse=True)
+    orf, lrf = R.merge_attn_states(a, la, b, lb)
+    torch.testing.assert_close(o.float(), orf.float(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(l, lrf, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_argmax(dt):
+    x = torch.randn(9, 128256, device=DEV, dtype=dt)
+    assert torch.equal(ops.argmax(x), x.float().argmax(-1)) or dt != torch.float32
+    y = x.float()
+    assert torch.equal(y.gather(1, ops.argmax(x)[:, None]), y.max(-1, keepdim=True).values)
+
+
+def test_sample_greedy_rows_and_filters():
+    S, V = 6, 32000
+    logits = torch.randn(S, V, device=DEV) * 3
+    temp = torch.tensor([0.0, 1.0, 0.7, 1.0, 1.5, 0.0], device=DEV)
+    topk = torch.tensor([0, 1, 5, 0, 50, 0], dtype=torch.int32, device=DEV)
+    topp = torch.tensor([1.0, 1.0, 1.0, 0.3, 0.9, 1.0], device=DEV)
+    seeds = torch.arange(S, device=DEV)
+    tok = ops.sample(logits, temp, topk, topp, None, seeds)
+    am = logits.argmax(-1)
+    assert tok[0] == am[0] and tok[5] == am[5] and tok[1] == am[1]   # greedy rows and top_k=1
+    assert tok[2] in logits[2].topk(5).indices
+    # row 3: token must be in the top-p=0.3 nucleus
+    p = torch.softmax(logits[3], -1)
+    sp, si = p.sort(descending=True)
+    nucleus = si[: int(((sp.cumsum(0) - sp) < 0.3).sum())]
+    assert tok[3] in nucleus
+    # same seed -> same draw
+    assert torch.equal(tok, ops.sample(logits, temp, topk, topp, None, seeds))
+
+
+def test_sample_distribution_matches_softmax():
+    V, n = 64, 40000
+    logits = torch.randn(1, V, device=DEV).repeat(n, 1)
+    seeds = torch.arange(n, device=DEV) * 7919 + 13
+    tok = ops.sample(logits, torch.ones(n, device=DEV), None, None, None, seeds)
+    emp = torch.bincount(tok, minlength=V).float() / n
+    torch.testing.assert_close(emp, torch.softmax(logits[0], -1), atol=0.012, rtol=0.0)
+
+
+def test_topk_topp_mask_matches_sort_reference():
+    S, V = 8, 50000
+    logits = torch.randn(S, V, device=DEV) * 4
+    k = torch.tensor([0, 1, 10, 100, 0, 40, 7, 0], dtype=torch.int32, device=DEV)
+    p = torch.tensor([1.0, 1.0, 0.5, 0.9, 0.2, 1.0, 0.99, 0.7], device=DEV)
+    mp = torch.tensor([0, 0, 0, 0, 0, 0.05, 0, 0.01], device=DEV)
+    a = ops.topk_topp_mask(logits.clone(), k, p, mp)
+    b = R.topk_topp_mask(logits.clone(), k, p, mp)
+    keep_a, keep_b = ~torch.isinf(a), ~torch.isinf(b)
+    # float summation order may move the top-p boundary by one token
+    assert (keep_a != keep_b).sum(dim=1).max() <= 1
+    assert torch.equal(a[keep_a & keep_b], logits[keep_a & keep_b])
+
+
+def test_penalties():
+    S, V = 4, 1000
+    logits = torch.randn(S, V, device=DEV)
+    pm = torch.rand(S, V, device=DEV) < 0.05
+    oc = (torch.rand(S, V, device=DEV) < 0.03).int() * torch.randint(1, 4, (S, V), device=DEV).int()
+    rep = torch.tensor([1.0, 1.3, 0.8, 1.1], device=DEV)
+    fr = torch.tensor([0.0, 0.5, 0.0, -0.2], device=DEV)
+    pr = torch.tensor([0.0, 0.0, 1.0, 0.3], device=DEV)
+    a = ops.apply_penalties(logits.clone(), pm, oc, rep, fr, pr)
+    b = R.apply_penalties(logits.clone(), pm, oc, rep, fr, pr)
+    torch.testing.assert_close(a, b, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_fp8_quant_roundtrip(dt):
+    x = torch.randn(64, 4096, device=DEV, dtype=dt) * 3
+    q, s = ops.scaled_fp8_quant(x)
+    qr, sr = R.scaled_fp8_quant(x)
+    torch.testing.assert_close(s, sr, rtol=1e-3, atol=0)
+    torch.testing.assert_close(q.float(), qr.float(), atol=0, rtol=0.13)
+    torch.testing.assert_close(ops.fp8_dequant(q, s, dt).float(), x.float(), atol=0.2, rtol=0.07)
+    q2, s2 = ops.per_token_fp8_quant(x)
+    q2r, s2r = R.per_token_fp8_quant(x)
+    torch.testing.assert_close(s2, s2r, rtol=1e-3, atol=0)
+    torch.testing.assert_close(q2.float() * s2, x.float(), atol=0.2, rtol=0.07)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M", [1, 3, 8, 16, 17, 48, 64])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (1024, 14336), (6144, 4096), (256, 768)])
+def test_skinny_gemm(dt, M, N, K):
+    x = torch.randn(M, K, device=DEV, dtype=dt) * 0.5
+    w = torch.randn(N, K, device=DEV, dtype=dt) * 0.05
+    b = torch.randn(N, device=DEV, dtype=dt)
+    y = ops.skinny_gemm(x, w, b)
+    ref = (x.float() @ w.float().T + b.float())
+    torch.testing.assert_close(y.float(), ref, atol=3e-2 if dt == torch.bfloat16 else 8e-3, rtol=2e-2)
+
+
+def test_copy_and_transfer_blocks():
+    c = torch.randn(10, 4, 16, 128, device=DEV, dtype=torch.bfloat16)
+    ref = c.clone()
+    pairs = torch.tensor([[1, 5], [2, 7]], device=DEV)
+    ops.copy_blocks(c, pairs)
+    ref[5], ref[7] = ref[1].clone(), ref[2].clone()
+    assert torch.equal(c, ref)
+    dst = torch.zeros_like(c)
+    ops.transfer_blocks(dst, c, torch.tensor([0, 3], device=DEV), torch.tensor([5, 9], device=DEV))
+    assert torch.equal(dst[0], c[5]) and torch.equal(dst[3], c[9]) and dst[1].abs().sum() == 0

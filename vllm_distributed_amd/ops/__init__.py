@@ -1,0 +1,346 @@
+"""Tensor-level op API.  Every function takes torch tensors; CUDA(HIP) tensors
+run the hand-written gfx950 kernels of ops/csrc, CPU tensors run the PyTorch
+reference (ops/reference.py).  Role of the reference's vllm/_custom_ops.py.
+
+KV cache layout used throughout:
+    k_cache [num_blocks, kv_heads, block_size, head_size]
+    v_cache [num_blocks, kv_heads, head_size, block_size]
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import envs
+from . import native as N
+from . import reference as R
+
+
+def _dev(x: torch.Tensor) -> bool:
+    return x.is_cuda and not envs.VDA_FORCE_TORCH_OPS
+
+
+def _contig_last(x: torch.Tensor) -> torch.Tensor:
+    return x if x.stride(-1) == 1 else x.contiguous()
+
+
+# ---- normalisation -----------------------------------------------------------
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None,
+             weight_bias: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = rmsnorm(x [+ residual]) * (weight + weight_bias); residual is updated in place."""
+    if not _dev(x):
+        y = R.rms_norm(x, weight, eps, residual, weight_bias)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    H = x.shape[-1]
+    x2 = _contig_last(x).view(-1, H) if x.dim() != 2 else _contig_last(x)
+    if out is None:
+        out = torch.empty(x2.shape, dtype=x.dtype, device=x.device)
+    o2 = out.view(-1, H)
+    r2 = residual.view(-1, H) if residual is not None else None
+    N.call("vda_rms_norm", o2.data_ptr(), x2.data_ptr(), N.ptr(r2), weight.data_ptr(), eps, x2.shape[0], H,
+           x2.stride(0), r2.stride(0) if r2 is not None else 0, o2.stride(0), weight_bias, 0, None, None, None,
+           N.dt(x.dtype), N.stream())
+    return out.view(x.shape)
+
+
+def rms_norm_fp8(x, weight, eps, residual=None, static_scale: Optional[torch.Tensor] = None,
+                 scale_ub: Optional[torch.Tensor] = None, weight_bias: float = 0.0):
+    """RMSNorm with fp8 output.  static_scale given -> per-tensor; else dynamic per-token.
+    Returns (fp8 tensor, scales)."""
+    H = x.shape[-1]
+    if not _dev(x):
+        y = R.rms_norm(x, weight, eps, residual, weight_bias)
+        return R.scaled_fp8_quant(y, static_scale) if static_scale is not None else R.per_token_fp8_quant(y, scale_ub)
+    x2 = _contig_last(x).view(-1, H)
+    out = torch.empty(x2.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    r2 = residual.view(-1, H) if residual is not None else None
+    if static_scale is not None:
+        scales, quant = static_scale, 1
+    else:
+        scales, quant = torch.empty((x2.shape[0], 1), dtype=torch.float32, device=x.device), 2
+    N.call("vda_rms_norm", out.data_ptr(), x2.data_ptr(), N.ptr(r2), weight.data_ptr(), eps, x2.shape[0], H,
+           x2.stride(0), r2.stride(0) if r2 is not None else 0, out.stride(0), weight_bias, quant,
+           scales.data_ptr() if quant == 1 else None, scales.data_ptr() if quant == 2 else None,
+           N.ptr(scale_ub), N.dt(x.dtype), N.stream())
+    return out.view(x.shape), scales
+
+
+def layer_norm(x, weight, bias, eps):
+    if not _dev(x):
+        return R.layer_norm(x, weight, bias, eps)
+    H = x.shape[-1]
+    x2 = _contig_last(x).view(-1, H)
+    out = torch.empty_like(x2)
+    N.call("vda_layer_norm", out.data_ptr(), x2.data_ptr(), weight.data_ptr(), N.ptr(bias), eps, x2.shape[0], H,
+           x2.stride(0), out.stride(0), N.dt(x.dtype), N.stream())
+    return out.view(x.shape)
+
+
+# ---- activations ----------------------------------------------------------------
+def act_and_mul(x, kind: str = "silu", act_first: bool = True, threshold: float = 0.0,
+                out: Optional[torch.Tensor] = None, fp8_scale: Optional[torch.Tensor] = None):
+    d = x.shape[-1] // 2
+    if not _dev(x):
+        y = R.act_and_mul(x, kind, act_first, threshold)
+        if fp8_scale is not None:
+            y = R.scaled_fp8_quant(y, fp8_scale)[0]
+        return y
+    x2 = _contig_last(x).view(-1, 2 * d)
+    if out is None:
+        out = torch.empty((x2.shape[0], d), device=x.device,
+                          dtype=torch.float8_e4m3fn if fp8_scale is not None else x.dtype)
+    N.call("vda_act_and_mul", out.data_ptr(), x2.data_ptr(), x2.shape[0], d, x2.stride(0), out.stride(0),
+           N.ACT[kind], int(act_first), threshold, N.ptr(fp8_scale), N.dt(x.dtype), N.stream())
+    return out.view(*x.shape[:-1], d)
+
+
+def silu_and_mul(x, out=None):
+    return act_and_mul(x, "silu", out=out)
+
+
+def activation(x, kind: str, threshold: float = 0.0):
+    if not _dev(x) or x.numel() % 8:
+        return R.activation(x, kind, threshold)
+    xc = x.contiguous()
+    out = torch.empty_like(xc)
+    N.call("vda_activation", out.data_ptr(), xc.data_ptr(), xc.numel(), N.ACT[kind], threshold, N.dt(x.dtype),
+           N.stream())
+    return out
+
+
+# ---- rotary + cache -----------------------------------------------------------------
+def rotary_embedding(positions, q, k, cos_sin_cache, rot_dim: int, head_size: int, is_neox: bool = True):
+    """In place.  q: [T, Hq*D] (row stride arbitrary), k: [T, Hkv*D] or None."""
+    if not _dev(q):
+        return R.rotary_embedding(positions, q, k, cos_sin_cache, rot_dim, head_size, is_neox)
+    T = q.shape[0]
+    N.call("vda_rotary_embedding", positions.data_ptr(), q.data_ptr(), N.ptr(k), cos_sin_cache.data_ptr(), T,
+           rot_dim, head_size, q.shape[-1] // head_size, (k.shape[-1] // head_size) if k is not None else 0,
+           q.stride(0), k.stride(0) if k is not None else 0, int(is_neox), N.dt(q.dtype), N.stream())
+
+
+def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping):
+    """k, v: [T, Hkv, D] (token stride arbitrary, heads contiguous)."""
+    if not _dev(k):
+        return R.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping)
+    T, Hkv, D = k.shape
+    N.call("vda_reshape_and_cache", k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+           slot_mapping.data_ptr(), T, Hkv, D, k_cache.shape[2], k.stride(0), v.stride(0), N.dt(k.dtype), N.stream())
+
+
+def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping, rot_dim: int, head_size: int,
+                   num_heads: int, num_kv_heads: int, is_neox: bool = True):
+    """Fused RoPE(q, k) in place + write of k, v into the paged cache.
+    qkv: [T, (Hq + 2*Hkv) * D]."""
+    T = qkv.shape[0]
+    if not _dev(qkv):
+        qs, ks = num_heads * head_size, num_kv_heads * head_size
+        q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
+        R.rotary_embedding(positions, q, k, cos_sin_cache, rot_dim, head_size, is_neox)
+        R.reshape_and_cache(k.reshape(T, num_kv_heads, head_size), v.reshape(T, num_kv_heads, head_size),
+                            k_cache, v_cache, slot_mapping)
+        return
+    N.call("vda_rope_and_cache", positions.data_ptr(), qkv.data_ptr(), cos_sin_cache.data_ptr(),
+           k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(), T, rot_dim, head_size, num_heads,
+           num_kv_heads, k_cache.shape[2], qkv.stride(0), int(is_neox), N.dt(qkv.dtype), N.stream())
+
+
+def copy_blocks(cache: torch.Tensor, pairs: torch.Tensor):
+    """cache: [num_blocks, ...]; pairs: int64 [n, 2] (src, dst) on the same device."""
+    if not _dev(cache):
+        return R.copy_blocks(cache, pairs)
+    N.call("vda_copy_blocks", cache.data_ptr(), pairs.data_ptr(), pairs.shape[0],
+           cache.stride(0) * cache.element_size(), N.stream())
+
+
+def transfer_blocks(dst: torch.Tensor, src: torch.Tensor, dst_ids: torch.Tensor, src_ids: torch.Tensor):
+    """dst[dst_ids[i]] = src[src_ids[i]] for whole blocks; the id tensors live on the launching device.
+    src may be peer-mapped memory of another GPU (xGMI) or pinned host memory."""
+    if not (dst.is_cuda or src.is_cuda) or envs.VDA_FORCE_TORCH_OPS:
+        return R.transfer_blocks(dst, src, dst_ids, src_ids)
+    N.call("vda_transfer_blocks", dst.data_ptr(), src.data_ptr(), dst_ids.data_ptr(), src_ids.data_ptr(),
+           dst_ids.numel(), dst.stride(0) * dst.element_size(), N.stream())
+
+
+def gather_cache(k_cache, v_cache, slots):
+    """Token-major copies [T, Hkv, D] of the K and V rows at the given slots."""
+    if not _dev(k_cache):
+        return R.gather_cache(k_cache, v_cache, slots)
+    T = slots.numel()
+    Hkv, D = k_cache.shape[1], k_cache.shape[3]
+    ko = torch.empty((T, Hkv, D), dtype=k_cache.dtype, device=k_cache.device)
+    vo = torch.empty_like(ko)
+    N.call("vda_gather_cache", ko.data_ptr(), vo.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+           slots.data_ptr(), T, Hkv, D, k_cache.shape[2], N.dt(k_cache.dtype), N.stream())
+    return ko, vo
+
+
+# ---- attention --------------------------------------------------------------------
+def decode_num_splits(num_seqs: int, num_kv_heads: int, max_seq_len: int) -> int:
+    """Split-KV factor so that a decode launch has enough workgroups for 256 CUs."""
+    wgs = max(num_seqs * num_kv_heads, 1)
+    target = envs.VDA_DECODE_SPLIT_TARGET_WGS
+    if wgs >= target:
+        return 1
+    by_len = max(max_seq_len // 256, 1)       # at least 256 keys per partition
+    return max(1, min(target // wgs, by_len, 64))
+
+
+def paged_attention_decode(out, q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale: float,
+                           num_splits: int = 1, max_q_len: int = 1, window: int = 0, softcap: float = 0.0,
+                           alibi: Optional[torch.Tensor] = None, workspace=None):
+    """q, out: [T, Hq, D].  Each sequence has <= max_q_len query tokens (1 for plain decode)."""
+    T, Hq, D = q.shape
+    if not _dev(q):
+        out.copy_(R.paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, window,
+                                    softcap, alibi))
+        return out
+    S = seq_lens.shape[0]
+    part_out = part_lse = None
+    if num_splits > 1:
+        if workspace is not None:
+            part_out, part_lse = workspace
+        else:
+            part_out = torch.empty((T, Hq, num_splits, D), dtype=torch.float32, device=q.device)
+            part_lse = torch.empty((T, Hq, num_splits), dtype=torch.float32, device=q.device)
+    N.call("vda_paged_attention_decode", out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+           block_table.data_ptr(), seq_lens.data_ptr(), q_start_loc.data_ptr(), N.ptr(alibi), N.ptr(part_out),
+           N.ptr(part_lse), S, T, Hq, k_cache.shape[1], D, k_cache.shape[2], block_table.stride(0), num_splits,
+           max_q_len, q.stride(0), out.stride(0), scale, softcap, window, N.dt(q.dtype), N.stream())
+    return out
+
+
+def paged_attention_prefill(out, q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale: float,
+                            window: int = 0, softcap: float = 0.0, alibi: Optional[torch.Tensor] = None):
+    T, Hq, D = q.shape
+    if not _dev(q):
+        out.copy_(R.paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, window,
+                                    softcap, alibi))
+        return out
+    N.call("vda_paged_attention_prefill", out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+           block_table.data_ptr(), seq_lens.data_ptr(), q_start_loc.data_ptr(), N.ptr(alibi), seq_lens.shape[0], T,
+           Hq, k_cache.shape[1], D, k_cache.shape[2], block_table.stride(0), q.stride(0), out.stride(0), scale,
+           softcap, window, N.dt(q.dtype), N.stream())
+    return out
+
+
+def merge_attn_states(prefix, prefix_lse, suffix, suffix_lse, return_lse: bool = False):
+    if not _dev(prefix):
+        o, l = R.merge_attn_states(prefix, prefix_lse, suffix, suffix_lse)
+        return (o, l) if return_lse else o
+    T, H, D = prefix.shape
+    out = torch.empty_like(prefix)
+    lse = torch.empty_like(prefix_lse) if return_lse else None
+    N.call("vda_merge_attn_states", out.data_ptr(), N.ptr(lse), prefix.data_ptr(), prefix_lse.data_ptr(),
+           suffix.data_ptr(), suffix_lse.data_ptr(), T, H, D, N.dt(prefix.dtype), N.stream())
+    return (out, lse) if return_lse else out
+
+
+# ---- sampling --------------------------------------------------------------------------
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    if not _dev(logits):
+        return logits.argmax(dim=-1)
+    S, V = logits.shape
+    out = torch.empty(S, dtype=torch.long, device=logits.device)
+    N.call("vda_argmax", logits.data_ptr(), out.data_ptr(), S, V, logits.stride(0), N.dt(logits.dtype), N.stream())
+    return out
+
+
+def sample(logits: torch.Tensor, temperature=None, top_k=None, top_p=None, min_p=None, seeds=None,
+           generator=None) -> torch.Tensor:
+    """Draw one token per row of fp32 logits.  temperature < 1e-5 means greedy for that row."""
+    if not _dev(logits):
+        return R.sample(logits, temperature, top_k, top_p, min_p, seeds, generator)
+    assert logits.dtype == torch.float32
+    S, V = logits.shape
+    out = torch.empty(S, dtype=torch.long, device=logits.device)
+    N.call("vda_sample", logits.data_ptr(), out.data_ptr(), N.ptr(temperature), N.ptr(top_k), N.ptr(top_p),
+           N.ptr(min_p), N.ptr(seeds), S, V, logits.stride(0), N.stream())
+    return out
+
+
+def topk_topp_mask(logits, top_k=None, top_p=None, min_p=None):
+    if not _dev(logits):
+        return R.topk_topp_mask(logits, top_k, top_p, min_p)
+    S, V = logits.shape
+    N.call("vda_topk_topp_mask", logits.data_ptr(), N.ptr(top_k), N.ptr(top_p), N.ptr(min_p), S, V,
+           logits.stride(0), N.stream())
+    return logits
+
+
+def apply_penalties(logits, prompt_mask, out_counts, rep, freq, pres):
+    """In place on fp32 logits [S, V]; prompt_mask bool/uint8 [S, V]; out_counts int32 [S, V]."""
+    if not _dev(logits):
+        return R.apply_penalties(logits, prompt_mask, out_counts, rep, freq, pres)
+    S, V = logits.shape
+    pm = prompt_mask.view(torch.uint8) if prompt_mask.dtype == torch.bool else prompt_mask
+    N.call("vda_apply_penalties", logits.data_ptr(), pm.data_ptr(), out_counts.data_ptr(), rep.data_ptr(),
+           freq.data_ptr(), pres.data_ptr(), S, V, logits.stride(0), N.stream())
+    return logits
+
+
+# ---- fp8 ---------------------------------------------------------------------------------
+def scaled_fp8_quant(x: torch.Tensor, scale: Optional[torch.Tensor] = None):
+    """Per-tensor fp8 (e4m3fn).  scale=None computes it (dynamic)."""
+    if not _dev(x) or x.numel() % 8:
+        return R.scaled_fp8_quant(x, scale)
+    xc = x.contiguous()
+    out = torch.empty(xc.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    mode = 0
+    if scale is None:
+        scale = torch.zeros(1, dtype=torch.float32, device=x.device)
+        mode = 1
+    N.call("vda_scaled_fp8_quant", out.data_ptr(), xc.data_ptr(), scale.data_ptr(), xc.numel(), mode,
+           N.dt(x.dtype), N.stream())
+    return out, scale
+
+
+def per_token_fp8_quant(x: torch.Tensor, scale_ub: Optional[torch.Tensor] = None):
+    if not _dev(x):
+        return R.per_token_fp8_quant(x, scale_ub)
+    H = x.shape[-1]
+    x2 = _contig_last(x).view(-1, H)
+    out = torch.empty(x2.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    scales = torch.empty((x2.shape[0], 1), dtype=torch.float32, device=x.device)
+    N.call("vda_per_token_fp8_quant", out.data_ptr(), scales.data_ptr(), x2.data_ptr(), N.ptr(scale_ub),
+           x2.shape[0], H, x2.stride(0), out.stride(0), N.dt(x.dtype), N.stream())
+    return out.view(x.shape), scales.view(*x.shape[:-1], 1)
+
+
+def fp8_dequant(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype):
+    if not _dev(q) or q.numel() % 8:
+        return R.fp8_dequant(q, scale, dtype)
+    out = torch.empty(q.shape, dtype=dtype, device=q.device)
+    N.call("vda_fp8_dequant", out.data_ptr(), q.contiguous().data_ptr(), scale.data_ptr(), q.numel(), N.dt(dtype),
+           N.stream())
+    return out
+
+
+# ---- GEMM -----------------------------------------------------------------------------------
+def skinny_gemm_ok(M: int, N_: int, K: int, dtype: torch.dtype) -> bool:
+    return (1 <= M <= envs.VDA_SKINNY_GEMM_MAX_M and N_ % 16 == 0 and K % 128 == 0
+            and dtype in (torch.bfloat16, torch.float16) and not envs.VDA_DISABLE_SKINNY_GEMM)
+
+
+def skinny_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ w.T (+ bias) for x [M<=64, K], w [N, K]."""
+    if not _dev(x):
+        return R.skinny_gemm(x, w, bias)
+    M, K = x.shape
+    N_ = w.shape[0]
+    y = torch.empty((M, N_), dtype=x.dtype, device=x.device)
+    N.call("vda_skinny_gemm", y.data_ptr(), x.data_ptr(), w.data_ptr(), N.ptr(bias), M, N_, K, x.stride(0),
+           w.stride(0), y.stride(0), N.dt(x.dtype), N.stream())
+    return y
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Unquantised linear: skinny MFMA kernel for decode-sized M, hipBLASLt otherwise."""
+    if x.is_cuda and x.dim() == 2 and x.stride(-1) == 1 and w.stride(-1) == 1 \
+            and skinny_gemm_ok(x.shape[0], w.shape[0], x.shape[1], x.dtype):
+        return skinny_gemm(x, w, bias)
+    return torch.nn.functional.linear(x, w, bias)

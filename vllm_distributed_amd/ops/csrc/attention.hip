@@ -1,0 +1,480 @@
+// Paged attention for gfx950: one MFMA kernel body serves decode (split-KV,
+// the 4 waves of a workgroup share the query columns and split the keys) and
+// varlen prefill / chunked prefill (each wave owns its own query columns).
+//
+// Covers what the reference spreads over csrc/rocm/attention.cu (MFMA decode),
+// csrc/attention/paged_attention_v{1,2}.cu, the Triton unified_attention kernel
+// (vllm/attention/ops/triton_unified_attention.py) and
+// csrc/attention/merge_attn_states.cu.
+//
+// Cache layout (chosen for MFMA operands, see sched/kv_cache_interface.py):
+//   K: [num_blocks, kv_heads, BS, D]    a token row is D contiguous elements
+//   V: [num_blocks, kv_heads, D, BS]    a d-row is BS contiguous tokens
+//
+// Data flow per 32-key step, per wave (lane l: r = l&15, g = l>>4):
+//   S^T = K . Q^T    A = K rows (token on the MFMA row), B = Q^T (query column r)
+//                    -> the lane owns scores of column r for keys 8g..8g+7 of the
+//                       step (the two 16-key tiles interleave keys so that this
+//                       holds), i.e. softmax statistics are per-lane scalars;
+//   O^T += V^T . P^T A = V^T rows (d on the MFMA row, 8 contiguous keys per lane
+//                       = one 16-byte load from the V layout above), B = P^T which
+//                       is exactly the 8 probabilities the lane already holds.
+// Nothing goes through LDS except the final cross-wave merge of the decode form.
+#include "common.h"
+
+struct AttnParams {
+  const void* q;            // [T, Hq, D]
+  const void* k_cache;
+  const void* v_cache;
+  void* out;                // [T, Hq, D]
+  float* part_out;          // [T, Hq, nsplit, D]   (split mode only)
+  float* part_lse;          // [T, Hq, nsplit]      log2-domain log-sum-exp
+  const int* block_table;   // [S, max_blocks]
+  const int* seq_lens;      // [S] keys visible to the LAST query token of the sequence
+  const int* q_start_loc;   // [S+1]
+  const float* alibi;       // [Hq] or nullptr
+  int num_seqs, Hq, Hkv, max_blocks, nsplit;
+  long q_stride, out_stride;   // elements between consecutive tokens
+  float scale, softcap;
+  int window;               // sliding window size, 0 = none
+  int q_tile;               // query tokens per workgroup (prefill form)
+};
+
+template <typename T, int D, int BS, int NCT, bool SPLIT>
+__global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr int KS = D / 32;       // MFMA k-steps over the head dimension
+  constexpr int NT = D / 16;       // 16-wide d tiles of the output
+  constexpr int DQ = D / 4;        // d elements owned by one lane group in QK^T
+  constexpr int COLS = 16 * NCT;   // query columns per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int kvh = blockIdx.y;
+  const int G = p.Hq / p.Hkv;
+
+  // ---- which sequence / query tokens does this workgroup own ----------------
+  int seq, q0;
+  if (SPLIT) {
+    seq = blockIdx.x;
+    q0 = 0;
+  } else {
+    // tiles of sequence s live in [qsl[s]/QT + s, qsl[s+1]/QT + s + 1): find s
+    const int tile = blockIdx.x;
+    int lo = 0, hi = p.num_seqs;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (mid < p.num_seqs && p.q_start_loc[mid] / p.q_tile + mid <= tile) lo = mid; else hi = mid - 1;
+    }
+    seq = lo;
+    q0 = (tile - (p.q_start_loc[seq] / p.q_tile + seq)) * p.q_tile;
+  }
+  const int qs = p.q_start_loc[seq];
+  const int q_len = p.q_start_loc[seq + 1] - qs;
+  const int seq_len = p.seq_lens[seq];
+  if (q0 >= q_len) return;
+  const int ctx = seq_len - q_len;        // keys that precede the first query token
+  const int* bt = p.block_table + (long)seq * p.max_blocks;
+  const int nblk_valid = (seq_len + BS - 1) / BS;
+
+  // ---- per-lane query columns -------------------------------------------------
+  // column c of the workgroup -> (query token c / G, head c % G)
+  int limit[NCT], lower[NCT];
+  long col_off[NCT];           // element offset of (token, head) in q / out
+  float slope[NCT];
+  V8 qf[NCT][KS];
+  int wave_hi = 0, wave_lo = 0x7fffffff;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int c = (SPLIT ? 0 : wave * COLS) + ct * 16 + r;
+    const int ti = c / G, h = c % G;
+    const int qt = q0 + ti;
+    const int qt_end = SPLIT ? q_len : min(q_len, q0 + p.q_tile);
+    const bool valid = qt < qt_end && (SPLIT ? c < COLS : true);
+    limit[ct] = valid ? ctx + qt + 1 : 0;
+    lower[ct] = (valid && p.window > 0) ? max(0, limit[ct] - p.window) : 0;
+    const int head = kvh * G + h;
+    slope[ct] = (p.alibi && valid) ? p.alibi[head] : 0.f;
+    const T* qp = (const T*)p.q + (long)(qs + (valid ? qt : q0)) * p.q_stride + (long)head * D + g * DQ;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      qf[ct][s] = valid ? ld16<V8>(qp + 8 * s) : V8{};
+    }
+    col_off[ct] = valid ? (long)(qs + qt) : -1;   // token index; -1 = padding column
+    if (valid) { wave_hi = max(wave_hi, limit[ct]); wave_lo = min(wave_lo, lower[ct]); }
+  }
+  // wave-uniform key range
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    wave_hi = max(wave_hi, __shfl_xor(wave_hi, o, 64));
+    wave_lo = min(wave_lo, __shfl_xor(wave_lo, o, 64));
+  }
+  int step_lo = wave_hi > 0 ? wave_lo / 32 : 0;
+  int step_hi = (wave_hi + 31) / 32;
+  int step_stride = 1;
+  if (SPLIT) {
+    // partition the steps over gridDim.z, then deal a partition's steps to the 4 waves
+    const int total = step_hi - step_lo;
+    const int per = (total + p.nsplit - 1) / p.nsplit;
+    const int a = step_lo + blockIdx.z * per;
+    step_hi = min(step_hi, a + per);
+    step_lo = a + wave;
+    step_stride = 4;
+  }
+
+  float m[NCT], l[NCT];
+  f32x4 acc[NCT][NT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    m[ct] = -INFINITY; l[ct] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[ct][n] = f32x4{0, 0, 0, 0};
+  }
+
+  const T* kc = (const T*)p.k_cache;
+  const T* vc = (const T*)p.v_cache;
+  // K row of this lane inside a step: tile u, row r  <->  key 8*(r>>2) + 4u + (r&3)
+  const int krow0 = 8 * (r >> 2) + (r & 3);
+
+  auto load_k = [&](int step, V8 (&kf)[2][KS]) {
+    const int tb = step * 32;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int tok = tb + krow0 + 4 * u;
+      const int bi = max(min(tok / BS, nblk_valid - 1), 0);
+      const long blk = bt[bi];
+      const T* kp = kc + ((blk * p.Hkv + kvh) * BS + (tok % BS)) * (long)D + g * DQ;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kf[u][s] = ld16<V8>(kp + 8 * s);
+    }
+  };
+  auto load_v = [&](int step, V8 (&vf)[NT]) {
+    const int tok = step * 32 + 8 * g;
+    const int bi = max(min(tok / BS, nblk_valid - 1), 0);
+    const long blk = bt[bi];
+    const T* vp = vc + ((blk * p.Hkv + kvh) * (long)D + r) * BS + (tok % BS);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) vf[n] = ld16<V8>(vp + (long)n * 16 * BS);
+  };
+
+  V8 kf[2][KS], kn[2][KS], vf[NT];
+  if (step_lo < step_hi) load_k(step_lo, kf);
+  for (int step = step_lo; step < step_hi; step += step_stride) {
+    load_v(step, vf);
+    const int nxt = step + step_stride;
+    if (nxt < step_hi) load_k(nxt, kn);
+    const int tb = step * 32 + 8 * g;   // first key of this lane's 8
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        s0 = mfma16(kf[0][s], qf[ct][s], s0);
+        s1 = mfma16(kf[1][s], qf[ct][s], s1);
+      }
+      float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int tok = tb + j;
+        float x = sv[j] * p.scale;
+        if (p.softcap > 0.f) x = p.softcap * tanhf(x / p.softcap);
+        x += slope[ct] * (float)(tok - (limit[ct] - 1));
+        x *= 1.4426950408889634f;
+        x = (tok < limit[ct] && tok >= lower[ct]) ? x : -INFINITY;
+        sv[j] = x;
+        mx = fmaxf(mx, x);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m[ct], mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f(m[ct] - m_use);
+      m[ct] = m_new;
+      float ps = 0.f;
+      V8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = exp2f(sv[j] - m_use);
+        ps += e;
+        pb[j] = (T)e;
+      }
+      l[ct] = l[ct] * alpha + ps;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[ct][n] *= alpha;
+        acc[ct][n] = mfma16(vf[n], pb, acc[ct][n]);
+      }
+    }
+    if (nxt < step_hi) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kf[u][s] = kn[u][s];
+    }
+  }
+
+  // lane-partial row sums -> full sums
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    l[ct] += __shfl_xor(l[ct], 16, 64);
+    l[ct] += __shfl_xor(l[ct], 32, 64);
+  }
+
+  if (!SPLIT) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      if (col_off[ct] < 0) continue;
+      const int c = wave * COLS + ct * 16 + r;
+      const int head = kvh * G + c % G;
+      const float inv = l[ct] > 0.f ? 1.f / l[ct] : 0.f;
+      T* op = (T*)p.out + col_off[ct] * p.out_stride + (long)head * D + 4 * g;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        V4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (T)(acc[ct][n][i] * inv);
+        *reinterpret_cast<V4*>(op + 16 * n) = o;
+      }
+    }
+    return;
+  } else {
+    // ---- merge the 4 waves: tree over LDS, lane-linear slots ---------------------
+    // Partner waves use the same lane -> element map, so a lane reads back exactly
+    // the slot positions its partner lane wrote: no layout change, no conflicts.
+    __shared__ f32x4 s_acc[2][NCT * NT][64];
+    __shared__ float s_ml[2][NCT][2][64];
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const int first = round == 0 ? 2 : 1;     // sending waves [first, first + cnt)
+      const int cnt = round == 0 ? 2 : 1;
+      if (wave >= first && wave < first + cnt) {
+        const int slot = wave - first;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          s_ml[slot][ct][0][lane] = m[ct];
+          s_ml[slot][ct][1][lane] = l[ct];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) s_acc[slot][ct * NT + n][lane] = acc[ct][n];
+        }
+      }
+      __syncthreads();
+      if (wave < cnt) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const float m2 = s_ml[wave][ct][0][lane], l2 = s_ml[wave][ct][1][lane];
+          const float M = fmaxf(m[ct], m2);
+          const float Mu = (M == -INFINITY) ? 0.f : M;
+          const float f1 = exp2f(m[ct] - Mu), f2 = exp2f(m2 - Mu);
+          l[ct] = l[ct] * f1 + l2 * f2;
+          m[ct] = M;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[ct][n] = acc[ct][n] * f1 + s_acc[wave][ct * NT + n][lane] * f2;
+        }
+      }
+      __syncthreads();
+    }
+    if (wave != 0) return;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      if (col_off[ct] < 0) continue;
+      const int c = ct * 16 + r;
+      const int head = kvh * G + c % G;
+      const float L = l[ct];
+      const float inv = L > 0.f ? 1.f / L : 0.f;
+      if (p.nsplit == 1) {
+        T* op = (T*)p.out + col_off[ct] * p.out_stride + (long)head * D + 4 * g;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          V4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (T)(acc[ct][n][i] * inv);
+          *reinterpret_cast<V4*>(op + 16 * n) = o;
+        }
+      } else {
+        const long pi = (col_off[ct] * p.Hq + head) * p.nsplit + blockIdx.z;
+        float* po = p.part_out + pi * D + 4 * g;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(po + 16 * n) = acc[ct][n] * inv;
+        if (g == 0) {
+          const float Mu = (m[ct] == -INFINITY) ? 0.f : m[ct];
+          p.part_lse[pi] = L > 0.f ? Mu + log2f(L) : -INFINITY;
+        }
+      }
+    }
+  }
+}
+
+// Merge split-KV partials: one wave per (token, head).
+template <typename T, int D>
+__global__ __launch_bounds__(64) void attn_reduce_kernel(T* out, const float* part_out, const float* part_lse,
+                                                         int Hq, int nsplit, long out_stride) {
+  const long th = blockIdx.x;          // token * Hq + head
+  const int lane = threadIdx.x;
+  const float* lse = part_lse + th * nsplit;
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, lse[s]);
+  const float Mu = (M == -INFINITY) ? 0.f : M;
+  constexpr int PER = D / 64 > 0 ? D / 64 : 1;
+  float o[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) o[i] = 0.f;
+  float W = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = exp2f(lse[s] - Mu);
+    W += w;
+    const float* po = part_out + (th * nsplit + s) * D;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) o[i] += w * po[d];
+    }
+  }
+  const float inv = W > 0.f ? 1.f / W : 0.f;
+  const long tok = th / Hq, head = th % Hq;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int d = lane + 64 * i;
+    if (d < D) out[tok * out_stride + head * D + d] = (T)(o[i] * inv);
+  }
+}
+
+// LSE-weighted merge of two partial attention outputs (cascade / prefix+suffix).
+// out, prefix, suffix: [T, H, D]; lse: [H, T] natural-log domain.
+template <typename T>
+__global__ void merge_attn_states_kernel(T* out, float* out_lse, const T* pre, const float* pre_lse,
+                                         const T* suf, const float* suf_lse, int Tn, int H, int D) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over T*H*D/8
+  const int per = D / 8;
+  if (idx >= (long)Tn * H * per) return;
+  const int d8 = (idx % per) * 8;
+  const long th = idx / per;
+  const int h = th % H;
+  const long t = th / H;
+  float a = pre_lse[(long)h * Tn + t], b = suf_lse[(long)h * Tn + t];
+  a = isinf(a) && a > 0 ? -INFINITY : a;
+  b = isinf(b) && b > 0 ? -INFINITY : b;
+  const float mx = fmaxf(a, b);
+  const float mu = (mx == -INFINITY) ? 0.f : mx;
+  const float ea = expf(a - mu), eb = expf(b - mu);
+  const float den = ea + eb;
+  const float wa = den > 0.f ? ea / den : 0.f, wb = den > 0.f ? eb / den : 0.f;
+  using V8 = typename Vec<T>::v8;
+  const V8 x = ld16<V8>(pre + th * D + d8), y = ld16<V8>(suf + th * D + d8);
+  V8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (T)((float)x[i] * wa + (float)y[i] * wb);
+  st16<V8>(out + th * D + d8, o);
+  if (out_lse && d8 == 0) out_lse[(long)h * Tn + t] = den > 0.f ? mu + logf(den) : -INFINITY;
+}
+
+// ---------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------
+template <typename T, int D, int BS>
+static int launch_attn(const AttnParams& p, int form, int grid_x, hipStream_t st) {
+  // form 0: decode (split over waves, NCT=1, up to 16 query columns per kv head)
+  // form 1: decode with up to 32 columns; form 2: prefill (NCT=2)
+  dim3 block(256);
+  if (form == 0) {
+    dim3 grid(grid_x, p.Hkv, p.nsplit);
+    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 1, true>), grid, block, 0, st, p);
+  } else if (form == 1) {
+    dim3 grid(grid_x, p.Hkv, p.nsplit);
+    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, true>), grid, block, 0, st, p);
+  } else {
+    dim3 grid(grid_x, p.Hkv, 1);
+    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, false>), grid, block, 0, st, p);
+  }
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int D>
+static int dispatch_bs(const AttnParams& p, int bs, int form, int grid_x, hipStream_t st) {
+  switch (bs) {
+    case 16: return launch_attn<T, D, 16>(p, form, grid_x, st);
+    case 32: return launch_attn<T, D, 32>(p, form, grid_x, st);
+    case 64: return launch_attn<T, D, 64>(p, form, grid_x, st);
+  }
+  return -2;
+}
+
+template <typename T>
+static int dispatch_d(const AttnParams& p, int d, int bs, int form, int grid_x, hipStream_t st) {
+  switch (d) {
+    case 64: return dispatch_bs<T, 64>(p, bs, form, grid_x, st);
+    case 128: return dispatch_bs<T, 128>(p, bs, form, grid_x, st);
+    case 256: return dispatch_bs<T, 256>(p, bs, form, grid_x, st);
+  }
+  return -3;
+}
+
+// Decode / speculative-verify attention.  Every sequence contributes
+// q_len = q_start_loc[s+1]-q_start_loc[s] query tokens with q_len * (Hq/Hkv) <= 32.
+// num_tokens is only needed to size the split-KV reduce.
+VDA_EXPORT int vda_paged_attention_decode(
+    void* out, const void* q, const void* k_cache, const void* v_cache, const int* block_table,
+    const int* seq_lens, const int* q_start_loc, const float* alibi, float* part_out, float* part_lse,
+    int num_seqs, int num_tokens, int Hq, int Hkv, int D, int block_size, int max_blocks, int nsplit,
+    int max_q_len, long q_stride, long out_stride, float scale, float softcap, int window, int dtype,
+    hipStream_t st) {
+  if (Hq % Hkv) return -1;
+  const int cols = max_q_len * (Hq / Hkv);
+  if (cols > 32 || (cols > 16 && D > 128)) return -4;
+  AttnParams p{q, k_cache, v_cache, out, part_out, part_lse, block_table, seq_lens, q_start_loc, alibi,
+               num_seqs, Hq, Hkv, max_blocks, nsplit, q_stride, out_stride, scale, softcap, window, 0};
+  const int form = cols <= 16 ? 0 : 1;
+  int rc = dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, form, num_seqs, st)
+                             : dispatch_d<f16_t>(p, D, block_size, form, num_seqs, st);
+  if (rc) return rc;
+  if (nsplit > 1) {
+    const long n = (long)num_tokens * Hq;
+#define RED(TT, DD) hipLaunchKernelGGL((attn_reduce_kernel<TT, DD>), dim3(n), dim3(64), 0, st, (TT*)out, \
+                                       part_out, part_lse, Hq, nsplit, out_stride)
+    if (dtype == VDA_BF16) {
+      if (D == 64) RED(bf16_t, 64); else if (D == 128) RED(bf16_t, 128); else RED(bf16_t, 256);
+    } else {
+      if (D == 64) RED(f16_t, 64); else if (D == 128) RED(f16_t, 128); else RED(f16_t, 256);
+    }
+#undef RED
+    VDA_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// Varlen causal attention of new tokens against the paged cache (the new tokens'
+// own K/V must already be in the cache).  q_tile = 128 / (Hq/Hkv) query tokens
+// per workgroup; the grid over-allocates one tile per sequence.
+VDA_EXPORT int vda_paged_attention_prefill(
+    void* out, const void* q, const void* k_cache, const void* v_cache, const int* block_table,
+    const int* seq_lens, const int* q_start_loc, const float* alibi, int num_seqs, int num_tokens,
+    int Hq, int Hkv, int D, int block_size, int max_blocks, long q_stride, long out_stride, float scale,
+    float softcap, int window, int dtype, hipStream_t st) {
+  if (Hq % Hkv) return -1;
+  const int G = Hq / Hkv;
+  if (G > 128) return -4;
+  const int q_tile = 128 / G;     // 4 waves x 32 columns
+  AttnParams p{q, k_cache, v_cache, out, nullptr, nullptr, block_table, seq_lens, q_start_loc, alibi,
+               num_seqs, Hq, Hkv, max_blocks, 1, q_stride, out_stride, scale, softcap, window, q_tile};
+  const int grid_x = num_tokens / q_tile + num_seqs;
+  return dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, 2, grid_x, st)
+                           : dispatch_d<f16_t>(p, D, block_size, 2, grid_x, st);
+}
+
+VDA_EXPORT int vda_merge_attn_states(void* out, float* out_lse, const void* pre, const float* pre_lse,
+                                     const void* suf, const float* suf_lse, int T, int H, int D, int dtype,
+                                     hipStream_t st) {
+  if (D % 8) return -1;
+  const long n = (long)T * H * (D / 8);
+  const int threads = 256;
+  const int blocks = (int)((n + threads - 1) / threads);
+  if (dtype == VDA_BF16)
+    hipLaunchKernelGGL(merge_attn_states_kernel<bf16_t>, dim3(blocks), dim3(threads), 0, st, (bf16_t*)out,
+                       out_lse, (const bf16_t*)pre, pre_lse, (const bf16_t*)suf, suf_lse, T, H, D);
+  else
+    hipLaunchKernelGGL(merge_attn_states_kernel<f16_t>, dim3(blocks), dim3(threads), 0, st, (f16_t*)out,
+                       out_lse, (const f16_t*)pre, pre_lse, (const f16_t*)suf, suf_lse, T, H, D);
+  VDA_CHECK_LAUNCH();
+  return 0;
+}

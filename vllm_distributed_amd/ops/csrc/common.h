@@ -1,0 +1,97 @@
+// Shared device helpers for the gfx950 op library.
+// Wave size is 64 everywhere; 16-bit activations are bf16 or fp16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VDA_EXPORT extern "C" __attribute__((visibility("default")))
+
+// dtype codes shared with ops/__init__.py
+enum VdaDtype { VDA_BF16 = 0, VDA_F16 = 1, VDA_F32 = 2, VDA_FP8 = 3 };
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> { using v8 = bf16x8; using v4 = bf16x4; };
+template <> struct Vec<f16_t> { using v8 = f16x8; using v4 = f16x4; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// 16-byte global load / store of 8 halfwords
+template <typename V> __device__ __forceinline__ V ld16(const void* p) {
+  return *reinterpret_cast<const V*>(p);
+}
+template <typename V> __device__ __forceinline__ void st16(void* p, V v) {
+  *reinterpret_cast<V*>(p) = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide reductions for blocks of up to 1024 threads (16 waves). `red` is
+// an LDS scratch of at least 16 floats; the result is returned to every thread.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = lane < nw ? red[lane] : 0.f;
+  return wave_sum(t);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = lane < nw ? red[lane] : -INFINITY;
+  return wave_max(t);
+}
+
+// OCP e4m3fn conversion (gfx950 hardware converts; saturating to +-448)
+__device__ __forceinline__ uint8_t f32_to_fp8(float x) {
+  x = fminf(fmaxf(x, -448.f), 448.f);
+  uint32_t r = __builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false);
+  return (uint8_t)(r & 0xff);
+}
+__device__ __forceinline__ float fp8_to_f32(uint8_t v) {
+  return __builtin_amdgcn_cvt_f32_fp8((uint32_t)v, 0);
+}
+
+__device__ __forceinline__ float clamp_fp8(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+// four floats -> four packed e4m3 bytes (element 0 in the low byte)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  uint32_t r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(a), clamp_fp8(b), 0, false);
+  return __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(c), clamp_fp8(d), r, true);
+}
+
+#define VDA_CHECK_LAUNCH() \
+  do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -1,0 +1,104 @@
+// Skinny GEMM for decode: y[M, N] = x[M, K] . W[N, K]^T (+ bias), M <= 64.
+// The weight matrix is streamed exactly once straight from HBM into MFMA A
+// operands (16 weight rows per workgroup, 64 contiguous bytes per lane per
+// 128-wide K chunk); the few activation rows ride on the MFMA column dimension,
+// so one kernel covers M = 1 .. 64 without a GEMV special case.  The 4 waves of
+// a workgroup split K and are summed through LDS.
+// Role of the reference's csrc/rocm/skinny_gemms.cu (LLMM1 / wvSplitK).
+#include "common.h"
+
+template <typename T, int MT>   // MT = number of 16-row activation tiles
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, const T* __restrict__ x,
+                                                          const T* __restrict__ w, const T* __restrict__ bias,
+                                                          int M, int N, int K, long x_stride, long w_stride,
+                                                          long y_stride) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const T* wp = w + (long)(n0 + r) * w_stride + g * 32;
+  const T* xp[MT];
+  bool xv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + r;
+    xv[mt] = m < M;
+    xp[mt] = x + (long)(xv[mt] ? m : 0) * x_stride + g * 32;
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0, 0, 0, 0};
+
+  const int nchunk = K >> 7;
+  // two chunks per iteration keep 8 weight loads per lane in flight
+  int c = wave;
+  for (; c + 4 < nchunk; c += 8) {
+    V8 wa[4], wb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      wa[s] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(wp + (long)c * 128 + 8 * s));
+      wb[s] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(wp + (long)(c + 4) * 128 + 8 * s));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)c * 128 + 8 * s) : V8{};
+        const V8 xb = xv[mt] ? ld16<V8>(xp[mt] + (long)(c + 4) * 128 + 8 * s) : V8{};
+        acc[mt] = mfma16(wa[s], xa, acc[mt]);
+        acc[mt] = mfma16(wb[s], xb, acc[mt]);
+      }
+    }
+  }
+  for (; c < nchunk; c += 4) {
+    V8 wa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      wa[s] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(wp + (long)c * 128 + 8 * s));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)c * 128 + 8 * s) : V8{};
+        acc[mt] = mfma16(wa[s], xa, acc[mt]);
+      }
+    }
+  }
+
+  __shared__ f32x4 red[3][MT][64];
+  if (wave > 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) red[wave - 1][mt][lane] = acc[mt];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // lane holds y[m = mt*16 + r][n0 + 4g + i]
+  V4 bv = V4{};
+  if (bias) bv = *reinterpret_cast<const V4*>(bias + n0 + 4 * g);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const f32x4 s = acc[mt] + red[0][mt][lane] + red[1][mt][lane] + red[2][mt][lane];
+    if (xv[mt]) {
+      V4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (T)(s[i] + (float)bv[i]);
+      *reinterpret_cast<V4*>(y + (long)(mt * 16 + r) * y_stride + n0 + 4 * g) = o;
+    }
+  }
+}
+
+VDA_EXPORT int vda_skinny_gemm(void* y, const void* x, const void* w, const void* bias, int M, int N, int K,
+                               long x_stride, long w_stride, long y_stride, int dtype, hipStream_t st) {
+  if (M < 1 || M > 64 || N % 16 || K % 128) return -1;
+  dim3 grid(N / 16), block(256);
+  const int mt = (M + 15) / 16;
+#define L(TT, MM) hipLaunchKernelGGL((skinny_gemm_kernel<TT, MM>), grid, block, 0, st, (TT*)y, (const TT*)x, \
+                                     (const TT*)w, (const TT*)bias, M, N, K, x_stride, w_stride, y_stride)
+#define BY(TT) do { if (mt == 1) L(TT, 1); else if (mt == 2) L(TT, 2); else if (mt == 3) L(TT, 3); else L(TT, 4); } while (0)
+  if (dtype == VDA_BF16) BY(bf16_t); else if (dtype == VDA_F16) BY(f16_t); else return -3;
+#undef BY
+#undef L
+  VDA_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,259 @@
+"""Plain PyTorch implementations of every op in this package.
+
+They serve two purposes: (1) the numerics oracle the HIP kernels are tested
+against (fp32 math, same layouts), and (2) the CPU plumbing path used when no
+GPU is present (role of the reference's csrc/cpu backend for the OPT-125m CPU
+configuration).  They are never used for CUDA tensors unless
+``VDA_FORCE_TORCH_OPS=1`` is set for debugging.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+FP8_MAX = 448.0
+
+
+# ---- norms -----------------------------------------------------------------
+def rms_norm(x, weight, eps, residual=None, weight_bias: float = 0.0):
+    dt = x.dtype
+    if residual is not None:
+        x = (x.float() + residual.float()).to(dt)
+        residual.copy_(x)
+    xf = x.float()
+    var = xf.pow(2).mean(-1, keepdim=True)
+    y = (xf * torch.rsqrt(var + eps)).to(dt)
+    return (y.float() * (weight.float() + weight_bias)).to(dt)
+
+
+def layer_norm(x, weight, bias, eps):
+    return F.layer_norm(x.float(), (x.shape[-1],), weight.float(),
+                        None if bias is None else bias.float(), eps).to(x.dtype)
+
+
+# ---- activations -------------------------------------------------------------
+def _act(kind: str, x: torch.Tensor, threshold: float = 0.0) -> torch.Tensor:
+    if kind == "silu":
+        return F.silu(x)
+    if kind == "gelu":
+        return F.gelu(x)
+    if kind in ("gelu_tanh", "gelu_pytorch_tanh", "gelu_new"):
+        return F.gelu(x, approximate="tanh")
+    if kind == "relu":
+        return F.relu(x)
+    if kind == "gelu_fast":
+        return 0.5 * x * (1.0 + torch.tanh(x * 0.79788456 * (1.0 + 0.044715 * x * x)))
+    if kind in ("quick_gelu", "gelu_quick"):
+        return x * torch.sigmoid(1.702 * x)
+    if kind == "fatrelu":
+        return torch.where(x > threshold, x, torch.zeros_like(x))
+    if kind == "relu2":
+        return F.relu(x).square()
+    raise ValueError(f"unknown activation {kind!r}")
+
+
+def act_and_mul(x, kind="silu", act_first=True, threshold=0.0):
+    d = x.shape[-1] // 2
+    a, b = x[..., :d].float(), x[..., d:].float()
+    y = _act(kind, a, threshold) * b if act_first else a * _act(kind, b, threshold)
+    return y.to(x.dtype)
+
+
+def activation(x, kind, threshold=0.0):
+    return _act(kind, x.float(), threshold).to(x.dtype)
+
+
+# ---- rotary ------------------------------------------------------------------
+def _rotate(x, cos, sin, rot_dim, is_neox):
+    # x: [T, H, D]; cos/sin: [T, rot_dim/2]
+    xr = x[..., :rot_dim].float()
+    cos, sin = cos[:, None, :], sin[:, None, :]
+    if is_neox:
+        x1, x2 = xr[..., : rot_dim // 2], xr[..., rot_dim // 2:]
+        out = torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1)
+    else:
+        x1, x2 = xr[..., 0::2], xr[..., 1::2]
+        out = torch.stack((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1).flatten(-2)
+    res = x.clone()
+    res[..., :rot_dim] = out.to(x.dtype)
+    return res
+
+
+def rotary_embedding(positions, q, k, cos_sin_cache, rot_dim, head_size, is_neox=True):
+    """In place on q [T, Hq*D] / k [T, Hkv*D] (k may be None)."""
+    cs = cos_sin_cache[positions.long()]
+    cos, sin = cs[:, : rot_dim // 2].float(), cs[:, rot_dim // 2:].float()
+    T = q.shape[0]
+    qv = q.view(T, -1, head_size)
+    qv.copy_(_rotate(qv, cos, sin, rot_dim, is_neox))
+    if k is not None:
+        kv = k.view(T, -1, head_size)
+        kv.copy_(_rotate(kv, cos, sin, rot_dim, is_neox))
+
+
+# ---- cache ---------------------------------------------------------------------
+def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping):
+    """k, v: [T, Hkv, D]; k_cache [nblk, Hkv, BS, D]; v_cache [nblk, Hkv, D, BS]."""
+    bs = k_cache.shape[2]
+    slots = slot_mapping.long()
+    keep = slots >= 0
+    slots = slots[keep]
+    blk, off = slots // bs, slots % bs
+    k_cache[blk, :, off, :] = k[keep].to(k_cache.dtype)
+    v_cache[blk, :, :, off] = v[keep].to(v_cache.dtype)
+
+
+def gather_cache(k_cache, v_cache, slots):
+    bs = k_cache.shape[2]
+    slots = slots.long()
+    blk, off = slots // bs, slots % bs
+    return k_cache[blk, :, off, :], v_cache[blk, :, :, off]
+
+
+def copy_blocks(cache, pairs):
+    for s, d in pairs.tolist():
+        cache[d].copy_(cache[s])
+
+
+def transfer_blocks(dst, src, dst_ids, src_ids):
+    dst[dst_ids.long().to(dst.device)] = src[src_ids.long().to(src.device)].to(dst.device)
+
+
+# ---- attention -------------------------------------------------------------------
+def paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale,
+                    window: int = 0, softcap: float = 0.0, alibi=None, return_lse: bool = False):
+    """Causal attention of the new tokens of every sequence against its paged
+    K/V (which already contain the new tokens).  q: [T, Hq, D] -> [T, Hq, D]."""
+    T, Hq, D = q.shape
+    Hkv, bs = k_cache.shape[1], k_cache.shape[2]
+    G = Hq // Hkv
+    out = torch.zeros_like(q)
+    lse = torch.full((Hq, T), float("-inf"), dtype=torch.float32, device=q.device)
+    qsl = q_start_loc.tolist()
+    for s, sl in enumerate(seq_lens.tolist()):
+        a, b = qsl[s], qsl[s + 1]
+        ql = b - a
+        if ql == 0 or sl == 0:
+            continue
+        nb = (sl + bs - 1) // bs
+        blocks = block_table[s, :nb].long()
+        k = k_cache[blocks].permute(1, 0, 2, 3).reshape(Hkv, nb * bs, D)[:, :sl].float()
+        v = v_cache[blocks].permute(1, 0, 3, 2).reshape(Hkv, nb * bs, D)[:, :sl].float()
+        k = k.repeat_interleave(G, dim=0)
+        v = v.repeat_interleave(G, dim=0)
+        qq = q[a:b].permute(1, 0, 2).float()                  # [Hq, ql, D]
+        sc = torch.matmul(qq, k.transpose(1, 2)) * scale      # [Hq, ql, sl]
+        if softcap > 0:
+            sc = softcap * torch.tanh(sc / softcap)
+        pos = torch.arange(sl - ql, sl, device=q.device)[:, None]
+        key = torch.arange(sl, device=q.device)[None, :]
+        if alibi is not None:
+            sc = sc + alibi.float()[:, None, None] * (key - pos)[None].float()
+        mask = key <= pos
+        if window > 0:
+            mask &= key > pos - window
+        sc = sc.masked_fill(~mask[None], float("-inf"))
+        lse[:, a:b] = torch.logsumexp(sc, dim=-1)
+        p = torch.softmax(sc, dim=-1)
+        out[a:b] = torch.matmul(p, v).permute(1, 0, 2).to(q.dtype)
+    return (out, lse) if return_lse else out
+
+
+def merge_attn_states(prefix, prefix_lse, suffix, suffix_lse):
+    """prefix/suffix: [T, H, D]; lse: [H, T]."""
+    a = torch.where(torch.isposinf(prefix_lse), torch.full_like(prefix_lse, float("-inf")), prefix_lse)
+    b = torch.where(torch.isposinf(suffix_lse), torch.full_like(suffix_lse, float("-inf")), suffix_lse)
+    mx = torch.maximum(a, b)
+    mu = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
+    ea, eb = torch.exp(a - mu), torch.exp(b - mu)
+    den = ea + eb
+    wa = torch.where(den > 0, ea / den, torch.zeros_like(den)).T[..., None]
+    wb = torch.where(den > 0, eb / den, torch.zeros_like(den)).T[..., None]
+    out = (prefix.float() * wa + suffix.float() * wb).to(prefix.dtype)
+    return out, torch.where(den > 0, mu + torch.log(den), torch.full_like(den, float("-inf")))
+
+
+# ---- sampling ------------------------------------------------------------------
+def apply_penalties(logits, prompt_mask, out_counts, rep, freq, pres):
+    seen = prompt_mask.bool() | (out_counts > 0)
+    r = rep[:, None]
+    pen = torch.where(logits > 0, logits / r, logits * r)
+    logits.copy_(torch.where(seen, pen, logits))
+    logits.sub_(freq[:, None] * out_counts.float())
+    logits.sub_(pres[:, None] * (out_counts > 0).float())
+    return logits
+
+
+def topk_topp_mask(logits, top_k=None, top_p=None, min_p=None):
+    """In place -inf masking, sort based (the oracle for the radix kernel)."""
+    S, V = logits.shape
+    if top_k is not None:
+        k = top_k.long().clone()
+        k[(k <= 0) | (k > V)] = V
+        srt = logits.sort(dim=-1, descending=True).values
+        thr = srt.gather(1, (k - 1)[:, None])
+        logits.masked_fill_(logits < thr, float("-inf"))
+    if top_p is not None:
+        probs = torch.softmax(logits, dim=-1)
+        sp, si = probs.sort(dim=-1, descending=True)
+        cum = sp.cumsum(-1)
+        # smallest set whose mass reaches p; the first token is always kept
+        drop = (cum - sp) >= top_p[:, None]
+        drop[:, 0] = False
+        thr = torch.where(drop, torch.full_like(sp, 2.0), sp).min(dim=-1, keepdim=True).values
+        logits.masked_fill_(probs < thr, float("-inf"))
+    if min_p is not None:
+        probs = torch.softmax(logits, dim=-1)
+        mx = probs.max(dim=-1, keepdim=True).values
+        logits.masked_fill_(probs < min_p[:, None] * mx, float("-inf"))
+    return logits
+
+
+def sample(logits, temperature=None, top_k=None, top_p=None, min_p=None, seeds=None, generator=None):
+    S, V = logits.shape
+    out = logits.argmax(dim=-1)
+    if temperature is None:
+        return out
+    rnd = temperature >= 1e-5
+    if not bool(rnd.any()):
+        return out
+    z = logits.float() / torch.where(rnd, temperature, torch.ones_like(temperature))[:, None]
+    z = topk_topp_mask(z, top_k, top_p, min_p)
+    probs = torch.softmax(z, dim=-1)
+    if seeds is not None:
+        draws = torch.empty(S, dtype=torch.long, device=logits.device)
+        for i in range(S):
+            g = torch.Generator(device=logits.device)
+            g.manual_seed(int(seeds[i]) & 0x7FFFFFFFFFFFFFFF)
+            draws[i] = torch.multinomial(probs[i], 1, generator=g)[0]
+    else:
+        draws = torch.multinomial(probs, 1, generator=generator)[:, 0]
+    return torch.where(rnd, draws, out)
+
+
+# ---- fp8 -------------------------------------------------------------------------
+def scaled_fp8_quant(x, scale=None):
+    if scale is None:
+        scale = (x.abs().max().float() / FP8_MAX).clamp(min=1e-12).reshape(1)
+    q = (x.float() / scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+def per_token_fp8_quant(x, scale_ub=None):
+    amax = x.abs().amax(dim=-1, keepdim=True).float()
+    if scale_ub is not None:
+        amax = amax.clamp(max=float(scale_ub))
+    scale = (amax / FP8_MAX).clamp(min=1.0 / (FP8_MAX * 512.0))
+    q = (x.float() / scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+def fp8_dequant(q, scale, dtype):
+    return (q.float() * scale).to(dtype)
+
+
+def skinny_gemm(x, w, bias=None):
+    return F.linear(x, w, bias)
