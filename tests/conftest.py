@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# in-process engine core by default; the multi-process tests opt in explicitly
+os.environ.setdefault("VLLM_ENABLE_V1_MULTIPROCESSING", "0")
 
 
 def pytest_configure(config):

@@ -201,8 +201,9 @@ class ModelConfig:
             self.served_model_name = self.model
         if self.task == "auto":
             arch = (self.architectures or [""])[0]
-            self.task = ("embed" if arch.endswith(("Model", "ForMaskedLM")) and "Causal" not in arch
-                         else "classify" if "SequenceClassification" in arch else "generate")
+            generative = "CausalLM" in arch or "LMHead" in arch or "ConditionalGeneration" in arch
+            self.task = ("generate" if generative else "classify" if "SequenceClassification" in arch
+                         else "embed" if arch.endswith(("Model", "ForMaskedLM")) else "generate")
 
     @staticmethod
     def _resolve_dtype(dtype, hf: HFConfig) -> torch.dtype:

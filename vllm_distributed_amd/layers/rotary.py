@@ -1,0 +1,193 @@
+"""Rotary position embeddings.
+
+Every variant only differs in how the fp32 ``cos_sin_cache [max_pos, rot_dim]``
+(``[cos | sin]``) is built; applying it is one HIP kernel (ops.rotary_embedding,
+or fused with the KV-cache write in ops.rope_and_cache).
+Reference: vllm/model_executor/layers/rotary_embedding.py (default :93, linear
+:376, dynamic NTK :467, YaRN :556, LongRoPE :653, Llama-3 :885, M-RoPE :968).
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def _inv_freq(base: float, rot_dim: int) -> torch.Tensor:
+    return 1.0 / (base ** (torch.arange(0, rot_dim, 2, dtype=torch.float32) / rot_dim))
+
+
+def _yarn_find_dim(num_rot: float, dim: int, base: float, max_pos: int) -> float:
+    return dim * math.log(max_pos / (num_rot * 2 * math.pi)) / (2 * math.log(base))
+
+
+def _yarn_range(low_rot, high_rot, dim, base, max_pos) -> tuple[int, int]:
+    lo = math.floor(_yarn_find_dim(low_rot, dim, base, max_pos))
+    hi = math.ceil(_yarn_find_dim(high_rot, dim, base, max_pos))
+    return max(lo, 0), min(hi, dim - 1)
+
+
+def _ramp(lo: float, hi: float, n: int) -> torch.Tensor:
+    if lo == hi:
+        hi += 0.001
+    return ((torch.arange(n, dtype=torch.float32) - lo) / (hi - lo)).clamp(0, 1)
+
+
+def yarn_mscale(scale: float = 1.0, mscale: float = 1.0) -> float:
+    return 1.0 if scale <= 1 else 0.1 * mscale * math.log(scale) + 1.0
+
+
+class RotaryEmbedding(nn.Module):
+    def __init__(self, head_size: int, rotary_dim: int, max_position: int, base: float, is_neox_style: bool):
+        super().__init__()
+        self.head_size, self.rotary_dim = head_size, rotary_dim
+        self.max_position, self.base, self.is_neox_style = max_position, base, is_neox_style
+        self.register_buffer("cos_sin_cache", self._build().float().contiguous(), persistent=False)
+
+    def _freqs(self) -> torch.Tensor:
+        return _inv_freq(self.base, self.rotary_dim)
+
+    def _positions(self) -> torch.Tensor:
+        return torch.arange(self.max_position, dtype=torch.float32)
+
+    def _mscale(self) -> float:
+        return 1.0
+
+    def _build(self) -> torch.Tensor:
+        f = torch.outer(self._positions(), self._freqs())
+        m = self._mscale()
+        return torch.cat((f.cos() * m, f.sin() * m), dim=-1)
+
+    def forward(self, positions: torch.Tensor, q: torch.Tensor, k: Optional[torch.Tensor] = None):
+        ops.rotary_embedding(positions, q, k, self.cos_sin_cache, self.rotary_dim, self.head_size,
+                             self.is_neox_style)
+        return q, k
+
+
+class LinearScalingRotaryEmbedding(RotaryEmbedding):
+    def __init__(self, head_size, rotary_dim, max_position, base, is_neox_style, factor: float):
+        self.factor = factor
+        super().__init__(head_size, rotary_dim, int(max_position * factor), base, is_neox_style)
+
+    def _positions(self):
+        return torch.arange(self.max_position, dtype=torch.float32) / self.factor
+
+
+class DynamicNTKScalingRotaryEmbedding(RotaryEmbedding):
+    def __init__(self, head_size, rotary_dim, max_position, base, is_neox_style, factor: float):
+        self.factor = factor
+        self.orig_max = max_position
+        super().__init__(head_size, rotary_dim, int(max_position * factor), base, is_neox_style)
+
+    def _freqs(self):
+        b = self.base * ((self.factor * self.max_position / self.orig_max) - (self.factor - 1)) ** (
+            self.rotary_dim / (self.rotary_dim - 2))
+        return _inv_freq(b, self.rotary_dim)
+
+
+class YaRNScalingRotaryEmbedding(RotaryEmbedding):
+    def __init__(self, head_size, rotary_dim, max_position, base, is_neox_style, factor: float,
+                 extrapolation_factor: float = 1, attn_factor: float = 1, beta_fast: int = 32, beta_slow: int = 1,
+                 mscale: Optional[float] = None):
+        self.factor, self.orig_max = factor, max_position
+        self.extrapolation_factor, self.beta_fast, self.beta_slow = extrapolation_factor, beta_fast, beta_slow
+        self._m = (mscale if mscale is not None else yarn_mscale(factor)) * attn_factor
+        super().__init__(head_size, rotary_dim, int(max_position * factor), base, is_neox_style)
+
+    def _freqs(self):
+        extra = _inv_freq(self.base, self.rotary_dim)
+        inter = extra / self.factor
+        lo, hi = _yarn_range(self.beta_fast, self.beta_slow, self.rotary_dim, self.base, self.orig_max)
+        mask = (1 - _ramp(lo, hi, self.rotary_dim // 2)) * self.extrapolation_factor
+        return inter * (1 - mask) + extra * mask
+
+    def _mscale(self):
+        return self._m
+
+
+class Llama3RotaryEmbedding(RotaryEmbedding):
+    def __init__(self, head_size, rotary_dim, max_position, base, is_neox_style, factor: float,
+                 low_freq_factor: float, high_freq_factor: float, orig_max_position: int):
+        self.factor, self.low, self.high, self.orig_max = factor, low_freq_factor, high_freq_factor, orig_max_position
+        super().__init__(head_size, rotary_dim, max_position, base, is_neox_style)
+
+    def _freqs(self):
+        inv = _inv_freq(self.base, self.rotary_dim)
+        wave = 2 * math.pi / inv
+        smooth = (self.orig_max / wave - self.low) / (self.high - self.low) if self.high != self.low else \
+            torch.zeros_like(inv)
+        low_w, high_w = self.orig_max / self.low, self.orig_max / self.high
+        mid = (1 - smooth) * inv / self.factor + smooth * inv
+        return torch.where(wave < high_w, inv, torch.where(wave > low_w, inv / self.factor, mid))
+
+
+class LongRoPEScaledRotaryEmbedding(RotaryEmbedding):
+    """Phi-3 style: per-dimension rescale factors, a short and a long table stacked
+    (positions >= original_max index the long table by adding an offset)."""
+
+    def __init__(self, head_size, rotary_dim, max_position, orig_max_position, base, is_neox_style,
+                 short_factor: list[float], long_factor: list[float]):
+        self.orig_max, self.short_factor, self.long_factor = orig_max_position, short_factor, long_factor
+        scale = max_position / orig_max_position
+        self._m = 1.0 if scale <= 1.0 else math.sqrt(1 + math.log(scale) / math.log(orig_max_position))
+        self.full_max = max_position
+        super().__init__(head_size, rotary_dim, max_position, base, is_neox_style)
+
+    def _table(self, n: int, factors: list[float]) -> torch.Tensor:
+        inv = 1.0 / (torch.tensor(factors, dtype=torch.float32) * self.base ** (
+            torch.arange(0, self.rotary_dim, 2, dtype=torch.float32) / self.rotary_dim))
+        f = torch.outer(torch.arange(n, dtype=torch.float32), inv)
+        return torch.cat((f.cos() * self._m, f.sin() * self._m), dim=-1)
+
+    def _build(self):
+        return torch.cat((self._table(self.orig_max, self.short_factor),
+                          self._table(self.full_max, self.long_factor)), dim=0)
+
+    def forward(self, positions, q, k=None):
+        # a sequence longer than the original window reads the long table for all of its tokens
+        use_long = bool((positions >= self.orig_max).any()) if positions.numel() else False
+        pos = positions + self.orig_max if use_long else positions
+        ops.rotary_embedding(pos, q, k, self.cos_sin_cache, self.rotary_dim, self.head_size, self.is_neox_style)
+        return q, k
+
+
+_CACHE: dict[Any, RotaryEmbedding] = {}
+
+
+def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is_neox_style: bool = True,
+             rope_scaling: Optional[dict] = None, partial_rotary_factor: float = 1.0) -> RotaryEmbedding:
+    if partial_rotary_factor < 1.0:
+        rotary_dim = int(rotary_dim * partial_rotary_factor)
+    key = (head_size, rotary_dim, max_position, base, is_neox_style,
+           None if rope_scaling is None else tuple(sorted((k, str(v)) for k, v in rope_scaling.items())))
+    if key in _CACHE:
+        return _CACHE[key]
+    kind = None if rope_scaling is None else rope_scaling.get("rope_type", rope_scaling.get("type"))
+    rs = rope_scaling or {}
+    if kind in (None, "default", "mrope"):
+        rope = RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style)
+    elif kind == "llama3":
+        rope = Llama3RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, rs["factor"],
+                                     rs["low_freq_factor"], rs["high_freq_factor"],
+                                     rs["original_max_position_embeddings"])
+    elif kind == "linear":
+        rope = LinearScalingRotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, rs["factor"])
+    elif kind == "dynamic":
+        rope = DynamicNTKScalingRotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style,
+                                                rs["factor"])
+    elif kind == "yarn":
+        orig = rs.get("original_max_position_embeddings", max_position)
+        extra = {k: rs[k] for k in ("extrapolation_factor", "attn_factor", "beta_fast", "beta_slow") if k in rs}
+        rope = YaRNScalingRotaryEmbedding(head_size, rotary_dim, orig, base, is_neox_style, rs["factor"], **extra)
+    elif kind in ("longrope", "su"):
+        rope = LongRoPEScaledRotaryEmbedding(head_size, rotary_dim, max_position,
+                                             rs["original_max_position_embeddings"], base, is_neox_style,
+                                             rs["short_factor"], rs["long_factor"])
+    else:
+        raise ValueError(f"unsupported rope scaling type {kind!r}")
+    _CACHE[key] = rope
+    return rope

@@ -1,0 +1,212 @@
+"""Llama-family decoder (Llama 2/3, Mistral, Qwen2, Qwen3 dense): pre-norm
+blocks, GQA attention with RoPE, gated SiLU MLP.
+
+Per layer the GPU executes: fused residual-add+RMSNorm -> QKV GEMM -> fused
+RoPE + KV-cache write -> paged attention -> O GEMM (+TP all-reduce) -> fused
+residual-add+RMSNorm -> gate/up GEMM -> SiLU*mul -> down GEMM (+TP all-reduce).
+
+Reference: vllm/model_executor/models/llama.py (MLP :60, attention :100-271,
+decoder layer :274, model :331-483, weight mapping :485-549, causal LM :552-693)
+including the fork's token-parallel variants (:85-127,179-195,256-271).
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from ..config import VllmConfig
+from ..layers.attention import Attention
+from ..layers.basic import LogitsProcessor, ParallelLMHead, RMSNorm, SiluAndMul, VocabParallelEmbedding
+from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+from ..layers.rotary import get_rope
+from ..parallel.state import get_pp_group, get_tensor_model_parallel_world_size
+from .utils import (IntermediateTensors, PPMissingLayer, load_weights_with_mapping, make_layers, maybe_prefix)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, hidden_size: int, intermediate_size: int, bias: bool = False, quant_config=None,
+                 prefix: str = "", reduce_results: bool = True):
+        super().__init__()
+        self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, bias=bias,
+                                                       quant_config=quant_config, prefix=f"{prefix}.gate_up_proj")
+        self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=bias, quant_config=quant_config,
+                                           reduce_results=reduce_results, prefix=f"{prefix}.down_proj")
+        self.act_fn = SiluAndMul()
+
+    def forward(self, x):
+        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, config, hidden_size: int, num_heads: int, num_kv_heads: int, rope_theta: float,
+                 rope_scaling: Optional[dict], max_position: int, bias: bool = False, o_bias: bool = False,
+                 sliding_window: Optional[int] = None, quant_config=None, prefix: str = "", qk_norm: bool = False,
+                 cache_dtype: str = "auto"):
+        super().__init__()
+        tp = get_tensor_model_parallel_world_size()
+        self.total_num_heads, self.total_num_kv_heads = num_heads, num_kv_heads
+        self.num_heads = num_heads // tp
+        self.num_kv_heads = max(1, num_kv_heads // tp)
+        self.head_dim = getattr(config, "head_dim", None) or hidden_size // num_heads
+        self.q_size, self.kv_size = self.num_heads * self.head_dim, self.num_kv_heads * self.head_dim
+        self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=bias,
+                                          quant_config=quant_config, prefix=f"{prefix}.qkv_proj")
+        self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=o_bias,
+                                        quant_config=quant_config, prefix=f"{prefix}.o_proj")
+        partial = getattr(config, "partial_rotary_factor", 1.0) or 1.0
+        self.rotary_emb = get_rope(self.head_dim, self.head_dim, max_position, rope_theta, True, rope_scaling,
+                                   partial)
+        self.attn = Attention(self.num_heads, self.head_dim, self.head_dim ** -0.5, self.num_kv_heads,
+                              sliding_window=sliding_window, prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
+        self.qk_norm = qk_norm
+        if qk_norm:
+            eps = getattr(config, "rms_norm_eps", 1e-6)
+            self.q_norm = RMSNorm(self.head_dim, eps)
+            self.k_norm = RMSNorm(self.head_dim, eps)
+
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
+        qkv = self.qkv_proj(hidden_states)
+        if self.qk_norm:
+            T = qkv.shape[0]
+            q = qkv[:, : self.q_size].reshape(T * self.num_heads, self.head_dim)
+            k = qkv[:, self.q_size: self.q_size + self.kv_size].reshape(T * self.num_kv_heads, self.head_dim)
+            qkv[:, : self.q_size] = self.q_norm(q).view(T, self.q_size)
+            qkv[:, self.q_size: self.q_size + self.kv_size] = self.k_norm(k).view(T, self.kv_size)
+        return self.o_proj(self.attn(qkv, positions, self.rotary_emb))
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, config, vllm_config: VllmConfig, quant_config=None, prefix: str = ""):
+        super().__init__()
+        mc = vllm_config.model_config
+        rope_scaling = getattr(config, "rope_scaling", None) or getattr(config, "rope_parameters", None)
+        if rope_scaling and "rope_type" not in rope_scaling and "type" not in rope_scaling:
+            rope_scaling = None
+        bias = bool(getattr(config, "attention_bias", False) or getattr(config, "bias", False))
+        arch = (mc.architectures or [""])[0]
+        if arch.startswith("Qwen2"):
+            bias = True
+        window = mc.get_sliding_window()
+        layer_idx = int(prefix.split(".")[-1])
+        if window is not None and getattr(config, "max_window_layers", None) is not None \
+                and arch.startswith("Qwen") and layer_idx < config.max_window_layers:
+            window = None
+        self.self_attn = LlamaAttention(
+            config, config.hidden_size, config.num_attention_heads,
+            getattr(config, "num_key_value_heads", None) or config.num_attention_heads,
+            getattr(config, "rope_theta", 10000.0), rope_scaling, mc.max_model_len, bias=bias, o_bias=False
+            if arch.startswith("Qwen") else bias, sliding_window=window, quant_config=quant_config,
+            prefix=f"{prefix}.self_attn", qk_norm=arch.startswith("Qwen3"),
+            cache_dtype=vllm_config.cache_config.cache_dtype)
+        self.mlp = self._make_mlp(config, vllm_config, quant_config, f"{prefix}.mlp")
+        eps = getattr(config, "rms_norm_eps", 1e-6)
+        self.input_layernorm = RMSNorm(config.hidden_size, eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps)
+
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        return LlamaMLP(config.hidden_size, config.intermediate_size, bool(getattr(config, "mlp_bias", False)),
+                        quant_config, prefix)
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class LlamaModel(nn.Module):
+    layer_cls = LlamaDecoderLayer
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__()
+        config = vllm_config.model_config.hf_config
+        quant_config = getattr(vllm_config, "quant_config", None)
+        self.config = config
+        pp = get_pp_group()
+        if pp.is_first_rank or (getattr(config, "tie_word_embeddings", False) and pp.is_last_rank):
+            self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size,
+                                                       prefix=f"{prefix}.embed_tokens")
+        else:
+            self.embed_tokens = PPMissingLayer()
+        self.start_layer, self.end_layer, self.layers = make_layers(
+            config.num_hidden_layers,
+            lambda p: self.layer_cls(config, vllm_config, quant_config, p), f"{prefix}.layers")
+        self.norm = RMSNorm(config.hidden_size, getattr(config, "rms_norm_eps", 1e-6)) if pp.is_last_rank \
+            else PPMissingLayer()
+
+    def get_input_embeddings(self, input_ids):
+        return self.embed_tokens(input_ids)
+
+    def forward(self, input_ids, positions, intermediate_tensors: Optional[IntermediateTensors] = None,
+                inputs_embeds: Optional[torch.Tensor] = None):
+        pp = get_pp_group()
+        if pp.is_first_rank:
+            hidden = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
+            residual = None
+        else:
+            hidden, residual = intermediate_tensors["hidden_states"], intermediate_tensors["residual"]
+        for layer in self.layers[self.start_layer:self.end_layer]:
+            hidden, residual = layer(positions, hidden, residual)
+        if not pp.is_last_rank:
+            return IntermediateTensors({"hidden_states": hidden, "residual": residual})
+        hidden, _ = self.norm(hidden, residual)
+        return hidden
+
+
+class LlamaForCausalLM(nn.Module):
+    model_cls = LlamaModel
+    stacked_params_mapping = [
+        (".qkv_proj", ".q_proj", "q"), (".qkv_proj", ".k_proj", "k"), (".qkv_proj", ".v_proj", "v"),
+        (".gate_up_proj", ".gate_proj", 0), (".gate_up_proj", ".up_proj", 1),
+    ]
+    packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"], "gate_up_proj": ["gate_proj", "up_proj"]}
+    supports_lora = True
+    supports_pp = True
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__()
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        self.model = self.model_cls(vllm_config, prefix=maybe_prefix(prefix, "model"))
+        pp = get_pp_group()
+        self.tie = bool(getattr(config, "tie_word_embeddings", False))
+        if pp.is_last_rank:
+            self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size,
+                                          prefix=maybe_prefix(prefix, "lm_head"))
+            if self.tie:
+                self.lm_head.tie_weights(self.model.embed_tokens)
+            self.logits_processor = LogitsProcessor(config.vocab_size, config.vocab_size,
+                                                    getattr(config, "logit_scale", 1.0))
+        else:
+            self.lm_head = PPMissingLayer()
+
+    def get_input_embeddings(self, input_ids):
+        return self.model.get_input_embeddings(input_ids)
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None):
+        return self.model(input_ids, positions, intermediate_tensors, inputs_embeds)
+
+    def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        return self.logits_processor(self.lm_head, hidden_states)
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
+        return load_weights_with_mapping(self, weights, self.stacked_params_mapping, tie_lm_head=self.tie)
+
+
+class MistralForCausalLM(LlamaForCausalLM):
+    pass
+
+
+class Qwen2ForCausalLM(LlamaForCausalLM):
+    pass
+
+
+class Qwen3ForCausalLM(LlamaForCausalLM):
+    pass

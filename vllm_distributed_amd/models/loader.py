@@ -1,0 +1,222 @@
+"""Checkpoint loading: HF safetensors / .bin / .pt directories, dummy (random)
+weights, and per-rank sharded-state save/load.
+
+Reference: vllm/model_executor/model_loader/default_loader.py:30-283 (iterator
+over checkpoint files, index de-duplication, strict all-weights-loaded check),
+dummy_loader.py, sharded_state_loader.py, weight_utils.py.
+"""
+from __future__ import annotations
+
+import contextlib
+import fnmatch
+import glob
+import json
+import os
+import time
+from typing import Iterable, Iterator, Optional
+
+import torch
+import torch.nn as nn
+
+from ..config import VllmConfig, set_current_vllm_config
+from ..logger import init_logger
+from .registry import ModelRegistry
+
+logger = init_logger(__name__)
+
+
+@contextlib.contextmanager
+def set_default_torch_dtype(dtype: torch.dtype):
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        yield
+    finally:
+        torch.set_default_dtype(old)
+
+
+def _quant_config(vllm_config: VllmConfig):
+    q = vllm_config.model_config.quantization
+    if q is None:
+        return None
+    from ..layers.quant import get_quant_config
+    return get_quant_config(vllm_config)
+
+
+def initialize_model(vllm_config: VllmConfig, prefix: str = "") -> nn.Module:
+    cls, arch = ModelRegistry.resolve_model_cls(vllm_config.model_config.architectures)
+    vllm_config.quant_config = _quant_config(vllm_config)
+    with set_current_vllm_config(vllm_config):
+        return cls(vllm_config=vllm_config, prefix=prefix)
+
+
+# ---- weight iterators ---------------------------------------------------------
+def _filter_by_index(files: list[str], folder: str, index_name: str) -> list[str]:
+    idx = os.path.join(folder, index_name)
+    if not os.path.isfile(idx):
+        return files
+    with open(idx) as f:
+        wm = json.load(f).get("weight_map", {})
+    keep = {os.path.join(folder, v) for v in wm.values()}
+    return [f for f in files if f in keep] or files
+
+
+def find_weight_files(folder: str, load_format: str, ignore_patterns: Optional[list[str]] = None) -> tuple[list[str], bool]:
+    if not os.path.isdir(folder):
+        raise FileNotFoundError(f"{folder} is not a checkpoint directory (no hub access on this machine); "
+                                "use load_format='dummy' for random weights")
+    patterns = {"auto": ["*.safetensors", "*.bin", "*.pt"], "safetensors": ["*.safetensors"],
+                "pt": ["*.pt", "*.bin"], "bin": ["*.bin"], "npcache": ["*.bin"]}[load_format]
+    for pat in patterns:
+        files = sorted(glob.glob(os.path.join(folder, pat)))
+        files = [f for f in files if not any(fnmatch.fnmatch(os.path.relpath(f, folder), ip)
+                                             for ip in (ignore_patterns or []))]
+        files = [f for f in files if os.path.basename(f) not in ("training_args.bin", "optimizer.bin",
+                                                                 "optimizer.pt", "scheduler.pt", "scaler.pt")]
+        if files:
+            st = pat == "*.safetensors"
+            if st:
+                files = _filter_by_index(files, folder, "model.safetensors.index.json")
+            else:
+                files = _filter_by_index(files, folder, "pytorch_model.bin.index.json")
+            return files, st
+    raise FileNotFoundError(f"no weight files matching {patterns} in {folder}")
+
+
+def safetensors_iterator(files: list[str]) -> Iterator[tuple[str, torch.Tensor]]:
+    from safetensors import safe_open
+    for path in files:
+        with safe_open(path, framework="pt", device="cpu") as f:
+            for name in f.keys():
+                yield name, f.get_tensor(name)
+
+
+def pt_iterator(files: list[str]) -> Iterator[tuple[str, torch.Tensor]]:
+    for path in files:
+        state = torch.load(path, map_location="cpu", weights_only=True)
+        if "state_dict" in state and isinstance(state["state_dict"], dict):
+            state = state["state_dict"]
+        yield from state.items()
+        del state
+
+
+def initialize_dummy_weights(model: nn.Module, low: float = -1e-3, high: float = 1e-3, seed: int = 1234) -> None:
+    """Small uniform random weights, generated on the parameter's device so that
+    a 70B model is filled in seconds; norm weights become ~1 so activations stay finite."""
+    for i, (name, p) in enumerate(model.state_dict().items()):
+        if not torch.is_floating_point(p):
+            continue
+        g = torch.Generator(device=p.device)
+        g.manual_seed(seed + i)
+        if p.dtype.itemsize < 2:       # fp8: fill through a wider dtype
+            tmp = torch.empty(p.shape, dtype=torch.float16, device=p.device).uniform_(low, high, generator=g)
+            p.copy_(tmp.to(p.dtype))
+        elif name.endswith("norm.weight") or "layernorm.weight" in name or name.endswith("ln_f.weight"):
+            p.uniform_(1 - 1e-3, 1 + 1e-3, generator=g)
+        elif "scale" in name.rsplit(".", 1)[-1]:
+            p.fill_(1.0)
+        else:
+            p.uniform_(low, high, generator=g)
+
+
+# ---- loaders ----------------------------------------------------------------------
+class BaseModelLoader:
+    def __init__(self, load_config):
+        self.load_config = load_config
+
+    def load_weights(self, model: nn.Module, vllm_config: VllmConfig) -> None:
+        raise NotImplementedError
+
+    def load_model(self, vllm_config: VllmConfig, device: Optional[torch.device] = None) -> nn.Module:
+        mc = vllm_config.model_config
+        device = device or torch.device(vllm_config.device_config.device)
+        t0 = time.time()
+        with set_default_torch_dtype(mc.dtype), device:
+            model = initialize_model(vllm_config)
+        self.load_weights(model, vllm_config)
+        for m in model.modules():
+            qm = getattr(m, "quant_method", None)
+            if qm is not None and hasattr(qm, "process_weights_after_loading"):
+                qm.process_weights_after_loading(m)
+        logger.info("model %s ready in %.1f s (%s)", mc.model, time.time() - t0, type(self).__name__)
+        return model.eval()
+
+
+class DefaultModelLoader(BaseModelLoader):
+    def get_all_weights(self, vllm_config: VllmConfig) -> Iterable[tuple[str, torch.Tensor]]:
+        folder = vllm_config.model_config.model
+        files, is_st = find_weight_files(folder, self.load_config.load_format, self.load_config.ignore_patterns)
+        return safetensors_iterator(files) if is_st else pt_iterator(files)
+
+    def load_weights(self, model: nn.Module, vllm_config: VllmConfig) -> None:
+        loaded = model.load_weights(self.get_all_weights(vllm_config))
+        if loaded is not None and vllm_config.model_config.quantization is None:
+            # strict: every parameter must have come from the checkpoint
+            missing = {n for n, _ in model.named_parameters()} - set(loaded)
+            if missing:
+                raise ValueError(f"these parameters were not initialised from the checkpoint: {sorted(missing)[:8]}"
+                                 f"{' ...' if len(missing) > 8 else ''}")
+
+
+class DummyModelLoader(BaseModelLoader):
+    def load_weights(self, model, vllm_config):
+        initialize_dummy_weights(model, seed=1234 + vllm_config.model_config.seed)
+
+
+class ShardedStateLoader(BaseModelLoader):
+    """Each rank reads back exactly the tensors it wrote with :meth:`save_model`
+    (already TP-sharded and post-processed): no re-slicing at load time."""
+    PATTERN = "model-rank-{rank}-part-{part}.safetensors"
+
+    def load_weights(self, model, vllm_config):
+        from safetensors.torch import load_file
+        from ..parallel.state import get_world_group
+        rank = get_world_group().rank
+        pat = (self.load_config.model_loader_extra_config or {}).get("pattern", self.PATTERN)
+        files = sorted(glob.glob(os.path.join(vllm_config.model_config.model, pat.format(rank=rank, part="*"))))
+        if not files:
+            raise FileNotFoundError(f"no sharded-state files for rank {rank} in {vllm_config.model_config.model}")
+        state = model.state_dict()
+        for f in files:
+            for k, t in load_file(f).items():
+                if k not in state:
+                    raise KeyError(f"unexpected tensor {k} in {f}")
+                state[k].copy_(t)
+                state.pop(k)
+        if state:
+            raise ValueError(f"tensors missing from the sharded checkpoint: {sorted(state)[:8]}")
+
+    @staticmethod
+    def save_model(model: nn.Module, path: str, pattern: Optional[str] = None, max_size: Optional[int] = None) -> None:
+        from safetensors.torch import save_file
+        from ..parallel.state import get_world_group
+        rank = get_world_group().rank
+        pattern = pattern or ShardedStateLoader.PATTERN
+        os.makedirs(path, exist_ok=True)
+        part, size, cur = 0, 0, {}
+        seen_ptrs = set()
+        for k, t in model.state_dict().items():
+            if t.data_ptr() in seen_ptrs:      # tied weights are stored once
+                continue
+            seen_ptrs.add(t.data_ptr())
+            n = t.numel() * t.element_size()
+            if max_size is not None and size + n > max_size and cur:
+                save_file(cur, os.path.join(path, pattern.format(rank=rank, part=part)))
+                part, size, cur = part + 1, 0, {}
+            cur[k] = t.detach().cpu().contiguous()
+            size += n
+        if cur:
+            save_file(cur, os.path.join(path, pattern.format(rank=rank, part=part)))
+
+
+def get_model_loader(load_config) -> BaseModelLoader:
+    fmt = load_config.load_format
+    if fmt == "dummy":
+        return DummyModelLoader(load_config)
+    if fmt == "sharded_state":
+        return ShardedStateLoader(load_config)
+    return DefaultModelLoader(load_config)
+
+
+def get_model(vllm_config: VllmConfig, device=None) -> nn.Module:
+    return get_model_loader(vllm_config.load_config).load_model(vllm_config, device)

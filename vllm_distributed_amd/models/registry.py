@@ -1,0 +1,58 @@
+"""Architecture name -> model class (reference: vllm/model_executor/models/registry.py).
+Classes are imported lazily; plugins may add entries with ``ModelRegistry.register_model``."""
+from __future__ import annotations
+
+import importlib
+from typing import Type, Union
+
+_MODELS: dict[str, tuple[str, str]] = {
+    "LlamaForCausalLM": ("llama", "LlamaForCausalLM"),
+    "LLaMAForCausalLM": ("llama", "LlamaForCausalLM"),
+    "MistralForCausalLM": ("llama", "MistralForCausalLM"),
+    "Qwen2ForCausalLM": ("llama", "Qwen2ForCausalLM"),
+    "Qwen3ForCausalLM": ("llama", "Qwen3ForCausalLM"),
+    "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
+    "Qwen2MoeForCausalLM": ("mixtral", "Qwen2MoeForCausalLM"),
+    "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
+    "OPTForCausalLM": ("opt", "OPTForCausalLM"),
+    "GPT2LMHeadModel": ("opt", "GPT2LMHeadModel"),
+    "LlamaModel": ("pooling", "LlamaEmbeddingModel"),
+    "LlamaForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
+    "Qwen2ForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
+    "EagleLlamaForCausalLM": ("eagle", "EagleLlamaForCausalLM"),
+    "LlamaForCausalLMEagle": ("eagle", "EagleLlamaForCausalLM"),
+    "MedusaModel": ("eagle", "MedusaModel"),
+}
+_CUSTOM: dict[str, Union[str, type]] = {}
+
+
+class _Registry:
+    def get_supported_archs(self) -> list[str]:
+        return sorted(set(_MODELS) | set(_CUSTOM))
+
+    def register_model(self, arch: str, model_cls: Union[str, type]) -> None:
+        """``model_cls`` is a class or a ``"module.path:ClassName"`` string."""
+        _CUSTOM[arch] = model_cls
+
+    def is_supported(self, arch: str) -> bool:
+        return arch in _MODELS or arch in _CUSTOM
+
+    def resolve_model_cls(self, architectures: list[str]) -> tuple[Type, str]:
+        for arch in architectures:
+            if arch in _CUSTOM:
+                c = _CUSTOM[arch]
+                if isinstance(c, str):
+                    mod, name = c.split(":")
+                    c = getattr(importlib.import_module(mod), name)
+                return c, arch
+            if arch in _MODELS:
+                mod, name = _MODELS[arch]
+                return getattr(importlib.import_module(f"{__package__}.{mod}"), name), arch
+        raise ValueError(f"model architectures {architectures} are not supported; "
+                         f"supported: {self.get_supported_archs()}")
+
+    def is_text_generation_model(self, architectures) -> bool:
+        return any("CausalLM" in a or "LMHead" in a for a in architectures)
+
+
+ModelRegistry = _Registry()

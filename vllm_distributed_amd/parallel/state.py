@@ -1,0 +1,516 @@
+"""Process groups and the rank mesh.
+
+Rank grid (outermost to innermost): ``[external DP, DP | TKNP, PP, TP]``; TP is
+the innermost, contiguous axis so that a TP group sits on xGMI-adjacent GPUs of
+one node.  EP is the DP(or TKNP) x TP plane flattened.
+Reference: vllm/distributed/parallel_state.py (GroupCoordinator :176-803, mesh
+:1107-1203, tensor-dict transport :629-749).
+
+Each :class:`GroupCoordinator` owns a device process group (RCCL through
+``torch.distributed`` backend "nccl") and a Gloo CPU group, plus an optional
+peer-memory communicator (parallel/custom_allreduce.py) that takes small and
+medium all-reduces off RCCL: on the fully connected xGMI mesh a direct
+one-shot/two-shot exchange uses all seven links at once where a ring uses one.
+
+With world size 1 nothing from ``torch.distributed`` is initialised: the groups
+are trivial and every collective is the identity.
+"""
+from __future__ import annotations
+
+import contextlib
+import pickle
+from dataclasses import dataclass
+from typing import Any, Optional, Sequence, Union
+
+import torch
+import torch.distributed as dist
+
+from .. import envs
+from ..logger import init_logger
+
+logger = init_logger(__name__)
+
+
+@dataclass
+class GraphCaptureContext:
+    stream: Any
+
+
+class GroupCoordinator:
+    def __init__(self, ranks: Sequence[int], rank: int, local_rank: int, backend: str, name: str,
+                 use_device_comm: bool = False, use_message_queue: bool = False):
+        self.name = name
+        self.ranks = list(ranks)
+        self.world_size = len(self.ranks)
+        self.rank = rank                         # global rank
+        self.local_rank = local_rank
+        self.rank_in_group = self.ranks.index(rank) if rank in self.ranks else 0
+        self.device_group = None
+        self.cpu_group = None
+        self.backend = backend
+        self.device = torch.device(f"cuda:{local_rank}") if backend == "nccl" else torch.device("cpu")
+        self.ca_comm = None       # peer-memory all-reduce
+        self.rccl_comm = None     # stream-explicit RCCL (graph capturable)
+        self.mq_broadcaster = None
+        self.all2all = None
+        self._use_device_comm = use_device_comm and backend == "nccl"
+        self._use_mq = use_message_queue
+
+    def _attach(self, device_group, cpu_group) -> None:
+        self.device_group, self.cpu_group = device_group, cpu_group
+        if self.world_size > 1 and self._use_device_comm:
+            self._init_device_comms()
+        if self.world_size > 1 and self._use_mq:
+            from .shm_ring import MessageQueue
+            self.mq_broadcaster = MessageQueue.create_from_process_group(self.cpu_group, 1 << 22, 6)
+
+    def _init_device_comms(self) -> None:
+        from ..platforms import current_platform
+        try:
+            from .rccl import RcclCommunicator
+            self.rccl_comm = RcclCommunicator(self.cpu_group, self.device)
+        except Exception as e:   # library missing or init failure: torch.distributed still works
+            logger.warning("stream-explicit RCCL communicator unavailable for group %s: %s", self.name, e)
+            self.rccl_comm = None
+        if "tp" in self.name and not envs.VLLM_DISABLE_CUSTOM_ALL_REDUCE \
+                and current_platform.use_custom_allreduce():
+            try:
+                from .custom_allreduce import CustomAllReduce
+                self.ca_comm = CustomAllReduce.maybe_create(self.cpu_group, self.device)
+            except Exception as e:
+                logger.warning("peer-memory all-reduce disabled for group %s: %s", self.name, e)
+                self.ca_comm = None
+
+    # ---- properties --------------------------------------------------------
+    @property
+    def first_rank(self) -> int:
+        return self.ranks[0]
+
+    @property
+    def last_rank(self) -> int:
+        return self.ranks[-1]
+
+    @property
+    def is_first_rank(self) -> bool:
+        return self.rank == self.first_rank
+
+    @property
+    def is_last_rank(self) -> bool:
+        return self.rank == self.last_rank
+
+    @property
+    def next_rank(self) -> int:
+        return self.ranks[(self.rank_in_group + 1) % self.world_size]
+
+    @property
+    def prev_rank(self) -> int:
+        return self.ranks[(self.rank_in_group - 1) % self.world_size]
+
+    # ---- collectives -------------------------------------------------------
+    def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        """Out of place for the peer-memory path, in place otherwise; always use the return value."""
+        if self.world_size == 1:
+            return x
+        if x.is_cuda:
+            if self.ca_comm is not None:
+                out = self.ca_comm.all_reduce(x)
+                if out is not None:
+                    return out
+            if self.rccl_comm is not None:
+                return self.rccl_comm.all_reduce(x)
+        dist.all_reduce(x, group=self.device_group if x.is_cuda else self.cpu_group)
+        return x
+
+    def all_gather(self, x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+        if self.world_size == 1:
+            return x
+        if dim < 0:
+            dim += x.dim()
+        x = x.contiguous()
+        out = torch.empty((self.world_size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        if x.is_cuda and self.rccl_comm is not None:
+            self.rccl_comm.all_gather(out, x)
+        else:
+            dist.all_gather_into_tensor(out, x, group=self.device_group if x.is_cuda else self.cpu_group)
+        if dim == 0:
+            return out.reshape((self.world_size * x.shape[0],) + tuple(x.shape[1:]))
+        out = out.movedim(0, dim)
+        return out.reshape(tuple(x.shape[:dim]) + (self.world_size * x.shape[dim],) + tuple(x.shape[dim + 1:]))
+
+    def reduce_scatter(self, x: torch.Tensor, dim: int = 0) -> torch.Tensor:
+        if self.world_size == 1:
+            return x
+        if dim < 0:
+            dim += x.dim()
+        xt = x.movedim(dim, 0).contiguous()
+        assert xt.shape[0] % self.world_size == 0
+        out = torch.empty((xt.shape[0] // self.world_size,) + tuple(xt.shape[1:]), dtype=x.dtype, device=x.device)
+        if x.is_cuda and self.rccl_comm is not None:
+            self.rccl_comm.reduce_scatter(out, xt)
+        else:
+            dist.reduce_scatter_tensor(out, xt, group=self.device_group if x.is_cuda else self.cpu_group)
+        return out.movedim(0, dim)
+
+    def gather(self, x: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Tensor]:
+        """Concatenate along ``dim`` on group rank ``dst``; None elsewhere."""
+        if self.world_size == 1:
+            return x
+        if dim < 0:
+            dim += x.dim()
+        x = x.contiguous()
+        lst = [torch.empty_like(x) for _ in range(self.world_size)] if self.rank_in_group == dst else None
+        dist.gather(x, lst, dst=self.ranks[dst], group=self.device_group if x.is_cuda else self.cpu_group)
+        return torch.cat(lst, dim=dim) if lst is not None else None
+
+    def broadcast(self, x: torch.Tensor, src: int = 0) -> torch.Tensor:
+        if self.world_size == 1:
+            return x
+        dist.broadcast(x, src=self.ranks[src], group=self.device_group if x.is_cuda else self.cpu_group)
+        return x
+
+    def all_to_all_single(self, out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None) -> torch.Tensor:
+        if self.world_size == 1:
+            out.copy_(inp)
+            return out
+        dist.all_to_all_single(out, inp, out_splits, in_splits,
+                               group=self.device_group if inp.is_cuda else self.cpu_group)
+        return out
+
+    def broadcast_object(self, obj: Any = None, src: int = 0) -> Any:
+        if self.world_size == 1:
+            return obj
+        if self.mq_broadcaster is not None and src == 0:
+            return self.mq_broadcaster.broadcast_object(obj)
+        box = [obj]
+        dist.broadcast_object_list(box, src=self.ranks[src], group=self.cpu_group)
+        return box[0]
+
+    def all_gather_object(self, obj: Any) -> list:
+        if self.world_size == 1:
+            return [obj]
+        out = [None] * self.world_size
+        dist.all_gather_object(out, obj, group=self.cpu_group)
+        return out
+
+    def send_object(self, obj: Any, dst: int) -> None:
+        data = torch.frombuffer(bytearray(pickle.dumps(obj)), dtype=torch.uint8)
+        size = torch.tensor([data.numel()], dtype=torch.long)
+        dist.send(size, dst=self.ranks[dst], group=self.cpu_group)
+        dist.send(data, dst=self.ranks[dst], group=self.cpu_group)
+
+    def recv_object(self, src: int) -> Any:
+        size = torch.empty(1, dtype=torch.long)
+        dist.recv(size, src=self.ranks[src], group=self.cpu_group)
+        data = torch.empty(int(size.item()), dtype=torch.uint8)
+        dist.recv(data, src=self.ranks[src], group=self.cpu_group)
+        return pickle.loads(data.numpy().tobytes())
+
+    def send(self, x: torch.Tensor, dst: Optional[int] = None) -> None:
+        dst = (self.rank_in_group + 1) % self.world_size if dst is None else dst
+        if x.is_cuda and self.rccl_comm is not None:
+            self.rccl_comm.send(x, dst)
+        else:
+            dist.send(x, self.ranks[dst], group=self.device_group if x.is_cuda else self.cpu_group)
+
+    def recv(self, size, dtype: torch.dtype, src: Optional[int] = None, device=None) -> torch.Tensor:
+        src = (self.rank_in_group - 1) % self.world_size if src is None else src
+        x = torch.empty(size, dtype=dtype, device=device or self.device)
+        if x.is_cuda and self.rccl_comm is not None:
+            self.rccl_comm.recv(x, src)
+        else:
+            dist.recv(x, self.ranks[src], group=self.device_group if x.is_cuda else self.cpu_group)
+        return x
+
+    # ---- tensor dicts ----------------------------------------------------------
+    @staticmethod
+    def _split_dict(d: dict) -> tuple[list, list[torch.Tensor]]:
+        meta, tensors = [], []
+        for k, v in d.items():
+            if isinstance(v, torch.Tensor):
+                meta.append((k, ("T", v.device.type, v.dtype, tuple(v.shape))))
+                tensors.append(v)
+            else:
+                meta.append((k, ("O", v)))
+        return meta, tensors
+
+    def broadcast_tensor_dict(self, d: Optional[dict] = None, src: int = 0) -> Optional[dict]:
+        if self.world_size == 1:
+            return d
+        if self.rank_in_group == src:
+            meta, tensors = self._split_dict(d)
+            self.broadcast_object(meta, src)
+            for t in tensors:
+                if t.numel():
+                    self.broadcast(t, src)
+            return d
+        meta = self.broadcast_object(None, src)
+        out = {}
+        for k, m in meta:
+            if m[0] == "T":
+                _, devt, dtype, shape = m
+                t = torch.empty(shape, dtype=dtype, device=self.device if devt == "cuda" else "cpu")
+                if t.numel():
+                    self.broadcast(t, src)
+                out[k] = t
+            else:
+                out[k] = m[1]
+        return out
+
+    def send_tensor_dict(self, d: dict, dst: Optional[int] = None, all_gather_group: "GroupCoordinator" = None) -> None:
+        """Metadata over Gloo, payload over the device link.  With ``all_gather_group``
+        (the TP group) each rank ships only its 1/TP slice and the receiver
+        all-gathers, so a PP hop costs M/TP per xGMI link instead of M."""
+        if self.world_size == 1:
+            return
+        dst = (self.rank_in_group + 1) % self.world_size if dst is None else dst
+        ag = all_gather_group
+        n, r = (ag.world_size, ag.rank_in_group) if ag is not None else (1, 0)
+        meta, tensors = self._split_dict(d)
+        self.send_object(meta, dst)
+        for t in tensors:
+            if not t.numel():
+                continue
+            if n > 1 and t.numel() % n == 0:
+                t = t.reshape(n, -1)[r]
+            self.send(t.contiguous(), dst)
+
+    def recv_tensor_dict(self, src: Optional[int] = None, all_gather_group: "GroupCoordinator" = None) -> Optional[dict]:
+        if self.world_size == 1:
+            return None
+        src = (self.rank_in_group - 1) % self.world_size if src is None else src
+        ag = all_gather_group
+        n = ag.world_size if ag is not None else 1
+        meta = self.recv_object(src)
+        out = {}
+        for k, m in meta:
+            if m[0] != "T":
+                out[k] = m[1]
+                continue
+            _, devt, dtype, shape = m
+            dev = self.device if devt == "cuda" else torch.device("cpu")
+            numel = 1
+            for s in shape:
+                numel *= s
+            if numel == 0:
+                out[k] = torch.empty(shape, dtype=dtype, device=dev)
+            elif n > 1 and numel % n == 0:
+                part = self.recv((numel // n,), dtype, src, dev)
+                out[k] = ag.all_gather(part, dim=0).reshape(shape)
+            else:
+                out[k] = self.recv(shape, dtype, src, dev)
+        return out
+
+    def barrier(self) -> None:
+        if self.world_size > 1:
+            dist.barrier(group=self.cpu_group)
+
+    @contextlib.contextmanager
+    def graph_capture(self, ctx: Optional[GraphCaptureContext] = None):
+        """Collectives issued inside are recorded into the hipGraph being captured."""
+        if ctx is None:
+            ctx = GraphCaptureContext(torch.cuda.Stream())
+        cm = self.ca_comm.capture() if self.ca_comm is not None else contextlib.nullcontext()
+        with cm:
+            yield ctx
+
+    def destroy(self) -> None:
+        if self.ca_comm is not None:
+            self.ca_comm.close()
+            self.ca_comm = None
+        if self.rccl_comm is not None:
+            self.rccl_comm.close()
+            self.rccl_comm = None
+        if self.mq_broadcaster is not None:
+            self.mq_broadcaster = None
+        for g in (self.device_group, self.cpu_group):
+            if g is not None:
+                try:
+                    dist.destroy_process_group(g)
+                except Exception:
+                    pass
+        self.device_group = self.cpu_group = None
+
+
+# ---------------------------------------------------------------------------
+_WORLD: Optional[GroupCoordinator] = None
+_TP: Optional[GroupCoordinator] = None
+_PP: Optional[GroupCoordinator] = None
+_DP: Optional[GroupCoordinator] = None
+_EP: Optional[GroupCoordinator] = None
+_TKNP: Optional[GroupCoordinator] = None
+_BACKEND = "gloo"
+_LOCAL_RANK = 0
+
+
+def _trivial(name: str) -> GroupCoordinator:
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    return GroupCoordinator([rank], rank, _LOCAL_RANK, _BACKEND, name)
+
+
+def init_distributed_environment(world_size: int = 1, rank: int = 0, distributed_init_method: str = "env://",
+                                 local_rank: int = 0, backend: str = "nccl") -> None:
+    global _WORLD, _BACKEND, _LOCAL_RANK
+    _BACKEND, _LOCAL_RANK = backend, local_rank
+    if world_size > 1 and not dist.is_initialized():
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device(f"cuda:{local_rank}")
+        dist.init_process_group(backend=backend, init_method=distributed_init_method, world_size=world_size,
+                                rank=rank, **kw)
+    if _WORLD is None:
+        if world_size > 1:
+            ranks = list(range(dist.get_world_size()))
+            _WORLD = _new_group([ranks], rank, local_rank, backend, "world")
+        else:
+            _WORLD = _trivial("world")
+
+
+def _new_group(all_ranks: list[list[int]], rank: int, local_rank: int, backend: str, name: str,
+               use_device_comm: bool = False, use_message_queue: bool = False) -> GroupCoordinator:
+    """Every process must create every subgroup (torch.distributed rule); keep ours."""
+    mine = None
+    for ranks in all_ranks:
+        dg = dist.new_group(ranks, backend=backend)
+        cg = dist.new_group(ranks, backend="gloo")
+        if rank in ranks:
+            mine = GroupCoordinator(ranks, rank, local_rank, backend, name, use_device_comm, use_message_queue)
+            mine._attach(dg, cg)
+    assert mine is not None, f"rank {rank} is in no {name} group"
+    return mine
+
+
+def build_mesh(world_size: int, tp: int, pp: int, mid: int) -> torch.Tensor:
+    """Rank grid [ext_dp, mid (DP or TKNP), pp, tp]."""
+    assert world_size % (tp * pp * mid) == 0, (world_size, tp, pp, mid)
+    return torch.arange(world_size).reshape(-1, mid, pp, tp)
+
+
+def group_ranks(mesh: torch.Tensor, axis: str) -> list[list[int]]:
+    if axis == "tp":
+        return [x.tolist() for x in mesh.reshape(-1, mesh.shape[-1]).unbind(0)]
+    if axis == "pp":
+        return [x.tolist() for x in mesh.transpose(2, 3).reshape(-1, mesh.shape[2]).unbind(0)]
+    if axis == "mid":
+        return [x.tolist() for x in mesh.transpose(1, 3).reshape(-1, mesh.shape[1]).unbind(0)]
+    if axis == "ep":
+        return [x.tolist() for x in mesh.transpose(1, 2).reshape(-1, mesh.shape[1] * mesh.shape[3]).unbind(0)]
+    raise ValueError(axis)
+
+
+def initialize_model_parallel(tensor_parallel_size: int = 1, pipeline_parallel_size: int = 1,
+                              data_parallel_size: int = 1, token_parallel_size: int = 1,
+                              backend: Optional[str] = None) -> None:
+    global _TP, _PP, _DP, _EP, _TKNP
+    if _WORLD is None:
+        init_distributed_environment()
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if token_parallel_size > 1 and data_parallel_size > 1:
+        raise ValueError("token parallelism and in-group data parallelism are mutually exclusive")
+    if world == 1:
+        _TP, _PP, _DP, _EP, _TKNP = (_trivial(n) for n in ("tp", "pp", "dp", "ep", "tknp"))
+        return
+    backend = backend or _BACKEND
+    rank = dist.get_rank()
+    mid = token_parallel_size if token_parallel_size > 1 else data_parallel_size
+    mesh = build_mesh(world, tensor_parallel_size, pipeline_parallel_size, mid)
+    _TP = _new_group(group_ranks(mesh, "tp"), rank, _LOCAL_RANK, backend, "tp", use_device_comm=True,
+                     use_message_queue=False)
+    _PP = _new_group(group_ranks(mesh, "pp"), rank, _LOCAL_RANK, backend, "pp", use_device_comm=True)
+    mid_groups = group_ranks(mesh, "mid")
+    if token_parallel_size > 1:
+        _TKNP = _new_group(mid_groups, rank, _LOCAL_RANK, backend, "tknp", use_device_comm=True)
+        _DP = _trivial("dp")
+    else:
+        _DP = _new_group(mid_groups, rank, _LOCAL_RANK, backend, "dp", use_device_comm=True)
+        _TKNP = _trivial("tknp")
+    _EP = _new_group(group_ranks(mesh, "ep"), rank, _LOCAL_RANK, backend, "ep", use_device_comm=True)
+    logger.info("rank %d: TP %d/%d PP %d/%d DP %d/%d TKNP %d/%d EP %d/%d", rank, _TP.rank_in_group,
+                _TP.world_size, _PP.rank_in_group, _PP.world_size, _DP.rank_in_group, _DP.world_size,
+                _TKNP.rank_in_group, _TKNP.world_size, _EP.rank_in_group, _EP.world_size)
+
+
+def ensure_model_parallel_initialized(tp: int, pp: int, dp: int = 1, tknp: int = 1) -> None:
+    if _TP is None:
+        initialize_model_parallel(tp, pp, dp, tknp)
+        return
+    assert _TP.world_size == tp and _PP.world_size == pp, "model-parallel groups already exist with other sizes"
+
+
+def model_parallel_is_initialized() -> bool:
+    return _TP is not None
+
+
+def _get(g: Optional[GroupCoordinator], name: str) -> GroupCoordinator:
+    if g is None:
+        # single-process convenience: layers can be built without any init call
+        if not dist.is_initialized():
+            initialize_model_parallel()
+            return globals()[{"tp": "_TP", "pp": "_PP", "dp": "_DP", "ep": "_EP", "tknp": "_TKNP",
+                              "world": "_WORLD"}[name]]
+        raise RuntimeError(f"{name} group is not initialised")
+    return g
+
+
+def get_world_group() -> GroupCoordinator: return _get(_WORLD, "world")
+def get_tp_group() -> GroupCoordinator: return _get(_TP, "tp")
+def get_pp_group() -> GroupCoordinator: return _get(_PP, "pp")
+def get_dp_group() -> GroupCoordinator: return _get(_DP, "dp")
+def get_ep_group() -> GroupCoordinator: return _get(_EP, "ep")
+def get_tknp_group() -> GroupCoordinator: return _get(_TKNP, "tknp")
+
+
+def get_tensor_model_parallel_world_size() -> int: return get_tp_group().world_size
+def get_tensor_model_parallel_rank() -> int: return get_tp_group().rank_in_group
+def get_tknp_world_size() -> int: return get_tknp_group().world_size
+def get_tknp_rank() -> int: return get_tknp_group().rank_in_group
+def is_tknp_root() -> bool: return get_tknp_group().rank_in_group == 0
+
+
+def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
+    return get_tp_group().all_reduce(x)
+
+
+def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    return get_tp_group().all_gather(x, dim)
+
+
+def tensor_model_parallel_reduce_scatter(x: torch.Tensor, dim: int = 0) -> torch.Tensor:
+    return get_tp_group().reduce_scatter(x, dim)
+
+
+def tensor_model_parallel_gather(x: torch.Tensor, dst: int = 0, dim: int = -1):
+    return get_tp_group().gather(x, dst, dim)
+
+
+@contextlib.contextmanager
+def graph_capture(device=None):
+    """Enter the capture contexts of the TP and PP communicators."""
+    ctx = GraphCaptureContext(torch.cuda.Stream(device=device))
+    with get_tp_group().graph_capture(ctx), get_pp_group().graph_capture(ctx):
+        yield ctx
+
+
+def destroy_model_parallel() -> None:
+    global _TP, _PP, _DP, _EP, _TKNP
+    for g in (_TP, _PP, _DP, _EP, _TKNP):
+        if g is not None and g.world_size > 1:
+            g.destroy()
+    _TP = _PP = _DP = _EP = _TKNP = None
+
+
+def destroy_distributed_environment() -> None:
+    global _WORLD
+    if _WORLD is not None and _WORLD.world_size > 1:
+        _WORLD.destroy()
+    _WORLD = None
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def cleanup_dist_env_and_memory() -> None:
+    destroy_model_parallel()
+    destroy_distributed_environment()
+    import gc
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()

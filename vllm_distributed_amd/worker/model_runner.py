@@ -1,0 +1,576 @@
+"""Runs the model for one scheduler step on one device.
+
+Per step: apply the scheduler's deltas to the persistent batch, order the
+scheduled requests decode-first, build the flat inputs with vectorised numpy,
+ship them to fixed device buffers, run the model (a replayed hipGraph when the
+step is pure decode and fits a captured size, eager otherwise), compute logits
+for the last token of every request and sample.  The only host sync is the
+read-back of the sampled ids.
+
+Reference: vllm/v1/worker/gpu_model_runner.py (_update_states :670-870,
+_prepare_inputs :892-1109, execute_model :1613-1923, _dummy_run :2303-2471,
+capture_model :2683-2723, KV allocation :2808-2987, get_kv_cache_spec :3010-3089)
+and its token-parallel hooks (:331-510, :1813-1843).
+"""
+from __future__ import annotations
+
+import gc
+import time
+from typing import Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import envs, ops
+from ..config import VllmConfig
+from ..forward_context import AttentionMetadata, TokenParallelMetadata, set_forward_context
+from ..layers.attention import Attention
+from ..layers.sampler import Sampler, SamplingMetadata
+from ..logger import init_logger
+from ..models.loader import get_model
+from ..models.utils import IntermediateTensors
+from ..parallel.state import get_pp_group, get_tknp_group, get_tp_group, graph_capture
+from ..request import LogprobsLists
+from ..sched.kv_cache_interface import KVCacheConfig, KVCacheSpec
+from ..sched.output import EMPTY_MODEL_RUNNER_OUTPUT, ModelRunnerOutput, SchedulerOutput
+from .input_batch import InputBatch
+
+logger = init_logger(__name__)
+
+
+class ModelRunner:
+    def __init__(self, vllm_config: VllmConfig, device: torch.device):
+        self.vllm_config = vllm_config
+        self.device = device
+        self.is_gpu = device.type == "cuda"
+        mc, cc, sc, pc = (vllm_config.model_config, vllm_config.cache_config, vllm_config.scheduler_config,
+                          vllm_config.parallel_config)
+        self.model_config, self.cache_config, self.scheduler_config, self.parallel_config = mc, cc, sc, pc
+        self.dtype = mc.dtype
+        self.block_size = cc.block_size
+        self.max_model_len = mc.max_model_len
+        self.max_num_tokens = sc.max_num_batched_tokens
+        self.max_num_reqs = sc.max_num_seqs
+        self.vocab_size = mc.get_vocab_size()
+        self.hidden_size = mc.get_hidden_size()
+        self.num_heads = mc.get_num_attention_heads(pc)
+        self.num_kv_heads = mc.get_num_kv_heads(pc)
+        self.head_size = mc.get_head_size()
+        spec = vllm_config.speculative_config
+        self.num_spec_tokens = spec.num_speculative_tokens if spec else 0
+        group = max(self.num_heads // self.num_kv_heads, 1)
+        # query tokens per sequence the split-KV kernel form can take (<= 32 MFMA columns per kv head)
+        self.max_decode_q = max(1, min(1 + self.num_spec_tokens, 32 // group if self.head_size <= 128 else 16 // group))
+        self.use_graphs = self.is_gpu and vllm_config.compilation_config.level > 0 and not mc.enforce_eager
+        self.capture_sizes = list(vllm_config.compilation_config.cudagraph_capture_sizes or []) if self.use_graphs else []
+        self.model: Optional[nn.Module] = None
+        self.sampler = Sampler()
+        self.kv_caches: list[tuple[torch.Tensor, torch.Tensor]] = []
+        self.kv_arena: Optional[torch.Tensor] = None
+        self.attn_layers: dict[str, Attention] = {}
+        self.input_batch: Optional[InputBatch] = None
+        self.graphs: dict[int, tuple] = {}
+        self.graph_pool = None
+        self._step = 0
+        self._rng = np.random.default_rng(mc.seed)
+        self.drafter = None
+        self.rejection_sampler = None
+        self.kv_connector = None
+        self.lora_manager = None
+        self.eplb_state = None
+        self._init_buffers()
+
+    # ------------------------------------------------------------------
+    def _init_buffers(self) -> None:
+        dev, T, S = self.device, self.max_num_tokens, self.max_num_reqs
+        Tpad = max(T, max(self.capture_sizes, default=0))
+        self.input_ids = torch.zeros(Tpad, dtype=torch.int32, device=dev)
+        self.positions = torch.zeros(Tpad, dtype=torch.int64, device=dev)
+        self.slot_mapping = torch.full((Tpad,), -1, dtype=torch.int64, device=dev)
+        Spad = max(S, max(self.capture_sizes, default=0))
+        self.max_blocks = -(-self.max_model_len // self.block_size)
+        self.block_table = torch.zeros((Spad, self.max_blocks), dtype=torch.int32, device=dev)
+        self.seq_lens = torch.zeros(Spad, dtype=torch.int32, device=dev)
+        self.query_start_loc = torch.zeros(Spad + 1, dtype=torch.int32, device=dev)
+        self.prefill_qsl = torch.zeros(Spad + 1, dtype=torch.int32, device=dev)
+        self.logits_indices = torch.zeros(Tpad, dtype=torch.int64, device=dev)
+        self.pin = self.is_gpu
+        self.intermediate: Optional[IntermediateTensors] = None
+
+    def _to_dev(self, dst: torch.Tensor, src: np.ndarray) -> None:
+        t = torch.from_numpy(src)
+        if self.pin:
+            t = t.pin_memory()
+        dst[: t.shape[0]].copy_(t, non_blocking=True)
+
+    # ------------------------------------------------------------------
+    def load_model(self) -> None:
+        t0 = time.time()
+        if self.is_gpu:
+            torch.cuda.synchronize()
+            before = torch.cuda.memory_allocated(self.device)
+        self.model = get_model(self.vllm_config, self.device)
+        if self.is_gpu:
+            self.model_memory = torch.cuda.memory_allocated(self.device) - before
+            logger.info("weights take %.2f GiB, loaded in %.1f s", self.model_memory / 2**30, time.time() - t0)
+        self.attn_layers = {n: m for n, m in self.model.named_modules() if isinstance(m, Attention)}
+        for n, m in self.attn_layers.items():
+            m.layer_name = n
+        spec = self.vllm_config.speculative_config
+        if spec is not None and get_pp_group().is_last_rank:
+            from ..spec_decode import make_proposer
+            from ..layers.rejection_sampler import RejectionSampler
+            self.drafter = make_proposer(self.vllm_config, self)
+            self.rejection_sampler = RejectionSampler()
+        if self.vllm_config.lora_config is not None:
+            from ..lora.manager import LoRAManager
+            self.lora_manager = LoRAManager(self.model, self.vllm_config, self.device)
+
+    def get_model(self) -> nn.Module:
+        return self.model
+
+    def get_kv_cache_spec(self) -> dict[str, KVCacheSpec]:
+        dt = self.dtype if self.cache_config.cache_dtype == "auto" else \
+            {"fp8": torch.float8_e4m3fn, "bfloat16": torch.bfloat16, "float16": torch.float16}[self.cache_config.cache_dtype]
+        if dt == torch.float8_e4m3fn:
+            raise NotImplementedError("fp8 KV cache is not wired into the attention kernels yet")
+        return {n: m.get_kv_cache_spec(self.block_size, dt) for n, m in self.attn_layers.items()}
+
+    def initialize_kv_cache(self, cfg: KVCacheConfig) -> None:
+        """One zero-filled arena for the whole cache (a single allocation is a single
+        IPC handle for the xGMI KV connector), carved into per-layer K and V views."""
+        self.kv_cache_config = cfg
+        total = sum(t.size for t in cfg.kv_cache_tensors)
+        self.kv_arena = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        spec_of = {}
+        for g in cfg.kv_cache_groups:
+            for n in g.layer_names:
+                spec_of[n] = g.kv_cache_spec
+        off = 0
+        self.kv_caches = []
+        self.kv_layer_offsets: dict[str, tuple[int, int]] = {}
+        nb = cfg.num_blocks
+        for t in cfg.kv_cache_tensors:
+            raw = self.kv_arena[off: off + t.size]
+            sp = spec_of[t.shared_by[0]]
+            half = t.size // 2
+            k = raw[:half].view(sp.dtype).view(nb, sp.num_kv_heads, sp.block_size, sp.head_size)
+            v = raw[half:].view(sp.dtype).view(nb, sp.num_kv_heads, sp.head_size, sp.block_size)
+            for n in t.shared_by:
+                self.attn_layers[n].bind_kv_cache(k, v)
+                self.kv_layer_offsets[n] = (off, half)
+            self.kv_caches.append((k, v))
+            off += t.size
+        self.input_batch = InputBatch(self.max_num_reqs, self.max_model_len, self.block_size, self.vocab_size,
+                                      max(len(cfg.kv_cache_groups), 1), self.pin)
+        if self.kv_connector is not None:
+            self.kv_connector.register_kv_caches(self)
+
+    # ------------------------------------------------------------------
+    # state updates
+    # ------------------------------------------------------------------
+    def _update_states(self, so: SchedulerOutput) -> None:
+        ib = self.input_batch
+        for rid in so.finished_req_ids:
+            ib.remove_request(rid)
+        for nr in so.scheduled_new_reqs:
+            ib.add_request(nr.req_id, nr.prompt_token_ids, nr.sampling_params, nr.block_ids, nr.num_computed_tokens,
+                           nr.pooling_params, nr.lora_request, nr.mm_inputs, nr.mm_positions)
+        cr = so.scheduled_cached_reqs
+        for i, rid in enumerate(cr.req_ids):
+            st = ib.reqs.get(rid)
+            if st is None:
+                raise RuntimeError(f"scheduler references unknown request {rid}")
+            row = st.row
+            ib.num_computed[row] = cr.num_computed_tokens[i]
+            if cr.resumed_from_preemption[i]:
+                ib.reset_blocks(row, cr.new_block_ids[i])
+            else:
+                ib.append_blocks(row, cr.new_block_ids[i])
+            new_toks = cr.new_token_ids[i]
+            if new_toks:
+                # tokens sampled elsewhere (other PP stage / before preemption): place them by position
+                s = int(cr.num_computed_tokens[i])
+                e = s + len(new_toks)
+                ib.token_ids[row, s:e] = new_toks
+                if e > ib.num_tokens[row]:
+                    ib.num_tokens[row] = e
+            spec = so.scheduled_spec_decode_tokens.get(rid)
+            if spec:
+                s = int(ib.num_tokens[row])
+                ib.token_ids[row, s:s + len(spec)] = spec
+
+    # ------------------------------------------------------------------
+    def _prepare_inputs(self, so: SchedulerOutput):
+        ib = self.input_batch
+        req_ids = list(so.num_scheduled_tokens)
+        n_sched = np.fromiter((so.num_scheduled_tokens[r] for r in req_ids), dtype=np.int32, count=len(req_ids))
+        rows = np.fromiter((ib.reqs[r].row for r in req_ids), dtype=np.int64, count=len(req_ids))
+        # decode-form requests first (stable), then prefill-form
+        is_dec = n_sched <= self.max_decode_q
+        order = np.argsort(~is_dec, kind="stable")
+        req_ids = [req_ids[i] for i in order]
+        n_sched, rows = n_sched[order], rows[order]
+        nd = int(is_dec.sum())
+        S = len(req_ids)
+        T = int(n_sched.sum())
+        ndt = int(n_sched[:nd].sum())
+        cu = np.zeros(S + 1, dtype=np.int32)
+        np.cumsum(n_sched, out=cu[1:])
+        req_idx = np.repeat(np.arange(S, dtype=np.int64), n_sched)
+        computed = ib.num_computed[rows].astype(np.int64)
+        pos = computed[req_idx] + (np.arange(T, dtype=np.int64) - cu[:-1].astype(np.int64)[req_idx])
+        tok_rows = rows[req_idx]
+        input_ids = ib.token_ids[tok_rows, pos]
+        bt = ib.block_tables[0]
+        slot = bt[tok_rows, pos // self.block_size].astype(np.int64) * self.block_size + pos % self.block_size
+        seq_lens = (computed + n_sched).astype(np.int32)
+        max_seq = int(seq_lens.max()) if S else 0
+        W = max(-(-max_seq // self.block_size), 1)
+        self._to_dev(self.input_ids, input_ids)
+        self._to_dev(self.positions, pos)
+        self._to_dev(self.slot_mapping, slot)
+        self._to_dev(self.seq_lens, seq_lens)
+        self._to_dev(self.query_start_loc, cu)
+        btv = torch.from_numpy(np.ascontiguousarray(bt[rows, :W]))
+        if self.pin:
+            btv = btv.pin_memory()
+        self.block_table[:S, :W].copy_(btv, non_blocking=True)
+        if nd < S:
+            self._to_dev(self.prefill_qsl, (cu[nd:] - cu[nd]).astype(np.int32))
+        logits_idx = (cu[1:] - 1).astype(np.int64)
+        return req_ids, rows, n_sched, cu, nd, ndt, S, T, seq_lens, logits_idx
+
+    def _decode_splits(self, num_seqs: int, max_seq_len: int, fixed: bool) -> int:
+        if num_seqs == 0:
+            return 1
+        if fixed:   # captured graphs: a function of the batch size only
+            max_seq_len = self.max_model_len
+        return ops.decode_num_splits(num_seqs, self.num_kv_heads, max_seq_len)
+
+    def _workspace(self, tokens: int, nsplit: int):
+        if nsplit <= 1 or not self.is_gpu:
+            return None
+        need = tokens * self.num_heads * nsplit
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws[2] < need:
+            po = torch.empty(need * self.head_size, dtype=torch.float32, device=self.device)
+            pl = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._ws = ws = (po, pl, need)
+        return ws[0], ws[1]
+
+    def _build_attn_metadata(self, S, T, nd, ndt, max_seq, max_q, nsplit) -> AttentionMetadata:
+        return AttentionMetadata(
+            num_actual_tokens=T, num_decode_seqs=nd, num_decode_tokens=ndt, num_prefill_seqs=S - nd,
+            num_prefill_tokens=T - ndt, slot_mapping=self.slot_mapping, block_table=self.block_table[:S],
+            seq_lens=self.seq_lens[:S], query_start_loc=self.query_start_loc[:S + 1],
+            prefill_query_start_loc=self.prefill_qsl[:S - nd + 1] if nd < S else None,
+            max_query_len=max_q, max_seq_len=max_seq, max_decode_query_len=self.max_decode_q,
+            decode_num_splits=nsplit, decode_workspace=self._workspace(max(ndt, 1), nsplit))
+
+    # ------------------------------------------------------------------
+    @torch.inference_mode()
+    def execute_model(self, so: SchedulerOutput, intermediate_tensors: Optional[IntermediateTensors] = None
+                      ) -> Union[ModelRunnerOutput, IntermediateTensors]:
+        self._update_states(so)
+        if not so.total_num_scheduled_tokens:
+            return self._finish_kv_only(so)
+        req_ids, rows, n_sched, cu, nd, ndt, S, T, seq_lens, logits_idx = self._prepare_inputs(so)
+        ib = self.input_batch
+        max_seq, max_q = int(seq_lens.max()), int(n_sched.max())
+        pure_decode = nd == S and max_q == 1
+        pp = get_pp_group()
+        graph_bs = None
+        if self.use_graphs and pure_decode and S <= (self.capture_sizes[0] if self.capture_sizes else 0) \
+                and self.graphs and self.lora_manager is None:
+            graph_bs = self.vllm_config.pad_for_cudagraph(S)
+        if self.lora_manager is not None:
+            self.lora_manager.set_active(req_ids, rows, n_sched, ib)
+        conn = self.kv_connector
+        if conn is not None:
+            conn.bind_connector_metadata(so.kv_connector_metadata)
+
+        if graph_bs is not None:
+            if graph_bs > S:
+                # padded sequences: zero keys, slot -1 (no cache write), one query token each
+                self.seq_lens[S:graph_bs].zero_()
+                self.slot_mapping[S:graph_bs].fill_(-1)
+                self.query_start_loc[S + 1: graph_bs + 1].copy_(
+                    torch.arange(S + 1, graph_bs + 1, dtype=torch.int32, device=self.device))
+            g, hidden_buf, md = self.graphs[graph_bs]
+            with set_forward_context(md, kv_connector=conn, num_tokens=T):
+                if conn is not None:
+                    conn.start_load_kv()
+                g.replay()
+            hidden = hidden_buf
+        else:
+            nsplit = self._decode_splits(nd, max_seq, False)
+            md = self._build_attn_metadata(S, T, nd, ndt, max_seq, max_q, nsplit)
+            inter = None
+            if not pp.is_first_rank:
+                inter = intermediate_tensors
+            with set_forward_context(md, kv_connector=conn, num_tokens=T):
+                if conn is not None:
+                    conn.start_load_kv()
+                hidden = self.model(self.input_ids[:T], self.positions[:T], inter, None)
+        if conn is not None:
+            conn.wait_for_save()
+            conn.clear_connector_metadata()
+        if not pp.is_last_rank:
+            return hidden
+        finished_sending, finished_recving = (conn.get_finished(so.finished_req_ids) if conn is not None
+                                              else (None, None))
+
+        # ---- logits + sampling ------------------------------------------------
+        spec_sched = so.scheduled_spec_decode_tokens
+        if spec_sched and self.rejection_sampler is not None:
+            out = self._sample_with_spec(so, hidden, req_ids, rows, n_sched, cu, S)
+        else:
+            self._to_dev(self.logits_indices, logits_idx)
+            sample_hidden = hidden[self.logits_indices[:S]]
+            logits = self.model.compute_logits(sample_hidden)
+            if envs.VLLM_COMPUTE_NANS_IN_LOGITS:
+                self._last_nans = {r: int(x) for r, x in zip(req_ids, logits.isnan().sum(-1).tolist())}
+            if so.grammar_bitmask is not None:
+                self._apply_grammar_bitmask(so, logits, req_ids)
+            smd = self._sampling_metadata(req_ids, rows)
+            sout = self.sampler(logits, smd)
+            sampled = sout.sampled_token_ids[:, 0]
+            out = (sampled, sout.logprobs_tensors, None)
+        sampled_t, logprobs_t, multi = out
+        prompt_lp = self._prompt_logprobs(so, hidden, req_ids, rows, n_sched, cu)
+
+        # the one host sync of the step
+        if multi is not None:
+            sampled_lists = multi
+        else:
+            sampled_lists = [[t] for t in sampled_t.tolist()]
+        # requests still in the middle of their prompt discard the sample
+        done = (ib.num_computed[rows] + n_sched) >= ib.num_tokens[rows]
+        for i, rid in enumerate(req_ids):
+            if not done[i]:
+                sampled_lists[i] = []
+                continue
+            st = ib.reqs[rid]
+            for tok in sampled_lists[i]:
+                ib.append_token(int(rows[i]), tok)
+                st.output_token_ids.append(tok)
+        spec_tokens = None
+        if self.drafter is not None:
+            spec_tokens = self.drafter.propose(self, req_ids, rows, sampled_lists, hidden, cu)
+        lp_lists = Sampler.to_lists(logprobs_t)
+        self._step += 1
+        return ModelRunnerOutput(
+            req_ids=req_ids, req_id_to_index={r: i for i, r in enumerate(req_ids)},
+            sampled_token_ids=sampled_lists, spec_token_ids=spec_tokens, logprobs=lp_lists,
+            prompt_logprobs_dict=prompt_lp, finished_sending=finished_sending, finished_recving=finished_recving,
+            num_nans_in_logits=getattr(self, "_last_nans", None))
+
+    def _finish_kv_only(self, so: SchedulerOutput) -> ModelRunnerOutput:
+        """No tokens scheduled: still drive the KV connector (async transfers)."""
+        conn = self.kv_connector
+        if conn is None:
+            return EMPTY_MODEL_RUNNER_OUTPUT
+        conn.bind_connector_metadata(so.kv_connector_metadata)
+        conn.start_load_kv()
+        fs, fr = conn.get_finished(so.finished_req_ids)
+        conn.clear_connector_metadata()
+        if not fs and not fr:
+            return EMPTY_MODEL_RUNNER_OUTPUT
+        return ModelRunnerOutput(finished_sending=fs, finished_recving=fr)
+
+    # ------------------------------------------------------------------
+    def _sampling_metadata(self, req_ids: list[str], rows: np.ndarray) -> SamplingMetadata:
+        ib = self.input_batch
+        dev = self.device
+        temp = ib.temperature[rows]
+        all_greedy = bool((temp < 1e-5).all())
+        all_random = bool((temp >= 1e-5).all())
+        nlp = ib.num_logprobs[rows]
+        max_lp = int(nlp.max()) if (nlp >= 0).any() else None
+        md = SamplingMetadata(temperature=None, all_greedy=all_greedy, all_random=all_random, max_num_logprobs=max_lp)
+
+        def dev_t(a):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            return (t.pin_memory() if self.pin else t).to(dev, non_blocking=True)
+
+        if not all_greedy:
+            md.temperature = dev_t(temp)
+            tk, tp, mp = ib.top_k[rows], ib.top_p[rows], ib.min_p[rows]
+            if (tk > 0).any():
+                md.top_k = dev_t(tk)
+            if (tp < 1.0).any():
+                md.top_p = dev_t(tp)
+            if (mp > 0).any():
+                md.min_p = dev_t(mp)
+            # per-step seeds: seeded requests are reproducible (seed, position); others draw fresh entropy
+            pos = ib.num_tokens[rows].astype(np.int64)
+            fresh = self._rng.integers(0, 2**62, size=len(rows), dtype=np.int64)
+            seeds = np.where(ib.has_seed[rows], ib.seed[rows] * np.int64(1000003) + pos, fresh)
+            md.seeds = dev_t(seeds)
+        sps = [ib.reqs[r].sampling_params for r in req_ids]
+        pen = (ib.freq_pen[rows] != 0) | (ib.pres_pen[rows] != 0) | (ib.rep_pen[rows] != 1.0)
+        need_out = bool(pen.any())
+        for i, sp in enumerate(sps):
+            if sp is None:
+                continue
+            if sp.min_tokens > 0 and sp.all_stop_token_ids:
+                md.min_tokens[i] = (sp.min_tokens, set(sp.all_stop_token_ids))
+                need_out = True
+            if sp.bad_words_token_ids:
+                md.bad_words_token_ids[i] = sp.bad_words_token_ids
+                need_out = True
+        if any(sp is not None and sp.logit_bias for sp in sps):
+            md.logit_bias = [sp.logit_bias if sp is not None else None for sp in sps]
+        if any(sp is not None and sp.allowed_token_ids for sp in sps):
+            mask = torch.zeros((len(sps), self.vocab_size), dtype=torch.bool)
+            for i, sp in enumerate(sps):
+                if sp is not None and sp.allowed_token_ids:
+                    mask[i] = True
+                    mask[i, sp.allowed_token_ids] = False
+            md.allowed_token_ids_mask = mask.to(dev)
+        if need_out:
+            md.output_token_ids = [ib.reqs[r].output_token_ids for r in req_ids]
+        if pen.any():
+            md.no_penalties = False
+            md.frequency_penalties, md.presence_penalties, md.repetition_penalties = \
+                dev_t(ib.freq_pen[rows]), dev_t(ib.pres_pen[rows]), dev_t(ib.rep_pen[rows])
+            Lp = max(ib.reqs[r].num_prompt_tokens for r in req_ids)
+            pt = np.full((len(rows), Lp), self.vocab_size, dtype=np.int64)
+            for i, r in enumerate(req_ids):
+                n = ib.reqs[r].num_prompt_tokens
+                pt[i, :n] = ib.token_ids[rows[i], :n]
+            md.prompt_token_ids = dev_t(pt)
+        return md
+
+    def _prompt_logprobs(self, so, hidden, req_ids, rows, n_sched, cu) -> dict[str, Optional[LogprobsLists]]:
+        ib = self.input_batch
+        out: dict[str, Optional[LogprobsLists]] = {}
+        want = ib.num_prompt_logprobs[rows]
+        if not (want >= 0).any():
+            return out
+        for i, rid in enumerate(req_ids):
+            k = int(want[i])
+            if k < 0:
+                continue
+            st = ib.reqs[rid]
+            row = int(rows[i])
+            start = int(ib.num_computed[row])
+            n = int(n_sched[i])
+            # positions [start, start+n) predict tokens [start+1, start+n]; only prompt targets count
+            n_tgt = min(start + n, st.num_prompt_tokens - 1) - start
+            if n_tgt <= 0:
+                continue
+            h = hidden[int(cu[i]): int(cu[i]) + n_tgt]
+            lp = torch.log_softmax(self.model.compute_logits(h).float(), dim=-1)
+            tgt = torch.from_numpy(ib.token_ids[row, start + 1: start + 1 + n_tgt].astype(np.int64)).to(self.device)
+            ids, lps, ranks = Sampler.gather_logprobs(lp, k, tgt)
+            out[rid] = LogprobsLists(ids.tolist(), lps.tolist(), ranks.tolist())
+        return out
+
+    def _apply_grammar_bitmask(self, so, logits, req_ids) -> None:
+        bm = so.grammar_bitmask
+        idx = so.structured_output_request_ids
+        if bm is None or not idx:
+            return
+        bm_t = torch.as_tensor(bm)
+        for i, rid in enumerate(req_ids):
+            j = idx.get(rid)
+            if j is None:
+                continue
+            words = bm_t[j].to(self.device).to(torch.int32)
+            bits = (words[:, None] >> torch.arange(32, device=self.device, dtype=torch.int32)) & 1
+            allowed = bits.reshape(-1)[: logits.shape[-1]].bool()
+            logits[i].masked_fill_(~allowed, float("-inf"))
+
+    def _sample_with_spec(self, so, hidden, req_ids, rows, n_sched, cu, S):
+        """Verify draft tokens: logits at every scheduled position of requests with drafts."""
+        ib = self.input_batch
+        drafts = [so.scheduled_spec_decode_tokens.get(r, []) for r in req_ids]
+        idx = []
+        for i in range(S):
+            nd_i = len(drafts[i])
+            last = int(cu[i + 1]) - 1
+            idx.extend(range(last - nd_i, last + 1))
+        sel = torch.tensor(idx, dtype=torch.int64, device=self.device)
+        logits = self.model.compute_logits(hidden[sel]).float()
+        smd = self._sampling_metadata(req_ids, rows)
+        lists = self.rejection_sampler(logits, drafts, smd, self.sampler)
+        return None, None, lists
+
+    # ------------------------------------------------------------------
+    # profiling / warm-up / capture
+    # ------------------------------------------------------------------
+    @torch.inference_mode()
+    def _dummy_run(self, num_tokens: int, with_metadata: bool = False, num_seqs: Optional[int] = None):
+        """Forward pass on zero inputs.  Without metadata the attention kernels are
+        skipped (memory profiling); with metadata a decode batch of ``num_seqs``
+        empty sequences runs the full kernel path."""
+        pp = get_pp_group()
+        inter = None
+        if not pp.is_first_rank:
+            inter = IntermediateTensors({
+                "hidden_states": torch.zeros((num_tokens, self.hidden_size), dtype=self.dtype, device=self.device),
+                "residual": torch.zeros((num_tokens, self.hidden_size), dtype=self.dtype, device=self.device)})
+        md = None
+        if with_metadata:
+            S = num_seqs or num_tokens
+            self.seq_lens[:S].zero_()
+            self.slot_mapping[:num_tokens].fill_(-1)
+            self.query_start_loc[:S + 1].copy_(torch.arange(S + 1, dtype=torch.int32, device=self.device))
+            nsplit = self._decode_splits(S, 0, True)
+            md = self._build_attn_metadata(S, num_tokens, S, num_tokens, 0, 1, nsplit)
+        with set_forward_context(md, num_tokens=0):
+            out = self.model(self.input_ids[:num_tokens], self.positions[:num_tokens], inter, None)
+        return out
+
+    @torch.inference_mode()
+    def profile_run(self) -> None:
+        hidden = self._dummy_run(self.max_num_tokens)
+        if get_pp_group().is_last_rank:
+            n = min(self.max_num_reqs, self.max_num_tokens)
+            logits = self.model.compute_logits(hidden[:n])
+            self.sampler(logits, SamplingMetadata(None, True, False))
+            del logits
+        if self.is_gpu:
+            torch.cuda.synchronize()
+        del hidden
+        gc.collect()
+
+    @torch.inference_mode()
+    def capture_model(self) -> None:
+        if not self.use_graphs or not self.capture_sizes:
+            return
+        t0 = time.time()
+        free0 = torch.cuda.mem_get_info(self.device)[0]
+        self.graph_pool = torch.cuda.graph_pool_handle()
+        with graph_capture(self.device) as cap:
+            for bs in sorted(self.capture_sizes, reverse=True):
+                nsplit = self._decode_splits(bs, 0, True)
+                self.seq_lens[:bs].zero_()
+                self.slot_mapping[:bs].fill_(-1)
+                self.query_start_loc[:bs + 1].copy_(torch.arange(bs + 1, dtype=torch.int32, device=self.device))
+                md = self._build_attn_metadata(bs, bs, bs, bs, 0, 1, nsplit)
+                for _ in range(self.vllm_config.compilation_config.cudagraph_num_of_warmups):
+                    with set_forward_context(md):
+                        self.model(self.input_ids[:bs], self.positions[:bs], self._capture_inter(bs), None)
+                g = torch.cuda.CUDAGraph()
+                with set_forward_context(md):
+                    with torch.cuda.graph(g, pool=self.graph_pool, stream=cap.stream):
+                        out = self.model(self.input_ids[:bs], self.positions[:bs], self._capture_inter(bs), None)
+                self.graphs[bs] = (g, out, md)
+        torch.cuda.synchronize()
+        used = free0 - torch.cuda.mem_get_info(self.device)[0]
+        logger.info("captured %d decode graphs in %.1f s (%.2f GiB)", len(self.graphs), time.time() - t0,
+                    used / 2**30)
+
+    def _capture_inter(self, bs: int):
+        if get_pp_group().is_first_rank:
+            return None
+        if self.intermediate is None:
+            n = max(self.capture_sizes)
+            self.intermediate = IntermediateTensors({
+                "hidden_states": torch.zeros((n, self.hidden_size), dtype=self.dtype, device=self.device),
+                "residual": torch.zeros((n, self.hidden_size), dtype=self.dtype, device=self.device)})
+        return self.intermediate[:bs]

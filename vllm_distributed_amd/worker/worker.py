@@ -1,0 +1,219 @@
+"""One worker = one device = one process (or the engine's own process with the
+uniproc executor).  Owns device set-up, the distributed environment, memory
+profiling for KV sizing, warm-up / hipGraph capture, and the per-step call.
+
+Reference: vllm/v1/worker/gpu_worker.py (init_device :129-180,
+determine_available_memory :199-248, compile_or_warm_up_model :267-307,
+execute_model :312-352, profile :354-362, sleep/wake :86-122).
+"""
+from __future__ import annotations
+
+import gc
+import os
+from typing import Any, Optional
+
+import torch
+
+from .. import envs
+from ..config import VllmConfig
+from ..logger import init_logger
+from ..models.utils import IntermediateTensors
+from ..parallel import state as pstate
+from ..platforms import current_platform
+from ..sched.kv_cache_interface import KVCacheConfig, KVCacheSpec
+from ..sched.output import ModelRunnerOutput, SchedulerOutput
+from .model_runner import ModelRunner
+
+logger = init_logger(__name__)
+
+
+class Worker:
+    def __init__(self, vllm_config: VllmConfig, local_rank: int = 0, rank: int = 0,
+                 distributed_init_method: Optional[str] = None, is_driver_worker: bool = True):
+        self.vllm_config = vllm_config
+        self.local_rank, self.rank = local_rank, rank
+        self.distributed_init_method = distributed_init_method or "env://"
+        self.is_driver_worker = is_driver_worker
+        self.parallel_config = vllm_config.parallel_config
+        self.parallel_config.rank = rank
+        self.device: Optional[torch.device] = None
+        self.model_runner: Optional[ModelRunner] = None
+        self.profiler = None
+        self._sleep_saved: dict[str, torch.Tensor] = {}
+        self._sleeping = 0
+        pdir = envs.VLLM_TORCH_PROFILER_DIR
+        if pdir:
+            acts = [torch.profiler.ProfilerActivity.CPU]
+            if torch.cuda.is_available():
+                acts.append(torch.profiler.ProfilerActivity.CUDA)
+            self.profiler = torch.profiler.profile(
+                activities=acts, with_stack=True,
+                on_trace_ready=torch.profiler.tensorboard_trace_handler(pdir, use_gzip=True))
+
+    # ------------------------------------------------------------------
+    def init_device(self) -> None:
+        dc = self.vllm_config.device_config
+        pc = self.parallel_config
+        if dc.device == "cuda":
+            self.device = torch.device(f"cuda:{self.local_rank}")
+            torch.cuda.set_device(self.device)
+            gc.collect()
+            torch.cuda.empty_cache()
+            free, total = torch.cuda.mem_get_info(self.device)
+            self.init_free, self.total_memory = free, total
+            want = total * self.vllm_config.cache_config.gpu_memory_utilization
+            if free < want:
+                raise ValueError(f"device has {free / 2**30:.1f} GiB free of {total / 2**30:.1f} GiB but "
+                                 f"gpu_memory_utilization asks for {want / 2**30:.1f} GiB")
+            backend = "nccl"
+        else:
+            self.device = torch.device("cpu")
+            self.init_free = self.total_memory = current_platform.total_memory()
+            backend = "gloo"
+        world = pc.world_size
+        pstate.init_distributed_environment(world, self.rank, self.distributed_init_method, self.local_rank, backend)
+        pstate.ensure_model_parallel_initialized(pc.tensor_parallel_size, pc.pipeline_parallel_size, 1,
+                                                 pc.token_parallel_size)
+        current_platform.seed_everything(self.vllm_config.model_config.seed)
+        self.model_runner = ModelRunner(self.vllm_config, self.device)
+        if self.vllm_config.kv_transfer_config is not None:
+            from ..parallel.kv_transfer.factory import KVConnectorFactory, KVConnectorRole
+            self.model_runner.kv_connector = KVConnectorFactory.create(self.vllm_config, KVConnectorRole.WORKER)
+
+    def load_model(self) -> None:
+        self.model_runner.load_model()
+
+    def get_model(self):
+        return self.model_runner.get_model()
+
+    def get_kv_cache_spec(self) -> dict[str, KVCacheSpec]:
+        return self.model_runner.get_kv_cache_spec()
+
+    @torch.inference_mode()
+    def determine_available_memory(self) -> int:
+        """Bytes left for the KV cache after weights, peak activations, comm arenas
+        and everything else already allocated on the device."""
+        cc = self.vllm_config.cache_config
+        if self.device.type != "cuda":
+            # CPU plumbing path: a fixed modest budget
+            return int(min(cc.swap_space, 4.0) * 2**30) if cc.num_gpu_blocks_override is None else 0
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(self.device)
+        self.model_runner.profile_run()
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info(self.device)
+        peak_torch = torch.cuda.max_memory_allocated(self.device)
+        now_torch = torch.cuda.memory_allocated(self.device)
+        torch.cuda.empty_cache()
+        free_after, _ = torch.cuda.mem_get_info(self.device)
+        # memory held outside the torch allocator (RCCL buffers, IPC arenas, HIP context)
+        non_torch = (total - free_after) - torch.cuda.memory_reserved(self.device)
+        activation_peak = peak_torch - now_torch
+        budget = total * cc.gpu_memory_utilization
+        # hipGraph pools are captured after the KV cache exists: reserve for them up front
+        graph_reserve = 0
+        if self.model_runner.use_graphs:
+            graph_reserve = int(1.5 * 2**30) + 64 * 2**20 * len(self.model_runner.capture_sizes) // 8
+        avail = budget - now_torch - activation_peak - max(non_torch, 0) - graph_reserve
+        logger.info("memory: total %.1f GiB, budget %.1f, weights+static %.1f, activation peak %.1f, "
+                    "non-torch %.1f, graph reserve %.1f -> KV cache %.1f GiB",
+                    total / 2**30, budget / 2**30, now_torch / 2**30, activation_peak / 2**30,
+                    max(non_torch, 0) / 2**30, graph_reserve / 2**30, avail / 2**30)
+        return int(max(avail, 0))
+
+    def initialize_from_config(self, kv_cache_config: KVCacheConfig) -> None:
+        self.model_runner.initialize_kv_cache(kv_cache_config)
+
+    def compile_or_warm_up_model(self) -> None:
+        mr = self.model_runner
+        if self.device.type == "cuda":
+            # touch the eager kernels at a few sizes so first requests do not pay lazy initialisation
+            for n in (1, 16, min(512, mr.max_num_tokens)):
+                mr._dummy_run(n, with_metadata=True, num_seqs=min(n, mr.max_num_reqs))
+            mr.capture_model()
+            torch.cuda.synchronize()
+        current_platform.seed_everything(self.vllm_config.model_config.seed)
+
+    # ------------------------------------------------------------------
+    @torch.inference_mode()
+    def execute_model(self, scheduler_output: SchedulerOutput) -> Optional[ModelRunnerOutput]:
+        pp = pstate.get_pp_group()
+        tp = pstate.get_tp_group()
+        inter = None
+        if not pp.is_first_rank and scheduler_output.total_num_scheduled_tokens:
+            d = pp.recv_tensor_dict(all_gather_group=tp)
+            inter = IntermediateTensors(d)
+        out = self.model_runner.execute_model(scheduler_output, inter)
+        if isinstance(out, IntermediateTensors):
+            pp.send_tensor_dict(out.tensors, all_gather_group=tp)
+            return None
+        return out if self.is_driver_worker or True else None
+
+    def profile(self, is_start: bool = True) -> None:
+        if self.profiler is None:
+            raise RuntimeError("set VLLM_TORCH_PROFILER_DIR to enable profiling")
+        if is_start:
+            self.profiler.start()
+        else:
+            self.profiler.stop()
+
+    def check_health(self) -> bool:
+        return True
+
+    # ---- sleep / wake (RLHF co-location) -------------------------------------
+    def sleep(self, level: int = 1) -> None:
+        """Level 1: weights to pinned host memory, KV cache dropped.  Level 2: both dropped
+        (weights must be reloaded or pushed again before waking)."""
+        if self.device.type != "cuda" or self._sleeping:
+            return
+        mr = self.model_runner
+        free0 = torch.cuda.mem_get_info(self.device)[0]
+        from ..device_allocator import offload_module, drop_tensor
+        self._sleep_saved = offload_module(mr.model, keep_copy=(level == 1))
+        if mr.kv_arena is not None:
+            self._kv_shape = mr.kv_arena.shape
+            drop_tensor(mr.kv_arena)
+        mr.graphs.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+        self._sleeping = level
+        logger.info("sleep level %d freed %.2f GiB", level,
+                    (torch.cuda.mem_get_info(self.device)[0] - free0) / 2**30)
+
+    def wake_up(self, tags: Optional[list[str]] = None) -> None:
+        if not self._sleeping:
+            return
+        mr = self.model_runner
+        from ..device_allocator import restore_module, restore_tensor
+        if tags is None or "weights" in tags:
+            restore_module(mr.model, self._sleep_saved, self.device)
+            self._sleep_saved = {}
+        if (tags is None or "kv_cache" in tags) and mr.kv_arena is not None:
+            restore_tensor(mr.kv_arena, self._kv_shape, self.device)
+            mr.initialize_kv_cache(mr.kv_cache_config)
+            mr.capture_model()
+        if tags is None or set(tags) >= {"weights", "kv_cache"}:
+            self._sleeping = 0
+
+    def is_sleeping(self) -> bool:
+        return bool(self._sleeping)
+
+    # ---- misc RPC targets --------------------------------------------------------
+    def save_sharded_state(self, path: str, pattern: Optional[str] = None, max_size: Optional[int] = None) -> None:
+        from ..models.loader import ShardedStateLoader
+        ShardedStateLoader.save_model(self.model_runner.model, path, pattern, max_size)
+
+    def add_lora(self, lora_request) -> bool:
+        return self.model_runner.lora_manager.add_adapter(lora_request)
+
+    def remove_lora(self, lora_id: int) -> bool:
+        return self.model_runner.lora_manager.remove_adapter(lora_id)
+
+    def list_loras(self) -> set[int]:
+        return self.model_runner.lora_manager.list_adapters()
+
+    def pin_lora(self, lora_id: int) -> bool:
+        return self.model_runner.lora_manager.pin_adapter(lora_id)
+
+    def shutdown(self) -> None:
+        pass
