@@ -1,0 +1,38 @@
+"""Peer-memory all-reduce: N processes sharing the one GPU of the test box map each
+other's arenas through HIP IPC and must reproduce Gloo sums exactly on integer data,
+eagerly and under hipGraph replay (modelled on the reference's
+tests/distributed/test_custom_all_reduce.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_custom_allreduce_shared_gpu(world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", VDA_COMM_SPIN_TIMEOUT_MS="5000")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "scripts", "car_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
+    print(outs[0])

@@ -1,0 +1,67 @@
+"""Tensor / pipeline parallel correctness on CPU (gloo, 2 processes, torchrun-style
+external launcher): every rank must produce the tokens of the single-process run
+(modelled on the reference's tests/distributed/test_torchrun_example.py and
+test_pipeline_parallel.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests.test_e2e_cpu import _save_tiny
+from vllm_distributed_amd import LLM, SamplingParams
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(world, model, out, kw):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "scripts", "run_parallel_llm.py"), model,
+                                       out, json.dumps(kw)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for p, l in zip(procs, logs):
+        assert p.returncode == 0, l[-3000:]
+    return [json.load(open(f"{out}.{r}")) for r in range(world)]
+
+
+def _reference(model):
+    prompts = [[(i * 7 + j) % 300 for j in range(20 + 5 * i)] for i in range(5)]
+    llm = LLM(model=model, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+              max_num_seqs=8, max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=10, ignore_eos=True))
+    llm.shutdown()
+    return [list(o.outputs[0].token_ids) for o in outs]
+
+
+@pytest.mark.parametrize("kind,kw", [("llama", {"tensor_parallel_size": 2}),
+                                     ("opt", {"tensor_parallel_size": 2}),
+                                     ("llama", {"pipeline_parallel_size": 2})])
+def test_two_rank_matches_single(tmp_path, kind, kw):
+    model, _ = _save_tiny(str(tmp_path), kind)
+    ref = _reference(model)
+    got = _launch(2, model, str(tmp_path / "out"), kw)
+    for r, toks in enumerate(got):
+        assert toks == ref, f"rank {r} diverged with {kw}"

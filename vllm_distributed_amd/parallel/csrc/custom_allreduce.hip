@@ -1,0 +1,264 @@
+// Peer-memory all-reduce over xGMI for one node (2..8 GPUs, fully connected).
+//
+// Every rank owns an IPC-exported arena: two staging halves (selected by the
+// parity of a per-block call counter, which removes the end-of-call barrier)
+// and a small uncached signal block.  A call first copies the input into the
+// rank's own staging half, so ANY device tensor can be reduced and nothing has
+// to be registered when a hipGraph is captured.
+//
+//   one-shot  (small, latency bound): barrier; every rank reads the whole buffer
+//             of all peers over all links at once and sums in fp32.
+//   two-shot  (large, bandwidth bound): barrier; rank r reduces slice r of all
+//             peers into its result area (direct reduce-scatter); barrier; every
+//             rank gathers slice s from peer s (direct all-gather).  Per link
+//             traffic is M/N per phase, all N-1 links busy in parallel; a ring would
+//             be bound by one link.
+//
+// Cross-device ordering: data stores -> system-scope fence -> release store of a
+// monotone arrival counter into the peer's signal block; the waiter acquires at
+// system scope before reading peer data.  Every spin is bounded: on time-out an
+// error word is set and the kernel leaves, so a lost peer can never hang the GPU.
+// Role of the reference's csrc/custom_all_reduce.cuh (1-stage :296-312, 2-stage
+// :319-364, ROCm scoped atomics :243-282) and csrc/quickreduce.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#define VDA_EXPORT extern "C" __attribute__((visibility("default")))
+#define MAX_RANKS 8
+#define MAX_BLOCKS 64
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct Signal {
+  // arrival[block][src_rank]: written by src_rank's block `block`, read by the owner
+  alignas(128) uint32_t arrival[MAX_BLOCKS][MAX_RANKS];
+  alignas(128) uint32_t counter[MAX_BLOCKS];   // owner only: barriers passed by this block
+  alignas(128) uint32_t calls[MAX_BLOCKS];     // owner only: calls made (parity selects the staging half)
+  alignas(128) uint32_t error;                 // non-zero after a time-out
+};
+
+struct CarCtx {
+  int rank, world;
+  size_t half_bytes;             // bytes of one staging half (input area + result area)
+  size_t in_bytes;               // input area bytes inside a half
+  char* data[MAX_RANKS];         // peer arenas (own entry is the local pointer)
+  Signal* sig[MAX_RANKS];
+  unsigned long long spin_limit;
+};
+
+struct CarArgs {
+  char* data[MAX_RANKS];
+  Signal* sig[MAX_RANKS];
+  int rank, world;
+  size_t half_bytes, in_bytes;
+  unsigned long long spin_limit;
+};
+
+template <typename T> struct Pack { T v[16 / sizeof(T)]; };
+
+template <typename T> __device__ __forceinline__ void acc_add(float* a, const u32x4& raw) {
+  constexpr int N = 16 / sizeof(T);
+  const T* p = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] += (float)p[i];
+}
+template <typename T> __device__ __forceinline__ u32x4 acc_pack(const float* a) {
+  constexpr int N = 16 / sizeof(T);
+  u32x4 raw;
+  T* p = reinterpret_cast<T*>(&raw);
+#pragma unroll
+  for (int i = 0; i < N; ++i) p[i] = (T)a[i];
+  return raw;
+}
+
+// All ranks' block `blockIdx.x` meet.  Returns false on time-out.
+__device__ __forceinline__ bool cross_barrier(const CarArgs& a, uint32_t target) {
+  __threadfence_system();
+  __syncthreads();
+  __shared__ int ok;
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  if (threadIdx.x < a.world) {
+    const int peer = threadIdx.x;
+    __scoped_atomic_store_n(&a.sig[peer]->arrival[blockIdx.x][a.rank], target, __ATOMIC_RELEASE,
+                            __MEMORY_SCOPE_SYSTEM);
+    unsigned long long spins = 0;
+    while ((int32_t)(__scoped_atomic_load_n(&a.sig[a.rank]->arrival[blockIdx.x][peer], __ATOMIC_ACQUIRE,
+                                            __MEMORY_SCOPE_SYSTEM) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > a.spin_limit) {
+        __scoped_atomic_store_n(&a.sig[a.rank]->error, 1u + (uint32_t)peer, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
+        ok = 0;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence_system();
+  return ok != 0;
+}
+
+// Element ownership is FIXED: 16-byte element i belongs to thread (i mod GRID_THREADS) of the
+// grid, for every call and every message size (the grid is always MAX_BLOCKS x 512).  Each
+// block only synchronises with the same block of the peers, and it only ever touches
+// elements it owns, so "my block passed barrier k+1" implies "the peer block finished
+// reading my call-k data": that is what makes the two staging halves (call parity) safe
+// without an end-of-call barrier.  In the two-shot form sweep j (elements j*GRID_THREADS..)
+// is reduced by rank j mod world, which keeps the ownership rule and spreads slices evenly.
+template <typename T, bool TWO_SHOT>
+__global__ __launch_bounds__(512) void car_kernel(CarArgs a, const u32x4* __restrict__ in, u32x4* __restrict__ out,
+                                                  size_t n16) {
+  Signal* me = a.sig[a.rank];
+  __shared__ uint32_t s_cnt, s_call;
+  if (threadIdx.x == 0) { s_cnt = me->counter[blockIdx.x]; s_call = me->calls[blockIdx.x]; }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;                       // barriers this block has passed so far
+  const size_t half_off = (size_t)(s_call & 1) * a.half_bytes;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  constexpr int N = 16 / sizeof(T);
+
+  // 0) my input -> my staging half (peers read it from there)
+  u32x4* my_in = reinterpret_cast<u32x4*>(a.data[a.rank] + half_off);
+  for (size_t i = tid; i < n16; i += stride) my_in[i] = in[i];
+  bool ok = cross_barrier(a, cnt + 1);
+
+  if (!TWO_SHOT) {
+    if (ok) {
+      for (size_t i = tid; i < n16; i += stride) {
+        u32x4 v[MAX_RANKS];
+#pragma unroll
+        for (int r = 0; r < MAX_RANKS; ++r)
+          if (r < a.world) v[r] = reinterpret_cast<const u32x4*>(a.data[r] + half_off)[i];
+        float acc[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r < MAX_RANKS; ++r)
+          if (r < a.world) acc_add<T>(acc, v[r]);
+        out[i] = acc_pack<T>(acc);
+      }
+    }
+    if (threadIdx.x == 0) { me->counter[blockIdx.x] = cnt + 1; me->calls[blockIdx.x] = s_call + 1; }
+    return;
+  }
+
+  u32x4* my_res = reinterpret_cast<u32x4*>(a.data[a.rank] + half_off + a.in_bytes);
+  if (ok) {
+    // sweeps j = rank, rank + world, ... are mine
+    size_t k = 0;
+    for (size_t i = tid + (size_t)a.rank * stride; i < n16; i += stride * a.world, ++k) {
+      u32x4 v[MAX_RANKS];
+#pragma unroll
+      for (int r = 0; r < MAX_RANKS; ++r)
+        if (r < a.world) v[r] = reinterpret_cast<const u32x4*>(a.data[(a.rank + r) % a.world] + half_off)[i];
+      float acc[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q) acc[q] = 0.f;
+#pragma unroll
+      for (int r = 0; r < MAX_RANKS; ++r)
+        if (r < a.world) acc_add<T>(acc, v[r]);
+      my_res[tid + k * stride] = acc_pack<T>(acc);
+    }
+  }
+  ok = cross_barrier(a, cnt + 2) && ok;
+  if (ok) {
+    size_t j = 0;
+    for (size_t i = tid; i < n16; i += stride, ++j) {
+      const int src = (int)(j % a.world);
+      const u32x4* res = reinterpret_cast<const u32x4*>(a.data[src] + half_off + a.in_bytes);
+      out[i] = res[tid + (j / a.world) * stride];
+    }
+  }
+  if (threadIdx.x == 0) { me->counter[blockIdx.x] = cnt + 2; me->calls[blockIdx.x] = s_call + 1; }
+}
+
+// ---------------------------------------------------------------------------
+// host API
+// ---------------------------------------------------------------------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// Allocate the arena (2 staging halves) and the uncached signal block; return IPC handles.
+VDA_EXPORT int vda_car_alloc(size_t arena_bytes, void** data, void** sig, char* data_handle /*64*/,
+                             char* sig_handle /*64*/) {
+  HIPCHK(hipMalloc(data, arena_bytes));
+  HIPCHK(hipMemset(*data, 0, arena_bytes));
+  HIPCHK(hipExtMallocWithFlags(sig, sizeof(Signal), hipDeviceMallocUncached));
+  HIPCHK(hipMemset(*sig, 0, sizeof(Signal)));
+  HIPCHK(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  HIPCHK(hipIpcGetMemHandle(&h, *data));
+  memcpy(data_handle, &h, sizeof(h));
+  HIPCHK(hipIpcGetMemHandle(&h, *sig));
+  memcpy(sig_handle, &h, sizeof(h));
+  return 0;
+}
+
+VDA_EXPORT int vda_car_open(const char* handle, void** ptr) {
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  HIPCHK(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+  return 0;
+}
+
+VDA_EXPORT int vda_car_close(void* ptr) { return (int)hipIpcCloseMemHandle(ptr); }
+VDA_EXPORT int vda_car_free(void* data, void* sig) { hipFree(data); hipFree(sig); return 0; }
+VDA_EXPORT int vda_car_handle_size() { return (int)sizeof(hipIpcMemHandle_t); }
+
+VDA_EXPORT void* vda_car_create(int rank, int world, void** peer_data, void** peer_sig, size_t half_bytes,
+                                unsigned long long spin_limit) {
+  if (world < 2 || world > MAX_RANKS) return nullptr;
+  CarCtx* c = new CarCtx();
+  c->rank = rank; c->world = world; c->half_bytes = half_bytes;
+  // input area : result area = world : 1 (a result slice is 1/world of the input)
+  // the result area holds ceil(sweeps / world) whole sweeps of MAX_BLOCKS*512 elements
+  const size_t sweep = (size_t)MAX_BLOCKS * 512 * 16;
+  size_t in_b = half_bytes / (world + 1) * world;
+  in_b -= in_b % sweep;
+  while (in_b > 0 && in_b + ((in_b / sweep + world - 1) / world) * sweep > half_bytes) in_b -= sweep;
+  if (in_b == 0) { delete c; return nullptr; }
+  c->in_bytes = in_b;
+  for (int i = 0; i < world; ++i) { c->data[i] = (char*)peer_data[i]; c->sig[i] = (Signal*)peer_sig[i]; }
+  c->spin_limit = spin_limit;
+  return c;
+}
+
+VDA_EXPORT void vda_car_destroy(void* ctx) { delete (CarCtx*)ctx; }
+VDA_EXPORT size_t vda_car_max_bytes(void* ctx) { return ((CarCtx*)ctx)->in_bytes; }
+
+VDA_EXPORT int vda_car_error(void* ctx) {
+  CarCtx* c = (CarCtx*)ctx;
+  uint32_t e = 0;
+  if (hipMemcpy(&e, &c->sig[c->rank]->error, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)e;
+}
+
+// dtype: 0 bf16, 1 f16, 2 f32.  nbytes must be a multiple of 16 and <= vda_car_max_bytes.
+// algo: 0 auto, 1 one-shot, 2 two-shot.  one-shot and two-shot calls share the call counters,
+// so the SAME algorithm must be chosen on every rank for a given call (it is a pure function
+// of nbytes and world size here).
+VDA_EXPORT int vda_car_allreduce(void* ctx, const void* in, void* out, size_t nbytes, int dtype, int algo,
+                                 size_t oneshot_max, hipStream_t st) {
+  CarCtx* c = (CarCtx*)ctx;
+  if (nbytes % 16 || nbytes > c->in_bytes || nbytes == 0) return -1;
+  const size_t n16 = nbytes / 16;
+  if (algo == 0) algo = (c->world == 2 || nbytes <= oneshot_max) ? 1 : 2;
+  CarArgs a;
+  for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
+  a.rank = c->rank; a.world = c->world; a.half_bytes = c->half_bytes; a.in_bytes = c->in_bytes;
+  a.spin_limit = c->spin_limit;
+  const int threads = 512;
+  const int blocks = MAX_BLOCKS;   // fixed grid: see the ownership rule above the kernel
+#define L(T, TS) hipLaunchKernelGGL((car_kernel<T, TS>), dim3(blocks), dim3(threads), 0, st, a, (const u32x4*)in, \
+                                    (u32x4*)out, n16)
+  if (algo == 1) {
+    if (dtype == 0) L(bf16_t, false); else if (dtype == 1) L(f16_t, false); else L(float, false);
+  } else {
+    if (dtype == 0) L(bf16_t, true); else if (dtype == 1) L(f16_t, true); else L(float, true);
+  }
+#undef L
+  return (int)hipGetLastError();
+}

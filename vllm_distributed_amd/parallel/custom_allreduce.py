@@ -1,0 +1,185 @@
+"""Python side of the peer-memory all-reduce (parallel/csrc/custom_allreduce.hip).
+
+Set-up: every rank allocates its arena + signal block, IPC handles are
+all-gathered over Gloo, peers are mapped, and a self-test against a Gloo
+all-reduce decides (collectively) whether the fast path is used at all.
+Because inputs are copied into the arena inside the kernel, there is nothing to
+register when hipGraphs are captured.
+Reference: vllm/distributed/device_communicators/custom_all_reduce.py:49-304,
+quick_all_reduce.py:46-278 (same role: take TP all-reduces off the ring).
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+import os
+import socket
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import envs
+from ..logger import init_logger
+
+logger = init_logger(__name__)
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+_LIB = None
+
+
+def comm_library() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        path = envs.VDA_COMM_LIBRARY or os.path.join(_HERE, "libvda_comm.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `python -m vllm_distributed_amd.ops.build`")
+        lib = ctypes.CDLL(path)
+        vp, sz, i32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_ulonglong
+        lib.vda_car_alloc.argtypes = [sz, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_char_p, ctypes.c_char_p]
+        lib.vda_car_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+        lib.vda_car_close.argtypes = [vp]
+        lib.vda_car_free.argtypes = [vp, vp]
+        lib.vda_car_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), sz, u64]
+        lib.vda_car_create.restype = vp
+        lib.vda_car_destroy.argtypes = [vp]
+        lib.vda_car_max_bytes.argtypes = [vp]
+        lib.vda_car_max_bytes.restype = sz
+        lib.vda_car_error.argtypes = [vp]
+        lib.vda_car_allreduce.argtypes = [vp, vp, vp, sz, i32, i32, sz, vp]
+        _LIB = lib
+    return _LIB
+
+
+class CustomAllReduce:
+    SUPPORTED_WORLD = (2, 3, 4, 5, 6, 7, 8)
+
+    def __init__(self, cpu_group, device: torch.device, arena_mb: int = 0):
+        self.lib = comm_library()
+        self.group = cpu_group
+        self.device = device
+        self.rank = dist.get_rank(cpu_group)
+        self.world = dist.get_world_size(cpu_group)
+        self.disabled = True
+        self.oneshot_max = envs.VDA_CUSTOM_AR_ONESHOT_BYTES
+        want = envs.VDA_CUSTOM_AR_MAX_BYTES
+        # one staging half = input area + result area (1/world of it), two halves in the arena
+        sweep = 64 * 512 * 16
+        in_b = -(-want // sweep) * sweep
+        half = in_b + (-(-(in_b // sweep) // self.world)) * sweep
+        self.half_bytes = half
+        hs = self.lib.vda_car_handle_size()
+        data, sig = ctypes.c_void_p(), ctypes.c_void_p()
+        hd, hsg = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        with torch.cuda.device(device):
+            rc = self.lib.vda_car_alloc(2 * half, ctypes.byref(data), ctypes.byref(sig), hd, hsg)
+        if rc:
+            raise RuntimeError(f"arena allocation failed with HIP error {rc}")
+        self._own = (data, sig)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (hd.raw[:hs], hsg.raw[:hs], socket.gethostname(), os.getpid()),
+                               group=cpu_group)
+        if len({h[2] for h in handles}) != 1:
+            raise RuntimeError("ranks are on different nodes")
+        self._opened = []
+        pd = (ctypes.c_void_p * self.world)()
+        ps = (ctypes.c_void_p * self.world)()
+        with torch.cuda.device(device):
+            for r, (h_d, h_s, _, _) in enumerate(handles):
+                if r == self.rank:
+                    pd[r], ps[r] = data, sig
+                    continue
+                for h, arr in ((h_d, pd), (h_s, ps)):
+                    p = ctypes.c_void_p()
+                    rc = self.lib.vda_car_open(h.ljust(64, b"\0"), ctypes.byref(p))
+                    if rc:
+                        raise RuntimeError(f"hipIpcOpenMemHandle failed with {rc} (peer {r})")
+                    arr[r] = p
+                    self._opened.append(p)
+        # ~100 ns per spin: bound the wait by the configured time-out
+        spins = int(envs.VDA_COMM_SPIN_TIMEOUT_MS * 1e4)
+        self.ctx = self.lib.vda_car_create(self.rank, self.world, pd, ps, half, spins)
+        if not self.ctx:
+            raise RuntimeError("could not create the all-reduce context")
+        self.max_bytes = int(self.lib.vda_car_max_bytes(self.ctx))
+        dist.barrier(group=cpu_group)
+        self.disabled = False
+
+    @classmethod
+    def maybe_create(cls, cpu_group, device: torch.device) -> Optional["CustomAllReduce"]:
+        world = dist.get_world_size(cpu_group)
+        if world not in cls.SUPPORTED_WORLD:
+            return None
+        ok, obj, err = 1, None, ""
+        try:
+            obj = cls(cpu_group, device)
+            ok = int(obj._self_test())
+        except Exception as e:  # noqa: BLE001 - any failure just disables the fast path
+            ok, err = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
+        if int(flag.item()) == 0:
+            if dist.get_rank(cpu_group) == 0:
+                logger.warning("peer-memory all-reduce disabled (%s); using RCCL", err or "self-test failed on a peer")
+            if obj is not None:
+                obj.disabled = True
+            return None
+        if dist.get_rank(cpu_group) == 0:
+            logger.info("peer-memory all-reduce enabled: %d ranks, up to %.0f MiB per launch, one-shot <= %d KiB",
+                        world, obj.max_bytes / 2**20, obj.oneshot_max // 1024)
+        return obj
+
+    def _self_test(self) -> bool:
+        for n in (1024, 300_000, 3_000_000):
+            x = ((torch.arange(n, device=self.device) % 7) + self.rank).to(torch.bfloat16)
+            exp = ((torch.arange(n, device=self.device) % 7) * self.world
+                   + sum(range(self.world))).to(torch.bfloat16)
+            for _ in range(3):          # consecutive calls exercise both staging halves
+                out = self._launch(x)
+                torch.cuda.synchronize(self.device)
+                if self.lib.vda_car_error(self.ctx) != 0 or not torch.equal(out, exp):
+                    return False
+        return True
+
+    def should_use(self, x: torch.Tensor) -> bool:
+        if self.disabled or x.dtype not in _DT or not x.is_contiguous():
+            return False
+        nb = x.numel() * x.element_size()
+        return nb % 16 == 0 and 0 < nb
+
+    def _launch(self, x: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(x)
+        nb = x.numel() * x.element_size()
+        st = torch.cuda.current_stream().cuda_stream
+        off = 0
+        # messages larger than the arena go through it in pieces (each piece keeps all links busy)
+        while off < nb:
+            n = min(self.max_bytes, nb - off)
+            rc = self.lib.vda_car_allreduce(self.ctx, x.data_ptr() + off, out.data_ptr() + off, n, _DT[x.dtype], 0,
+                                            self.oneshot_max, st)
+            if rc:
+                raise RuntimeError(f"peer-memory all-reduce launch failed with {rc}")
+            off += n
+        return out
+
+    def all_reduce(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """Out-of-place sum over the group, or None when this tensor should take the RCCL path."""
+        if not self.should_use(x):
+            return None
+        return self._launch(x)
+
+    def check_error(self) -> int:
+        return int(self.lib.vda_car_error(self.ctx))
+
+    @contextlib.contextmanager
+    def capture(self):
+        yield     # nothing to register: inputs are staged inside the kernel
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None):
+            self.lib.vda_car_destroy(self.ctx)
+            self.ctx = None
+            for p in self._opened:
+                self.lib.vda_car_close(p)
+            self.lib.vda_car_free(*self._own)
+        self.disabled = True

@@ -127,11 +127,14 @@ class GroupCoordinator:
         if dim < 0:
             dim += x.dim()
         x = x.contiguous()
-        out = torch.empty((self.world_size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        if x.dim() == 0:
+            x = x.reshape(1)
+        flat = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         if x.is_cuda and self.rccl_comm is not None:
-            self.rccl_comm.all_gather(out, x)
+            self.rccl_comm.all_gather(flat, x)
         else:
-            dist.all_gather_into_tensor(out, x, group=self.device_group if x.is_cuda else self.cpu_group)
+            dist.all_gather_into_tensor(flat, x, group=self.device_group if x.is_cuda else self.cpu_group)
+        out = flat.view((self.world_size,) + tuple(x.shape))
         if dim == 0:
             return out.reshape((self.world_size * x.shape[0],) + tuple(x.shape[1:]))
         out = out.movedim(0, dim)

@@ -144,10 +144,16 @@ class Worker:
             d = pp.recv_tensor_dict(all_gather_group=tp)
             inter = IntermediateTensors(d)
         out = self.model_runner.execute_model(scheduler_output, inter)
+        # torchrun mode: every rank runs its own scheduler and needs the sampled tokens, so the
+        # last stage shares its result with the earlier stages
+        share = pp.world_size > 1 and scheduler_output.total_num_scheduled_tokens > 0 and \
+            self.parallel_config.distributed_executor_backend == "external_launcher"
         if isinstance(out, IntermediateTensors):
             pp.send_tensor_dict(out.tensors, all_gather_group=tp)
-            return None
-        return out if self.is_driver_worker or True else None
+            return pp.broadcast_object(None, src=pp.world_size - 1) if share else None
+        if share:
+            pp.broadcast_object(out, src=pp.world_size - 1)
+        return out
 
     def profile(self, is_start: bool = True) -> None:
         if self.profiler is None:
