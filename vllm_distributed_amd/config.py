@@ -88,6 +88,12 @@ class HFConfig:
         except KeyError:
             raise AttributeError(k) from None
 
+    def __getstate__(self):
+        return self.__dict__["_d"]
+
+    def __setstate__(self, d):
+        self.__dict__["_d"] = d
+
     def __setattr__(self, k, v):
         self._d[k] = v
 
