@@ -1,0 +1,137 @@
+"""OpenAI-compatible server end to end on CPU: AsyncLLM (engine core in a child
+process) + FastAPI app driven through httpx's ASGI transport (modelled on the
+reference's tests/entrypoints/openai/*)."""
+import asyncio
+import json
+import os
+
+import httpx
+import pytest
+
+from tests.test_e2e_cpu import _save_tiny
+
+
+def _add_tokenizer(path):
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {f"w{i}": i for i in range(316)}
+    vocab.update({"<unk>": 316, "<s>": 317, "</s>": 318, "<pad>": 319})
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>",
+                                   pad_token="<pad>")
+    fast.chat_template = ("{% for m in messages %}{{ m['role'] }} {{ m['content'] }} {% endfor %}"
+                          "{% if add_generation_prompt %}assistant {% endif %}")
+    fast.save_pretrained(path)
+
+
+@pytest.fixture(scope="module")
+def server(tmp_path_factory):
+    from vllm_distributed_amd.entrypoints.openai.api_server import build_app, make_arg_parser
+    from vllm_distributed_amd.engine.arg_utils import AsyncEngineArgs
+    from vllm_distributed_amd.engine.async_llm import AsyncLLM
+    tmp = str(tmp_path_factory.mktemp("srv"))
+    path, _ = _save_tiny(tmp, "llama")
+    _add_tokenizer(path)
+    args = make_arg_parser().parse_args(["--model", path, "--dtype", "float32", "--device", "cpu",
+                                         "--max-model-len", "256", "--max-num-seqs", "8",
+                                         "--max-num-batched-tokens", "64", "--served-model-name", "tiny"])
+    engine = AsyncLLM.from_engine_args(AsyncEngineArgs.from_cli_args(args))
+    app = build_app(args, engine)
+    # the engine's reader tasks live on one event loop: every test must run on it
+    loop = asyncio.new_event_loop()
+    yield app, loop
+    engine.shutdown()
+    loop.close()
+
+
+def _run(server, coro_fn):
+    app, loop = server
+
+    async def go():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://t") as c:
+            return await asyncio.wait_for(coro_fn(c), timeout=120)
+    return loop.run_until_complete(go())
+
+
+def test_models_health_tokenize(server):
+    async def f(c):
+        assert (await c.get("/health")).status_code == 200
+        m = (await c.get("/v1/models")).json()
+        assert m["data"][0]["id"] == "tiny"
+        t = (await c.post("/tokenize", json={"prompt": "w1 w2 w3", "add_special_tokens": False})).json()
+        assert t["tokens"] == [1, 2, 3] and t["count"] == 3
+        d = (await c.post("/detokenize", json={"tokens": [4, 5]})).json()
+        assert d["prompt"] == "w4 w5"
+        assert (await c.post("/v1/completions", json={"model": "nope", "prompt": "w1"})).status_code == 404
+    _run(server, f)
+
+
+def test_completion_and_streaming_agree(server):
+    async def f(c):
+        body = {"model": "tiny", "prompt": "w1 w2 w3 w4", "max_tokens": 8, "temperature": 0, "ignore_eos": True,
+                "logprobs": 2}
+        r = (await c.post("/v1/completions", json=body)).json()
+        ch = r["choices"][0]
+        assert r["usage"]["completion_tokens"] == 8 and ch["finish_reason"] == "length"
+        assert len(ch["logprobs"]["tokens"]) == 8
+        text = ""
+        async with c.stream("POST", "/v1/completions", json={**body, "stream": True, "logprobs": None}) as s:
+            async for line in s.aiter_lines():
+                if line.startswith("data: ") and line != "data: [DONE]":
+                    d = json.loads(line[6:])
+                    if d["choices"]:
+                        text += d["choices"][0]["text"]
+        assert text == ch["text"]
+        # two prompts, n=2
+        r = (await c.post("/v1/completions", json={"prompt": ["w1 w2", "w9"], "max_tokens": 3, "n": 2,
+                                                   "temperature": 0.8, "seed": 1})).json()
+        assert len(r["choices"]) == 4
+    _run(server, f)
+
+
+def test_chat_completion(server):
+    async def f(c):
+        r = (await c.post("/v1/chat/completions", json={"model": "tiny", "max_tokens": 5, "temperature": 0,
+                                                        "messages": [{"role": "user", "content": "w7 w8"}],
+                                                        "logprobs": True, "top_logprobs": 2})).json()
+        ch = r["choices"][0]
+        assert ch["message"]["role"] == "assistant" and r["usage"]["completion_tokens"] == 5
+        assert len(ch["logprobs"]["content"]) == 5 and len(ch["logprobs"]["content"][0]["top_logprobs"]) == 2
+        n = 0
+        async with c.stream("POST", "/v1/chat/completions", json={
+                "messages": [{"role": "user", "content": "w7 w8"}], "max_tokens": 5, "temperature": 0,
+                "stream": True, "stream_options": {"include_usage": True}}) as s:
+            async for line in s.aiter_lines():
+                if line.startswith("data: ") and line != "data: [DONE]":
+                    d = json.loads(line[6:])
+                    if d.get("usage"):
+                        n = d["usage"]["completion_tokens"]
+        assert n == 5
+    _run(server, f)
+
+
+def test_metrics_endpoint(server):
+    async def f(c):
+        await c.post("/v1/completions", json={"prompt": "w1", "max_tokens": 2})
+        txt = (await c.get("/metrics")).text
+        assert "vllm:generation_tokens_total" in txt and "vllm:time_to_first_token_seconds" in txt
+    _run(server, f)
+
+
+def test_serving_benchmark_client(server):
+    """The online benchmark client against the in-process app: all requests succeed and the
+    summary has the streaming latency metrics."""
+    import argparse
+    from vllm_distributed_amd.benchmarks import serve as bs
+    from vllm_distributed_amd.benchmarks.datasets import RandomDataset
+    app, loop = server
+    p = argparse.ArgumentParser()
+    bs.add_cli_args(p)
+    args = p.parse_args(["--model", "tiny", "--base-url", "http://t", "--num-prompts", "6", "--ignore-eos",
+                         "--request-rate", "200", "--max-concurrency", "4", "--goodput", "ttft:60000"])
+    reqs = RandomDataset(None, 0).sample(None, 6, input_len=12, output_len=5, vocab_size=300)
+    res = loop.run_until_complete(asyncio.wait_for(
+        bs.benchmark(args, reqs, transport=httpx.ASGITransport(app=app)), timeout=120))
+    assert res["completed"] == 6 and res["failed"] == 0
+    assert res["total_output_tokens"] == 30 and res["median_ttft_ms"] > 0 and res["request_goodput"] > 0

@@ -1,0 +1,1 @@
+"""Benchmark suite: latency / throughput / online serving (reference: vllm/benchmarks/*, benchmarks/*.py)."""

@@ -271,7 +271,7 @@ class EngineArgs:
 
 @dataclass
 class AsyncEngineArgs(EngineArgs):
-    disable_log_requests: bool = False
+    disable_log_requests: bool = True
 
     @classmethod
     def add_cli_args(cls, parser: argparse.ArgumentParser, async_args_only: bool = False):

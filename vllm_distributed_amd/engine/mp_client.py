@@ -257,15 +257,20 @@ class AsyncMPClient(MPClient):
         self._utility: dict[int, asyncio.Future] = {}
         self._reader_tasks: list[asyncio.Task] = []
         self._loop: Optional[asyncio.AbstractEventLoop] = None
+        self._started: Optional[asyncio.Future] = None
 
     async def _ensure_started(self) -> None:
-        if self.outputs is not None:
+        if self._started is not None:
+            if not self._started.done():      # another coroutine is half-way through the start
+                await asyncio.shield(self._started)
             return
-        self.outputs = asyncio.Queue()
         self._loop = asyncio.get_running_loop()
+        self._started = self._loop.create_future()
+        self.outputs = asyncio.Queue()
         for i, c in enumerate(self.conns):
             self.aconns[i] = await AsyncConnection.from_connection(c)
             self._reader_tasks.append(asyncio.create_task(self._read_loop(i)))
+        self._started.set_result(None)
 
     async def _read_loop(self, i: int) -> None:
         ac = self.aconns[i]

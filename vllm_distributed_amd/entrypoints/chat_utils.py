@@ -1,0 +1,71 @@
+"""Chat templating and content-part handling (reference: vllm/entrypoints/chat_utils.py)."""
+from __future__ import annotations
+
+import json
+from typing import Any, Optional
+
+_FALLBACK_TEMPLATE = (
+    "{% for m in messages %}<|{{ m['role'] }}|>\n{{ m['content'] }}\n{% endfor %}"
+    "{% if add_generation_prompt %}<|assistant|>\n{% endif %}")
+
+
+def _flatten_content(content: Any) -> tuple[str, list[dict]]:
+    """OpenAI content may be a string or a list of typed parts; returns (text, media parts)."""
+    if content is None:
+        return "", []
+    if isinstance(content, str):
+        return content, []
+    texts, media = [], []
+    for part in content:
+        if isinstance(part, str):
+            texts.append(part)
+            continue
+        t = part.get("type")
+        if t in ("text", "input_text"):
+            texts.append(part.get("text", ""))
+        elif t in ("image_url", "audio_url", "video_url", "input_audio", "image_embeds"):
+            media.append(part)
+        elif t == "refusal":
+            texts.append(part.get("refusal", ""))
+        else:
+            raise ValueError(f"unknown content part type {t!r}")
+    return "\n".join(texts), media
+
+
+def parse_chat_messages(messages: list[dict]) -> tuple[list[dict], list[dict]]:
+    conv, media_all = [], []
+    for m in messages:
+        if "role" not in m:
+            raise ValueError("every message needs a role")
+        text, media = _flatten_content(m.get("content"))
+        out = {"role": m["role"], "content": text}
+        if m.get("tool_calls"):
+            tcs = []
+            for tc in m["tool_calls"]:
+                fn = dict(tc.get("function", {}))
+                if isinstance(fn.get("arguments"), str):
+                    try:
+                        fn["arguments"] = json.loads(fn["arguments"])
+                    except json.JSONDecodeError:
+                        pass
+                tcs.append({**tc, "function": fn})
+            out["tool_calls"] = tcs
+        for k in ("name", "tool_call_id"):
+            if k in m:
+                out[k] = m[k]
+        conv.append(out)
+        media_all += media
+    return conv, media_all
+
+
+def apply_chat_template(tokenizer, messages: list[dict], chat_template: Optional[str] = None,
+                        add_generation_prompt: bool = True, continue_final_message: bool = False,
+                        tools: Optional[list[dict]] = None, **kwargs) -> str:
+    conv, _ = parse_chat_messages(messages)
+    template = chat_template or getattr(tokenizer, "chat_template", None)
+    if template is None:
+        from jinja2 import Template
+        return Template(_FALLBACK_TEMPLATE).render(messages=conv, add_generation_prompt=add_generation_prompt)
+    return tokenizer.apply_chat_template(conv, chat_template=chat_template, tokenize=False,
+                                         add_generation_prompt=add_generation_prompt,
+                                         continue_final_message=continue_final_message, tools=tools, **kwargs)
