@@ -65,3 +65,39 @@ def test_two_rank_matches_single(tmp_path, kind, kw):
     got = _launch(2, model, str(tmp_path / "out"), kw)
     for r, toks in enumerate(got):
         assert toks == ref, f"rank {r} diverged with {kw}"
+
+
+@pytest.mark.parametrize("kw", [{"tensor_parallel_size": 2}, {"pipeline_parallel_size": 2}])
+def test_multiproc_executor_matches_single(tmp_path, kw):
+    """Worker processes behind the shared-memory RPC ring (the default executor for TP/PP>1);
+    PP=2 also exercises the batch queue with two batches in flight."""
+    model, _ = _save_tiny(str(tmp_path), "llama")
+    ref = _reference(model)
+    prompts = [[(i * 7 + j) % 300 for j in range(20 + 5 * i)] for i in range(5)]
+    llm = LLM(model=model, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+              max_num_seqs=8, max_num_batched_tokens=64, distributed_executor_backend="mp", **kw)
+    try:
+        outs = llm.generate(prompt_token_ids=prompts,
+                            sampling_params=SamplingParams(temperature=0, max_tokens=10, ignore_eos=True))
+        assert [list(o.outputs[0].token_ids) for o in outs] == ref
+        ex = llm.llm_engine.engine_core.engine_core.model_executor
+        assert ex.collective_rpc("check_health") == [True, True]
+    finally:
+        llm.shutdown()
+
+
+def test_multiproc_executor_reports_worker_death(tmp_path):
+    import signal
+    import threading
+    model, _ = _save_tiny(str(tmp_path), "llama")
+    llm = LLM(model=model, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128,
+              max_num_seqs=4, max_num_batched_tokens=64, distributed_executor_backend="mp", tensor_parallel_size=2)
+    ex = llm.llm_engine.engine_core.engine_core.model_executor
+    fired = threading.Event()
+    ex.register_failure_callback(fired.set)
+    os.kill(ex.workers[1].proc.pid, signal.SIGKILL)
+    assert fired.wait(20)
+    assert ex.is_failed
+    with pytest.raises(RuntimeError):
+        ex.collective_rpc("check_health")
+    llm.shutdown()

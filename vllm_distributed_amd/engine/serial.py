@@ -18,7 +18,8 @@ import msgpack
 import numpy as np
 import torch
 
-_EXT_NDARRAY, _EXT_TENSOR, _EXT_STRUCT, _EXT_SET, _EXT_TUPLE, _EXT_ENUM, _EXT_BYTES_ENUM = 1, 2, 3, 4, 5, 6, 7
+_EXT_NDARRAY, _EXT_TENSOR, _EXT_STRUCT, _EXT_SET, _EXT_TUPLE, _EXT_ENUM, _EXT_BYTES_ENUM, _EXT_DTYPE = \
+    1, 2, 3, 4, 5, 6, 7, 8
 _BY_ID: dict[int, type] = {}
 _BY_CLS: dict[type, int] = {}
 _ENUMS: dict[int, type] = {}
@@ -63,6 +64,8 @@ def _default(obj: Any):
         name = str(t.dtype).replace("torch.", "")
         raw = t.view(torch.uint8).numpy().tobytes() if t.numel() else b""
         return msgpack.ExtType(_EXT_TENSOR, _pack([name, list(t.shape), raw]))
+    if isinstance(obj, torch.dtype):
+        return msgpack.ExtType(_EXT_DTYPE, str(obj).replace("torch.", "").encode())
     if isinstance(obj, np.ndarray):
         a = np.ascontiguousarray(obj)
         return msgpack.ExtType(_EXT_NDARRAY, _pack([a.dtype.str, list(a.shape), a.tobytes()]))
@@ -98,6 +101,8 @@ def _ext_hook(code: int, data: bytes):
     if code == _EXT_NDARRAY:
         dts, shape, raw = _unpack(data)
         return np.frombuffer(raw, dtype=np.dtype(dts)).reshape(shape).copy()
+    if code == _EXT_DTYPE:
+        return getattr(torch, data.decode())
     if code == _EXT_SET:
         return set(_unpack(data))
     if code == _EXT_TUPLE:
@@ -142,6 +147,10 @@ def _register_engine_types() -> None:
                              S.SchedulerStats, S.PrefixCacheStats, S.SpecDecodingStats,
                              O.NewRequestData, O.CachedRequestData, O.SchedulerOutput, O.ModelRunnerOutput,
                              O.TokenParallelAllocation, GuidedDecodingParams), start=1):
+        wire_struct(i)(cls)
+    from ..sched import kv_cache_interface as K
+    for i, cls in enumerate((K.FullAttentionSpec, K.SlidingWindowSpec, K.MambaSpec, K.KVCacheTensor,
+                             K.KVCacheGroupSpec, K.KVCacheConfig), start=40):
         wire_struct(i)(cls)
     wire_custom(100, SamplingParams, SamplingParams.to_wire, SamplingParams.from_wire)
     wire_custom(101, PoolingParams, PoolingParams.to_wire, PoolingParams.from_wire)

@@ -5,7 +5,8 @@ without a GPU).
 
 Produces, next to this file:
     libvda_ops.so    HIP kernels of ops/csrc/*.hip (C ABI, loaded with ctypes)
-    libvda_comm.so   peer-memory collectives + host runtime of parallel/csrc
+    libvda_comm.so   peer-memory collectives of parallel/csrc
+    libvda_host.so   host-only runtime of runtime/csrc (g++): shared-memory RPC ring
 Object files and content hashes live in ops/build/ so unchanged sources are
 not recompiled.
 """
@@ -34,6 +35,13 @@ LIBS = {
         "out": os.path.join(PKG, "parallel", "libvda_comm.so"),
         "ldflags": ["-lpthread", "-lrt"],
     },
+    # host-only runtime (no device code): shared-memory RPC ring, block hashing
+    "libvda_host.so": {
+        "dir": os.path.join(PKG, "runtime", "csrc"),
+        "out": os.path.join(PKG, "runtime", "libvda_host.so"),
+        "ldflags": ["-lpthread", "-lrt"],
+        "host": True,
+    },
 }
 
 
@@ -53,12 +61,12 @@ def _digest(path: str, extra: str) -> str:
     return h.hexdigest()
 
 
-def _compile_one(src: str, obj: str, flags: list[str], force: bool) -> tuple[str, bool]:
+def _compile_one(src: str, obj: str, flags: list[str], force: bool, cc: str | None = None) -> tuple[str, bool]:
     stamp = obj + ".sha"
     want = _digest(src, " ".join(flags))
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return src, False
-    cmd = [_hipcc(), *flags, "-c", src, "-o", obj]
+    cmd = [cc or _hipcc(), *flags, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -83,14 +91,18 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
         os.makedirs(objdir, exist_ok=True)
         objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in srcs]
         changed = False
+        host = spec.get("host", False)
+        cc = (shutil.which("g++") or "g++") if host else None
+        fl = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DNDEBUG"] if host else flags
         with ThreadPoolExecutor(jobs) as ex:
-            for src, did in ex.map(lambda a: _compile_one(a[0], a[1], flags, force), zip(srcs, objs)):
+            for src, did in ex.map(lambda a: _compile_one(a[0], a[1], fl, force, cc), zip(srcs, objs)):
                 changed |= did
                 if verbose and did:
                     print(f"[build] compiled {os.path.relpath(src, PKG)}", flush=True)
         out = spec["out"]
         if changed or not os.path.exists(out):
-            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs, *spec["ldflags"]]
+            cmd = [cc, "-shared", "-fPIC", "-o", out, *objs, *spec["ldflags"]] if host else \
+                [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs, *spec["ldflags"]]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"link failed for {name}:\n{r.stdout}\n{r.stderr}")

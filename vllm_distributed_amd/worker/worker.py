@@ -121,7 +121,9 @@ class Worker:
                     max(non_torch, 0) / 2**30, graph_reserve / 2**30, avail / 2**30)
         return int(max(avail, 0))
 
-    def initialize_from_config(self, kv_cache_config: KVCacheConfig) -> None:
+    def initialize_from_config(self, kv_cache_config) -> None:
+        if isinstance(kv_cache_config, (list, tuple)):      # one entry per rank, or one for all
+            kv_cache_config = kv_cache_config[self.rank if len(kv_cache_config) > 1 else 0]
         self.model_runner.initialize_kv_cache(kv_cache_config)
 
     def compile_or_warm_up_model(self) -> None:
