@@ -125,7 +125,8 @@ class AsyncLLM:
             if self.tracer is not None:
                 from ..tracing import record_request_span
                 record_request_span(self.tracer, request_id, t0, out, trace_headers)
-        except asyncio.CancelledError:
+        except (asyncio.CancelledError, GeneratorExit):
+            # task cancelled (client disconnect) or generator closed early by the caller
             await self.abort(request_id)
             if self.log_requests:
                 logger.info("request %s aborted (client cancelled)", request_id)
@@ -149,7 +150,7 @@ class AsyncLLM:
                 out = q.get_nowait() or await q.get()
                 finished = out.finished
                 yield out
-        except asyncio.CancelledError:
+        except (asyncio.CancelledError, GeneratorExit):
             await self.abort(request_id)
             raise
 

@@ -175,6 +175,9 @@ class EngineCore:
                        kwargs: Optional[dict] = None) -> list:
         return self.model_executor.collective_rpc(method, timeout, args, kwargs)
 
+    def execute_dummy_batch(self) -> None:
+        self.model_executor.collective_rpc("execute_dummy_batch")
+
     def get_request_counts(self) -> tuple[int, int]:
         return self.scheduler.get_request_counts()
 

@@ -410,6 +410,14 @@ class DPAsyncMPClient(AsyncMPClient):
         if msg.wave_complete is not None:
             self.current_wave = max(self.current_wave, msg.wave_complete + 1)
             self.engines_running = False
+        if msg.start_wave is not None and (not self.engines_running or msg.start_wave >= self.current_wave):
+            # an engine got a request stamped with a wave that is already over: wake the others
+            self.current_wave = msg.start_wave
+            self.engines_running = True
+            for i in range(len(self.conns)):
+                if i != engine:
+                    asyncio.ensure_future(self._send(i, EngineCoreRequestType.START_DP_WAVE,
+                                                     (self.current_wave, engine)))
         if msg.scheduler_stats is not None:
             self.counts[engine] = [msg.scheduler_stats.num_waiting_reqs, msg.scheduler_stats.num_running_reqs]
 

@@ -119,8 +119,9 @@ class MultiprocExecutor(Executor):
         ctx = mp.get_context(envs.VLLM_WORKER_MULTIPROC_METHOD)
         self.workers: list[_WorkerHandle] = []
         ready = []
-        # with DP each engine owns a contiguous window of the node's devices
-        base = pc.data_parallel_rank_local * self.world_size if pc.data_parallel_size > 1 else 0
+        # a data-parallel engine sees only its own window of the node's devices (the engine
+        # manager masks them), so local ranks always start at 0
+        base = 0
         try:
             for rank in range(self.world_size):
                 parent, child = ctx.Pipe(duplex=False)

@@ -70,9 +70,15 @@ class Worker:
             self.device = torch.device("cpu")
             self.init_free = self.total_memory = current_platform.total_memory()
             backend = "gloo"
-        world = pc.world_size
-        pstate.init_distributed_environment(world, self.rank, self.distributed_init_method, self.local_rank, backend)
-        pstate.ensure_model_parallel_initialized(pc.tensor_parallel_size, pc.pipeline_parallel_size, 1,
+        world, rank, init, dp = pc.world_size, self.rank, self.distributed_init_method, 1
+        from ..engine.dp import needs_lockstep
+        if needs_lockstep(self.vllm_config):
+            # expert parallelism spans the data-parallel replicas: one world over all of them
+            dp = pc.data_parallel_size
+            world, rank = dp * pc.world_size, pc.data_parallel_rank * pc.world_size + self.rank
+            init = f"tcp://{pc.data_parallel_master_ip}:{pc.data_parallel_master_port}"
+        pstate.init_distributed_environment(world, rank, init, self.local_rank, backend)
+        pstate.ensure_model_parallel_initialized(pc.tensor_parallel_size, pc.pipeline_parallel_size, dp,
                                                  pc.token_parallel_size)
         current_platform.seed_everything(self.vllm_config.model_config.seed)
         self.model_runner = ModelRunner(self.vllm_config, self.device)
@@ -167,6 +173,12 @@ class Worker:
 
     def check_health(self) -> bool:
         return True
+
+    @torch.inference_mode()
+    def execute_dummy_batch(self) -> None:
+        """One-token forward pass that produces nothing: keeps cross-replica collectives matched
+        while this data-parallel replica has no requests."""
+        self.model_runner._dummy_run(1)
 
     # ---- sleep / wake (RLHF co-location) -------------------------------------
     def sleep(self, level: int = 1) -> None:
