@@ -29,13 +29,31 @@ def _save_tiny(tmp, kind):
     elif kind == "gpt2":
         cfg = tf.GPT2Config(vocab_size=320, n_embd=128, n_layer=2, n_head=2, n_positions=256)
         m = tf.GPT2LMHeadModel(cfg)
+    elif kind == "mixtral":
+        cfg = tf.MixtralConfig(vocab_size=320, hidden_size=128, intermediate_size=128, num_hidden_layers=2,
+                               num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                               num_local_experts=4, num_experts_per_tok=2, sliding_window=None, head_dim=64)
+        m = tf.MixtralForCausalLM(cfg)
+    elif kind == "qwen2_moe":
+        cfg = tf.Qwen2MoeConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=256,
+                                num_experts=4, num_experts_per_tok=2, moe_intermediate_size=128,
+                                shared_expert_intermediate_size=128, decoder_sparse_step=1, norm_topk_prob=False,
+                                use_sliding_window=False)
+        m = tf.Qwen2MoeForCausalLM(cfg)
+    elif kind == "qwen3_moe":
+        cfg = tf.Qwen3MoeConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=256,
+                                num_experts=4, num_experts_per_tok=2, moe_intermediate_size=128, head_dim=64,
+                                decoder_sparse_step=1, norm_topk_prob=True, use_sliding_window=False)
+        m = tf.Qwen3MoeForCausalLM(cfg)
     m = m.float().eval()
     path = os.path.join(tmp, kind)
     m.save_pretrained(path, safe_serialization=True)
     return path, m
 
 
-@pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2"])
+@pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2", "mixtral", "qwen2_moe", "qwen3_moe"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

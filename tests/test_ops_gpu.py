@@ -341,3 +341,89 @@ def test_copy_and_transfer_blocks():
     dst = torch.zeros_like(c)
     ops.transfer_blocks(dst, c, torch.tensor([0, 3], device=DEV), torch.tensor([5, 9], device=DEV))
     assert torch.equal(dst[0], c[5]) and torch.equal(dst[3], c[9]) and dst[1].abs().sum() == 0
+
+
+# ---- mixture of experts -------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("T,E,k", [(1, 8, 2), (33, 8, 2), (257, 128, 8), (5, 60, 4), (64, 256, 6)])
+@pytest.mark.parametrize("renorm", [True, False])
+def test_moe_topk_softmax(dt, T, E, k, renorm):
+    lg = torch.randn(T, E, device=DEV, dtype=dt)
+    w, ids = ops.moe_topk_softmax(lg, k, renorm)
+    w_ref, ids_ref = R.moe_topk_softmax(lg, k, renorm)
+    assert torch.equal(ids.sort(dim=-1).values, ids_ref.sort(dim=-1).values)
+    # same expert -> same weight, whatever the order inside the top-k
+    dense = torch.zeros(T, E, device=DEV).scatter_(1, ids.long(), w)
+    dense_ref = torch.zeros(T, E, device=DEV).scatter_(1, ids_ref.long(), w_ref)
+    torch.testing.assert_close(dense, dense_ref, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,E,k,H,I", [(1, 8, 2, 512, 256), (17, 8, 2, 1024, 512), (130, 8, 2, 512, 384),
+                                       (64, 64, 6, 256, 128), (300, 4, 2, 256, 128)])
+def test_fused_moe_grouped(dt, T, E, k, H, I):
+    x = torch.randn(T, H, device=DEV, dtype=dt) * 0.5
+    w13 = torch.randn(E, 2 * I, H, device=DEV, dtype=dt) * (H ** -0.5)
+    w2 = torch.randn(E, H, I, device=DEV, dtype=dt) * (I ** -0.5)
+    tw, ids = R.moe_topk_softmax(torch.randn(T, E, device=DEV), k, True)
+    out = ops.fused_moe(x, w13, w2, tw, ids)
+    ref = R.fused_moe(x, w13, w2, tw, ids)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
+def test_fused_moe_expert_parallel_mask_and_large_path(monkeypatch):
+    dt = torch.bfloat16
+    T, E, k, H, I = 96, 8, 2, 512, 256
+    x = torch.randn(T, H, device=DEV, dtype=dt) * 0.5
+    w13 = torch.randn(E, 2 * I, H, device=DEV, dtype=dt) * (H ** -0.5)
+    w2 = torch.randn(E, H, I, device=DEV, dtype=dt) * (I ** -0.5)
+    tw, ids = R.moe_topk_softmax(torch.randn(T, E, device=DEV), k, True)
+    # this "rank" owns experts 2..5 only: global -> local map with -1 elsewhere
+    emap = torch.full((E,), -1, dtype=torch.int32, device=DEV)
+    emap[2:6] = torch.arange(4, dtype=torch.int32, device=DEV)
+    local = emap[ids.long()]
+    ref = R.fused_moe(x, w13[2:6], w2[2:6], tw, local)
+    out = ops.fused_moe(x, w13[2:6].contiguous(), w2[2:6].contiguous(), tw, local)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+    monkeypatch.setenv("VDA_MOE_GROUPED_MAX_PAIRS", "16")        # force the sorted hipBLASLt path
+    out2 = ops.fused_moe(x, w13[2:6].contiguous(), w2[2:6].contiguous(), tw, local)
+    torch.testing.assert_close(out2.float(), ref.float(), **tol(dt))
+
+
+def test_fused_moe_fp8_weights():
+    dt = torch.bfloat16
+    T, E, k, H, I = 40, 8, 2, 512, 256
+    x = torch.randn(T, H, device=DEV, dtype=dt) * 0.5
+    w13 = torch.randn(E, 2 * I, H, device=DEV, dtype=dt) * (H ** -0.5)
+    w2 = torch.randn(E, H, I, device=DEV, dtype=dt) * (I ** -0.5)
+    s13 = w13.float().abs().amax(dim=(1, 2)) / 448.0
+    s2 = w2.float().abs().amax(dim=(1, 2)) / 448.0
+    q13 = (w13.float() / s13.view(E, 1, 1)).to(torch.float8_e4m3fn)
+    q2 = (w2.float() / s2.view(E, 1, 1)).to(torch.float8_e4m3fn)
+    tw, ids = R.moe_topk_softmax(torch.randn(T, E, device=DEV), k, True)
+    out = ops.fused_moe(x, q13, q2, tw, ids, s13, s2)
+    ref = R.fused_moe(x, q13, q2, tw, ids, s13, s2)
+    torch.testing.assert_close(out.float(), ref.float(), atol=3e-2, rtol=3e-2)
+
+
+def test_fused_moe_graph_capture():
+    dt = torch.bfloat16
+    T, E, k, H, I = 16, 8, 2, 512, 256
+    x = torch.randn(T, H, device=DEV, dtype=dt) * 0.5
+    w13 = torch.randn(E, 2 * I, H, device=DEV, dtype=dt) * (H ** -0.5)
+    w2 = torch.randn(E, H, I, device=DEV, dtype=dt) * (I ** -0.5)
+    lg = torch.randn(T, E, device=DEV, dtype=dt)
+
+    def run():
+        tw, ids = ops.moe_topk_softmax(lg, k, True)
+        return ops.fused_moe(x, w13, w2, tw, ids)
+    run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = run()
+    lg.copy_(torch.randn(T, E, device=DEV, dtype=dt))      # new routing, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    tw, ids = R.moe_topk_softmax(lg, k, True)
+    torch.testing.assert_close(out.float(), R.fused_moe(x, w13, w2, tw, ids).float(), **tol(dt))

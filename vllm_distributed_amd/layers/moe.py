@@ -1,0 +1,188 @@
+"""Routed mixture-of-experts layer with tensor- and expert-parallel sharding.
+
+Weights of all local experts live in two stacked tensors, K-contiguous per row:
+    w13_weight [E_local, 2 * I_shard, H]   gate rows then up rows
+    w2_weight  [E_local, H, I_shard]
+Tensor parallel shards I; expert parallel (``enable_expert_parallel``) instead gives each rank
+of the EP group (TP x DP ranks) a contiguous range of whole experts and leaves I unsharded.
+Either way every rank computes a partial sum over its weights for the tokens it sees and the
+partial sums are all-reduced over the TP group; with data-parallel attention in front, tokens
+are first all-gathered over the DP group and the result is reduce-scattered back (dispatch /
+combine of parallel/all2all.py).
+
+Reference: vllm/model_executor/layers/fused_moe/layer.py (FusedMoE :829-1568: expert map :780,
+weight_loader :1045-1259, select_experts :1261-1364, forward_impl :1496), fused_moe.py.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..config import get_current_vllm_config
+from ..parallel.state import (get_dp_group, get_ep_group, get_tensor_model_parallel_rank,
+                              get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce)
+from .linear import set_weight_attrs
+
+
+def determine_expert_map(ep_size: int, ep_rank: int, global_num_experts: int) -> tuple[int, Optional[torch.Tensor]]:
+    """Contiguous ranges, the first ``E % ep`` ranks take one extra expert.  Returns the local count
+    and a [E_global] int32 map global id -> local id (-1 = elsewhere); None without EP."""
+    if ep_size == 1:
+        return global_num_experts, None
+    base, rem = divmod(global_num_experts, ep_size)
+    local = base + (1 if ep_rank < rem else 0)
+    start = ep_rank * base + min(ep_rank, rem)
+    m = torch.full((global_num_experts,), -1, dtype=torch.int32)
+    m[start:start + local] = torch.arange(local, dtype=torch.int32)
+    return local, m
+
+
+def grouped_topk(scores: torch.Tensor, k: int, renormalize: bool, num_expert_group: int, topk_group: int,
+                 bias: Optional[torch.Tensor] = None):
+    """DeepSeek-style routing: keep the best ``topk_group`` groups of experts, then top-k inside."""
+    T, E = scores.shape
+    sel = scores + bias.unsqueeze(0) if bias is not None else scores
+    g = sel.view(T, num_expert_group, -1)
+    gscore = g.topk(2, dim=-1)[0].sum(-1) if bias is not None else g.max(dim=-1).values
+    gidx = gscore.topk(topk_group, dim=-1, sorted=False)[1]
+    gmask = torch.zeros_like(gscore).scatter_(1, gidx, 1.0)
+    mask = gmask.unsqueeze(-1).expand(T, num_expert_group, E // num_expert_group).reshape(T, E)
+    masked = sel.masked_fill(mask == 0, float("-inf"))
+    ids = masked.topk(k, dim=-1, sorted=False)[1]
+    w = scores.gather(1, ids)
+    if renormalize:
+        w = w / w.sum(dim=-1, keepdim=True)
+    return w.float(), ids.to(torch.int32)
+
+
+class UnquantizedMoEMethod:
+    def create_weights(self, layer: "FusedMoE", E: int, H: int, I: int, dtype: torch.dtype) -> None:
+        w13 = nn.Parameter(torch.empty(E, 2 * I, H, dtype=dtype), requires_grad=False)
+        w2 = nn.Parameter(torch.empty(E, H, I, dtype=dtype), requires_grad=False)
+        layer.register_parameter("w13_weight", w13)
+        layer.register_parameter("w2_weight", w2)
+        for p in (w13, w2):
+            set_weight_attrs(p, {"weight_loader": layer.weight_loader})
+
+    def process_weights_after_loading(self, layer: "FusedMoE") -> None:
+        pass
+
+    def apply(self, layer: "FusedMoE", x: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+        return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids)
+
+
+class FusedMoE(nn.Module):
+    def __init__(self, num_experts: int, top_k: int, hidden_size: int, intermediate_size: int,
+                 params_dtype: Optional[torch.dtype] = None, reduce_results: bool = True, renormalize: bool = True,
+                 use_grouped_topk: bool = False, num_expert_group: Optional[int] = None,
+                 topk_group: Optional[int] = None, quant_config=None, prefix: str = "",
+                 custom_routing_function: Optional[Callable] = None, scoring_func: str = "softmax",
+                 e_score_correction_bias: Optional[torch.Tensor] = None, routed_scaling_factor: float = 1.0):
+        super().__init__()
+        self.params_dtype = params_dtype or torch.get_default_dtype()
+        self.global_num_experts, self.top_k = num_experts, top_k
+        self.hidden_size = hidden_size
+        self.prefix = prefix
+        self.reduce_results, self.renormalize = reduce_results, renormalize
+        self.use_grouped_topk, self.num_expert_group, self.topk_group = use_grouped_topk, num_expert_group, topk_group
+        self.custom_routing_function, self.scoring_func = custom_routing_function, scoring_func
+        self.e_score_correction_bias = e_score_correction_bias
+        self.routed_scaling_factor = routed_scaling_factor
+        pc = get_current_vllm_config().parallel_config
+        self.tp_size, self.tp_rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        self.dp_size = get_dp_group().world_size
+        self.use_ep = bool(pc.enable_expert_parallel) and get_ep_group().world_size > 1
+        if self.use_ep:
+            ep = get_ep_group()
+            self.ep_size, self.ep_rank = ep.world_size, ep.rank_in_group
+            self.local_num_experts, emap = determine_expert_map(self.ep_size, self.ep_rank, num_experts)
+            self.register_buffer("expert_map", emap, persistent=False)
+            self.shard_size, self.shard_rank = 1, 0           # whole experts: I is not split
+        else:
+            self.ep_size, self.ep_rank = 1, 0
+            self.local_num_experts, self.expert_map = num_experts, None
+            self.shard_size, self.shard_rank = self.tp_size, self.tp_rank
+        if intermediate_size % self.shard_size:
+            raise ValueError(f"{prefix}: intermediate size {intermediate_size} not divisible by TP {self.shard_size}")
+        self.intermediate_size_per_partition = intermediate_size // self.shard_size
+        qm = quant_config.get_quant_method(self, prefix) if quant_config is not None else None
+        self.quant_method = qm or UnquantizedMoEMethod()
+        self.quant_method.create_weights(self, self.local_num_experts, hidden_size,
+                                         self.intermediate_size_per_partition, self.params_dtype)
+
+    # ---- weight loading -------------------------------------------------------------------
+    def weight_loader(self, param: nn.Parameter, loaded: torch.Tensor, shard_id: str, expert_id: int) -> bool:
+        """``shard_id`` in {"w1" (gate), "w3" (up), "w2" (down)}; ``expert_id`` is global.
+        Returns False when the expert is not local (nothing loaded)."""
+        local = expert_id
+        if self.expert_map is not None:
+            local = int(self.expert_map[expert_id])
+            if local < 0:
+                return False
+        I = self.intermediate_size_per_partition
+        kind = getattr(param, "moe_kind", "weight")
+        if kind == "scale_per_expert":
+            # one scalar per (expert, projection); w1/w3 kept apart until post-processing
+            if param.dim() == 2:
+                param.data[local, {"w1": 0, "w3": 1}.get(shard_id, 0)] = loaded.reshape(()).to(param.dtype)
+            else:
+                param.data[local] = loaded.reshape(()).to(param.dtype)
+            return True
+        if shard_id == "w2":
+            src = loaded.narrow(1, self.shard_rank * I, I) if self.shard_size > 1 else loaded
+            param.data[local].copy_(src)
+        else:
+            src = loaded.narrow(0, self.shard_rank * I, I) if self.shard_size > 1 else loaded
+            off = 0 if shard_id == "w1" else I
+            param.data[local, off:off + I].copy_(src)
+        return True
+
+    @staticmethod
+    def make_expert_params_mapping(gate_name: str, down_name: str, up_name: str, num_experts: int
+                                   ) -> list[tuple[str, str, int, str]]:
+        """(param fragment, checkpoint fragment, expert id, shard id) for every expert/projection."""
+        out = []
+        for e in range(num_experts):
+            for sid, ck in (("w1", gate_name), ("w2", down_name), ("w3", up_name)):
+                out.append(("experts.w13_" if sid != "w2" else "experts.w2_", f"experts.{e}.{ck}.", e, sid))
+        return out
+
+    # ---- routing + compute ----------------------------------------------------------------------
+    def select_experts(self, router_logits: torch.Tensor):
+        k = self.top_k
+        if self.custom_routing_function is not None:
+            w, ids = self.custom_routing_function(router_logits, k, self.renormalize)
+            return w.float(), ids.to(torch.int32)
+        if self.use_grouped_topk:
+            scores = torch.softmax(router_logits.float(), -1) if self.scoring_func == "softmax" \
+                else torch.sigmoid(router_logits.float())
+            return grouped_topk(scores, k, self.renormalize, self.num_expert_group, self.topk_group,
+                                self.e_score_correction_bias)
+        if self.scoring_func == "sigmoid":
+            scores = torch.sigmoid(router_logits.float())
+            w, ids = scores.topk(k, dim=-1)
+            if self.renormalize:
+                w = w / w.sum(-1, keepdim=True)
+            return w, ids.to(torch.int32)
+        return ops.moe_topk_softmax(router_logits, k, self.renormalize)
+
+    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
+        x, lg = hidden_states, router_logits
+        dispatch = self.dp_size > 1
+        if dispatch:
+            from ..parallel.all2all import dp_combine, dp_dispatch
+            x, lg, meta = dp_dispatch(x, lg)
+        topk_w, topk_ids = self.select_experts(lg)
+        if self.expert_map is not None:
+            topk_ids = self.expert_map[topk_ids.long()]
+        if self.routed_scaling_factor != 1.0:
+            topk_w = topk_w * self.routed_scaling_factor
+        out = self.quant_method.apply(self, x, topk_w, topk_ids)
+        if dispatch:
+            out = dp_combine(out, meta)
+        if self.reduce_results and (self.tp_size > 1 or self.ep_size > 1):
+            out = tensor_model_parallel_all_reduce(out)
+        return out

@@ -82,6 +82,8 @@ class LlamaDecoderLayer(nn.Module):
         super().__init__()
         mc = vllm_config.model_config
         rope_scaling = getattr(config, "rope_scaling", None) or getattr(config, "rope_parameters", None)
+        # newer HF configs keep theta inside rope_parameters
+        rope_theta = getattr(config, "rope_theta", None) or (rope_scaling or {}).get("rope_theta") or 10000.0
         if rope_scaling and "rope_type" not in rope_scaling and "type" not in rope_scaling:
             rope_scaling = None
         bias = bool(getattr(config, "attention_bias", False) or getattr(config, "bias", False))
@@ -96,7 +98,7 @@ class LlamaDecoderLayer(nn.Module):
         self.self_attn = LlamaAttention(
             config, config.hidden_size, config.num_attention_heads,
             getattr(config, "num_key_value_heads", None) or config.num_attention_heads,
-            getattr(config, "rope_theta", 10000.0), rope_scaling, mc.max_model_len, bias=bias, o_bias=False
+            rope_theta, rope_scaling, mc.max_model_len, bias=bias, o_bias=False
             if arch.startswith("Qwen") else bias, sliding_window=window, quant_config=quant_config,
             prefix=f"{prefix}.self_attn", qk_norm=arch.startswith("Qwen3"),
             cache_dtype=vllm_config.cache_config.cache_dtype)

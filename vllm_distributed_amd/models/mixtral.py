@@ -1,0 +1,133 @@
+"""Sparse mixture-of-experts decoders: Mixtral (8x7B / 8x22B) and Qwen2-MoE / Qwen3-MoE.
+
+Attention is the Llama block; the MLP is a replicated router GEMM followed by the fused
+routed-expert layer (top-k softmax -> counting sort -> grouped gate/up + down GEMMs -> sum),
+optionally plus a shared dense expert (Qwen2-MoE).
+Reference: vllm/model_executor/models/mixtral.py (MixtralMoE :60-122, load_weights :362-470),
+qwen2_moe.py (Qwen2MoeSparseMoeBlock :102-177), qwen3_moe.py.
+"""
+from __future__ import annotations
+
+from typing import Iterable
+
+import torch
+import torch.nn as nn
+
+from ..layers.linear import ReplicatedLinear
+from ..layers.moe import FusedMoE
+from ..parallel.state import get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce
+from .llama import LlamaDecoderLayer, LlamaForCausalLM, LlamaMLP, LlamaModel
+from .utils import load_weights_with_mapping
+
+
+def _num_experts(config) -> int:
+    # "num_experts" in Qwen checkpoints, "num_local_experts" in Mixtral ones and in configs
+    # re-saved by recent transformers
+    for k in ("num_experts", "num_local_experts", "n_routed_experts"):
+        v = getattr(config, k, None)
+        if v:
+            return int(v)
+    return 0
+
+
+class SparseMoeBlock(nn.Module):
+    def __init__(self, hidden_size: int, intermediate_size: int, num_experts: int, top_k: int, renormalize: bool,
+                 quant_config=None, prefix: str = "", shared_intermediate: int = 0, shared_gate: bool = False):
+        super().__init__()
+        self.gate = ReplicatedLinear(hidden_size, num_experts, bias=False, quant_config=None, prefix=f"{prefix}.gate")
+        self.tp = get_tensor_model_parallel_world_size()
+        self.has_shared = shared_intermediate > 0
+        # with a shared expert both partial results are summed once, after adding them
+        self.experts = FusedMoE(num_experts, top_k, hidden_size, intermediate_size, reduce_results=not self.has_shared,
+                                renormalize=renormalize, quant_config=quant_config, prefix=f"{prefix}.experts")
+        if self.has_shared:
+            self.shared_expert = LlamaMLP(hidden_size, shared_intermediate, quant_config=quant_config,
+                                          prefix=f"{prefix}.shared_expert", reduce_results=False)
+            self.shared_expert_gate = ReplicatedLinear(hidden_size, 1, bias=False, prefix=f"{prefix}.shared_expert_gate") \
+                if shared_gate else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        out = self.experts(x, self.gate(x))
+        if self.has_shared:
+            s = self.shared_expert(x)
+            if self.shared_expert_gate is not None:
+                s = torch.sigmoid(self.shared_expert_gate(x)) * s
+            out = out + s
+            if self.tp > 1 or self.experts.ep_size > 1:
+                out = tensor_model_parallel_all_reduce(out)
+        return out
+
+
+class MixtralDecoderLayer(LlamaDecoderLayer):
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        # checkpoint names: model.layers.N.block_sparse_moe.{gate, experts.E.{w1,w2,w3}}
+        return SparseMoeBlock(config.hidden_size, config.intermediate_size, _num_experts(config),
+                              config.num_experts_per_tok, True, quant_config,
+                              prefix.replace(".mlp", ".block_sparse_moe"))
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = ""):
+        super().__init__(config, vllm_config, quant_config, prefix)
+        self.block_sparse_moe = self.mlp           # parameter names follow the checkpoint
+        del self.mlp
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.block_sparse_moe(hidden_states), residual
+
+
+class MixtralModel(LlamaModel):
+    layer_cls = MixtralDecoderLayer
+
+
+class MixtralForCausalLM(LlamaForCausalLM):
+    model_cls = MixtralModel
+    stacked_params_mapping = [(".qkv_proj", ".q_proj", "q"), (".qkv_proj", ".k_proj", "k"), (".qkv_proj", ".v_proj", "v")]
+    packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"]}
+    supports_lora = False
+    expert_names = ("w1", "w2", "w3")              # gate, down, up
+
+    def num_experts(self) -> int:
+        return _num_experts(self.config)
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
+        g, d, u = self.expert_names
+        experts = FusedMoE.make_expert_params_mapping(g, d, u, self.num_experts())
+        return load_weights_with_mapping(self, weights, self.stacked_params_mapping, tie_lm_head=self.tie,
+                                         expert_mapping=experts)
+
+
+class QwenMoeDecoderLayer(LlamaDecoderLayer):
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        layer_idx = int(prefix.split(".")[-2])
+        sparse_step = getattr(config, "decoder_sparse_step", 1) or 1
+        only_dense = layer_idx in (getattr(config, "mlp_only_layers", None) or [])
+        if only_dense or _num_experts(config) <= 0 or (layer_idx + 1) % sparse_step:
+            return LlamaMLP(config.hidden_size, config.intermediate_size, False, quant_config, prefix)
+        return SparseMoeBlock(config.hidden_size, config.moe_intermediate_size, _num_experts(config),
+                              config.num_experts_per_tok, bool(getattr(config, "norm_topk_prob", False)), quant_config,
+                              prefix, shared_intermediate=int(getattr(config, "shared_expert_intermediate_size", 0) or 0),
+                              shared_gate=hasattr(config, "shared_expert_intermediate_size"))
+
+
+class QwenMoeModel(LlamaModel):
+    layer_cls = QwenMoeDecoderLayer
+
+
+class Qwen2MoeForCausalLM(MixtralForCausalLM):
+    model_cls = QwenMoeModel
+    stacked_params_mapping = LlamaForCausalLM.stacked_params_mapping
+    packed_modules_mapping = LlamaForCausalLM.packed_modules_mapping
+    expert_names = ("gate_proj", "down_proj", "up_proj")
+
+    def num_experts(self) -> int:
+        return _num_experts(self.config)
+
+
+class Qwen3MoeForCausalLM(Qwen2MoeForCausalLM):
+    pass

@@ -76,17 +76,21 @@ def load_weights_with_mapping(model: nn.Module, weights: Iterable[tuple[str, tor
                               stacked: list[tuple[str, str, object]] = (),
                               skip_substrings: tuple[str, ...] = ("rotary_emb.inv_freq",),
                               rename: Optional[Callable[[str], Optional[str]]] = None,
-                              tie_lm_head: bool = False) -> set[str]:
+                              tie_lm_head: bool = False,
+                              expert_mapping: list[tuple[str, str, int, str]] = ()) -> set[str]:
     """Route checkpoint tensors to parameters.
 
     ``stacked`` maps (fused_param_fragment, checkpoint_fragment, shard_id): a
     checkpoint name containing ``checkpoint_fragment`` is loaded into the
     parameter obtained by replacing it with ``fused_param_fragment``, with the
     parameter's ``weight_loader(param, tensor, shard_id)``.
+    ``expert_mapping`` rows (param_fragment, checkpoint_fragment, expert_id, shard_id) route
+    per-expert checkpoint tensors into the stacked expert parameters.
     Returns the set of parameter names that received data.
     """
     params = dict(model.named_parameters())
     loaded: set[str] = set()
+    by_frag = {frag: (pfrag, eid, sid) for pfrag, frag, eid, sid in expert_mapping}
     for name, tensor in weights:
         if any(s in name for s in skip_substrings):
             continue
@@ -96,6 +100,22 @@ def load_weights_with_mapping(model: nn.Module, weights: Iterable[tuple[str, tor
                 continue
         if tie_lm_head and name.startswith("lm_head."):
             continue
+        if by_frag and ".experts." in name:
+            i = name.index("experts.")
+            parts = name[i:].split(".")            # experts, <id>, <proj>, <suffix...>
+            key = ".".join(parts[:3]) + "."
+            if key in by_frag:
+                pfrag, eid, sid = by_frag[key]
+                target = name[:i] + pfrag + "_".join(parts[3:])
+                if is_pp_missing_parameter(target, model):
+                    continue
+                if target not in params:
+                    logger.warning_once("checkpoint tensor %s has no matching expert parameter %s", name, target)
+                    continue
+                p = params[target]
+                if p.weight_loader(p, tensor, sid, eid):
+                    loaded.add(target)
+                continue
         for fused, frag, shard_id in stacked:
             if frag not in name:
                 continue

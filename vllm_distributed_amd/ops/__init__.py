@@ -344,3 +344,86 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
             and skinny_gemm_ok(x.shape[0], w.shape[0], x.shape[1], x.dtype):
         return skinny_gemm(x, w, bias)
     return torch.nn.functional.linear(x, w, bias)
+
+
+# ---- mixture of experts ------------------------------------------------------------------------
+def moe_topk_softmax(logits: torch.Tensor, k: int, renormalize: bool = True):
+    """Router: softmax over experts then top-k.  Returns (weights f32 [T,k], ids i32 [T,k])."""
+    if not _dev(logits) or logits.shape[-1] > 512:
+        return R.moe_topk_softmax(logits, k, renormalize)
+    lg = _contig_last(logits)
+    T, E = lg.shape
+    w = torch.empty((T, k), dtype=torch.float32, device=lg.device)
+    ids = torch.empty((T, k), dtype=torch.int32, device=lg.device)
+    N.call("vda_moe_topk_softmax", w.data_ptr(), ids.data_ptr(), lg.data_ptr(), T, E, k, int(renormalize),
+           lg.stride(0), N.dt(lg.dtype), N.stream())
+    return w, ids
+
+
+def moe_grouped_ok(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor) -> bool:
+    I = w13.shape[1] // 2
+    return (x.dtype in (torch.bfloat16, torch.float16) and w13.shape[2] % 128 == 0 and I % 128 == 0
+            and w2.shape[1] % 16 == 0 and w13.dtype in (x.dtype, torch.float8_e4m3fn) and w13.dtype == w2.dtype
+            and w13.shape[0] <= 1024)
+
+
+def _moe_large(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale):
+    """Prefill-sized batches: sort the (token, slot) pairs by expert and run one hipBLASLt GEMM
+    pair per expert on the contiguous slices (compute bound: the library GEMM is the right tool)."""
+    T, k = topk_ids.shape
+    E, I2, _ = w13.shape
+    I = I2 // 2
+    flat = topk_ids.reshape(-1)
+    keys = torch.where(flat < 0, E, flat)
+    order = torch.argsort(keys, stable=True)
+    counts = torch.bincount(keys, minlength=E + 1)[:E].tolist()
+    xg = x[order // k]
+    out2 = torch.zeros((T * k, w2.shape[1]), dtype=x.dtype, device=x.device)
+    s = 0
+    for e, c in enumerate(counts):
+        if c == 0:
+            continue
+        a, b = w13[e], w2[e]
+        if a.dtype == torch.float8_e4m3fn:
+            a = fp8_dequant(a, w13_scale[e:e + 1], x.dtype)
+            b = fp8_dequant(b, w2_scale[e:e + 1], x.dtype)
+        h = act_and_mul(torch.mm(xg[s:s + c], a.t()))
+        o = torch.mm(h, b.t())
+        idx = order[s:s + c]
+        out2[idx] = o * topk_w.reshape(-1)[idx].to(x.dtype).unsqueeze(1)
+        s += c
+    return out2.view(T, k, -1).sum(dim=1)
+
+
+def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,
+              w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Routed SwiGLU expert MLPs.  x [T,H]; w13 [E,2I,H] (gate rows then up rows); w2 [E,H,I];
+    topk_w f32 [T,k]; topk_ids i32 [T,k] with local expert ids, negative = not on this rank."""
+    if not _dev(x) or not moe_grouped_ok(x, w13, w2):
+        return R.fused_moe(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale)
+    T, H = x.shape
+    k = topk_ids.shape[1]
+    E, I2, _ = w13.shape
+    I = I2 // 2
+    if T * k > envs.VDA_MOE_GROUPED_MAX_PAIRS:
+        return _moe_large(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale)
+    x = _contig_last(x)
+    dev = x.device
+    ids = topk_ids.contiguous()
+    tw = topk_w.contiguous()
+    sorted_ids = torch.empty(T * k, dtype=torch.int32, device=dev)
+    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    st = N.stream()
+    N.call("vda_moe_align", sorted_ids.data_ptr(), offsets.data_ptr(), ids.data_ptr(), T * k, E, st)
+    inter = torch.empty((T * k, I), dtype=x.dtype, device=dev)
+    out2 = torch.empty((T * k, H), dtype=x.dtype, device=dev)
+    out = torch.empty((T, H), dtype=x.dtype, device=dev)
+    wd = N.dt(w13.dtype)
+    # one expert can receive at most one slot of every token
+    max_pairs = T
+    N.call("vda_moe_gate_up", inter.data_ptr(), x.data_ptr(), w13.data_ptr(), N.ptr(w13_scale), sorted_ids.data_ptr(),
+           offsets.data_ptr(), E, I, H, k, max_pairs, x.stride(0), N.dt(x.dtype), wd, st)
+    N.call("vda_moe_down", out2.data_ptr(), inter.data_ptr(), w2.data_ptr(), N.ptr(w2_scale), tw.data_ptr(),
+           sorted_ids.data_ptr(), offsets.data_ptr(), E, H, I, max_pairs, N.dt(x.dtype), wd, st)
+    N.call("vda_moe_sum", out.data_ptr(), out2.data_ptr(), ids.data_ptr(), T, H, k, out.stride(0), N.dt(x.dtype), st)
+    return out

@@ -1,0 +1,303 @@
+// Mixture-of-experts kernels for gfx950.
+//
+//   vda_moe_topk_softmax   router: softmax over experts + top-k (+ renormalise), one wave per token
+//   vda_moe_align          counting sort of the (token, slot) pairs by expert -> sorted ids + offsets
+//   vda_moe_gate_up        grouped skinny GEMM  inter[p, :] = silu(x[t] . Wg_e^T) * (x[t] . Wu_e^T)
+//   vda_moe_down           grouped skinny GEMM  out2[p, :] = w[p] * (inter[p] . Wd_e^T)
+//   vda_moe_sum            out[t] = sum_j out2[t*k + j]   (entries routed to non-local experts skipped)
+//
+// p = t * top_k + j is the flat (token, slot) index.  The grouped GEMMs stream each expert's weight
+// rows straight from HBM into MFMA A operands (16 rows per workgroup, the 4 waves split K) while up
+// to 64 gathered tokens ride on the MFMA column dimension -- the decode regime, where expert weights
+// are the traffic.  Work distribution is read from device memory (offsets), so nothing syncs with the
+// host and the whole layer is hipGraph-capturable; workgroups beyond an expert's token count exit.
+// Counterpart of the reference's csrc/moe/{topk_softmax_kernels,moe_align_sum_kernels}.cu and the
+// Triton fused_moe kernel (vllm/model_executor/layers/fused_moe/fused_moe.py).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void moe_topk_softmax_kernel(float* __restrict__ topk_w, int* __restrict__ topk_id,
+                                                               const T* __restrict__ logits, int num_tokens, int E,
+                                                               int k, int renorm, long stride) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= num_tokens) return;
+  constexpr int PER = 8;                 // up to 512 experts
+  float v[PER];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = lane + 64 * i;
+    v[i] = e < E ? (float)logits[(long)t * stride + e] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = (lane + 64 * i) < E ? __expf(v[i] - mx) : -1.f;     // -1 marks "not a candidate"
+    sum += fmaxf(v[i], 0.f);
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  float picked = 0.f;
+  float my_w = 0.f;
+  int my_id = 0;
+  for (int j = 0; j < k; ++j) {
+    float best = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if (v[i] > best) { best = v[i]; bi = lane + 64 * i; }
+    }
+    // wave arg-max, lowest expert index wins ties
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((bi & 63) == lane) v[bi >> 6] = -1.f;
+    picked += best;
+    if (lane == j) { my_w = best; my_id = bi; }
+  }
+  if (lane < k) {
+    const float scale = renorm ? 1.f / picked : inv;
+    topk_w[(long)t * k + lane] = my_w * scale;
+    topk_id[(long)t * k + lane] = my_id;
+  }
+}
+
+VDA_EXPORT int vda_moe_topk_softmax(float* topk_w, int* topk_id, const void* logits, int num_tokens, int E, int k,
+                                    int renorm, long stride, int dtype, hipStream_t st) {
+  if (E > 512 || k > 64 || k > E || num_tokens < 0) return -1;
+  if (num_tokens == 0) return 0;
+  dim3 grid((num_tokens + 3) / 4), block(256);
+  if (dtype == VDA_BF16)
+    hipLaunchKernelGGL(moe_topk_softmax_kernel<bf16_t>, grid, block, 0, st, topk_w, topk_id, (const bf16_t*)logits,
+                       num_tokens, E, k, renorm, stride);
+  else if (dtype == VDA_F16)
+    hipLaunchKernelGGL(moe_topk_softmax_kernel<f16_t>, grid, block, 0, st, topk_w, topk_id, (const f16_t*)logits,
+                       num_tokens, E, k, renorm, stride);
+  else if (dtype == VDA_F32)
+    hipLaunchKernelGGL(moe_topk_softmax_kernel<float>, grid, block, 0, st, topk_w, topk_id, (const float*)logits,
+                       num_tokens, E, k, renorm, stride);
+  else return -3;
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ids[p] in [0, E) or negative (expert lives on another rank).  One workgroup; E <= 1024.
+__global__ __launch_bounds__(1024) void moe_align_kernel(int* __restrict__ sorted, int* __restrict__ offsets,
+                                                         const int* __restrict__ ids, int n, int E) {
+  __shared__ int cnt[1024];
+  __shared__ int pos[1025];
+  const int tid = threadIdx.x;
+  if (tid < E) cnt[tid] = 0;
+  __syncthreads();
+  for (int p = tid; p < n; p += 1024) {
+    const int e = ids[p];
+    if (e >= 0 && e < E) atomicAdd(&cnt[e], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int e = 0; e < E; ++e) { pos[e] = acc; offsets[e] = acc; acc += cnt[e]; }
+    offsets[E] = acc;
+  }
+  __syncthreads();
+  for (int p = tid; p < n; p += 1024) {
+    const int e = ids[p];
+    if (e >= 0 && e < E) sorted[atomicAdd(&pos[e], 1)] = p;
+  }
+}
+
+VDA_EXPORT int vda_moe_align(int* sorted, int* offsets, const int* ids, int n, int E, hipStream_t st) {
+  if (E > 1024 || n < 0) return -1;
+  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), 0, st, sorted, offsets, ids, n, E);
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight loaders: 8 consecutive K elements of one weight row as an MFMA operand.
+template <typename T> struct WLoad {
+  using V8 = typename Vec<T>::v8;
+  static __device__ __forceinline__ V8 ld(const void* base, long elem_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const V8*>(reinterpret_cast<const T*>(base) + elem_off));
+  }
+};
+// e4m3 weights, widened in registers (W8A16): half the HBM bytes of the 16-bit path
+template <typename T> struct WLoadFp8 {
+  using V8 = typename Vec<T>::v8;
+  static __device__ __forceinline__ V8 ld(const void* base, long elem_off) {
+    const u32x2 raw = __builtin_nontemporal_load(
+        reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(base) + elem_off));
+    V8 o;
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], true);
+    o[0] = (T)a[0]; o[1] = (T)a[1]; o[2] = (T)b[0]; o[3] = (T)b[1];
+    o[4] = (T)c[0]; o[5] = (T)c[1]; o[6] = (T)d[0]; o[7] = (T)d[1];
+    return o;
+  }
+};
+
+// GATE_UP: rows n0..n0+15 of the gate half AND of the up half of W13[e] ([2I, K]); epilogue silu(g)*u.
+// else   : rows n0..n0+15 of W2[e] ([H, K=I]); epilogue * routing weight.
+template <typename T, typename WL, bool GATE_UP>
+__global__ __launch_bounds__(256) void moe_grouped_kernel(
+    T* __restrict__ out, const T* __restrict__ act, const void* __restrict__ w, const float* __restrict__ w_scale,
+    const float* __restrict__ topk_w, const int* __restrict__ sorted, const int* __restrict__ offsets,
+    int N, int K, int top_k, long act_stride, long out_stride, long w_expert_stride) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  const int e = blockIdx.y;
+  const int beg = offsets[e] + blockIdx.z * 64, end = offsets[e + 1];
+  if (beg >= end) return;
+  const int cnt = min(end - beg, 64);
+  const int mt_n = (cnt + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const long wrow0 = (long)e * w_expert_stride + (long)(n0 + r) * K + g * 32;
+  const long wrow1 = wrow0 + (long)N * K;           // the "up" half (GATE_UP only)
+
+  const T* xp[4];
+  int pid[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int i = mt * 16 + r;
+    pid[mt] = i < cnt ? sorted[beg + i] : -1;
+    const int row = pid[mt] < 0 ? 0 : (GATE_UP ? pid[mt] / top_k : pid[mt]);
+    xp[mt] = act + (long)row * act_stride + g * 32;
+  }
+  f32x4 acc0[4], acc1[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) { acc0[mt] = f32x4{0, 0, 0, 0}; acc1[mt] = f32x4{0, 0, 0, 0}; }
+
+  const int nchunk = K >> 7;
+  for (int c = wave; c < nchunk; c += 4) {
+    V8 wa[4], wb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      wa[s] = WL::ld(w, wrow0 + (long)c * 128 + 8 * s);
+      if (GATE_UP) wb[s] = WL::ld(w, wrow1 + (long)c * 128 + 8 * s);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (mt < mt_n) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const V8 xa = pid[mt] >= 0 ? ld16<V8>(xp[mt] + (long)c * 128 + 8 * s) : V8{};
+          acc0[mt] = mfma16(wa[s], xa, acc0[mt]);
+          if (GATE_UP) acc1[mt] = mfma16(wb[s], xa, acc1[mt]);
+        }
+      }
+    }
+  }
+
+  __shared__ f32x4 red[3][2][4][64];
+  if (wave > 0) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      red[wave - 1][0][mt][lane] = acc0[mt];
+      if (GATE_UP) red[wave - 1][1][mt][lane] = acc1[mt];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const float ws = w_scale ? w_scale[e] : 1.f;
+  // lane holds result[token pid[mt]][n0 + 4g + i]
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    if (mt < mt_n && pid[mt] >= 0) {
+      f32x4 a = acc0[mt] + red[0][0][mt][lane] + red[1][0][mt][lane] + red[2][0][mt][lane];
+      V4 o;
+      if (GATE_UP) {
+        const f32x4 b = acc1[mt] + red[0][1][mt][lane] + red[1][1][mt][lane] + red[2][1][mt][lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float gte = a[i] * ws, up = b[i] * ws;
+          o[i] = (T)(gte / (1.f + __expf(-gte)) * up);
+        }
+      } else {
+        const float tw = topk_w[pid[mt]] * ws;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (T)(a[i] * tw);
+      }
+      *reinterpret_cast<V4*>(out + (long)pid[mt] * out_stride + n0 + 4 * g) = o;
+    }
+  }
+}
+
+// w13: [E, 2*I, K] (gate rows then up rows), w2: [E, H, I]; wdtype VDA_FP8 selects e4m3 weights with
+// a per-expert fp32 scale.  max_pairs bounds the tokens of one expert (grid.z = ceil(max_pairs/64)).
+VDA_EXPORT int vda_moe_gate_up(void* inter, const void* x, const void* w13, const float* w_scale, const int* sorted,
+                               const int* offsets, int E, int I, int K, int top_k, int max_pairs, long x_stride,
+                               int dtype, int wdtype, hipStream_t st) {
+  if (I % 16 || K % 128 || E < 1 || max_pairs < 1) return -1;
+  dim3 grid(I / 16, E, (max_pairs + 63) / 64), block(256);
+  const long es = (long)2 * I * K;
+#define L(TT, WL) hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, true>), grid, block, 0, st, (TT*)inter, (const TT*)x, \
+                                     w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es)
+  if (dtype == VDA_BF16) { if (wdtype == VDA_FP8) L(bf16_t, WLoadFp8<bf16_t>); else L(bf16_t, WLoad<bf16_t>); }
+  else if (dtype == VDA_F16) { if (wdtype == VDA_FP8) L(f16_t, WLoadFp8<f16_t>); else L(f16_t, WLoad<f16_t>); }
+  else return -3;
+#undef L
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
+VDA_EXPORT int vda_moe_down(void* out2, const void* inter, const void* w2, const float* w_scale, const float* topk_w,
+                            const int* sorted, const int* offsets, int E, int H, int I, int max_pairs, int dtype,
+                            int wdtype, hipStream_t st) {
+  if (H % 16 || I % 128 || E < 1 || max_pairs < 1) return -1;
+  dim3 grid(H / 16, E, (max_pairs + 63) / 64), block(256);
+  const long es = (long)H * I;
+#define L(TT, WL) hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, false>), grid, block, 0, st, (TT*)out2, (const TT*)inter, \
+                                     w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es)
+  if (dtype == VDA_BF16) { if (wdtype == VDA_FP8) L(bf16_t, WLoadFp8<bf16_t>); else L(bf16_t, WLoad<bf16_t>); }
+  else if (dtype == VDA_F16) { if (wdtype == VDA_FP8) L(f16_t, WLoadFp8<f16_t>); else L(f16_t, WLoad<f16_t>); }
+  else return -3;
+#undef L
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void moe_sum_kernel(T* __restrict__ out, const T* __restrict__ out2,
+                                                      const int* __restrict__ ids, int H, int k, long out_stride) {
+  using V8 = typename Vec<T>::v8;
+  const int t = blockIdx.x;
+  for (int h = threadIdx.x * 8; h < H; h += 256 * 8) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < k; ++j) {
+      if (ids[(long)t * k + j] < 0) continue;
+      const V8 v = ld16<V8>(out2 + ((long)t * k + j) * H + h);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+    }
+    V8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (T)acc[i];
+    st16<V8>(out + (long)t * out_stride + h, o);
+  }
+}
+
+VDA_EXPORT int vda_moe_sum(void* out, const void* out2, const int* ids, int num_tokens, int H, int k, long out_stride,
+                           int dtype, hipStream_t st) {
+  if (H % 8 || num_tokens < 0) return -1;
+  if (num_tokens == 0) return 0;
+  if (dtype == VDA_BF16)
+    hipLaunchKernelGGL(moe_sum_kernel<bf16_t>, dim3(num_tokens), dim3(256), 0, st, (bf16_t*)out, (const bf16_t*)out2,
+                       ids, H, k, out_stride);
+  else if (dtype == VDA_F16)
+    hipLaunchKernelGGL(moe_sum_kernel<f16_t>, dim3(num_tokens), dim3(256), 0, st, (f16_t*)out, (const f16_t*)out2, ids,
+                       H, k, out_stride);
+  else return -3;
+  VDA_CHECK_LAUNCH();
+  return 0;
+}

@@ -257,3 +257,33 @@ def fp8_dequant(q, scale, dtype):
 
 def skinny_gemm(x, w, bias=None):
     return F.linear(x, w, bias)
+
+
+# ---- mixture of experts ------------------------------------------------------------------
+def moe_topk_softmax(logits: torch.Tensor, k: int, renormalize: bool):
+    probs = torch.softmax(logits.float(), dim=-1)
+    w, ids = torch.topk(probs, k, dim=-1)
+    if renormalize:
+        w = w / w.sum(dim=-1, keepdim=True)
+    return w, ids.to(torch.int32)
+
+
+def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,
+              w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[t] = sum_j topk_w[t, j] * W2_e( silu(Wg_e x_t) * (Wu_e x_t) ), e = topk_ids[t, j];
+    negative ids (expert on another rank) contribute nothing.  fp32 accumulation."""
+    T, H = x.shape
+    E, I2, _ = w13.shape
+    I = I2 // 2
+    out = torch.zeros((T, w2.shape[1]), dtype=torch.float32, device=x.device)
+    xf = x.float()
+    for e in range(E):
+        tok, slot = torch.where(topk_ids == e)
+        if tok.numel() == 0:
+            continue
+        a = w13[e].float() * (w13_scale[e].float() if w13_scale is not None else 1.0)
+        b = w2[e].float() * (w2_scale[e].float() if w2_scale is not None else 1.0)
+        h = xf[tok] @ a.t()
+        act = (torch.nn.functional.silu(h[:, :I]) * h[:, I:]).to(x.dtype).float()
+        out.index_add_(0, tok, (act @ b.t()) * topk_w[tok, slot].float().unsqueeze(1))
+    return out.to(x.dtype)
