@@ -427,3 +427,32 @@ def test_fused_moe_graph_capture():
     torch.cuda.synchronize()
     tw, ids = R.moe_topk_softmax(lg, k, True)
     torch.testing.assert_close(out.float(), R.fused_moe(x, w13, w2, tw, ids).float(), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 1024, 8192), (33, 512, 1024), (64, 6144, 4096)])
+def test_skinny_gemm_fp8_weights(dt, M, N, K):
+    x = torch.randn(M, K, device=DEV, dtype=dt)
+    w = torch.randn(N, K, device=DEV, dtype=dt) * (K ** -0.5)
+    s = (w.abs().amax().float() / 448.0).reshape(1)
+    q = (w.float() / s).to(torch.float8_e4m3fn)
+    b = torch.randn(N, device=DEV, dtype=dt)
+    y = ops.skinny_gemm(x, q, b, s)
+    torch.testing.assert_close(y.float(), R.skinny_gemm(x, q, b, s).float(), **tol(dt))
+
+
+@pytest.mark.parametrize("M", [4, 48, 300])
+@pytest.mark.parametrize("static", [False, True])
+def test_fp8_linear_paths(M, static):
+    from vllm_distributed_amd.layers.quant import apply_fp8_linear
+    dt = torch.bfloat16
+    N, K = 1024, 2048
+    x = torch.randn(M, K, device=DEV, dtype=dt)
+    w = torch.randn(N, K, device=DEV, dtype=dt) * (K ** -0.5)
+    s = (w.abs().amax().float() / 448.0).reshape(())
+    q = (w.float() / s).to(torch.float8_e4m3fn)
+    ins = (x.abs().amax().float() / 448.0).reshape(()) if static else None
+    y = apply_fp8_linear(x, q, s, ins, None)
+    ref = x.float() @ (q.float() * s).t()
+    # M=300 goes through activation quantisation + fp8 MFMA: looser
+    torch.testing.assert_close(y.float(), ref, atol=0.15 if M > 64 else 3e-2, rtol=5e-2)

@@ -1,0 +1,287 @@
+"""fp8 (OCP e4m3fn) quantisation: linear layers, routed experts, KV-cache scales.
+
+Two regimes on MI355X:
+  * decode-sized M: weights are the traffic, so the skinny MFMA kernel streams e4m3 weights and
+    widens them in registers (W8A16) -- half the HBM bytes, activations untouched;
+  * prefill-sized M: activations are quantised (per-tensor static scale from the checkpoint or
+    per-token dynamic) and the GEMM runs on the fp8 matrix cores through hipBLASLt
+    (``torch._scaled_mm``), ~2x the bf16 MFMA rate.
+Checkpoints already in fp8 ("quant_method": "fp8") load directly; bf16 checkpoints can be
+quantised while loading (``quantization="fp8"``).
+Reference: vllm/model_executor/layers/quantization/fp8.py (Fp8Config :58, Fp8LinearMethod :169,
+Fp8MoEMethod :439, Fp8KVCacheMethod), utils/w8a8_utils.py (requantize_with_max_scale, Fp8LinearOp),
+kv_cache.py (BaseKVCacheMethod).
+"""
+from __future__ import annotations
+
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import envs, ops
+from ..logger import init_logger
+from .linear import LinearBase, UnquantizedLinearMethod, set_weight_attrs
+
+logger = init_logger(__name__)
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+class QuantizationConfig:
+    """Maps layers to quantisation methods."""
+
+    name = "none"
+
+    @classmethod
+    def from_config(cls, cfg: dict) -> "QuantizationConfig":
+        raise NotImplementedError
+
+    def get_quant_method(self, layer: nn.Module, prefix: str):
+        raise NotImplementedError
+
+    def get_cache_scale_name(self, name: str) -> Optional[str]:
+        """Checkpoint name of a KV scale -> parameter name on the Attention module."""
+        for a, b in ((".k_proj.output_scale", ".attn.k_scale"), (".v_proj.output_scale", ".attn.v_scale"),
+                     (".self_attn.k_scale", ".self_attn.attn.k_scale"), (".self_attn.v_scale", ".self_attn.attn.v_scale")):
+            if name.endswith(a):
+                return name[: -len(a)] + b
+        return None
+
+
+def _is_ignored(prefix: str, ignored: list[str], fused: dict[str, list[str]]) -> bool:
+    if not ignored:
+        return False
+    leaf = prefix.rsplit(".", 1)[-1]
+    names = [prefix]
+    if leaf in fused:           # a fused module is skipped when its parts are
+        names = [prefix[: -len(leaf)] + part for part in fused[leaf]]
+    hit = [any(n == ig or n.endswith("." + ig) or ig in n for ig in ignored) for n in names]
+    if any(hit) and not all(hit):
+        raise ValueError(f"{prefix}: the parts of a fused layer must be quantised alike")
+    return all(hit)
+
+
+class Fp8Config(QuantizationConfig):
+    name = "fp8"
+    FUSED = {"qkv_proj": ["q_proj", "k_proj", "v_proj"], "gate_up_proj": ["gate_proj", "up_proj"]}
+
+    def __init__(self, is_checkpoint_fp8_serialized: bool = False, activation_scheme: str = "dynamic",
+                 ignored_layers: Optional[list[str]] = None, weight_block_size: Optional[list[int]] = None):
+        if activation_scheme not in ("static", "dynamic"):
+            raise ValueError(f"unsupported activation scheme {activation_scheme!r}")
+        if weight_block_size is not None:
+            raise ValueError("block-wise fp8 weights are not supported; use per-tensor fp8 checkpoints")
+        self.is_checkpoint_fp8_serialized = is_checkpoint_fp8_serialized
+        self.activation_scheme = activation_scheme
+        self.ignored_layers = ignored_layers or []
+
+    @classmethod
+    def from_config(cls, cfg: dict) -> "Fp8Config":
+        return cls("fp8" in str(cfg.get("quant_method", "")), cfg.get("activation_scheme", "dynamic"),
+                   cfg.get("ignored_layers") or cfg.get("modules_to_not_convert"), cfg.get("weight_block_size"))
+
+    def get_quant_method(self, layer: nn.Module, prefix: str):
+        from .attention import Attention
+        from .moe import FusedMoE
+        if isinstance(layer, LinearBase):
+            if _is_ignored(prefix, self.ignored_layers, self.FUSED) or prefix.endswith("lm_head"):
+                return UnquantizedLinearMethod()
+            return Fp8LinearMethod(self)
+        if isinstance(layer, FusedMoE):
+            return Fp8MoEMethod(self)
+        if isinstance(layer, Attention):
+            return Fp8KVCacheMethod(self)
+        return None
+
+
+def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
+    mc = vllm_config.model_config
+    q = mc.quantization
+    if q is None:
+        return None
+    hf_q = mc.hf_config.get("quantization_config") if hasattr(mc.hf_config, "get") else \
+        getattr(mc.hf_config, "quantization_config", None)
+    if q == "fp8":
+        return Fp8Config.from_config(hf_q) if hf_q else Fp8Config(False, "dynamic")
+    if q in ("compressed-tensors", "quark"):
+        # accept only the plain per-tensor fp8 flavour of these container formats
+        groups = (hf_q or {}).get("config_groups") or {}
+        ok = all(str(g.get("weights", {}).get("type", "")).startswith("float") and
+                 int(g.get("weights", {}).get("num_bits", 8)) == 8 for g in groups.values())
+        if not groups or not ok:
+            raise ValueError(f"{q}: only per-tensor fp8 weight schemes are supported")
+        dyn = any(g.get("input_activations", {}).get("dynamic", True) for g in groups.values())
+        return Fp8Config(True, "dynamic" if dyn else "static", (hf_q or {}).get("ignore"))
+    raise ValueError(f"unsupported quantization {q!r}")
+
+
+def per_tensor_quantize(w: torch.Tensor, scale: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, torch.Tensor]:
+    if scale is None:
+        scale = (w.abs().amax().float() / FP8_MAX).clamp(min=1e-12)
+    q = (w.float() / scale).clamp(-FP8_MAX, FP8_MAX).to(FP8)
+    return q, scale.reshape(()).float()
+
+
+def requantize_with_max_scale(weight: torch.Tensor, scales: torch.Tensor, logical_widths: list[int]
+                              ) -> tuple[torch.Tensor, torch.Tensor]:
+    """Fused projections arrive with one scale per logical shard; the GEMM wants one scale."""
+    mx = scales.max()
+    if scales.numel() == 1 or bool((scales == mx).all()):
+        return weight, mx.reshape(())
+    off = 0
+    for i, wdt in enumerate(logical_widths):
+        shard = weight[off:off + wdt]
+        shard.copy_((shard.float() * scales[i] / mx).clamp(-FP8_MAX, FP8_MAX).to(FP8))
+        off += wdt
+    return weight, mx.reshape(())
+
+
+def _scaled_mm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return x.is_cuda and x.shape[0] >= 1 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0
+
+
+def apply_fp8_linear(x: torch.Tensor, weight: torch.Tensor, weight_scale: torch.Tensor,
+                     input_scale: Optional[torch.Tensor], bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """x [M, K] 16-bit, weight [N, K] e4m3, weight_scale scalar."""
+    M = x.shape[0]
+    if x.is_cuda and x.stride(-1) == 1 and \
+            ops.skinny_gemm_ok(M, weight.shape[0], weight.shape[1], x.dtype, envs.VDA_FP8_W8A16_MAX_M):
+        return ops.skinny_gemm(x, weight, bias, weight_scale.reshape(1))
+    if _scaled_mm_ok(x, weight) and not envs.VDA_FORCE_TORCH_OPS:
+        if input_scale is not None:
+            xq, xs = ops.scaled_fp8_quant(x, input_scale.reshape(1))
+            sa, sb = xs.reshape(()), weight_scale.reshape(())
+        else:
+            xq, xs = ops.per_token_fp8_quant(x)          # [M,1] row scales
+            sa, sb = xs.view(M, 1), weight_scale.reshape(1, 1).expand(1, weight.shape[0]).contiguous()
+        return torch._scaled_mm(xq, weight.t(), scale_a=sa, scale_b=sb, out_dtype=x.dtype, bias=bias)
+    # CPU / odd shapes: dequantise
+    w = (weight.float() * weight_scale.float()).to(x.dtype)
+    return torch.nn.functional.linear(x, w, bias)
+
+
+class Fp8LinearMethod:
+    def __init__(self, cfg: Fp8Config):
+        self.cfg = cfg
+
+    def create_weights(self, layer: nn.Module, in_per_rank: int, out_per_rank: int, dtype: torch.dtype) -> None:
+        serialized = self.cfg.is_checkpoint_fp8_serialized
+        w = nn.Parameter(torch.empty(out_per_rank, in_per_rank, dtype=FP8 if serialized else dtype), requires_grad=False)
+        set_weight_attrs(w, {"input_dim": 1, "output_dim": 0})
+        layer.register_parameter("weight", w)
+        layer.orig_dtype = dtype
+        n_shards = len(getattr(layer, "output_sizes", [0]))
+        layer.logical_widths = [s // getattr(layer, "tp_size", 1) for s in getattr(layer, "output_sizes", [out_per_rank])] \
+            if hasattr(layer, "output_sizes") else [out_per_rank]
+        if serialized:
+            ws = nn.Parameter(torch.full((n_shards,), torch.finfo(torch.float32).min), requires_grad=False)
+            set_weight_attrs(ws, {"per_shard_scalar": n_shards > 1})
+            layer.register_parameter("weight_scale", ws)
+            if self.cfg.activation_scheme == "static":
+                ins = nn.Parameter(torch.full((n_shards,), torch.finfo(torch.float32).min), requires_grad=False)
+                set_weight_attrs(ins, {"per_shard_scalar": n_shards > 1})
+                layer.register_parameter("input_scale", ins)
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        if not self.cfg.is_checkpoint_fp8_serialized:
+            q, s = per_tensor_quantize(layer.weight.data)
+            layer.weight = nn.Parameter(q, requires_grad=False)
+            layer.weight_scale = nn.Parameter(s, requires_grad=False)
+            layer.input_scale = None
+            return
+        w, s = requantize_with_max_scale(layer.weight.data, layer.weight_scale.data, layer.logical_widths)
+        layer.weight = nn.Parameter(w, requires_grad=False)
+        layer.weight_scale = nn.Parameter(s.float(), requires_grad=False)
+        ins = getattr(layer, "input_scale", None)
+        layer.input_scale = nn.Parameter(ins.data.max().reshape(()), requires_grad=False) if ins is not None else None
+
+    def apply(self, layer: nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]) if x.dim() != 2 else x
+        y = apply_fp8_linear(x2, layer.weight, layer.weight_scale, getattr(layer, "input_scale", None), bias)
+        return y if x.dim() == 2 else y.view(*shape[:-1], -1)
+
+
+class Fp8MoEMethod:
+    """Per-expert per-tensor weight scales; activations stay 16-bit inside the grouped kernels."""
+
+    def __init__(self, cfg: Fp8Config):
+        self.cfg = cfg
+
+    def create_weights(self, layer, E: int, H: int, I: int, dtype: torch.dtype) -> None:
+        serialized = self.cfg.is_checkpoint_fp8_serialized
+        wdt = FP8 if serialized else dtype
+        w13 = nn.Parameter(torch.empty(E, 2 * I, H, dtype=wdt), requires_grad=False)
+        w2 = nn.Parameter(torch.empty(E, H, I, dtype=wdt), requires_grad=False)
+        layer.register_parameter("w13_weight", w13)
+        layer.register_parameter("w2_weight", w2)
+        for p in (w13, w2):
+            set_weight_attrs(p, {"weight_loader": layer.weight_loader})
+        if serialized:
+            s13 = nn.Parameter(torch.ones(E, 2, dtype=torch.float32), requires_grad=False)
+            s2 = nn.Parameter(torch.ones(E, dtype=torch.float32), requires_grad=False)
+            layer.register_parameter("w13_weight_scale", s13)
+            layer.register_parameter("w2_weight_scale", s2)
+            for p in (s13, s2):
+                set_weight_attrs(p, {"weight_loader": layer.weight_loader, "moe_kind": "scale_per_expert"})
+            if self.cfg.activation_scheme == "static":
+                # loaded for completeness; the W8A16 kernels do not quantise activations
+                a13 = nn.Parameter(torch.ones(E, 2, dtype=torch.float32), requires_grad=False)
+                a2 = nn.Parameter(torch.ones(E, dtype=torch.float32), requires_grad=False)
+                layer.register_parameter("w13_input_scale", a13)
+                layer.register_parameter("w2_input_scale", a2)
+                for p in (a13, a2):
+                    set_weight_attrs(p, {"weight_loader": layer.weight_loader, "moe_kind": "scale_per_expert"})
+
+    def process_weights_after_loading(self, layer) -> None:
+        E = layer.w13_weight.shape[0]
+        I = layer.w13_weight.shape[1] // 2
+        if not self.cfg.is_checkpoint_fp8_serialized:
+            q13 = torch.empty_like(layer.w13_weight.data, dtype=FP8)
+            q2 = torch.empty_like(layer.w2_weight.data, dtype=FP8)
+            s13 = torch.empty(E, dtype=torch.float32, device=q13.device)
+            s2 = torch.empty(E, dtype=torch.float32, device=q13.device)
+            for e in range(E):
+                q13[e], s13[e] = per_tensor_quantize(layer.w13_weight.data[e])
+                q2[e], s2[e] = per_tensor_quantize(layer.w2_weight.data[e])
+            layer.w13_weight = nn.Parameter(q13, requires_grad=False)
+            layer.w2_weight = nn.Parameter(q2, requires_grad=False)
+            layer.w13_weight_scale = nn.Parameter(s13, requires_grad=False)
+            layer.w2_weight_scale = nn.Parameter(s2, requires_grad=False)
+            return
+        s = layer.w13_weight_scale.data
+        mx = s.max(dim=1).values
+        w = layer.w13_weight.data
+        for e in range(E):
+            for half in range(2):
+                if s[e, half] != mx[e]:
+                    blk = w[e, half * I:(half + 1) * I]
+                    blk.copy_((blk.float() * s[e, half] / mx[e]).clamp(-FP8_MAX, FP8_MAX).to(FP8))
+        layer.w13_weight_scale = nn.Parameter(mx.contiguous(), requires_grad=False)
+
+    def apply(self, layer, x: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+        return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids, layer.w13_weight_scale,
+                             layer.w2_weight_scale)
+
+
+class Fp8KVCacheMethod:
+    """Adds k_scale / v_scale to an Attention layer (fp8 KV cache); 1.0 when the checkpoint has none."""
+
+    def __init__(self, cfg: QuantizationConfig):
+        self.cfg = cfg
+
+    def create_weights(self, layer: nn.Module) -> None:
+        layer.k_scale = nn.Parameter(torch.tensor(-1.0), requires_grad=False)
+        layer.v_scale = nn.Parameter(torch.tensor(-1.0), requires_grad=False)
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        k, v = float(layer.k_scale), float(layer.v_scale)
+        if k <= 0 and v <= 0:
+            k = v = 1.0
+        elif k <= 0 or v <= 0:
+            k = v = max(k, v)
+        if getattr(layer, "cache_dtype", "auto") not in ("fp8", "fp8_e4m3") and (k != 1.0 or v != 1.0):
+            logger.warning_once("checkpoint has KV-cache scales but kv_cache_dtype is not fp8; they are unused")
+        layer._k_scale_float, layer._v_scale_float = k, v
+        del layer.k_scale, layer.v_scale

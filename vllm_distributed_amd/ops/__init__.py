@@ -321,20 +321,22 @@ def fp8_dequant(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype):
 
 
 # ---- GEMM -----------------------------------------------------------------------------------
-def skinny_gemm_ok(M: int, N_: int, K: int, dtype: torch.dtype) -> bool:
-    return (1 <= M <= envs.VDA_SKINNY_GEMM_MAX_M and N_ % 16 == 0 and K % 128 == 0
+def skinny_gemm_ok(M: int, N_: int, K: int, dtype: torch.dtype, max_m: Optional[int] = None) -> bool:
+    return (1 <= M <= min(max_m or envs.VDA_SKINNY_GEMM_MAX_M, 64) and N_ % 16 == 0 and K % 128 == 0
             and dtype in (torch.bfloat16, torch.float16) and not envs.VDA_DISABLE_SKINNY_GEMM)
 
 
-def skinny_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ w.T (+ bias) for x [M<=64, K], w [N, K]."""
+def skinny_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                w_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ w.T (+ bias) for x [M<=64, K], w [N, K]; w may be e4m3 with a per-tensor ``w_scale``
+    (weights widened in registers: half the HBM traffic of 16-bit weights)."""
     if not _dev(x):
-        return R.skinny_gemm(x, w, bias)
+        return R.skinny_gemm(x, w, bias, w_scale)
     M, K = x.shape
     N_ = w.shape[0]
     y = torch.empty((M, N_), dtype=x.dtype, device=x.device)
-    N.call("vda_skinny_gemm", y.data_ptr(), x.data_ptr(), w.data_ptr(), N.ptr(bias), M, N_, K, x.stride(0),
-           w.stride(0), y.stride(0), N.dt(x.dtype), N.stream())
+    N.call("vda_skinny_gemm", y.data_ptr(), x.data_ptr(), w.data_ptr(), N.ptr(bias), N.ptr(w_scale), M, N_, K,
+           x.stride(0), w.stride(0), y.stride(0), N.dt(x.dtype), N.dt(w.dtype), N.stream())
     return y
 
 

@@ -93,5 +93,27 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
   return __builtin_amdgcn_cvt_pk_fp8_f32(clamp_fp8(c), clamp_fp8(d), r, true);
 }
 
+// Weight loaders: 8 consecutive K elements of one weight row as an MFMA operand.
+template <typename T> struct WLoad {
+  using V8 = typename Vec<T>::v8;
+  static __device__ __forceinline__ V8 ld(const void* base, long elem_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const V8*>(reinterpret_cast<const T*>(base) + elem_off));
+  }
+};
+// e4m3 weights, widened in registers (W8A16): half the HBM bytes of the 16-bit path
+template <typename T> struct WLoadFp8 {
+  using V8 = typename Vec<T>::v8;
+  static __device__ __forceinline__ V8 ld(const void* base, long elem_off) {
+    const u32x2 raw = __builtin_nontemporal_load(
+        reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(base) + elem_off));
+    V8 o;
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], true);
+    o[0] = (T)a[0]; o[1] = (T)a[1]; o[2] = (T)b[0]; o[3] = (T)b[1];
+    o[4] = (T)c[0]; o[5] = (T)c[1]; o[6] = (T)d[0]; o[7] = (T)d[1];
+    return o;
+  }
+};
+
 #define VDA_CHECK_LAUNCH() \
   do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

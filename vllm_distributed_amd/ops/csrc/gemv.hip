@@ -7,9 +7,10 @@
 // Role of the reference's csrc/rocm/skinny_gemms.cu (LLMM1 / wvSplitK).
 #include "common.h"
 
-template <typename T, int MT>   // MT = number of 16-row activation tiles
+template <typename T, int MT, typename WL>   // MT = number of 16-row activation tiles, WL = weight loader
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, const T* __restrict__ x,
-                                                          const T* __restrict__ w, const T* __restrict__ bias,
+                                                          const void* __restrict__ w, const T* __restrict__ bias,
+                                                          const float* __restrict__ w_scale,
                                                           int M, int N, int K, long x_stride, long w_stride,
                                                           long y_stride) {
   using V8 = typename Vec<T>::v8;
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const T* wp = w + (long)(n0 + r) * w_stride + g * 32;
+  const long wp = (long)(n0 + r) * w_stride + g * 32;   // element offset into w
   const T* xp[MT];
   bool xv[MT];
 #pragma unroll
@@ -37,8 +38,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, con
     V8 wa[4], wb[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      wa[s] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(wp + (long)c * 128 + 8 * s));
-      wb[s] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(wp + (long)(c + 4) * 128 + 8 * s));
+      wa[s] = WL::ld(w, wp + (long)c * 128 + 8 * s);
+      wb[s] = WL::ld(w, wp + (long)(c + 4) * 128 + 8 * s);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, con
     V8 wa[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      wa[s] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(wp + (long)c * 128 + 8 * s));
+      wa[s] = WL::ld(w, wp + (long)c * 128 + 8 * s);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, con
   __syncthreads();
   if (wave != 0) return;
   // lane holds y[m = mt*16 + r][n0 + 4g + i]
+  const float ws = w_scale ? w_scale[0] : 1.f;
   V4 bv = V4{};
   if (bias) bv = *reinterpret_cast<const V4*>(bias + n0 + 4 * g);
 #pragma unroll
@@ -82,21 +84,27 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, con
     if (xv[mt]) {
       V4 o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (T)(s[i] + (float)bv[i]);
+      for (int i = 0; i < 4; ++i) o[i] = (T)(s[i] * ws + (float)bv[i]);
       *reinterpret_cast<V4*>(y + (long)(mt * 16 + r) * y_stride + n0 + 4 * g) = o;
     }
   }
 }
 
-VDA_EXPORT int vda_skinny_gemm(void* y, const void* x, const void* w, const void* bias, int M, int N, int K,
-                               long x_stride, long w_stride, long y_stride, int dtype, hipStream_t st) {
+// wdtype VDA_FP8: w holds e4m3 bytes and w_scale (device, 1 float) dequantises the result (W8A16).
+VDA_EXPORT int vda_skinny_gemm(void* y, const void* x, const void* w, const void* bias, const float* w_scale, int M,
+                               int N, int K, long x_stride, long w_stride, long y_stride, int dtype, int wdtype,
+                               hipStream_t st) {
   if (M < 1 || M > 64 || N % 16 || K % 128) return -1;
   dim3 grid(N / 16), block(256);
   const int mt = (M + 15) / 16;
-#define L(TT, MM) hipLaunchKernelGGL((skinny_gemm_kernel<TT, MM>), grid, block, 0, st, (TT*)y, (const TT*)x, \
-                                     (const TT*)w, (const TT*)bias, M, N, K, x_stride, w_stride, y_stride)
-#define BY(TT) do { if (mt == 1) L(TT, 1); else if (mt == 2) L(TT, 2); else if (mt == 3) L(TT, 3); else L(TT, 4); } while (0)
-  if (dtype == VDA_BF16) BY(bf16_t); else if (dtype == VDA_F16) BY(f16_t); else return -3;
+#define L(TT, MM, WL) hipLaunchKernelGGL((skinny_gemm_kernel<TT, MM, WL>), grid, block, 0, st, (TT*)y, (const TT*)x, \
+                                         w, (const TT*)bias, w_scale, M, N, K, x_stride, w_stride, y_stride)
+#define BY(TT, WL) do { if (mt == 1) L(TT, 1, WL); else if (mt == 2) L(TT, 2, WL); else if (mt == 3) L(TT, 3, WL); \
+                        else L(TT, 4, WL); } while (0)
+  const bool f8 = wdtype == VDA_FP8;
+  if (dtype == VDA_BF16) { if (f8) BY(bf16_t, WLoadFp8<bf16_t>); else BY(bf16_t, WLoad<bf16_t>); }
+  else if (dtype == VDA_F16) { if (f8) BY(f16_t, WLoadFp8<f16_t>); else BY(f16_t, WLoad<f16_t>); }
+  else return -3;
 #undef BY
 #undef L
   VDA_CHECK_LAUNCH();

@@ -122,28 +122,6 @@ VDA_EXPORT int vda_moe_align(int* sorted, int* offsets, const int* ids, int n, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight loaders: 8 consecutive K elements of one weight row as an MFMA operand.
-template <typename T> struct WLoad {
-  using V8 = typename Vec<T>::v8;
-  static __device__ __forceinline__ V8 ld(const void* base, long elem_off) {
-    return __builtin_nontemporal_load(reinterpret_cast<const V8*>(reinterpret_cast<const T*>(base) + elem_off));
-  }
-};
-// e4m3 weights, widened in registers (W8A16): half the HBM bytes of the 16-bit path
-template <typename T> struct WLoadFp8 {
-  using V8 = typename Vec<T>::v8;
-  static __device__ __forceinline__ V8 ld(const void* base, long elem_off) {
-    const u32x2 raw = __builtin_nontemporal_load(
-        reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(base) + elem_off));
-    V8 o;
-    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], true);
-    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], true);
-    o[0] = (T)a[0]; o[1] = (T)a[1]; o[2] = (T)b[0]; o[3] = (T)b[1];
-    o[4] = (T)c[0]; o[5] = (T)c[1]; o[6] = (T)d[0]; o[7] = (T)d[1];
-    return o;
-  }
-};
-
 // GATE_UP: rows n0..n0+15 of the gate half AND of the up half of W13[e] ([2I, K]); epilogue silu(g)*u.
 // else   : rows n0..n0+15 of W2[e] ([H, K=I]); epilogue * routing weight.
 template <typename T, typename WL, bool GATE_UP>

@@ -255,7 +255,9 @@ def fp8_dequant(q, scale, dtype):
     return (q.float() * scale).to(dtype)
 
 
-def skinny_gemm(x, w, bias=None):
+def skinny_gemm(x, w, bias=None, w_scale=None):
+    if w.dtype == torch.float8_e4m3fn:
+        w = (w.float() * (w_scale.float() if w_scale is not None else 1.0)).to(x.dtype)
     return F.linear(x, w, bias)
 
 
