@@ -101,3 +101,23 @@ def test_multiproc_executor_reports_worker_death(tmp_path):
     with pytest.raises(RuntimeError):
         ex.collective_rpc("check_health")
     llm.shutdown()
+
+
+TKNP = {"enable_token_parallel": True, "token_parallel_size": 2}
+
+
+@pytest.mark.parametrize("world,kw", [
+    (2, dict(TKNP)),
+    (2, dict(TKNP, additional_config={"tknp_policy": "blockwise"})),
+    (3, {"enable_token_parallel": True, "token_parallel_size": 3}),
+    (4, dict(TKNP, tensor_parallel_size=2)),
+])
+def test_token_parallel_matches_single(tmp_path, world, kw):
+    """Token parallelism: requests (and their KV) are spread over the TKNP ranks, the root holds
+    the weights; 5 requests with chunked prefill (64-token budget) and continuous batching make the
+    per-rank rows non-contiguous, which the explicit row permutation must handle."""
+    model, _ = _save_tiny(str(tmp_path), "llama")
+    ref = _reference(model)
+    got = _launch(world, model, str(tmp_path / "out"), kw)
+    for r, toks in enumerate(got):
+        assert toks == ref, f"rank {r} diverged with {kw}"

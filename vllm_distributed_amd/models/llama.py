@@ -21,6 +21,7 @@ from ..layers.attention import Attention
 from ..layers.basic import LogitsProcessor, ParallelLMHead, RMSNorm, SiluAndMul, VocabParallelEmbedding
 from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
 from ..layers.rotary import get_rope
+from ..layers.token_parallel import tknp_metadata, token_parallel_attention
 from ..parallel.state import get_pp_group, get_tensor_model_parallel_world_size
 from .utils import (IntermediateTensors, PPMissingLayer, load_weights_with_mapping, make_layers, maybe_prefix)
 
@@ -43,7 +44,7 @@ class LlamaAttention(nn.Module):
     def __init__(self, config, hidden_size: int, num_heads: int, num_kv_heads: int, rope_theta: float,
                  rope_scaling: Optional[dict], max_position: int, bias: bool = False, o_bias: bool = False,
                  sliding_window: Optional[int] = None, quant_config=None, prefix: str = "", qk_norm: bool = False,
-                 cache_dtype: str = "auto"):
+                 cache_dtype: str = "auto", attention_only: bool = False):
         super().__init__()
         tp = get_tensor_model_parallel_world_size()
         self.total_num_heads, self.total_num_kv_heads = num_heads, num_kv_heads
@@ -51,20 +52,31 @@ class LlamaAttention(nn.Module):
         self.num_kv_heads = max(1, num_kv_heads // tp)
         self.head_dim = getattr(config, "head_dim", None) or hidden_size // num_heads
         self.q_size, self.kv_size = self.num_heads * self.head_dim, self.num_kv_heads * self.head_dim
-        self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=bias,
-                                          quant_config=quant_config, prefix=f"{prefix}.qkv_proj")
-        self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=o_bias,
-                                        quant_config=quant_config, prefix=f"{prefix}.o_proj")
+        self.attention_only = attention_only
+        if not attention_only:
+            self._make_projections(hidden_size, num_heads, num_kv_heads, bias, o_bias, quant_config, prefix)
         partial = getattr(config, "partial_rotary_factor", 1.0) or 1.0
         self.rotary_emb = get_rope(self.head_dim, self.head_dim, max_position, rope_theta, True, rope_scaling,
                                    partial)
         self.attn = Attention(self.num_heads, self.head_dim, self.head_dim ** -0.5, self.num_kv_heads,
                               sliding_window=sliding_window, prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
-        self.qk_norm = qk_norm
-        if qk_norm:
+        self.qk_norm = qk_norm and not attention_only
+        if self.qk_norm:
             eps = getattr(config, "rms_norm_eps", 1e-6)
             self.q_norm = RMSNorm(self.head_dim, eps)
             self.k_norm = RMSNorm(self.head_dim, eps)
+
+    def _make_projections(self, hidden_size, num_heads, num_kv_heads, bias, o_bias, quant_config, prefix):
+        self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=bias,
+                                          quant_config=quant_config, prefix=f"{prefix}.qkv_proj")
+        self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=o_bias,
+                                        quant_config=quant_config, prefix=f"{prefix}.o_proj")
+
+    def forward_attention_only(self, positions: torch.Tensor, dtype: torch.dtype) -> None:
+        """Non-root token-parallel rank: this layer's share of the attention, nothing else."""
+        md = tknp_metadata()
+        token_parallel_attention(self.attn, self.rotary_emb, None, positions, md, self.q_size + 2 * self.kv_size,
+                                 self.q_size, dtype, positions.device)
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
         qkv = self.qkv_proj(hidden_states)
@@ -74,11 +86,17 @@ class LlamaAttention(nn.Module):
             k = qkv[:, self.q_size: self.q_size + self.kv_size].reshape(T * self.num_kv_heads, self.head_dim)
             qkv[:, : self.q_size] = self.q_norm(q).view(T, self.q_size)
             qkv[:, self.q_size: self.q_size + self.kv_size] = self.k_norm(k).view(T, self.kv_size)
+        md = tknp_metadata()
+        if md is not None:
+            o = token_parallel_attention(self.attn, self.rotary_emb, qkv, positions, md, qkv.shape[1], self.q_size,
+                                         qkv.dtype, qkv.device)
+            return self.o_proj(o)
         return self.o_proj(self.attn(qkv, positions, self.rotary_emb))
 
 
 class LlamaDecoderLayer(nn.Module):
-    def __init__(self, config, vllm_config: VllmConfig, quant_config=None, prefix: str = ""):
+    def __init__(self, config, vllm_config: VllmConfig, quant_config=None, prefix: str = "",
+                 attention_only: bool = False):
         super().__init__()
         mc = vllm_config.model_config
         rope_scaling = getattr(config, "rope_scaling", None) or getattr(config, "rope_parameters", None)
@@ -101,7 +119,9 @@ class LlamaDecoderLayer(nn.Module):
             rope_theta, rope_scaling, mc.max_model_len, bias=bias, o_bias=False
             if arch.startswith("Qwen") else bias, sliding_window=window, quant_config=quant_config,
             prefix=f"{prefix}.self_attn", qk_norm=arch.startswith("Qwen3"),
-            cache_dtype=vllm_config.cache_config.cache_dtype)
+            cache_dtype=vllm_config.cache_config.cache_dtype, attention_only=attention_only)
+        if attention_only:
+            return
         self.mlp = self._make_mlp(config, vllm_config, quant_config, f"{prefix}.mlp")
         eps = getattr(config, "rms_norm_eps", 1e-6)
         self.input_layernorm = RMSNorm(config.hidden_size, eps)
@@ -212,3 +232,36 @@ class Qwen2ForCausalLM(LlamaForCausalLM):
 
 class Qwen3ForCausalLM(LlamaForCausalLM):
     pass
+
+
+class TokenParallelWorkerModel(nn.Module):
+    """What a non-root token-parallel rank runs: the attention of every local layer (same module
+    names as the full model, so KV-cache binding is identical) and nothing that needs weights."""
+    is_tknp_worker = True
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = "", layer_cls=LlamaDecoderLayer):
+        super().__init__()
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        self.dtype = vllm_config.model_config.dtype
+        self.model = nn.Module()
+        mp = maybe_prefix(prefix, "model")
+        self.model.start_layer, self.model.end_layer, self.model.layers = make_layers(
+            config.num_hidden_layers, lambda p: layer_cls(config, vllm_config, None, p, attention_only=True),
+            f"{mp}.layers")
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None):
+        if tknp_metadata() is None:          # memory profiling: nothing to run without the root
+            return None
+        m = self.model
+        for layer in m.layers[m.start_layer:m.end_layer]:
+            layer.self_attn.forward_attention_only(positions, self.dtype)
+        return None
+
+    def load_weights(self, weights) -> None:
+        for _ in ():                          # no parameters: the checkpoint is not even opened
+            pass
+        return None
+
+
+LlamaForCausalLM.tknp_worker_cls = TokenParallelWorkerModel

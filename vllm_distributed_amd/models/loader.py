@@ -46,6 +46,15 @@ def _quant_config(vllm_config: VllmConfig):
 def initialize_model(vllm_config: VllmConfig, prefix: str = "") -> nn.Module:
     cls, arch = ModelRegistry.resolve_model_cls(vllm_config.model_config.architectures)
     vllm_config.quant_config = _quant_config(vllm_config)
+    if vllm_config.parallel_config.token_parallel_size > 1:
+        from ..parallel.state import is_tknp_root
+        worker_cls = getattr(cls, "tknp_worker_cls", None)
+        if worker_cls is None:
+            raise ValueError(f"{arch} does not support token parallelism")
+        if not is_tknp_root():
+            # non-root token-parallel ranks hold no weights: attention + KV cache only
+            with set_current_vllm_config(vllm_config):
+                return worker_cls(vllm_config=vllm_config, prefix=prefix)
     with set_current_vllm_config(vllm_config):
         return cls(vllm_config=vllm_config, prefix=prefix)
 
@@ -133,7 +142,8 @@ class BaseModelLoader:
         t0 = time.time()
         with set_default_torch_dtype(mc.dtype), device:
             model = initialize_model(vllm_config)
-        self.load_weights(model, vllm_config)
+        if not getattr(model, "is_tknp_worker", False):
+            self.load_weights(model, vllm_config)
         for m in model.modules():
             qm = getattr(m, "quant_method", None)
             if qm is not None and hasattr(qm, "process_weights_after_loading"):

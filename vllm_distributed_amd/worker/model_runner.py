@@ -62,7 +62,11 @@ class ModelRunner:
         group = max(self.num_heads // self.num_kv_heads, 1)
         # query tokens per sequence the split-KV kernel form can take (<= 32 MFMA columns per kv head)
         self.max_decode_q = max(1, min(1 + self.num_spec_tokens, 32 // group if self.head_size <= 128 else 16 // group))
-        self.use_graphs = self.is_gpu and vllm_config.compilation_config.level > 0 and not mc.enforce_eager
+        self.tknp_size = pc.token_parallel_size
+        self.tknp_rank = get_tknp_group().rank_in_group if self.tknp_size > 1 else 0
+        # token parallelism exchanges a different number of rows every step: eager only
+        self.use_graphs = self.is_gpu and vllm_config.compilation_config.level > 0 and not mc.enforce_eager \
+            and self.tknp_size == 1
         self.capture_sizes = list(vllm_config.compilation_config.cudagraph_capture_sizes or []) if self.use_graphs else []
         self.model: Optional[nn.Module] = None
         self.sampler = Sampler()
@@ -202,6 +206,44 @@ class ModelRunner:
                 ib.token_ids[row, s:s + len(spec)] = spec
 
     # ------------------------------------------------------------------
+    def _flat_arrays(self, rows: np.ndarray, n_sched: np.ndarray):
+        """Per-token arrays of a list of requests (batch rows ``rows``, ``n_sched`` tokens each)."""
+        ib = self.input_batch
+        S = len(rows)
+        T = int(n_sched.sum())
+        cu = np.zeros(S + 1, dtype=np.int32)
+        np.cumsum(n_sched, out=cu[1:])
+        req_idx = np.repeat(np.arange(S, dtype=np.int64), n_sched)
+        computed = ib.num_computed[rows].astype(np.int64)
+        pos = computed[req_idx] + (np.arange(T, dtype=np.int64) - cu[:-1].astype(np.int64)[req_idx])
+        tok_rows = rows[req_idx]
+        bt = ib.block_tables[0]
+        slot = bt[tok_rows, pos // self.block_size].astype(np.int64) * self.block_size + pos % self.block_size
+        seq_lens = (computed + n_sched).astype(np.int32)
+        return cu, req_idx, pos, tok_rows, slot, seq_lens
+
+    def _upload_attention_inputs(self, rows, n_sched, cu, pos, slot, seq_lens) -> tuple[int, int]:
+        """Ship the attention-side arrays of the requests this rank attends for; returns
+        (decode-form sequence count, decode-form token count)."""
+        ib = self.input_batch
+        S = len(rows)
+        nd = int((n_sched <= self.max_decode_q).sum())
+        ndt = int(n_sched[:nd].sum())
+        max_seq = int(seq_lens.max()) if S else 0
+        W = max(-(-max_seq // self.block_size), 1)
+        self._to_dev(self.positions, pos)
+        self._to_dev(self.slot_mapping, slot)
+        self._to_dev(self.seq_lens, seq_lens)
+        self._to_dev(self.query_start_loc, cu)
+        if S:
+            btv = torch.from_numpy(np.ascontiguousarray(ib.block_tables[0][rows, :W]))
+            if self.pin:
+                btv = btv.pin_memory()
+            self.block_table[:S, :W].copy_(btv, non_blocking=True)
+        if nd < S:
+            self._to_dev(self.prefill_qsl, (cu[nd:] - cu[nd]).astype(np.int32))
+        return nd, ndt
+
     def _prepare_inputs(self, so: SchedulerOutput):
         ib = self.input_batch
         req_ids = list(so.num_scheduled_tokens)
@@ -212,35 +254,50 @@ class ModelRunner:
         order = np.argsort(~is_dec, kind="stable")
         req_ids = [req_ids[i] for i in order]
         n_sched, rows = n_sched[order], rows[order]
-        nd = int(is_dec.sum())
         S = len(req_ids)
-        T = int(n_sched.sum())
-        ndt = int(n_sched[:nd].sum())
-        cu = np.zeros(S + 1, dtype=np.int32)
-        np.cumsum(n_sched, out=cu[1:])
-        req_idx = np.repeat(np.arange(S, dtype=np.int64), n_sched)
-        computed = ib.num_computed[rows].astype(np.int64)
-        pos = computed[req_idx] + (np.arange(T, dtype=np.int64) - cu[:-1].astype(np.int64)[req_idx])
-        tok_rows = rows[req_idx]
-        input_ids = ib.token_ids[tok_rows, pos]
-        bt = ib.block_tables[0]
-        slot = bt[tok_rows, pos // self.block_size].astype(np.int64) * self.block_size + pos % self.block_size
-        seq_lens = (computed + n_sched).astype(np.int32)
-        max_seq = int(seq_lens.max()) if S else 0
-        W = max(-(-max_seq // self.block_size), 1)
-        self._to_dev(self.input_ids, input_ids)
-        self._to_dev(self.positions, pos)
-        self._to_dev(self.slot_mapping, slot)
-        self._to_dev(self.seq_lens, seq_lens)
-        self._to_dev(self.query_start_loc, cu)
-        btv = torch.from_numpy(np.ascontiguousarray(bt[rows, :W]))
-        if self.pin:
-            btv = btv.pin_memory()
-        self.block_table[:S, :W].copy_(btv, non_blocking=True)
-        if nd < S:
-            self._to_dev(self.prefill_qsl, (cu[nd:] - cu[nd]).astype(np.int32))
+        cu, req_idx, pos, tok_rows, slot, seq_lens = self._flat_arrays(rows, n_sched)
+        T = int(cu[-1])
+        tmd = None
+        if self.tknp_size > 1:
+            tmd, att = self._prepare_token_parallel(so, req_ids, rows, n_sched, req_idx, tok_rows, pos)
+        else:
+            self._to_dev(self.input_ids, ib.token_ids[tok_rows, pos])
+            nd, ndt = self._upload_attention_inputs(rows, n_sched, cu, pos, slot, seq_lens)
+            att = (S, T, nd, ndt, int(seq_lens.max()) if S else 0, int(n_sched.max()) if S else 0)
         logits_idx = (cu[1:] - 1).astype(np.int64)
-        return req_ids, rows, n_sched, cu, nd, ndt, S, T, seq_lens, logits_idx
+        return req_ids, rows, n_sched, cu, S, T, logits_idx, att, tmd
+
+    def _prepare_token_parallel(self, so, req_ids, rows, n_sched, req_idx, tok_rows, pos):
+        """Token parallelism: the root feeds all T rows through the dense layers, but every rank
+        (root included) attends only for the requests it owns.  Rows are grouped by owner with an
+        explicit permutation; the local request list keeps the batch order (decode-form first)."""
+        ib = self.input_batch
+        alloc = so.tknp
+        if alloc is None:
+            raise RuntimeError("token parallelism is enabled but the scheduler sent no rank assignment")
+        is_root = self.tknp_rank == 0
+        owner = np.fromiter((alloc.req_to_rank[r] for r in req_ids), dtype=np.int64, count=len(req_ids))
+        tok_owner = owner[req_idx]
+        per_rank = np.bincount(tok_owner, minlength=self.tknp_size).astype(np.int64)
+        T = len(tok_owner)
+        sel = owner == self.tknp_rank
+        rows_l, n_l = rows[sel], n_sched[sel]
+        cu_l, _, pos_l, _, slot_l, seq_l = self._flat_arrays(rows_l, n_l)
+        nd, ndt = self._upload_attention_inputs(rows_l, n_l, cu_l, pos_l, slot_l, seq_l)
+        S_l, T_l = len(rows_l), int(cu_l[-1])
+        perm_t = inv_t = None
+        if is_root:
+            self._to_dev(self.input_ids, ib.token_ids[tok_rows, pos])
+            perm = np.argsort(tok_owner, kind="stable")
+            if not np.array_equal(perm, np.arange(T)):
+                inv = np.empty_like(perm)
+                inv[perm] = np.arange(T)
+                perm_t = torch.from_numpy(perm).to(self.device, non_blocking=True)
+                inv_t = torch.from_numpy(inv).to(self.device, non_blocking=True)
+        tmd = TokenParallelMetadata(tokens_per_rank=per_rank.tolist(), perm=perm_t, inv_perm=inv_t,
+                                    num_local_tokens=T_l, num_total_tokens=T, is_root=is_root)
+        att = (S_l, T_l, nd, ndt, int(seq_l.max()) if S_l else 0, int(n_l.max()) if S_l else 0)
+        return tmd, att
 
     def _decode_splits(self, num_seqs: int, max_seq_len: int, fixed: bool) -> int:
         if num_seqs == 0:
@@ -276,9 +333,9 @@ class ModelRunner:
         self._update_states(so)
         if not so.total_num_scheduled_tokens:
             return self._finish_kv_only(so)
-        req_ids, rows, n_sched, cu, nd, ndt, S, T, seq_lens, logits_idx = self._prepare_inputs(so)
+        req_ids, rows, n_sched, cu, S, T, logits_idx, att, tmd = self._prepare_inputs(so)
+        S_a, T_a, nd, ndt, max_seq, max_q = att        # what THIS rank attends for (== the batch without TKNP)
         ib = self.input_batch
-        max_seq, max_q = int(seq_lens.max()), int(n_sched.max())
         pure_decode = nd == S and max_q == 1
         pp = get_pp_group()
         graph_bs = None
@@ -306,17 +363,24 @@ class ModelRunner:
             hidden = hidden_buf
         else:
             nsplit = self._decode_splits(nd, max_seq, False)
-            md = self._build_attn_metadata(S, T, nd, ndt, max_seq, max_q, nsplit)
+            md = self._build_attn_metadata(S_a, T_a, nd, ndt, max_seq, max_q, nsplit)
             inter = None
             if not pp.is_first_rank:
                 inter = intermediate_tensors
-            with set_forward_context(md, kv_connector=conn, num_tokens=T):
+            with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T):
                 if conn is not None:
                     conn.start_load_kv()
-                hidden = self.model(self.input_ids[:T], self.positions[:T], inter, None)
+                hidden = self.model(self.input_ids[:T], self.positions[:T_a], inter, None)
         if conn is not None:
             conn.wait_for_save()
             conn.clear_connector_metadata()
+        if tmd is not None and not tmd.is_root:
+            # the root samples; everybody applies the same tokens to the persistent batch
+            if not pp.is_last_rank:
+                return EMPTY_MODEL_RUNNER_OUTPUT
+            out = get_tknp_group().broadcast_object(None, src=0)
+            self._apply_sampled(out.req_ids, out.sampled_token_ids)
+            return out
         if not pp.is_last_rank:
             return hidden
         finished_sending, finished_recving = (conn.get_finished(so.finished_req_ids) if conn is not None
@@ -348,24 +412,33 @@ class ModelRunner:
             sampled_lists = [[t] for t in sampled_t.tolist()]
         # requests still in the middle of their prompt discard the sample
         done = (ib.num_computed[rows] + n_sched) >= ib.num_tokens[rows]
-        for i, rid in enumerate(req_ids):
+        for i in range(len(req_ids)):
             if not done[i]:
                 sampled_lists[i] = []
-                continue
-            st = ib.reqs[rid]
-            for tok in sampled_lists[i]:
-                ib.append_token(int(rows[i]), tok)
-                st.output_token_ids.append(tok)
+        self._apply_sampled(req_ids, sampled_lists)
         spec_tokens = None
         if self.drafter is not None:
             spec_tokens = self.drafter.propose(self, req_ids, rows, sampled_lists, hidden, cu)
         lp_lists = Sampler.to_lists(logprobs_t)
         self._step += 1
-        return ModelRunnerOutput(
+        result = ModelRunnerOutput(
             req_ids=req_ids, req_id_to_index={r: i for i, r in enumerate(req_ids)},
             sampled_token_ids=sampled_lists, spec_token_ids=spec_tokens, logprobs=lp_lists,
             prompt_logprobs_dict=prompt_lp, finished_sending=finished_sending, finished_recving=finished_recving,
             num_nans_in_logits=getattr(self, "_last_nans", None))
+        if tmd is not None:
+            get_tknp_group().broadcast_object(result, src=0)
+        return result
+
+    def _apply_sampled(self, req_ids: list[str], sampled_lists: list[list[int]]) -> None:
+        ib = self.input_batch
+        for rid, toks in zip(req_ids, sampled_lists):
+            if not toks:
+                continue
+            st = ib.reqs[rid]
+            for tok in toks:
+                ib.append_token(st.row, tok)
+                st.output_token_ids.append(tok)
 
     def _finish_kv_only(self, so: SchedulerOutput) -> ModelRunnerOutput:
         """No tokens scheduled: still drive the KV connector (async transfers)."""
@@ -528,7 +601,7 @@ class ModelRunner:
     @torch.inference_mode()
     def profile_run(self) -> None:
         hidden = self._dummy_run(self.max_num_tokens)
-        if get_pp_group().is_last_rank:
+        if get_pp_group().is_last_rank and hidden is not None:
             n = min(self.max_num_reqs, self.max_num_tokens)
             logits = self.model.compute_logits(hidden[:n])
             self.sampler(logits, SamplingMetadata(None, True, False))

@@ -148,7 +148,9 @@ class Worker:
         pp = pstate.get_pp_group()
         tp = pstate.get_tp_group()
         inter = None
-        if not pp.is_first_rank and scheduler_output.total_num_scheduled_tokens:
+        # non-root token-parallel ranks run attention only: no activations travel between their stages
+        attn_only = getattr(self.model_runner.model, "is_tknp_worker", False)
+        if not pp.is_first_rank and scheduler_output.total_num_scheduled_tokens and not attn_only:
             d = pp.recv_tensor_dict(all_gather_group=tp)
             inter = IntermediateTensors(d)
         out = self.model_runner.execute_model(scheduler_output, inter)
@@ -160,7 +162,7 @@ class Worker:
             pp.send_tensor_dict(out.tensors, all_gather_group=tp)
             return pp.broadcast_object(None, src=pp.world_size - 1) if share else None
         if share:
-            pp.broadcast_object(out, src=pp.world_size - 1)
+            out = pp.broadcast_object(out if pp.is_last_rank else None, src=pp.world_size - 1)
         return out
 
     def profile(self, is_start: bool = True) -> None:
