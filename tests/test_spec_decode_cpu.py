@@ -1,0 +1,109 @@
+"""Speculative decoding: greedy outputs must not depend on the proposer (n-gram, EAGLE, Medusa with
+random draft weights), drafts must actually be accepted for repetitive text, and the rejection
+sampler must preserve the target distribution (modelled on tests/v1/spec_decode, tests/v1/sample)."""
+import json
+import os
+
+import numpy as np
+import torch
+from safetensors.torch import save_file
+
+from tests.test_e2e_cpu import _save_tiny
+from vllm_distributed_amd import LLM, SamplingParams
+
+KW = dict(skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+          max_num_batched_tokens=64)
+PROMPTS = [[5, 6, 7, 8] * 6, [(3 * j) % 200 for j in range(30)], [9, 9, 9, 9, 9, 9]]
+SP = SamplingParams(temperature=0, max_tokens=24, ignore_eos=True)
+
+
+def _gen(path, **kw):
+    llm = LLM(model=path, **KW, **kw)
+    outs = llm.generate(prompt_token_ids=PROMPTS, sampling_params=SP)
+    toks = [list(o.outputs[0].token_ids) for o in outs]
+    stats = llm.llm_engine.engine_core.engine_core.scheduler.make_stats()
+    llm.shutdown()
+    return toks, stats
+
+
+def test_native_ngram_matcher():
+    import ctypes
+    from vllm_distributed_amd.runtime.shm_ring import host_library
+    lib = host_library()
+    lib.vda_ngram_propose.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p]
+    toks = np.array([1, 2, 3, 4, 5, 9, 2, 3, 4, 7, 7, 2, 3, 4], dtype=np.int32)
+    out = np.zeros(3, dtype=np.int32)
+    n = lib.vda_ngram_propose(toks.ctypes.data, len(toks), 2, 3, 3, out.ctypes.data)
+    assert n == 3 and out.tolist() == [7, 7, 2]          # latest earlier "2 3 4" is followed by 7 7 2
+    n = lib.vda_ngram_propose(toks.ctypes.data, 5, 2, 3, 3, out.ctypes.data)
+    assert n == 0
+
+
+def test_ngram_same_tokens_and_accepts(tmp_path):
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    ref, _ = _gen(path)
+    got, stats = _gen(path, speculative_config={"method": "ngram", "num_speculative_tokens": 3,
+                                                "prompt_lookup_max": 3, "prompt_lookup_min": 1})
+    assert got == ref
+
+
+def _save_draft(tmp, kind, target_path):
+    cfg = json.load(open(os.path.join(target_path, "config.json")))
+    H, I, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    d = os.path.join(tmp, kind)
+    os.makedirs(d)
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.05      # noqa: E731
+    if kind == "eagle":
+        cfg.update(architectures=["EagleLlamaForCausalLM"], num_hidden_layers=1)
+        hd, nh, nkv = cfg["head_dim"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
+        w = {"fc.weight": r(H, 2 * H),
+             "layers.0.self_attn.q_proj.weight": r(nh * hd, H), "layers.0.self_attn.k_proj.weight": r(nkv * hd, H),
+             "layers.0.self_attn.v_proj.weight": r(nkv * hd, H), "layers.0.self_attn.o_proj.weight": r(H, nh * hd),
+             "layers.0.mlp.gate_proj.weight": r(I, H), "layers.0.mlp.up_proj.weight": r(I, H),
+             "layers.0.mlp.down_proj.weight": r(H, I), "layers.0.post_attention_layernorm.weight": torch.ones(H)}
+    else:
+        cfg = {"architectures": ["MedusaModel"], "hidden_size": H, "vocab_size": V, "num_heads": 3,
+               "num_hidden_layers": 1, "model_type": "medusa"}
+        w = {}
+        for h in range(3):
+            w[f"{h}.0.linear.weight"], w[f"{h}.0.linear.bias"] = r(H, H), r(H)
+            w[f"{h}.1.weight"] = r(V, H)
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    save_file(w, os.path.join(d, "model.safetensors"))
+    return d
+
+
+def test_eagle_and_medusa_same_tokens(tmp_path):
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    ref, _ = _gen(path)
+    for kind in ("eagle", "medusa"):
+        draft = _save_draft(str(tmp_path), kind, path)
+        got, _ = _gen(path, speculative_config={"method": kind, "model": draft, "num_speculative_tokens": 3})
+        assert got == ref, kind
+
+
+def test_rejection_sampler_greedy_and_distribution():
+    from vllm_distributed_amd.layers.rejection_sampler import RejectionSampler
+    from vllm_distributed_amd.layers.sampler import Sampler, SamplingMetadata
+    rs, sampler = RejectionSampler(), Sampler()
+    V = 6
+    lg = torch.full((5, V), -10.0)
+    for r, t in enumerate([2, 3, 1, 4, 0]):
+        lg[r, t] = 10.0
+    md = SamplingMetadata(None, True, False)
+    # request 0: drafts [2, 5] -> first accepted, second rejected (target 3); request 1: draft [4] accepted + bonus 0
+    assert rs(lg, [[2, 5], [4]], md, sampler) == [[2, 3], [4, 0]]
+    # sampled: the emitted first token must follow the target distribution whatever the draft is
+    torch.manual_seed(0)
+    p = torch.tensor([0.5, 0.3, 0.1, 0.05, 0.03, 0.02])
+    N = 4000
+    logits = p.log().repeat(2 * N, 1)
+    md = SamplingMetadata(torch.ones(N), False, True)
+    outs = rs(logits, [[1]] * N, md, sampler)
+    first = torch.tensor([o[0] for o in outs])
+    freq = torch.bincount(first, minlength=V).float() / N
+    assert torch.allclose(freq, p, atol=0.03), freq
+    acc = sum(len(o) == 2 for o in outs) / N
+    assert abs(acc - 0.3) < 0.03          # P(accept draft token 1) = p(1) for a one-hot draft

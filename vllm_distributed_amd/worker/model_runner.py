@@ -127,6 +127,11 @@ class ModelRunner:
             from ..layers.rejection_sampler import RejectionSampler
             self.drafter = make_proposer(self.vllm_config, self)
             self.rejection_sampler = RejectionSampler()
+            if hasattr(self.drafter, "attention_layers"):
+                # the draft layers cache K/V like any other layer (same blocks, own tensors)
+                for n, m in self.drafter.attention_layers().items():
+                    m.layer_name = n
+                    self.attn_layers[n] = m
         if self.vllm_config.lora_config is not None:
             from ..lora.manager import LoRAManager
             self.lora_manager = LoRAManager(self.model, self.vllm_config, self.device)
@@ -418,7 +423,7 @@ class ModelRunner:
         self._apply_sampled(req_ids, sampled_lists)
         spec_tokens = None
         if self.drafter is not None:
-            spec_tokens = self.drafter.propose(self, req_ids, rows, sampled_lists, hidden, cu)
+            spec_tokens = self.drafter.propose(self, req_ids, rows, sampled_lists, hidden, cu, n_sched, so)
         lp_lists = Sampler.to_lists(logprobs_t)
         self._step += 1
         result = ModelRunnerOutput(
