@@ -1,0 +1,62 @@
+"""Rank program of the GPU disaggregation test: `producer` prefills and serves its KV arena,
+`consumer` pulls the blocks over peer memory and decodes."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ["VLLM_ENABLE_V1_MULTIPROCESSING"] = "0"
+os.environ.setdefault("VLLM_LOGGING_LEVEL", "WARNING")
+
+from vllm_distributed_amd import LLM, SamplingParams  # noqa: E402
+
+PROMPTS = [[(7 * i + 3 * j) % 300 for j in range(150 + 40 * i)] for i in range(4)]
+
+
+def main():
+    role, model, port, workdir = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    kw = dict(skip_tokenizer_init=True, dtype="bfloat16", max_model_len=512, max_num_seqs=8,
+              max_num_batched_tokens=256, gpu_memory_utilization=0.05, enforce_eager=True)
+    kt = dict(kv_connector="XgmiConnector", kv_port=port)
+    if role == "producer":
+        llm = LLM(model=model, kv_transfer_config=dict(kt, kv_role="kv_producer"), **kw)
+        sp = SamplingParams(temperature=0, max_tokens=1, ignore_eos=True,
+                            extra_args={"kv_transfer_params": {"do_remote_decode": True}})
+        outs = llm.generate(prompt_token_ids=PROMPTS, sampling_params=sp)
+        with open(os.path.join(workdir, "params.json.tmp"), "w") as f:
+            json.dump([o.kv_transfer_params for o in outs], f)
+        os.replace(os.path.join(workdir, "params.json.tmp"), os.path.join(workdir, "params.json"))
+        t0 = time.time()
+        while not os.path.exists(os.path.join(workdir, "consumer.done")) and time.time() - t0 < 120:
+            time.sleep(0.1)
+        pool = llm.llm_engine.engine_core.engine_core.scheduler.kv_cache_manager.block_pool
+        before = pool.get_num_free_blocks()
+        llm.generate(prompt_token_ids=[[1, 2, 3]], sampling_params=SamplingParams(max_tokens=2))
+        with open(os.path.join(workdir, "producer.json"), "w") as f:
+            json.dump({"freed": pool.get_num_free_blocks() - before}, f)
+        llm.shutdown()
+    else:
+        t0 = time.time()
+        while not os.path.exists(os.path.join(workdir, "params.json")) and time.time() - t0 < 120:
+            time.sleep(0.1)
+        params = json.load(open(os.path.join(workdir, "params.json")))
+        ref_llm = LLM(model=model, **kw)
+        sp = SamplingParams(temperature=0, max_tokens=8, ignore_eos=True)
+        ref = [list(o.outputs[0].token_ids) for o in ref_llm.generate(prompt_token_ids=PROMPTS, sampling_params=sp)]
+        ref_llm.shutdown()
+        llm = LLM(model=model, kv_transfer_config=dict(kt, kv_role="kv_consumer"), **kw)
+        sps = [SamplingParams(temperature=0, max_tokens=8, ignore_eos=True, extra_args={"kv_transfer_params": p})
+               for p in params]
+        outs = llm.generate(prompt_token_ids=PROMPTS, sampling_params=sps)
+        conn = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.kv_connector
+        mapped = any(p.region is not None for p in conn._peers.values())
+        with open(os.path.join(workdir, "consumer.json"), "w") as f:
+            json.dump({"ref": ref, "got": [list(o.outputs[0].token_ids) for o in outs], "peer_memory": mapped,
+                       "cached": [o.num_cached_tokens for o in outs]}, f)
+        open(os.path.join(workdir, "consumer.done"), "w").close()
+        llm.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,7 +151,15 @@ class ModelRunner:
         IPC handle for the xGMI KV connector), carved into per-layer K and V views."""
         self.kv_cache_config = cfg
         total = sum(t.size for t in cfg.kv_cache_tensors)
-        self.kv_arena = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        kt = self.vllm_config.kv_transfer_config
+        self.kv_region = None
+        if self.is_gpu and kt is not None and kt.is_kv_producer and kt.kv_connector != "SharedStorageConnector":
+            # peers map this arena over xGMI: it must be one IPC-shareable allocation
+            from ..device_allocator import alloc_shareable
+            self.kv_region = alloc_shareable(total, self.device)
+            self.kv_arena = self.kv_region.tensor
+        else:
+            self.kv_arena = torch.zeros(total, dtype=torch.uint8, device=self.device)
         spec_of = {}
         for g in cfg.kv_cache_groups:
             for n in g.layer_names:
