@@ -11,12 +11,12 @@ os.environ.setdefault("VLLM_LOGGING_LEVEL", "WARNING")
 
 from vllm_distributed_amd import LLM, SamplingParams  # noqa: E402
 
-PROMPTS = [[(7 * i + 3 * j) % 300 for j in range(150 + 40 * i)] for i in range(4)]
+PROMPTS = [[(7 * i + 3 * j) % 300 for j in range(100 + 30 * i)] for i in range(4)]
 
 
 def main():
     role, model, port, workdir = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    kw = dict(skip_tokenizer_init=True, dtype="bfloat16", max_model_len=512, max_num_seqs=8,
+    kw = dict(skip_tokenizer_init=True, dtype="bfloat16", max_model_len=256, max_num_seqs=8,
               max_num_batched_tokens=256, gpu_memory_utilization=0.05, enforce_eager=True)
     kt = dict(kv_connector="XgmiConnector", kv_port=port)
     if role == "producer":

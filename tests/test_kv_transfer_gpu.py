@@ -37,5 +37,5 @@ def test_prefill_decode_over_peer_memory(tmp_path):
     c = json.load(open(tmp_path / "consumer.json"))
     assert c["peer_memory"], "the consumer fell back to the socket data plane"
     assert c["got"] == c["ref"]
-    assert all(n > 100 for n in c["cached"])
+    assert all(n >= 96 for n in c["cached"])
     assert json.load(open(tmp_path / "producer.json"))["freed"] > 0
