@@ -1,0 +1,2 @@
+"""Multi-LoRA serving."""
+from .manager import LoRAManager, LoRAModel  # noqa: F401

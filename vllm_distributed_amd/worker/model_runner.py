@@ -387,6 +387,8 @@ class ModelRunner:
         if conn is not None:
             conn.wait_for_save()
             conn.clear_connector_metadata()
+        if self.lora_manager is not None:
+            self.lora_manager.clear_active()       # the output head and warm-up runs are not adapted
         if tmd is not None and not tmd.is_root:
             # the root samples; everybody applies the same tokens to the persistent batch
             if not pp.is_last_rank:
