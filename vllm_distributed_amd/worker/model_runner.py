@@ -401,6 +401,9 @@ class ModelRunner:
         finished_sending, finished_recving = (conn.get_finished(so.finished_req_ids) if conn is not None
                                               else (None, None))
 
+        if getattr(self.model, "is_pooling_model", False):
+            return self._pool(so, hidden, req_ids, rows, n_sched, cu, finished_sending, finished_recving)
+
         # ---- logits + sampling ------------------------------------------------
         spec_sched = so.scheduled_spec_decode_tokens
         if spec_sched and self.rejection_sampler is not None:
@@ -444,6 +447,25 @@ class ModelRunner:
         if tmd is not None:
             get_tknp_group().broadcast_object(result, src=0)
         return result
+
+    def _pool(self, so, hidden, req_ids, rows, n_sched, cu, fs, fr) -> ModelRunnerOutput:
+        """Pooling models: one vector (or score) per request once its whole prompt has been run."""
+        ib = self.input_batch
+        done = (ib.num_computed[rows] + n_sched) >= ib.num_tokens[rows]
+        whole = self.model.pooler.needs_whole_prompt
+        outs = []
+        for i, rid in enumerate(req_ids):
+            if not done[i]:
+                outs.append(None)
+                continue
+            if whole and ib.num_computed[rows[i]] > 0:
+                raise RuntimeError("mean/cls pooling needs the whole prompt in one step: disable chunked prefill "
+                                   "and prefix caching for this model")
+            h = hidden[int(cu[i]): int(cu[i + 1])]
+            outs.append(self.model.pool(h, ib.reqs[rid].pooling_params).cpu())
+        return ModelRunnerOutput(req_ids=req_ids, req_id_to_index={r: i for i, r in enumerate(req_ids)},
+                                 sampled_token_ids=[[] for _ in req_ids], pooler_output=outs,
+                                 finished_sending=fs, finished_recving=fr)
 
     def _apply_sampled(self, req_ids: list[str], sampled_lists: list[list[int]]) -> None:
         ib = self.input_batch
@@ -616,7 +638,7 @@ class ModelRunner:
     @torch.inference_mode()
     def profile_run(self) -> None:
         hidden = self._dummy_run(self.max_num_tokens)
-        if get_pp_group().is_last_rank and hidden is not None:
+        if get_pp_group().is_last_rank and hidden is not None and hasattr(self.model, "compute_logits"):
             n = min(self.max_num_reqs, self.max_num_tokens)
             logits = self.model.compute_logits(hidden[:n])
             self.sampler(logits, SamplingMetadata(None, True, False))
