@@ -15,6 +15,8 @@ PROMPTS = [[(7 * i + 3 * j) % 300 for j in range(100 + 30 * i)] for i in range(4
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(70, exit=True)      # a hang ends with stacks instead of silence
     role, model, port, workdir = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     kw = dict(skip_tokenizer_init=True, dtype="bfloat16", max_model_len=256, max_num_seqs=8,
               max_num_batched_tokens=256, gpu_memory_utilization=0.05, enforce_eager=True)
@@ -28,7 +30,7 @@ def main():
             json.dump([o.kv_transfer_params for o in outs], f)
         os.replace(os.path.join(workdir, "params.json.tmp"), os.path.join(workdir, "params.json"))
         t0 = time.time()
-        while not os.path.exists(os.path.join(workdir, "consumer.done")) and time.time() - t0 < 120:
+        while not os.path.exists(os.path.join(workdir, "consumer.done")) and time.time() - t0 < 45:
             time.sleep(0.1)
         pool = llm.llm_engine.engine_core.engine_core.scheduler.kv_cache_manager.block_pool
         before = pool.get_num_free_blocks()
@@ -38,7 +40,7 @@ def main():
         llm.shutdown()
     else:
         t0 = time.time()
-        while not os.path.exists(os.path.join(workdir, "params.json")) and time.time() - t0 < 120:
+        while not os.path.exists(os.path.join(workdir, "params.json")) and time.time() - t0 < 45:
             time.sleep(0.1)
         params = json.load(open(os.path.join(workdir, "params.json")))
         ref_llm = LLM(model=model, **kw)

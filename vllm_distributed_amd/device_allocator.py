@@ -58,8 +58,20 @@ def _lib():
     return lib
 
 
+def ipc_safe_size(nbytes: int) -> int:
+    """Smallest size >= nbytes that another process can map.  On this ROCm stack
+    hipIpcOpenMemHandle never returns for a region whose size has bit 31 set (size mod 4 GiB >=
+    2 GiB: 2, 3, 6, 7, 14 GiB stall; 1, 4, 5, 8, 12, 13, 40, 100 GiB map in ~1 ms), so such sizes are
+    rounded up to the next multiple of 4 GiB."""
+    if nbytes & 0x80000000:
+        return (nbytes + 0xFFFFFFFF) & ~0xFFFFFFFF
+    return nbytes
+
+
 def alloc_shareable(nbytes: int, device: torch.device) -> SharedRegion:
-    """Zero-filled device region with an IPC handle (GPU only)."""
+    """Zero-filled device region with an IPC handle (GPU only); may be larger than asked
+    (see ``ipc_safe_size``), ``tensor`` covers the whole region."""
+    nbytes = ipc_safe_size(nbytes)
     ptr = ctypes.c_void_p()
     handle = ctypes.create_string_buffer(HANDLE_BYTES)
     rc = _lib().vda_mem_alloc(nbytes, device.index or 0, ctypes.byref(ptr), handle)

@@ -91,6 +91,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VLLM_NIXL_SIDE_CHANNEL_HOST": (str, "127.0.0.1"),
     "VLLM_NIXL_SIDE_CHANNEL_PORT": (int, 5557),
     "VLLM_NIXL_ABORT_REQUEST_TIMEOUT": (int, 120),
+    "VDA_KV_IPC_CHUNK_GB": (float, 0.0),         # >0: split an exported KV cache into IPC regions of at most this size
     "VDA_KV_SIDE_CHANNEL_HOST": (str, "127.0.0.1"),
     "VDA_KV_SIDE_CHANNEL_PORT": (int, 5600),
     # ---- serving

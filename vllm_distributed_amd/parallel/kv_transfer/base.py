@@ -25,7 +25,7 @@ class KVConnectorBase:
 
     # ---- worker side ------------------------------------------------------------------------
     def register_kv_caches(self, runner) -> None:
-        """Called once the KV arena exists (``runner.kv_arena``, ``runner.kv_layer_offsets``)."""
+        """Called once the KV arena exists (``runner.kv_chunks``, ``runner.kv_layer_loc``)."""
 
     def bind_connector_metadata(self, meta: Optional[KVConnectorMetadata]) -> None:
         self._meta = meta

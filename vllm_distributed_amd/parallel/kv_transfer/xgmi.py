@@ -141,11 +141,11 @@ class XgmiConnector(KVConnectorBase):
 
     def _layout(self) -> dict:
         r = self.runner
-        region = getattr(r, "kv_region", None)
-        return {"engine_id": self.engine_id, "arena_bytes": int(r.kv_arena.numel()),
+        regions = r.kv_regions
+        return {"engine_id": self.engine_id, "chunk_bytes": [int(c.numel()) for c in r.kv_chunks],      # full region sizes (may be padded)
                 "num_blocks": int(r.kv_cache_config.num_blocks),
-                "layers": {n: [int(off), int(half)] for n, (off, half) in r.kv_layer_offsets.items()},
-                "ipc_handle": region.handle if region is not None else None,
+                "layers": {n: [int(ci), int(off), int(half)] for n, (ci, off, half) in r.kv_layer_loc.items()},
+                "ipc_handles": [x.handle for x in regions] if regions else None,
                 "device_index": r.device.index if r.is_gpu else -1, "hostname": socket.gethostname(),
                 "pid": os.getpid(), "block_size": self.block_size}
 
@@ -175,19 +175,24 @@ class XgmiConnector(KVConnectorBase):
         except (EOFError, OSError):
             pass
 
-    def _block_views(self, arena: torch.Tensor, layout_layers: dict, num_blocks: int):
-        """Per layer: (k rows [num_blocks, bytes_per_block], v rows [...]) as uint8 views of an arena."""
+    @staticmethod
+    def _block_views(chunks: list, layout_layers: dict, num_blocks: int):
+        """Per layer: (k rows [num_blocks, bytes_per_block], v rows [...]) as uint8 views of the chunks."""
         out = {}
-        for n, (off, half) in layout_layers.items():
+        for n, (ci, off, half) in layout_layers.items():
             per = half // num_blocks
-            out[n] = (arena[off: off + half].view(num_blocks, per), arena[off + half: off + 2 * half].view(num_blocks, per))
+            c = chunks[ci]
+            out[n] = (c[off: off + half].view(num_blocks, per), c[off + half: off + 2 * half].view(num_blocks, per))
         return out
+
+    def _my_views(self):
+        r = self.runner
+        return self._block_views(r.kv_chunks, r.kv_layer_loc, r.kv_cache_config.num_blocks)
 
     def _read_blocks(self, block_ids: list[int]) -> dict:
         r = self.runner
-        idx = torch.tensor(block_ids, dtype=torch.int64, device=r.kv_arena.device)
-        views = self._block_views(r.kv_arena, {n: list(v) for n, v in r.kv_layer_offsets.items()},
-                                  r.kv_cache_config.num_blocks)
+        idx = torch.tensor(block_ids, dtype=torch.int64, device=r.device)
+        views = self._my_views()
         return {n: [k.index_select(0, idx).cpu(), v.index_select(0, idx).cpu()] for n, (k, v) in views.items()}
 
     # ---- consumer: pulling ------------------------------------------------------------------------
@@ -202,10 +207,11 @@ class XgmiConnector(KVConnectorBase):
         region = None
         r = self.runner
         same_node = info["hostname"] == socket.gethostname()
-        if r.is_gpu and same_node and info.get("ipc_handle") is not None and info["pid"] != os.getpid():
+        if r.is_gpu and same_node and info.get("ipc_handles") and info["pid"] != os.getpid():
             from ...device_allocator import open_shared
-            region = open_shared(info["ipc_handle"], info["arena_bytes"], r.device)
-            logger.info("mapped the KV arena of engine %s (GPU %s) over xGMI", info["engine_id"], info["device_index"])
+            region = [open_shared(h, n, r.device) for h, n in zip(info["ipc_handles"], info["chunk_bytes"])]
+            logger.info("mapped the KV cache of engine %s (GPU %s, %d chunks) over xGMI", info["engine_id"],
+                        info["device_index"], len(region))
         p = self._peers[key] = _Peer(conn, info, region)
         return p
 
@@ -237,9 +243,8 @@ class XgmiConnector(KVConnectorBase):
         dev = r.device
         dst_ids = torch.tensor(spec.local_block_ids, dtype=torch.int64, device=dev)
         src_ids = torch.tensor(spec.remote_block_ids, dtype=torch.int64, device=dev)
-        mine = self._block_views(r.kv_arena, {n: list(v) for n, v in r.kv_layer_offsets.items()},
-                                 r.kv_cache_config.num_blocks)
-        theirs = self._block_views(peer.region.tensor, peer.info["layers"], peer.info["num_blocks"])
+        mine = self._my_views()
+        theirs = self._block_views([x.tensor for x in peer.region], peer.info["layers"], peer.info["num_blocks"])
         self._stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._stream):
             for n, (k, v) in mine.items():
@@ -256,9 +261,8 @@ class XgmiConnector(KVConnectorBase):
             with peer.lock:
                 peer.conn.send(("READ", spec.remote_block_ids))
                 data = peer.conn.recv()
-            idx = torch.tensor(spec.local_block_ids, dtype=torch.int64, device=r.kv_arena.device)
-            mine = self._block_views(r.kv_arena, {n: list(v) for n, v in r.kv_layer_offsets.items()},
-                                     r.kv_cache_config.num_blocks)
+            idx = torch.tensor(spec.local_block_ids, dtype=torch.int64, device=r.device)
+            mine = self._my_views()
             for n, (k, v) in mine.items():
                 sk, sv = data[n]
                 k.index_copy_(0, idx, sk.to(k.device))
@@ -320,8 +324,8 @@ class XgmiConnector(KVConnectorBase):
             self.listener.close()
         for p in self._peers.values():
             p.conn.close()
-            if p.region is not None:
-                p.region.close()
+            for x in p.region or ():
+                x.close()
 
 
 def _register_wire_types() -> None:

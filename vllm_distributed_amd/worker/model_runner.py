@@ -147,38 +147,60 @@ class ModelRunner:
         return {n: m.get_kv_cache_spec(self.block_size, dt) for n, m in self.attn_layers.items()}
 
     def initialize_kv_cache(self, cfg: KVCacheConfig) -> None:
-        """One zero-filled arena for the whole cache (a single allocation is a single
-        IPC handle for the xGMI KV connector), carved into per-layer K and V views."""
+        """The cache is one zero-filled allocation carved into per-layer K and V views (a single
+        allocation is a single IPC handle for the xGMI KV connector).  An instance that exports KV
+        to peers allocates it IPC-shareable; ``VDA_KV_IPC_CHUNK_GB`` > 0 splits it into several
+        regions at layer boundaries."""
         self.kv_cache_config = cfg
-        total = sum(t.size for t in cfg.kv_cache_tensors)
         kt = self.vllm_config.kv_transfer_config
-        self.kv_region = None
-        if self.is_gpu and kt is not None and kt.is_kv_producer and kt.kv_connector != "SharedStorageConnector":
-            # peers map this arena over xGMI: it must be one IPC-shareable allocation
-            from ..device_allocator import alloc_shareable
-            self.kv_region = alloc_shareable(total, self.device)
-            self.kv_arena = self.kv_region.tensor
-        else:
-            self.kv_arena = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        shareable = self.is_gpu and kt is not None and kt.is_kv_producer and kt.kv_connector != "SharedStorageConnector"
+        tensors = list(cfg.kv_cache_tensors)
+        # group layer tensors into chunks
+        limit = int(envs.VDA_KV_IPC_CHUNK_GB * 2**30) if (shareable and envs.VDA_KV_IPC_CHUNK_GB > 0) else None
+        groups: list[list] = [[]]
+        used = 0
+        for t in tensors:
+            if limit is not None and t.size > limit:
+                raise ValueError(f"one layer's KV cache ({t.size / 2**30:.1f} GiB) exceeds the IPC chunk limit "
+                                 f"({envs.VDA_KV_IPC_CHUNK_GB} GiB); lower gpu_memory_utilization on this exporter")
+            if limit is not None and used + t.size > limit and groups[-1]:
+                groups.append([])
+                used = 0
+            groups[-1].append(t)
+            used += t.size
+        self.kv_regions = []
+        self.kv_chunks: list[torch.Tensor] = []
+        for g in groups:
+            nbytes = sum(t.size for t in g)
+            if shareable:
+                from ..device_allocator import alloc_shareable
+                r = alloc_shareable(nbytes, self.device)
+                self.kv_regions.append(r)
+                self.kv_chunks.append(r.tensor)
+            else:
+                self.kv_chunks.append(torch.zeros(nbytes, dtype=torch.uint8, device=self.device))
+        self.kv_arena = self.kv_chunks[0] if len(self.kv_chunks) == 1 else None
         spec_of = {}
         for g in cfg.kv_cache_groups:
             for n in g.layer_names:
                 spec_of[n] = g.kv_cache_spec
-        off = 0
         self.kv_caches = []
-        self.kv_layer_offsets: dict[str, tuple[int, int]] = {}
+        # layer name -> (chunk index, byte offset of K inside the chunk, bytes of K == bytes of V)
+        self.kv_layer_loc: dict[str, tuple[int, int, int]] = {}
         nb = cfg.num_blocks
-        for t in cfg.kv_cache_tensors:
-            raw = self.kv_arena[off: off + t.size]
-            sp = spec_of[t.shared_by[0]]
-            half = t.size // 2
-            k = raw[:half].view(sp.dtype).view(nb, sp.num_kv_heads, sp.block_size, sp.head_size)
-            v = raw[half:].view(sp.dtype).view(nb, sp.num_kv_heads, sp.head_size, sp.block_size)
-            for n in t.shared_by:
-                self.attn_layers[n].bind_kv_cache(k, v)
-                self.kv_layer_offsets[n] = (off, half)
-            self.kv_caches.append((k, v))
-            off += t.size
+        for ci, g in enumerate(groups):
+            off = 0
+            for t in g:
+                raw = self.kv_chunks[ci][off: off + t.size]
+                sp = spec_of[t.shared_by[0]]
+                half = t.size // 2
+                k = raw[:half].view(sp.dtype).view(nb, sp.num_kv_heads, sp.block_size, sp.head_size)
+                v = raw[half:].view(sp.dtype).view(nb, sp.num_kv_heads, sp.head_size, sp.block_size)
+                for n in t.shared_by:
+                    self.attn_layers[n].bind_kv_cache(k, v)
+                    self.kv_layer_loc[n] = (ci, off, half)
+                self.kv_caches.append((k, v))
+                off += t.size
         self.input_batch = InputBatch(self.max_num_reqs, self.max_model_len, self.block_size, self.vocab_size,
                                       max(len(cfg.kv_cache_groups), 1), self.pin)
         if self.kv_connector is not None:

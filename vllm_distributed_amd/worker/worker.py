@@ -112,8 +112,10 @@ class Worker:
         now_torch = torch.cuda.memory_allocated(self.device)
         torch.cuda.empty_cache()
         free_after, _ = torch.cuda.mem_get_info(self.device)
-        # memory held outside the torch allocator (RCCL buffers, IPC arenas, HIP context)
-        non_torch = (total - free_after) - torch.cuda.memory_reserved(self.device)
+        # memory this process holds outside the torch allocator (RCCL buffers, IPC arenas, HIP context):
+        # measured against the free memory seen at start-up, so that other processes on the device
+        # (a co-located instance, a trainer) are not billed to this one
+        non_torch = (self.init_free - free_after) - torch.cuda.memory_reserved(self.device)
         activation_peak = peak_torch - now_torch
         budget = total * cc.gpu_memory_utilization
         # hipGraph pools are captured after the KV cache exists: reserve for them up front
@@ -190,11 +192,15 @@ class Worker:
             return
         mr = self.model_runner
         free0 = torch.cuda.mem_get_info(self.device)[0]
-        from ..device_allocator import offload_module, drop_tensor
+        from ..device_allocator import offload_module
         self._sleep_saved = offload_module(mr.model, keep_copy=(level == 1))
-        if mr.kv_arena is not None:
-            self._kv_shape = mr.kv_arena.shape
-            drop_tensor(mr.kv_arena)
+        # KV cache: drop every view and chunk (exported IPC regions are closed too)
+        for m in mr.attn_layers.values():
+            m.k_cache = m.v_cache = None
+        mr.kv_caches = []
+        for r in getattr(mr, "kv_regions", []):
+            r.close()
+        mr.kv_regions, mr.kv_chunks, mr.kv_arena = [], [], None
         mr.graphs.clear()
         gc.collect()
         torch.cuda.empty_cache()
@@ -206,12 +212,11 @@ class Worker:
         if not self._sleeping:
             return
         mr = self.model_runner
-        from ..device_allocator import restore_module, restore_tensor
+        from ..device_allocator import restore_module
         if tags is None or "weights" in tags:
             restore_module(mr.model, self._sleep_saved, self.device)
             self._sleep_saved = {}
-        if (tags is None or "kv_cache" in tags) and mr.kv_arena is not None:
-            restore_tensor(mr.kv_arena, self._kv_shape, self.device)
+        if (tags is None or "kv_cache" in tags) and not mr.kv_caches:
             mr.initialize_kv_cache(mr.kv_cache_config)
             mr.capture_model()
         if tags is None or set(tags) >= {"weights", "kv_cache"}:
