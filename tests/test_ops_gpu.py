@@ -456,3 +456,59 @@ def test_fp8_linear_paths(M, static):
     ref = x.float() @ (q.float() * s).t()
     # M=300 goes through activation quantisation + fp8 MFMA: looser
     torch.testing.assert_close(y.float(), ref, atol=0.15 if M > 64 else 3e-2, rtol=5e-2)
+
+
+# ---- fp8 KV cache ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Hq,Hkv,D,bs", [(32, 8, 128, 16), (12, 12, 64, 32), (8, 1, 128, 64)])
+def test_fp8_kv_cache_write_and_attention(dt, Hq, Hkv, D, bs):
+    """Write K/V through the fused RoPE+cache kernel into e4m3 caches, then decode / prefill attention
+    must equal the reference evaluated on the SAME quantised caches (same bytes, same scales)."""
+    f8 = torch.float8_e4m3fn
+    seq_lens, q_lens = [33, 300, 129, 64], [33, 300, 129, 64]
+    T = sum(q_lens)
+    nblk = sum((s + bs - 1) // bs for s in seq_lens) + 2
+    kc = torch.zeros(nblk, Hkv, bs, D, device=DEV, dtype=f8)
+    vc = torch.zeros(nblk, Hkv, D, bs, device=DEV, dtype=f8)
+    kr, vr = kc.clone(), vc.clone()
+    ks, vs = 0.05, 0.02
+    cs = _cos_sin(512, D)
+    qkv = torch.randn(T, (Hq + 2 * Hkv) * D, device=DEV, dtype=dt)
+    ref = qkv.clone()
+    # slots: sequence i occupies consecutive blocks
+    maxb = max((s + bs - 1) // bs for s in seq_lens)
+    bt = torch.zeros(len(seq_lens), maxb, dtype=torch.int32, device=DEV)
+    slots, pos, b = [], [], 1
+    for i, s in enumerate(seq_lens):
+        n = (s + bs - 1) // bs
+        bt[i, :n] = torch.arange(b, b + n, dtype=torch.int32)
+        slots += [b * bs + j for j in range(s)]
+        pos += list(range(s))
+        b += n
+    slots = torch.tensor(slots, device=DEV)
+    pos = torch.tensor(pos, device=DEV)
+    ops.rope_and_cache(pos, qkv, cs, kc, vc, slots, D, D, Hq, Hkv, True, ks, vs)
+    q, k, v = ref[:, :Hq * D], ref[:, Hq * D:(Hq + Hkv) * D], ref[:, (Hq + Hkv) * D:]
+    R.rotary_embedding(pos, q, k, cs, D, D, True)
+    R.reshape_and_cache(k.reshape(T, Hkv, D), v.reshape(T, Hkv, D), kr, vr, slots, ks, vs)
+    # quantisation may differ by one e4m3 step where rounding is on the edge
+    dk = (kc.float() - kr.float()).abs()
+    assert (dk <= kr.float().abs() * 0.13 + 1e-3).all()
+    assert (dk > 0).float().mean() < 0.02
+    scale = 1.0 / math.sqrt(D)
+    qsl = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    sl = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+    qq = qkv[:, :Hq * D].reshape(T, Hq, D).contiguous()
+    out = torch.empty_like(qq)
+    ops.paged_attention_prefill(out, qq, kc, vc, bt, sl, qsl, scale, k_scale=ks, v_scale=vs)
+    want = R.paged_attention(qq, kc, vc, bt, sl, qsl, scale, k_scale=ks, v_scale=vs)
+    torch.testing.assert_close(out.float(), want.float(), **tol(dt))
+    # decode: last token of every sequence as the single query
+    last = (qsl[1:] - 1).long()
+    qd = qq[last].contiguous()
+    qsl1 = torch.arange(len(seq_lens) + 1, dtype=torch.int32, device=DEV)
+    for nsplit in (1, 3):
+        od = torch.empty_like(qd)
+        ops.paged_attention_decode(od, qd, kc, vc, bt, sl, qsl1, scale, num_splits=nsplit, k_scale=ks, v_scale=vs)
+        wd = R.paged_attention(qd, kc, vc, bt, sl, qsl1, scale, k_scale=ks, v_scale=vs)
+        torch.testing.assert_close(od.float(), wd.float(), **tol(dt))

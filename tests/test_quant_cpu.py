@@ -79,3 +79,17 @@ def test_serialized_fp8_checkpoint_matches_dequantised_reference(tmp_path):
         r.shutdown()
         for x, y in zip(lp, ref_lp):
             assert abs(x[0] - y[0]) < 0.03, kind      # only the fused-shard requantisation differs
+
+
+def test_fp8_kv_cache_close_to_16bit(tmp_path):
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    a = LLM(model=path, **KW)
+    ref_lp, ref_tok = _first_logprobs(a)
+    a.shutdown()
+    b = LLM(model=path, kv_cache_dtype="fp8", **KW)
+    layer = next(iter(b.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.attn_layers.values()))
+    assert layer.k_cache.dtype == torch.float8_e4m3fn
+    lp, tok = _first_logprobs(b)
+    b.shutdown()
+    for x, y in zip(lp, ref_lp):
+        assert abs(x[0] - y[0]) < 0.05

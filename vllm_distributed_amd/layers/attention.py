@@ -29,6 +29,14 @@ class Attention(nn.Module):
         self.softcap = float(logits_soft_cap or 0.0)
         self.layer_name = prefix
         self.cache_dtype = cache_dtype
+        # fp8 KV cache scales: stored value = x / scale (1.0 unless the checkpoint carries calibrated scales)
+        self._k_scale_float = self._v_scale_float = 1.0
+        from ..config import get_current_vllm_config_or_none
+        cfg = get_current_vllm_config_or_none()
+        qc = getattr(cfg, "quant_config", None) if cfg is not None else None
+        self.quant_method = qc.get_quant_method(self, prefix) if qc is not None else None
+        if self.quant_method is not None:
+            self.quant_method.create_weights(self)
         if alibi_slopes is not None:
             self.register_buffer("alibi_slopes", torch.tensor(alibi_slopes, dtype=torch.float32), persistent=False)
         else:
@@ -64,15 +72,16 @@ class Attention(nn.Module):
             out.zero_()
             return out.view(T, qs)
         n = md.num_actual_tokens
+        ksc, vsc = self._k_scale_float, self._v_scale_float
         conn = ctx.kv_connector
         if conn is not None:
             conn.wait_for_layer_load(self.layer_name)
         if rotary is not None:
             ops.rope_and_cache(positions[:n], qkv[:n], rotary.cos_sin_cache, self.k_cache, self.v_cache,
-                               md.slot_mapping[:n], rotary.rotary_dim, D, Hq, Hkv, rotary.is_neox_style)
+                               md.slot_mapping[:n], rotary.rotary_dim, D, Hq, Hkv, rotary.is_neox_style, ksc, vsc)
         else:
             ops.reshape_and_cache(qkv[:n, qs:qs + ks].view(n, Hkv, D), qkv[:n, qs + ks:].view(n, Hkv, D),
-                                  self.k_cache, self.v_cache, md.slot_mapping[:n])
+                                  self.k_cache, self.v_cache, md.slot_mapping[:n], ksc, vsc)
         q = qkv[:, :qs].view(T, Hq, D)
         nd, ndt = md.num_decode_seqs, md.num_decode_tokens
         if nd > 0:
@@ -80,12 +89,13 @@ class Attention(nn.Module):
                                        md.seq_lens[:nd], md.query_start_loc[:nd + 1], self.scale,
                                        num_splits=md.decode_num_splits, max_q_len=md.max_decode_query_len,
                                        window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
-                                       workspace=md.decode_workspace)
+                                       workspace=md.decode_workspace, k_scale=ksc, v_scale=vsc)
         if md.num_prefill_seqs > 0:
             e = ndt + md.num_prefill_tokens
             ops.paged_attention_prefill(out[ndt:e], q[ndt:e], self.k_cache, self.v_cache, md.block_table[nd:],
                                         md.seq_lens[nd:], md.prefill_query_start_loc, self.scale,
-                                        window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes)
+                                        window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
+                                        k_scale=ksc, v_scale=vsc)
         if conn is not None:
             conn.save_kv_layer(self.layer_name, (self.k_cache, self.v_cache), md)
         return out.view(T, qs)

@@ -100,6 +100,15 @@ def load_weights_with_mapping(model: nn.Module, weights: Iterable[tuple[str, tor
                 continue
         if tie_lm_head and name.startswith("lm_head."):
             continue
+        if name.endswith(("k_scale", "v_scale", ".output_scale")):
+            # calibrated KV-cache scales live on the Attention module
+            from ..layers.quant import QuantizationConfig
+            target = QuantizationConfig.get_cache_scale_name(None, name)
+            if target is None or target not in params:
+                continue
+            params[target].data.fill_(float(tensor.float().max()))
+            loaded.add(target)
+            continue
         if by_frag and ".experts." in name:
             i = name.index("experts.")
             parts = name[i:].split(".")            # experts, <id>, <proj>, <suffix...>

@@ -123,17 +123,23 @@ def rotary_embedding(positions, q, k, cos_sin_cache, rot_dim: int, head_size: in
            q.stride(0), k.stride(0) if k is not None else 0, int(is_neox), N.dt(q.dtype), N.stream())
 
 
-def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping):
-    """k, v: [T, Hkv, D] (token stride arbitrary, heads contiguous)."""
+def _kv_fp8(cache: torch.Tensor) -> int:
+    return int(cache.dtype == torch.float8_e4m3fn)
+
+
+def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, k_scale: float = 1.0, v_scale: float = 1.0):
+    """k, v: [T, Hkv, D] (token stride arbitrary, heads contiguous).  fp8 caches store x / scale."""
     if not _dev(k):
-        return R.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping)
+        return R.reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, k_scale, v_scale)
     T, Hkv, D = k.shape
     N.call("vda_reshape_and_cache", k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
-           slot_mapping.data_ptr(), T, Hkv, D, k_cache.shape[2], k.stride(0), v.stride(0), N.dt(k.dtype), N.stream())
+           slot_mapping.data_ptr(), T, Hkv, D, k_cache.shape[2], k.stride(0), v.stride(0), N.dt(k.dtype),
+           _kv_fp8(k_cache), k_scale, v_scale, N.stream())
 
 
 def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping, rot_dim: int, head_size: int,
-                   num_heads: int, num_kv_heads: int, is_neox: bool = True):
+                   num_heads: int, num_kv_heads: int, is_neox: bool = True, k_scale: float = 1.0,
+                   v_scale: float = 1.0):
     """Fused RoPE(q, k) in place + write of k, v into the paged cache.
     qkv: [T, (Hq + 2*Hkv) * D]."""
     T = qkv.shape[0]
@@ -142,11 +148,12 @@ def rope_and_cache(positions, qkv, cos_sin_cache, k_cache, v_cache, slot_mapping
         q, k, v = qkv[:, :qs], qkv[:, qs:qs + ks], qkv[:, qs + ks:]
         R.rotary_embedding(positions, q, k, cos_sin_cache, rot_dim, head_size, is_neox)
         R.reshape_and_cache(k.reshape(T, num_kv_heads, head_size), v.reshape(T, num_kv_heads, head_size),
-                            k_cache, v_cache, slot_mapping)
+                            k_cache, v_cache, slot_mapping, k_scale, v_scale)
         return
     N.call("vda_rope_and_cache", positions.data_ptr(), qkv.data_ptr(), cos_sin_cache.data_ptr(),
            k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(), T, rot_dim, head_size, num_heads,
-           num_kv_heads, k_cache.shape[2], qkv.stride(0), int(is_neox), N.dt(qkv.dtype), N.stream())
+           num_kv_heads, k_cache.shape[2], qkv.stride(0), int(is_neox), N.dt(qkv.dtype), _kv_fp8(k_cache), k_scale,
+           v_scale, N.stream())
 
 
 def copy_blocks(cache: torch.Tensor, pairs: torch.Tensor):
@@ -192,12 +199,13 @@ def decode_num_splits(num_seqs: int, num_kv_heads: int, max_seq_len: int) -> int
 
 def paged_attention_decode(out, q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale: float,
                            num_splits: int = 1, max_q_len: int = 1, window: int = 0, softcap: float = 0.0,
-                           alibi: Optional[torch.Tensor] = None, workspace=None):
+                           alibi: Optional[torch.Tensor] = None, workspace=None, k_scale: float = 1.0,
+                           v_scale: float = 1.0):
     """q, out: [T, Hq, D].  Each sequence has <= max_q_len query tokens (1 for plain decode)."""
     T, Hq, D = q.shape
     if not _dev(q):
         out.copy_(R.paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, window,
-                                    softcap, alibi))
+                                    softcap, alibi, k_scale=k_scale, v_scale=v_scale))
         return out
     S = seq_lens.shape[0]
     part_out = part_lse = None
@@ -210,21 +218,23 @@ def paged_attention_decode(out, q, k_cache, v_cache, block_table, seq_lens, q_st
     N.call("vda_paged_attention_decode", out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
            block_table.data_ptr(), seq_lens.data_ptr(), q_start_loc.data_ptr(), N.ptr(alibi), N.ptr(part_out),
            N.ptr(part_lse), S, T, Hq, k_cache.shape[1], D, k_cache.shape[2], block_table.stride(0), num_splits,
-           max_q_len, q.stride(0), out.stride(0), scale, softcap, window, N.dt(q.dtype), N.stream())
+           max_q_len, q.stride(0), out.stride(0), scale, softcap, window, N.dt(q.dtype), _kv_fp8(k_cache), k_scale,
+           v_scale, N.stream())
     return out
 
 
 def paged_attention_prefill(out, q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale: float,
-                            window: int = 0, softcap: float = 0.0, alibi: Optional[torch.Tensor] = None):
+                            window: int = 0, softcap: float = 0.0, alibi: Optional[torch.Tensor] = None,
+                            k_scale: float = 1.0, v_scale: float = 1.0):
     T, Hq, D = q.shape
     if not _dev(q):
         out.copy_(R.paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, window,
-                                    softcap, alibi))
+                                    softcap, alibi, k_scale=k_scale, v_scale=v_scale))
         return out
     N.call("vda_paged_attention_prefill", out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
            block_table.data_ptr(), seq_lens.data_ptr(), q_start_loc.data_ptr(), N.ptr(alibi), seq_lens.shape[0], T,
            Hq, k_cache.shape[1], D, k_cache.shape[2], block_table.stride(0), q.stride(0), out.stride(0), scale,
-           softcap, window, N.dt(q.dtype), N.stream())
+           softcap, window, N.dt(q.dtype), _kv_fp8(k_cache), k_scale, v_scale, N.stream())
     return out
 
 

@@ -35,14 +35,16 @@ struct AttnParams {
   const float* alibi;       // [Hq] or nullptr
   int num_seqs, Hq, Hkv, max_blocks, nsplit;
   long q_stride, out_stride;   // elements between consecutive tokens
-  float scale, softcap;
+  float scale, softcap;    // scale already includes the K-cache scale of an fp8 cache
+  float v_scale;            // V-cache scale (1 for 16-bit caches)
   int window;               // sliding window size, 0 = none
   int q_tile;               // query tokens per workgroup (prefill form)
 };
 
-template <typename T, int D, int BS, int NCT, bool SPLIT>
+template <typename T, int D, int BS, int NCT, bool SPLIT, bool F8>
 __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
   using V8 = typename Vec<T>::v8;
+  using CT = typename KVElem<T, F8>::type;
   using V4 = typename Vec<T>::v4;
   constexpr int KS = D / 32;       // MFMA k-steps over the head dimension
   constexpr int NT = D / 16;       // 16-wide d tiles of the output
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
     for (int n = 0; n < NT; ++n) acc[ct][n] = f32x4{0, 0, 0, 0};
   }
 
-  const T* kc = (const T*)p.k_cache;
-  const T* vc = (const T*)p.v_cache;
+  const CT* kc = (const CT*)p.k_cache;
+  const CT* vc = (const CT*)p.v_cache;
   // K row of this lane inside a step: tile u, row r  <->  key 8*(r>>2) + 4u + (r&3)
   const int krow0 = 8 * (r >> 2) + (r & 3);
 
@@ -143,18 +145,18 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
       const int tok = tb + krow0 + 4 * u;
       const int bi = max(min(tok / BS, nblk_valid - 1), 0);
       const long blk = bt[bi];
-      const T* kp = kc + ((blk * p.Hkv + kvh) * BS + (tok % BS)) * (long)D + g * DQ;
+      const CT* kp = kc + ((blk * p.Hkv + kvh) * BS + (tok % BS)) * (long)D + g * DQ;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) kf[u][s] = ld16<V8>(kp + 8 * s);
+      for (int s = 0; s < KS; ++s) kf[u][s] = KVLoad<T, F8>::ld(kp + 8 * s);
     }
   };
   auto load_v = [&](int step, V8 (&vf)[NT]) {
     const int tok = step * 32 + 8 * g;
     const int bi = max(min(tok / BS, nblk_valid - 1), 0);
     const long blk = bt[bi];
-    const T* vp = vc + ((blk * p.Hkv + kvh) * (long)D + r) * BS + (tok % BS);
+    const CT* vp = vc + ((blk * p.Hkv + kvh) * (long)D + r) * BS + (tok % BS);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) vf[n] = ld16<V8>(vp + (long)n * 16 * BS);
+    for (int n = 0; n < NT; ++n) vf[n] = KVLoad<T, F8>::ld(vp + (long)n * 16 * BS);
   };
 
   V8 kf[2][KS], kn[2][KS], vf[NT];
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
       if (col_off[ct] < 0) continue;
       const int c = wave * COLS + ct * 16 + r;
       const int head = kvh * G + c % G;
-      const float inv = l[ct] > 0.f ? 1.f / l[ct] : 0.f;
+      const float inv = l[ct] > 0.f ? p.v_scale / l[ct] : 0.f;
       T* op = (T*)p.out + col_off[ct] * p.out_stride + (long)head * D + 4 * g;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
       const int c = ct * 16 + r;
       const int head = kvh * G + c % G;
       const float L = l[ct];
-      const float inv = L > 0.f ? 1.f / L : 0.f;
+      const float inv = L > 0.f ? p.v_scale / L : 0.f;
       if (p.nsplit == 1) {
         T* op = (T*)p.out + col_off[ct] * p.out_stride + (long)head * D + 4 * g;
 #pragma unroll
@@ -371,43 +373,50 @@ __global__ void merge_attn_states_kernel(T* out, float* out_lse, const T* pre, c
 // ---------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------
-template <typename T, int D, int BS>
+template <typename T, int D, int BS, bool F8>
 static int launch_attn(const AttnParams& p, int form, int grid_x, hipStream_t st) {
   // form 0: decode (split over waves, NCT=1, up to 16 query columns per kv head)
   // form 1: decode with up to 32 columns; form 2: prefill (NCT=2)
   dim3 block(256);
   if (form == 0) {
     dim3 grid(grid_x, p.Hkv, p.nsplit);
-    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 1, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 1, true, F8>), grid, block, 0, st, p);
   } else if (form == 1) {
     dim3 grid(grid_x, p.Hkv, p.nsplit);
-    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, true>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, true, F8>), grid, block, 0, st, p);
   } else {
     dim3 grid(grid_x, p.Hkv, 1);
-    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, false, F8>), grid, block, 0, st, p);
   }
   VDA_CHECK_LAUNCH();
   return 0;
 }
 
-template <typename T, int D>
+template <typename T, int D, bool F8>
 static int dispatch_bs(const AttnParams& p, int bs, int form, int grid_x, hipStream_t st) {
   switch (bs) {
-    case 16: return launch_attn<T, D, 16>(p, form, grid_x, st);
-    case 32: return launch_attn<T, D, 32>(p, form, grid_x, st);
-    case 64: return launch_attn<T, D, 64>(p, form, grid_x, st);
+    case 16: return launch_attn<T, D, 16, F8>(p, form, grid_x, st);
+    case 32: return launch_attn<T, D, 32, F8>(p, form, grid_x, st);
+    case 64: return launch_attn<T, D, 64, F8>(p, form, grid_x, st);
   }
   return -2;
 }
 
-template <typename T>
-static int dispatch_d(const AttnParams& p, int d, int bs, int form, int grid_x, hipStream_t st) {
+template <typename T, bool F8>
+static int dispatch_d8(const AttnParams& p, int d, int bs, int form, int grid_x, hipStream_t st) {
   switch (d) {
-    case 64: return dispatch_bs<T, 64>(p, bs, form, grid_x, st);
-    case 128: return dispatch_bs<T, 128>(p, bs, form, grid_x, st);
-    case 256: return dispatch_bs<T, 256>(p, bs, form, grid_x, st);
+    case 64: return dispatch_bs<T, 64, F8>(p, bs, form, grid_x, st);
+    case 128: return dispatch_bs<T, 128, F8>(p, bs, form, grid_x, st);
+    case 256: return dispatch_bs<T, 256, F8>(p, bs, form, grid_x, st);
   }
   return -3;
+}
+
+template <typename T>
+static int dispatch_d(const AttnParams& p, int d, int bs, int form, int grid_x, hipStream_t st, int kv_fp8) {
+  // fp8 caches: head sizes 64 / 128 (the common ones) to bound the number of kernel variants
+  if (kv_fp8) return d == 256 ? -3 : dispatch_d8<T, true>(p, d, bs, form, grid_x, st);
+  return dispatch_d8<T, false>(p, d, bs, form, grid_x, st);
 }
 
 // Decode / speculative-verify attention.  Every sequence contributes
@@ -418,15 +427,16 @@ VDA_EXPORT int vda_paged_attention_decode(
     const int* seq_lens, const int* q_start_loc, const float* alibi, float* part_out, float* part_lse,
     int num_seqs, int num_tokens, int Hq, int Hkv, int D, int block_size, int max_blocks, int nsplit,
     int max_q_len, long q_stride, long out_stride, float scale, float softcap, int window, int dtype,
-    hipStream_t st) {
+    int kv_fp8, float k_scale, float v_scale, hipStream_t st) {
   if (Hq % Hkv) return -1;
   const int cols = max_q_len * (Hq / Hkv);
   if (cols > 32 || (cols > 16 && D > 128)) return -4;
   AttnParams p{q, k_cache, v_cache, out, part_out, part_lse, block_table, seq_lens, q_start_loc, alibi,
-               num_seqs, Hq, Hkv, max_blocks, nsplit, q_stride, out_stride, scale, softcap, window, 0};
+               num_seqs, Hq, Hkv, max_blocks, nsplit, q_stride, out_stride, scale * (kv_fp8 ? k_scale : 1.f), softcap,
+               kv_fp8 ? v_scale : 1.f, window, 0};
   const int form = cols <= 16 ? 0 : 1;
-  int rc = dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, form, num_seqs, st)
-                             : dispatch_d<f16_t>(p, D, block_size, form, num_seqs, st);
+  int rc = dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, form, num_seqs, st, kv_fp8)
+                             : dispatch_d<f16_t>(p, D, block_size, form, num_seqs, st, kv_fp8);
   if (rc) return rc;
   if (nsplit > 1) {
     const long n = (long)num_tokens * Hq;
@@ -450,16 +460,17 @@ VDA_EXPORT int vda_paged_attention_prefill(
     void* out, const void* q, const void* k_cache, const void* v_cache, const int* block_table,
     const int* seq_lens, const int* q_start_loc, const float* alibi, int num_seqs, int num_tokens,
     int Hq, int Hkv, int D, int block_size, int max_blocks, long q_stride, long out_stride, float scale,
-    float softcap, int window, int dtype, hipStream_t st) {
+    float softcap, int window, int dtype, int kv_fp8, float k_scale, float v_scale, hipStream_t st) {
   if (Hq % Hkv) return -1;
   const int G = Hq / Hkv;
   if (G > 128) return -4;
   const int q_tile = 128 / G;     // 4 waves x 32 columns
   AttnParams p{q, k_cache, v_cache, out, nullptr, nullptr, block_table, seq_lens, q_start_loc, alibi,
-               num_seqs, Hq, Hkv, max_blocks, 1, q_stride, out_stride, scale, softcap, window, q_tile};
+               num_seqs, Hq, Hkv, max_blocks, 1, q_stride, out_stride, scale * (kv_fp8 ? k_scale : 1.f), softcap,
+               kv_fp8 ? v_scale : 1.f, window, q_tile};
   const int grid_x = num_tokens / q_tile + num_seqs;
-  return dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, 2, grid_x, st)
-                           : dispatch_d<f16_t>(p, D, block_size, 2, grid_x, st);
+  return dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, 2, grid_x, st, kv_fp8)
+                           : dispatch_d<f16_t>(p, D, block_size, 2, grid_x, st, kv_fp8);
 }
 
 VDA_EXPORT int vda_merge_attn_states(void* out, float* out_lse, const void* pre, const float* pre_lse,

@@ -115,5 +115,43 @@ template <typename T> struct WLoadFp8 {
   }
 };
 
+// KV-cache element access: 16-bit caches hold T, fp8 caches hold e4m3 bytes (value = byte * scale).
+template <typename T, bool F8> struct KVElem { using type = T; };
+template <typename T> struct KVElem<T, true> { using type = uint8_t; };
+
+// 8 consecutive cache elements -> MFMA operand
+template <typename T, bool F8> struct KVLoad {
+  using V8 = typename Vec<T>::v8;
+  static __device__ __forceinline__ V8 ld(const T* p) { return ld16<V8>(p); }
+};
+template <typename T> struct KVLoad<T, true> {
+  using V8 = typename Vec<T>::v8;
+  static __device__ __forceinline__ V8 ld(const uint8_t* p) {
+    const u32x2 raw = *reinterpret_cast<const u32x2*>(p);
+    V8 o;
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(raw[0], true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8(raw[1], true);
+    o[0] = (T)a[0]; o[1] = (T)a[1]; o[2] = (T)b[0]; o[3] = (T)b[1];
+    o[4] = (T)c[0]; o[5] = (T)c[1]; o[6] = (T)d[0]; o[7] = (T)d[1];
+    return o;
+  }
+};
+// store 8 consecutive elements (inv = 1 / scale for fp8) and one element
+template <typename T, bool F8> struct KVStore {
+  using V8 = typename Vec<T>::v8;
+  static __device__ __forceinline__ void st8(T* p, V8 v, float) { st16<V8>(p, v); }
+  static __device__ __forceinline__ void st1(T* p, T v, float) { *p = v; }
+};
+template <typename T> struct KVStore<T, true> {
+  using V8 = typename Vec<T>::v8;
+  static __device__ __forceinline__ void st8(uint8_t* p, V8 v, float inv) {
+    u32x2 o;
+    o[0] = pack_fp8x4((float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv);
+    o[1] = pack_fp8x4((float)v[4] * inv, (float)v[5] * inv, (float)v[6] * inv, (float)v[7] * inv);
+    *reinterpret_cast<u32x2*>(p) = o;
+  }
+  static __device__ __forceinline__ void st1(uint8_t* p, T v, float inv) { *p = f32_to_fp8((float)v * inv); }
+};
+
 #define VDA_CHECK_LAUNCH() \
   do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -66,12 +66,15 @@ __global__ __launch_bounds__(256) void rotary_kernel(const long* __restrict__ po
 }
 
 // Write k [T, Hkv, D], v [T, Hkv, D] into the paged cache by slot_mapping (-1 = skip).
-template <typename T>
+template <typename T, bool F8>
 __global__ __launch_bounds__(256) void reshape_and_cache_kernel(const T* __restrict__ k, const T* __restrict__ v,
-                                                                T* __restrict__ kc, T* __restrict__ vc,
+                                                                typename KVElem<T, F8>::type* __restrict__ kc,
+                                                                typename KVElem<T, F8>::type* __restrict__ vc,
                                                                 const long* __restrict__ slot_mapping, int Hkv,
-                                                                int D, int BS, long k_stride, long v_stride) {
+                                                                int D, int BS, long k_stride, long v_stride,
+                                                                float k_inv, float v_inv) {
   using V8 = typename Vec<T>::v8;
+  using CT = typename KVElem<T, F8>::type;
   const long t = blockIdx.x;
   const long slot = slot_mapping[t];
   if (slot < 0) return;
@@ -81,22 +84,24 @@ __global__ __launch_bounds__(256) void reshape_and_cache_kernel(const T* __restr
   for (int i = threadIdx.x; i < nv; i += blockDim.x) {
     const int h = i / (D >> 3), d8 = (i % (D >> 3)) * 8;
     const V8 kk = ld16<V8>(k + t * k_stride + (long)h * D + d8);
-    st16<V8>(kc + ((blk * Hkv + h) * BS + off) * (long)D + d8, kk);
+    KVStore<T, F8>::st8(kc + ((blk * Hkv + h) * BS + off) * (long)D + d8, kk, k_inv);
     const V8 vv = ld16<V8>(v + t * v_stride + (long)h * D + d8);
-    T* vp = vc + ((blk * Hkv + h) * (long)D + d8) * BS + off;
+    CT* vp = vc + ((blk * Hkv + h) * (long)D + d8) * BS + off;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vp[(long)j * BS] = vv[j];
+    for (int j = 0; j < 8; ++j) KVStore<T, F8>::st1(vp + (long)j * BS, vv[j], v_inv);
   }
 }
 
 // Fused: rotate q in place, rotate k and write it to the K cache, write v to the
 // V cache.  qkv is one row-major buffer [T, (Hq + 2 Hkv) * D].
-template <typename T, bool NEOX>
+template <typename T, bool NEOX, bool F8>
 __global__ __launch_bounds__(256) void rope_and_cache_kernel(
     const long* __restrict__ positions, T* __restrict__ qkv, const float* __restrict__ cos_sin,
-    T* __restrict__ kc, T* __restrict__ vc, const long* __restrict__ slot_mapping, int rot_dim, int D, int Hq,
-    int Hkv, int BS, long row_stride) {
+    typename KVElem<T, F8>::type* __restrict__ kc, typename KVElem<T, F8>::type* __restrict__ vc,
+    const long* __restrict__ slot_mapping, int rot_dim, int D, int Hq, int Hkv, int BS, long row_stride,
+    float k_inv, float v_inv) {
   using V8 = typename Vec<T>::v8;
+  using CT = typename KVElem<T, F8>::type;
   const long t = blockIdx.x;
   T* row = qkv + t * row_stride;
   T* q = row;
@@ -119,11 +124,11 @@ __global__ __launch_bounds__(256) void rope_and_cache_kernel(
   for (int i = threadIdx.x; i < nv; i += blockDim.x) {
     const int h = i / (D >> 3), d8 = (i % (D >> 3)) * 8;
     const V8 kk = ld16<V8>(k + (long)h * D + d8);
-    st16<V8>(kc + ((blk * Hkv + h) * BS + off) * (long)D + d8, kk);
+    KVStore<T, F8>::st8(kc + ((blk * Hkv + h) * BS + off) * (long)D + d8, kk, k_inv);
     const V8 vv = ld16<V8>(v + (long)h * D + d8);
-    T* vp = vc + ((blk * Hkv + h) * (long)D + d8) * BS + off;
+    CT* vp = vc + ((blk * Hkv + h) * (long)D + d8) * BS + off;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vp[(long)j * BS] = vv[j];
+    for (int j = 0; j < 8; ++j) KVStore<T, F8>::st1(vp + (long)j * BS, vv[j], v_inv);
   }
 }
 
@@ -143,34 +148,41 @@ VDA_EXPORT int vda_rotary_embedding(const long* positions, void* q, void* k, con
   return 0;
 }
 
+// kv_fp8 != 0: the caches hold e4m3 bytes, stored value = x / scale.
 VDA_EXPORT int vda_reshape_and_cache(const void* k, const void* v, void* kc, void* vc, const long* slot_mapping,
                                      int T_, int Hkv, int D, int BS, long k_stride, long v_stride, int dtype,
-                                     hipStream_t st) {
+                                     int kv_fp8, float k_scale, float v_scale, hipStream_t st) {
   if (D % 8) return -1;
   if (T_ == 0) return 0;
   dim3 grid(T_), block(256);
-  if (dtype == VDA_BF16)
-    hipLaunchKernelGGL(reshape_and_cache_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)k, (const bf16_t*)v,
-                       (bf16_t*)kc, (bf16_t*)vc, slot_mapping, Hkv, D, BS, k_stride, v_stride);
-  else if (dtype == VDA_F16)
-    hipLaunchKernelGGL(reshape_and_cache_kernel<f16_t>, grid, block, 0, st, (const f16_t*)k, (const f16_t*)v,
-                       (f16_t*)kc, (f16_t*)vc, slot_mapping, Hkv, D, BS, k_stride, v_stride);
+  const float ki = 1.f / k_scale, vi = 1.f / v_scale;
+#define L(TT, F) hipLaunchKernelGGL((reshape_and_cache_kernel<TT, F>), grid, block, 0, st, (const TT*)k, (const TT*)v, \
+                                    (typename KVElem<TT, F>::type*)kc, (typename KVElem<TT, F>::type*)vc, slot_mapping, \
+                                    Hkv, D, BS, k_stride, v_stride, ki, vi)
+  if (dtype == VDA_BF16) { if (kv_fp8) L(bf16_t, true); else L(bf16_t, false); }
+  else if (dtype == VDA_F16) { if (kv_fp8) L(f16_t, true); else L(f16_t, false); }
   else return -3;
+#undef L
   VDA_CHECK_LAUNCH();
   return 0;
 }
 
 VDA_EXPORT int vda_rope_and_cache(const long* positions, void* qkv, const float* cos_sin, void* kc, void* vc,
                                   const long* slot_mapping, int T_, int rot_dim, int D, int Hq, int Hkv, int BS,
-                                  long row_stride, int is_neox, int dtype, hipStream_t st) {
+                                  long row_stride, int is_neox, int dtype, int kv_fp8, float k_scale,
+                                  float v_scale, hipStream_t st) {
   if (rot_dim % 16 || D % 8 || rot_dim > D) return -1;
   if (T_ == 0) return 0;
   dim3 grid(T_), block(256);
-#define L(TT, N) hipLaunchKernelGGL((rope_and_cache_kernel<TT, N>), grid, block, 0, st, positions, (TT*)qkv, cos_sin, \
-                                    (TT*)kc, (TT*)vc, slot_mapping, rot_dim, D, Hq, Hkv, BS, row_stride)
-  if (dtype == VDA_BF16) { if (is_neox) L(bf16_t, true); else L(bf16_t, false); }
-  else if (dtype == VDA_F16) { if (is_neox) L(f16_t, true); else L(f16_t, false); }
+  const float ki = 1.f / k_scale, vi = 1.f / v_scale;
+#define L(TT, N, F) hipLaunchKernelGGL((rope_and_cache_kernel<TT, N, F>), grid, block, 0, st, positions, (TT*)qkv, \
+                                       cos_sin, (typename KVElem<TT, F>::type*)kc, (typename KVElem<TT, F>::type*)vc, \
+                                       slot_mapping, rot_dim, D, Hq, Hkv, BS, row_stride, ki, vi)
+#define LN(TT, F) do { if (is_neox) L(TT, true, F); else L(TT, false, F); } while (0)
+  if (dtype == VDA_BF16) { if (kv_fp8) LN(bf16_t, true); else LN(bf16_t, false); }
+  else if (dtype == VDA_F16) { if (kv_fp8) LN(f16_t, true); else LN(f16_t, false); }
   else return -3;
+#undef LN
 #undef L
   VDA_CHECK_LAUNCH();
   return 0;

@@ -32,13 +32,13 @@ _SIGS = {
     "vda_act_and_mul": [P, P, L, I, L, L, I, I, F, P, I, P],
     "vda_activation": [P, P, L, I, F, I, P],
     "vda_rotary_embedding": [P, P, P, P, I, I, I, I, I, L, L, I, I, P],
-    "vda_reshape_and_cache": [P, P, P, P, P, I, I, I, I, L, L, I, P],
-    "vda_rope_and_cache": [P, P, P, P, P, P, I, I, I, I, I, I, L, I, I, P],
+    "vda_reshape_and_cache": [P, P, P, P, P, I, I, I, I, L, L, I, I, F, F, P],
+    "vda_rope_and_cache": [P, P, P, P, P, P, I, I, I, I, I, I, L, I, I, I, F, F, P],
     "vda_copy_blocks": [P, P, I, L, P],
     "vda_transfer_blocks": [P, P, P, P, I, L, P],
     "vda_gather_cache": [P, P, P, P, P, I, I, I, I, I, P],
-    "vda_paged_attention_decode": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, F, I, I, P],
-    "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, P],
+    "vda_paged_attention_decode": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, P],
+    "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, P],
     "vda_merge_attn_states": [P, P, P, P, P, P, I, I, I, I, P],
     "vda_argmax": [P, P, I, I, L, I, P],
     "vda_sample": [P, P, P, P, P, P, P, I, I, L, P],

@@ -95,15 +95,19 @@ def rotary_embedding(positions, q, k, cos_sin_cache, rot_dim, head_size, is_neox
 
 
 # ---- cache ---------------------------------------------------------------------
-def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping):
-    """k, v: [T, Hkv, D]; k_cache [nblk, Hkv, BS, D]; v_cache [nblk, Hkv, D, BS]."""
+def reshape_and_cache(k, v, k_cache, v_cache, slot_mapping, k_scale: float = 1.0, v_scale: float = 1.0):
+    """k, v: [T, Hkv, D]; k_cache [nblk, Hkv, BS, D]; v_cache [nblk, Hkv, D, BS]; fp8 caches hold x / scale."""
     bs = k_cache.shape[2]
     slots = slot_mapping.long()
     keep = slots >= 0
     slots = slots[keep]
     blk, off = slots // bs, slots % bs
-    k_cache[blk, :, off, :] = k[keep].to(k_cache.dtype)
-    v_cache[blk, :, :, off] = v[keep].to(v_cache.dtype)
+    kk, vv = k[keep], v[keep]
+    if k_cache.dtype == torch.float8_e4m3fn:
+        kk = (kk.float() / k_scale).clamp(-448, 448)
+        vv = (vv.float() / v_scale).clamp(-448, 448)
+    k_cache[blk, :, off, :] = kk.to(k_cache.dtype)
+    v_cache[blk, :, :, off] = vv.to(v_cache.dtype)
 
 
 def gather_cache(k_cache, v_cache, slots):
@@ -124,7 +128,8 @@ def transfer_blocks(dst, src, dst_ids, src_ids):
 
 # ---- attention -------------------------------------------------------------------
 def paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale,
-                    window: int = 0, softcap: float = 0.0, alibi=None, return_lse: bool = False):
+                    window: int = 0, softcap: float = 0.0, alibi=None, return_lse: bool = False,
+                    k_scale: float = 1.0, v_scale: float = 1.0):
     """Causal attention of the new tokens of every sequence against its paged
     K/V (which already contain the new tokens).  q: [T, Hq, D] -> [T, Hq, D]."""
     T, Hq, D = q.shape
@@ -142,6 +147,8 @@ def paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, sca
         blocks = block_table[s, :nb].long()
         k = k_cache[blocks].permute(1, 0, 2, 3).reshape(Hkv, nb * bs, D)[:, :sl].float()
         v = v_cache[blocks].permute(1, 0, 3, 2).reshape(Hkv, nb * bs, D)[:, :sl].float()
+        if k_cache.dtype == torch.float8_e4m3fn:
+            k, v = k * k_scale, v * v_scale
         k = k.repeat_interleave(G, dim=0)
         v = v.repeat_interleave(G, dim=0)
         qq = q[a:b].permute(1, 0, 2).float()                  # [Hq, ql, D]
