@@ -31,7 +31,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="llama-3-70b")
-    ap.add_argument("--batch", type=int, default=128, help="requests per round (global, fixed as N grows)")
+    ap.add_argument("--batch", type=int, default=256, help="requests per round (global, fixed as N grows)")
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--output-len", type=int, default=128)
     ap.add_argument("--max-num-batched-tokens", type=int, default=16384)

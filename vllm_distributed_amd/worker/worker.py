@@ -66,6 +66,7 @@ class Worker:
                 raise ValueError(f"device has {free / 2**30:.1f} GiB free of {total / 2**30:.1f} GiB but "
                                  f"gpu_memory_utilization asks for {want / 2**30:.1f} GiB")
             backend = "nccl"
+            self._load_gemm_selections()
         else:
             self.device = torch.device("cpu")
             self.init_free = self.total_memory = current_platform.total_memory()
@@ -85,6 +86,29 @@ class Worker:
         if self.vllm_config.kv_transfer_config is not None:
             from ..parallel.kv_transfer.factory import KVConnectorFactory, KVConnectorRole
             self.model_runner.kv_connector = KVConnectorFactory.create(self.vllm_config, KVConnectorRole.WORKER)
+
+    @staticmethod
+    def _load_gemm_selections() -> None:
+        """Library-GEMM algorithm table for decode-sized batches, produced offline on this GPU generation
+        (benchmarks_dev/tune_gemms.py).  Lookup only: nothing is tuned at run time, unknown shapes use
+        the library heuristic."""
+        path = envs.VDA_GEMM_SELECTIONS
+        if path is None:
+            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ops", "tuned",
+                                "gfx950_gemm.csv")
+        if not path or path == "off" or not os.path.isfile(path):
+            return
+        try:
+            import torch.cuda.tunable as tn
+            tn.enable(True)
+            tn.tuning_enable(False)
+            tn.record_untuned_enable(False)
+            ok = tn.read_file(path)
+            logger.info("GEMM selection table %s %s", path, "loaded" if ok else "rejected (library versions differ)")
+            if not ok:
+                tn.enable(False)
+        except Exception as e:   # noqa: BLE001 - an optimisation only
+            logger.warning("GEMM selection table not used: %s", e)
 
     def load_model(self) -> None:
         self.model_runner.load_model()
