@@ -307,6 +307,258 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
   }
 }
 
+// Prefill form with K/V staged through LDS.  The direct-to-register form above makes every wave of a
+// workgroup fetch the same keys from L2 (4x the traffic) and is L2-bandwidth bound in prefill; here the
+// 256 threads copy each 32-key K tile and V tile once (fully coalesced 16-byte pieces, fp8 caches are
+// widened on the way in), double-buffered so that the next tile's global loads fly during the MFMAs, and
+// every wave then reads its MFMA operands from LDS.  16-byte pieces are XOR-swizzled so that the eight
+// lanes served per LDS cycle hit eight different bank groups for both the row-per-lane K reads and the
+// d-row-per-lane V reads.
+template <typename T, int D, int BS, bool F8>
+__global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  using CT = typename KVElem<T, F8>::type;
+  constexpr int KS = D / 32, NT = D / 16, DQ = D / 4, NCT = 2, COLS = 32;
+  constexpr int KCH = D / 8;          // 16-byte pieces per K row
+  constexpr int KP = 32 * KCH;        // K pieces per 32-key step
+  constexpr int VP = D * 4;           // V pieces per step (D rows x 4 groups of 8 keys)
+  constexpr int KPT = KP / 256, VPT = VP / 256;
+  static_assert(KP % 256 == 0 && VP % 256 == 0, "head size must be a multiple of 64");
+  __shared__ V8 sK[2][KP];
+  __shared__ V8 sV[2][VP];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int kvh = blockIdx.y;
+  const int G = p.Hq / p.Hkv;
+
+  const int tile = blockIdx.x;
+  int lo = 0, hi = p.num_seqs;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (mid < p.num_seqs && p.q_start_loc[mid] / p.q_tile + mid <= tile) lo = mid; else hi = mid - 1;
+  }
+  const int seq = lo;
+  const int q0 = (tile - (p.q_start_loc[seq] / p.q_tile + seq)) * p.q_tile;
+  const int qs = p.q_start_loc[seq];
+  const int q_len = p.q_start_loc[seq + 1] - qs;
+  const int seq_len = p.seq_lens[seq];
+  if (q0 >= q_len) return;                  // uniform over the workgroup
+  const int ctx = seq_len - q_len;
+  const int* bt = p.block_table + (long)seq * p.max_blocks;
+  const int nblk_valid = (seq_len + BS - 1) / BS;
+  const int qt_end = min(q_len, q0 + p.q_tile);
+
+  int limit[NCT], lower[NCT];
+  long col_off[NCT];
+  float slope[NCT];
+  V8 qf[NCT][KS];
+  int wave_hi = 0, wave_lo = 0x7fffffff;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int c = wave * COLS + ct * 16 + r;
+    const int ti = c / G, h = c % G;
+    const int qt = q0 + ti;
+    const bool valid = qt < qt_end;
+    limit[ct] = valid ? ctx + qt + 1 : 0;
+    lower[ct] = (valid && p.window > 0) ? max(0, limit[ct] - p.window) : 0;
+    const int head = kvh * G + h;
+    slope[ct] = (p.alibi && valid) ? p.alibi[head] : 0.f;
+    const T* qp = (const T*)p.q + (long)(qs + (valid ? qt : q0)) * p.q_stride + (long)head * D + g * DQ;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[ct][s] = valid ? ld16<V8>(qp + 8 * s) : V8{};
+    col_off[ct] = valid ? (long)(qs + qt) : -1;
+    if (valid) { wave_hi = max(wave_hi, limit[ct]); wave_lo = min(wave_lo, lower[ct]); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    wave_hi = max(wave_hi, __shfl_xor(wave_hi, o, 64));
+    wave_lo = min(wave_lo, __shfl_xor(wave_lo, o, 64));
+  }
+  // workgroup-uniform key range (all waves take part in every tile copy)
+  const int wg_hi = ctx + qt_end;
+  const int wg_lo = p.window > 0 ? max(0, ctx + q0 + 1 - p.window) : 0;
+  const int step_lo = wg_lo / 32, step_hi = (wg_hi + 31) / 32;
+
+  float m[NCT], l[NCT];
+  f32x4 acc[NCT][NT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    m[ct] = -INFINITY; l[ct] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[ct][n] = f32x4{0, 0, 0, 0};
+  }
+  const CT* kc = (const CT*)p.k_cache;
+  const CT* vc = (const CT*)p.v_cache;
+
+  // Two register stages: tile t+2 is requested from memory while tile t is consumed and tile t+1 (requested one
+  // iteration earlier) moves from registers into the other LDS buffer -- a full iteration of latency cover.
+  V8 rkA[KPT], rvA[VPT], rkB[KPT], rvB[VPT];
+  auto gload = [&](int step, V8 (&rk)[KPT], V8 (&rv)[VPT]) {
+    const int tb = step * 32;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int pi = tid + 256 * i;
+      const int key = pi / KCH, ch = pi % KCH;
+      const int tok = tb + key;
+      const long blk = bt[max(min(tok / BS, nblk_valid - 1), 0)];
+      rk[i] = KVLoad<T, F8>::ld(kc + ((blk * p.Hkv + kvh) * BS + (tok % BS)) * (long)D + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int pi = tid + 256 * i;
+      const int d = pi >> 2, c = pi & 3;
+      const int tok = tb + 8 * c;
+      const long blk = bt[max(min(tok / BS, nblk_valid - 1), 0)];
+      rv[i] = KVLoad<T, F8>::ld(vc + ((blk * p.Hkv + kvh) * (long)D + d) * BS + (tok % BS));
+    }
+  };
+  auto sstore = [&](int buf, const V8 (&rk)[KPT], const V8 (&rv)[VPT]) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int pi = tid + 256 * i;
+      const int key = pi / KCH, ch = pi % KCH;
+      const int swz = (key & 3) | (((key >> 3) & 1) << 2);
+      sK[buf][key * KCH + (ch ^ swz)] = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const int pi = tid + 256 * i;
+      const int d = pi >> 2, c = pi & 3;
+      sV[buf][d * 4 + (c ^ ((d >> 1) & 3))] = rv[i];
+    }
+  };
+
+  const int krow0 = 8 * (r >> 2) + (r & 3);
+  // Tiles strictly below every column's causal limit and above every window edge need no masking; with no
+  // soft-cap and no ALiBi the score transform is then a single multiply.  Both tests are wave-uniform.
+  int full_hi = 0x7fffffff, full_lo = 0;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    if (col_off[ct] >= 0) { full_hi = min(full_hi, limit[ct]); full_lo = max(full_lo, lower[ct]); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    full_hi = min(full_hi, __shfl_xor(full_hi, o, 64));
+    full_lo = max(full_lo, __shfl_xor(full_lo, o, 64));
+  }
+  const bool plain = !(p.softcap > 0.f) && p.alibi == nullptr;
+  const float sl2 = p.scale * 1.4426950408889634f;
+  auto compute = [&](int step, int buf) {
+    const int tb0 = step * 32;
+    if (!(tb0 < wave_hi && tb0 + 32 > wave_lo)) return;   // wave-uniform: tile outside this wave's causal range
+    const bool fast = plain && tb0 + 32 <= full_hi && tb0 >= full_lo;
+    V8 kf[2][KS], vf[NT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int key = krow0 + 4 * u;
+      const int swz = (key & 3) | (((key >> 3) & 1) << 2);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kf[u][s] = sK[buf][key * KCH + ((g * KS + s) ^ swz)];
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int d = 16 * n + r;
+      vf[n] = sV[buf][d * 4 + (g ^ ((d >> 1) & 3))];
+    }
+    const int tb = tb0 + 8 * g;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        s0 = mfma16(kf[0][s], qf[ct][s], s0);
+        s1 = mfma16(kf[1][s], qf[ct][s], s1);
+      }
+      float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      float mx = -INFINITY;
+      if (fast) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sv[j] *= sl2;
+          mx = fmaxf(mx, sv[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int tok = tb + j;
+          float x = sv[j] * p.scale;
+          if (p.softcap > 0.f) x = p.softcap * tanhf(x / p.softcap);
+          x += slope[ct] * (float)(tok - (limit[ct] - 1));
+          x *= 1.4426950408889634f;
+          x = (tok < limit[ct] && tok >= lower[ct]) ? x : -INFINITY;
+          sv[j] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m[ct], mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f(m[ct] - m_use);
+      m[ct] = m_new;
+      float ps = 0.f;
+      V8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = exp2f(sv[j] - m_use);
+        ps += e;
+        pb[j] = (T)e;
+      }
+      l[ct] = l[ct] * alpha + ps;
+      if (__any(alpha != 1.f)) {          // the running maximum settles early: most tiles need no rescale
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[ct][n] *= alpha;
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[ct][n] = mfma16(vf[n], pb, acc[ct][n]);
+    }
+  };
+
+  // prologue: tile 0 -> LDS buffer 0, tile 1 -> register stage A
+  if (step_lo < step_hi) {
+    gload(step_lo, rkA, rvA);
+    sstore(0, rkA, rvA);
+    if (step_lo + 1 < step_hi) gload(step_lo + 1, rkA, rvA);
+  }
+  __syncthreads();
+  for (int step = step_lo; step < step_hi; step += 2) {
+    // even half: consume buffer 0, stage A holds tile step+1, request tile step+2 into stage B
+    if (step + 2 < step_hi) gload(step + 2, rkB, rvB);
+    compute(step, 0);
+    if (step + 1 < step_hi) sstore(1, rkA, rvA);
+    __syncthreads();
+    if (step + 1 >= step_hi) break;
+    // odd half: consume buffer 1, stage B holds tile step+2, request tile step+3 into stage A
+    if (step + 3 < step_hi) gload(step + 3, rkA, rvA);
+    compute(step + 1, 1);
+    if (step + 2 < step_hi) sstore(0, rkB, rvB);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    l[ct] += __shfl_xor(l[ct], 16, 64);
+    l[ct] += __shfl_xor(l[ct], 32, 64);
+  }
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    if (col_off[ct] < 0) continue;
+    const int c = wave * COLS + ct * 16 + r;
+    const int head = kvh * G + c % G;
+    const float inv = l[ct] > 0.f ? p.v_scale / l[ct] : 0.f;
+    T* op = (T*)p.out + col_off[ct] * p.out_stride + (long)head * D + 4 * g;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      V4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (T)(acc[ct][n][i] * inv);
+      *reinterpret_cast<V4*>(op + 16 * n) = o;
+    }
+  }
+}
+
 // Merge split-KV partials: one wave per (token, head).
 template <typename T, int D>
 __global__ __launch_bounds__(64) void attn_reduce_kernel(T* out, const float* part_out, const float* part_lse,
@@ -384,6 +636,13 @@ static int launch_attn(const AttnParams& p, int form, int grid_x, hipStream_t st
   } else if (form == 1) {
     dim3 grid(grid_x, p.Hkv, p.nsplit);
     hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, true, F8>), grid, block, 0, st, p);
+  } else if (form == 3) {
+    dim3 grid(grid_x, p.Hkv, 1);
+    if constexpr (D <= 128) {
+      hipLaunchKernelGGL((paged_prefill_lds_kernel<T, D, BS, F8>), grid, block, 0, st, p);
+    } else {
+      hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, false, F8>), grid, block, 0, st, p);
+    }
   } else {
     dim3 grid(grid_x, p.Hkv, 1);
     hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, false, F8>), grid, block, 0, st, p);
@@ -453,6 +712,10 @@ VDA_EXPORT int vda_paged_attention_decode(
   return 0;
 }
 
+// 1 (default): K/V staged through LDS; 0: direct-to-register form (kept for A/B measurements)
+static int g_prefill_variant = 1;
+VDA_EXPORT int vda_set_prefill_variant(int v) { g_prefill_variant = v; return 0; }
+
 // Varlen causal attention of new tokens against the paged cache (the new tokens'
 // own K/V must already be in the cache).  q_tile = 128 / (Hq/Hkv) query tokens
 // per workgroup; the grid over-allocates one tile per sequence.
@@ -469,8 +732,9 @@ VDA_EXPORT int vda_paged_attention_prefill(
                num_seqs, Hq, Hkv, max_blocks, 1, q_stride, out_stride, scale * (kv_fp8 ? k_scale : 1.f), softcap,
                kv_fp8 ? v_scale : 1.f, window, q_tile};
   const int grid_x = num_tokens / q_tile + num_seqs;
-  return dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, 2, grid_x, st, kv_fp8)
-                           : dispatch_d<f16_t>(p, D, block_size, 2, grid_x, st, kv_fp8);
+  const int form = g_prefill_variant == 0 ? 2 : 3;
+  return dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, form, grid_x, st, kv_fp8)
+                           : dispatch_d<f16_t>(p, D, block_size, form, grid_x, st, kv_fp8);
 }
 
 VDA_EXPORT int vda_merge_attn_states(void* out, float* out_lse, const void* pre, const float* pre_lse,
