@@ -15,8 +15,10 @@ def main():
     model, out_path = sys.argv[1], sys.argv[2]
     kw = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}
     prompts = [[(i * 7 + j) % 300 for j in range(20 + 5 * i)] for i in range(5)]
-    llm = LLM(model=model, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
-              max_num_seqs=8, max_num_batched_tokens=64, distributed_executor_backend="external_launcher", **kw)
+    base = dict(skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+                max_num_batched_tokens=64, distributed_executor_backend="external_launcher")
+    base.update(kw)          # GPU rehearsals override device / dtype / memory settings
+    llm = LLM(model=model, **base)
     outs = llm.generate(prompt_token_ids=prompts,
                         sampling_params=SamplingParams(temperature=0, max_tokens=10, ignore_eos=True))
     toks = [list(o.outputs[0].token_ids) for o in outs]

@@ -71,6 +71,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_FORCE_TORCH_OPS": (_bool, False),       # CPU/reference ops even on GPU (debug)
     "VDA_DECODE_SPLIT_TARGET_WGS": (int, 1024),  # split-KV until grid has this many WGs
     "VDA_SKINNY_GEMM_MAX_M": (int, 8),
+    "VDA_REHEARSE_ON_ONE_GPU": (_bool, False),   # all ranks share cuda:0: gloo groups + peer-memory all-reduce (tests)
     "VDA_GEMM_SELECTIONS": (str, None),          # CSV of library-GEMM algorithm choices; "off" disables
     "VDA_DISABLE_SKINNY_GEMM": (_bool, False),
     "VDA_FP8_W8A16_MAX_M": (int, 64),            # fp8 linear: up to this M stream weights, beyond use fp8 MFMA GEMM

@@ -48,12 +48,17 @@ class GroupCoordinator:
         self.device_group = None
         self.cpu_group = None
         self.backend = backend
-        self.device = torch.device(f"cuda:{local_rank}") if backend == "nccl" else torch.device("cpu")
+        # "gloo+hip": rehearsal of a multi-rank GPU run on ONE device (every rank uses cuda:0; RCCL refuses
+        # two ranks per device, so process groups are gloo, device tensors are staged through the host and
+        # only the peer-memory all-reduce runs on the device)
+        self.staged = backend == "gloo+hip"
+        self.device = torch.device(f"cuda:{local_rank}") if backend == "nccl" else \
+            (torch.device("cuda:0") if self.staged else torch.device("cpu"))
         self.ca_comm = None       # peer-memory all-reduce
         self.rccl_comm = None     # stream-explicit RCCL (graph capturable)
         self.mq_broadcaster = None
         self.all2all = None
-        self._use_device_comm = use_device_comm and backend == "nccl"
+        self._use_device_comm = use_device_comm and backend in ("nccl", "gloo+hip")
         self._use_mq = use_message_queue
 
     def _attach(self, device_group, cpu_group) -> None:
@@ -66,12 +71,13 @@ class GroupCoordinator:
 
     def _init_device_comms(self) -> None:
         from ..platforms import current_platform
-        try:
-            from .rccl import RcclCommunicator
-            self.rccl_comm = RcclCommunicator(self.cpu_group, self.device)
-        except Exception as e:   # library missing or init failure: torch.distributed still works
-            logger.warning("stream-explicit RCCL communicator unavailable for group %s: %s", self.name, e)
-            self.rccl_comm = None
+        if not self.staged:
+            try:
+                from .rccl import RcclCommunicator
+                self.rccl_comm = RcclCommunicator(self.cpu_group, self.device)
+            except Exception as e:   # library missing or init failure: torch.distributed still works
+                logger.warning("stream-explicit RCCL communicator unavailable for group %s: %s", self.name, e)
+                self.rccl_comm = None
         if "tp" in self.name and not envs.VLLM_DISABLE_CUSTOM_ALL_REDUCE \
                 and current_platform.use_custom_allreduce():
             try:
@@ -107,6 +113,13 @@ class GroupCoordinator:
         return self.ranks[(self.rank_in_group - 1) % self.world_size]
 
     # ---- collectives -------------------------------------------------------
+    def _pg(self, x: torch.Tensor):
+        return self.device_group if (x.is_cuda and not self.staged) else self.cpu_group
+
+    def _down(self, x: torch.Tensor) -> torch.Tensor:
+        """Host copy of a device tensor in staged mode, the tensor itself otherwise."""
+        return x.cpu() if (self.staged and x.is_cuda) else x
+
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """Out of place for the peer-memory path, in place otherwise; always use the return value."""
         if self.world_size == 1:
@@ -118,7 +131,10 @@ class GroupCoordinator:
                     return out
             if self.rccl_comm is not None:
                 return self.rccl_comm.all_reduce(x)
-        dist.all_reduce(x, group=self.device_group if x.is_cuda else self.cpu_group)
+        h = self._down(x)
+        dist.all_reduce(h, group=self._pg(x))
+        if h is not x:
+            x.copy_(h)
         return x
 
     def all_gather(self, x: torch.Tensor, dim: int = -1) -> torch.Tensor:
@@ -133,7 +149,10 @@ class GroupCoordinator:
         if x.is_cuda and self.rccl_comm is not None:
             self.rccl_comm.all_gather(flat, x)
         else:
-            dist.all_gather_into_tensor(flat, x, group=self.device_group if x.is_cuda else self.cpu_group)
+            hf, hx = self._down(flat), self._down(x)
+            dist.all_gather_into_tensor(hf, hx, group=self._pg(x))
+            if hf is not flat:
+                flat.copy_(hf)
         out = flat.view((self.world_size,) + tuple(x.shape))
         if dim == 0:
             return out.reshape((self.world_size * x.shape[0],) + tuple(x.shape[1:]))
@@ -151,7 +170,15 @@ class GroupCoordinator:
         if x.is_cuda and self.rccl_comm is not None:
             self.rccl_comm.reduce_scatter(out, xt)
         else:
-            dist.reduce_scatter_tensor(out, xt, group=self.device_group if x.is_cuda else self.cpu_group)
+            ho, hx = self._down(out), self._down(xt)
+            if self.staged and x.is_cuda:     # gloo has no reduce-scatter: all-reduce and slice
+                dist.all_reduce(hx, group=self.cpu_group)
+                n = ho.shape[0]
+                ho.copy_(hx[self.rank_in_group * n:(self.rank_in_group + 1) * n])
+            else:
+                dist.reduce_scatter_tensor(ho, hx, group=self._pg(x))
+            if ho is not out:
+                out.copy_(ho)
         return out.movedim(0, dim)
 
     def gather(self, x: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Tensor]:
@@ -161,22 +188,28 @@ class GroupCoordinator:
         if dim < 0:
             dim += x.dim()
         x = x.contiguous()
-        lst = [torch.empty_like(x) for _ in range(self.world_size)] if self.rank_in_group == dst else None
-        dist.gather(x, lst, dst=self.ranks[dst], group=self.device_group if x.is_cuda else self.cpu_group)
-        return torch.cat(lst, dim=dim) if lst is not None else None
+        hx = self._down(x)
+        lst = [torch.empty_like(hx) for _ in range(self.world_size)] if self.rank_in_group == dst else None
+        dist.gather(hx, lst, dst=self.ranks[dst], group=self._pg(x))
+        return torch.cat(lst, dim=dim).to(x.device) if lst is not None else None
 
     def broadcast(self, x: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.world_size == 1:
             return x
-        dist.broadcast(x, src=self.ranks[src], group=self.device_group if x.is_cuda else self.cpu_group)
+        h = self._down(x)
+        dist.broadcast(h, src=self.ranks[src], group=self._pg(x))
+        if h is not x:
+            x.copy_(h)
         return x
 
     def all_to_all_single(self, out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None) -> torch.Tensor:
         if self.world_size == 1:
             out.copy_(inp)
             return out
-        dist.all_to_all_single(out, inp, out_splits, in_splits,
-                               group=self.device_group if inp.is_cuda else self.cpu_group)
+        ho, hi = self._down(out), self._down(inp)
+        dist.all_to_all_single(ho, hi, out_splits, in_splits, group=self._pg(inp))
+        if ho is not out:
+            out.copy_(ho)
         return out
 
     def broadcast_object(self, obj: Any = None, src: int = 0) -> Any:
@@ -213,7 +246,7 @@ class GroupCoordinator:
         if x.is_cuda and self.rccl_comm is not None:
             self.rccl_comm.send(x, dst)
         else:
-            dist.send(x, self.ranks[dst], group=self.device_group if x.is_cuda else self.cpu_group)
+            dist.send(self._down(x), self.ranks[dst], group=self._pg(x))
 
     def recv(self, size, dtype: torch.dtype, src: Optional[int] = None, device=None) -> torch.Tensor:
         src = (self.rank_in_group - 1) % self.world_size if src is None else src
@@ -221,7 +254,10 @@ class GroupCoordinator:
         if x.is_cuda and self.rccl_comm is not None:
             self.rccl_comm.recv(x, src)
         else:
-            dist.recv(x, self.ranks[src], group=self.device_group if x.is_cuda else self.cpu_group)
+            h = self._down(x)
+            dist.recv(h, self.ranks[src], group=self._pg(x))
+            if h is not x:
+                x.copy_(h)
         return x
 
     # ---- tensor dicts ----------------------------------------------------------
@@ -358,8 +394,8 @@ def init_distributed_environment(world_size: int = 1, rank: int = 0, distributed
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device(f"cuda:{local_rank}")
-        dist.init_process_group(backend=backend, init_method=distributed_init_method, world_size=world_size,
-                                rank=rank, **kw)
+        dist.init_process_group(backend="gloo" if backend == "gloo+hip" else backend,
+                                init_method=distributed_init_method, world_size=world_size, rank=rank, **kw)
     if _WORLD is None:
         if world_size > 1:
             ranks = list(range(dist.get_world_size()))
@@ -373,7 +409,7 @@ def _new_group(all_ranks: list[list[int]], rank: int, local_rank: int, backend: 
     """Every process must create every subgroup (torch.distributed rule); keep ours."""
     mine = None
     for ranks in all_ranks:
-        dg = dist.new_group(ranks, backend=backend)
+        dg = dist.new_group(ranks, backend="gloo" if backend == "gloo+hip" else backend)
         cg = dist.new_group(ranks, backend="gloo")
         if rank in ranks:
             mine = GroupCoordinator(ranks, rank, local_rank, backend, name, use_device_comm, use_message_queue)

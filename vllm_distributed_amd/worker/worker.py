@@ -55,7 +55,8 @@ class Worker:
         dc = self.vllm_config.device_config
         pc = self.parallel_config
         if dc.device == "cuda":
-            self.device = torch.device(f"cuda:{self.local_rank}")
+            rehearse = envs.VDA_REHEARSE_ON_ONE_GPU
+            self.device = torch.device("cuda:0" if rehearse else f"cuda:{self.local_rank}")
             torch.cuda.set_device(self.device)
             gc.collect()
             torch.cuda.empty_cache()
@@ -65,7 +66,7 @@ class Worker:
             if free < want:
                 raise ValueError(f"device has {free / 2**30:.1f} GiB free of {total / 2**30:.1f} GiB but "
                                  f"gpu_memory_utilization asks for {want / 2**30:.1f} GiB")
-            backend = "nccl"
+            backend = "gloo+hip" if rehearse else "nccl"
             self._load_gemm_selections()
         else:
             self.device = torch.device("cpu")
