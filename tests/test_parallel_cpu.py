@@ -121,3 +121,17 @@ def test_token_parallel_matches_single(tmp_path, world, kw):
     got = _launch(world, model, str(tmp_path / "out"), kw)
     for r, toks in enumerate(got):
         assert toks == ref, f"rank {r} diverged with {kw}"
+
+
+def test_expert_parallel_with_eplb_matches_single(tmp_path):
+    """Mixtral with experts spread over two ranks (EP), two redundant slots and a rebalance every 3 steps:
+    replicas and moved weights must not change a single token."""
+    model, _ = _save_tiny(str(tmp_path), "mixtral")
+    ref = _reference(model)
+    kw = dict(tensor_parallel_size=2, enable_expert_parallel=True, enable_eplb=True, num_redundant_experts=2,
+              eplb_window_size=8, eplb_step_interval=3)
+    got = _launch(2, model, str(tmp_path / "out"), kw)
+    for r, toks in enumerate(got):
+        assert toks == ref, f"rank {r} diverged"
+    plain = _launch(2, model, str(tmp_path / "out2"), dict(tensor_parallel_size=2, enable_expert_parallel=True))
+    assert plain[0] == ref

@@ -95,10 +95,18 @@ class FusedMoE(nn.Module):
         self.tp_size, self.tp_rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
         self.dp_size = get_dp_group().world_size
         self.use_ep = bool(pc.enable_expert_parallel) and get_ep_group().world_size > 1
+        # EPLB: physical slots (logical experts + replicas of hot ones), re-placed at run time
+        self.eplb_state = None
+        self.eplb_layer = -1
+        self.num_physical_experts = num_experts
+        if self.use_ep and pc.enable_eplb:
+            self.num_physical_experts = num_experts + pc.num_redundant_experts
+            if self.num_physical_experts % get_ep_group().world_size:
+                raise ValueError("num_experts + num_redundant_experts must be divisible by the EP size for EPLB")
         if self.use_ep:
             ep = get_ep_group()
             self.ep_size, self.ep_rank = ep.world_size, ep.rank_in_group
-            self.local_num_experts, emap = determine_expert_map(self.ep_size, self.ep_rank, num_experts)
+            self.local_num_experts, emap = determine_expert_map(self.ep_size, self.ep_rank, self.num_physical_experts)
             self.register_buffer("expert_map", emap, persistent=False)
             self.shard_size, self.shard_rank = 1, 0           # whole experts: I is not split
         else:
@@ -117,6 +125,15 @@ class FusedMoE(nn.Module):
     def weight_loader(self, param: nn.Parameter, loaded: torch.Tensor, shard_id: str, expert_id: int) -> bool:
         """``shard_id`` in {"w1" (gate), "w3" (up), "w2" (down)}; ``expert_id`` is global.
         Returns False when the expert is not local (nothing loaded)."""
+        if self.num_physical_experts != self.global_num_experts:
+            # initial EPLB placement: physical slot s hosts logical expert s % num_logical
+            ok = False
+            for slot in range(expert_id, self.num_physical_experts, self.global_num_experts):
+                ok |= self._load_slot(param, loaded, shard_id, slot)
+            return ok
+        return self._load_slot(param, loaded, shard_id, expert_id)
+
+    def _load_slot(self, param: nn.Parameter, loaded: torch.Tensor, shard_id: str, expert_id: int) -> bool:
         local = expert_id
         if self.expert_map is not None:
             local = int(self.expert_map[expert_id])
@@ -150,6 +167,11 @@ class FusedMoE(nn.Module):
                 out.append(("experts.w13_" if sid != "w2" else "experts.w2_", f"experts.{e}.{ck}.", e, sid))
         return out
 
+    def expert_weight_tensors(self) -> list[torch.Tensor]:
+        """Tensors whose first dimension is the local physical expert slot (moved by EPLB)."""
+        return [p.data for n, p in self.named_parameters(recurse=False)
+                if p.dim() >= 1 and p.shape[0] == self.local_num_experts]
+
     # ---- routing + compute ----------------------------------------------------------------------
     def select_experts(self, router_logits: torch.Tensor):
         k = self.top_k
@@ -176,6 +198,9 @@ class FusedMoE(nn.Module):
             from ..parallel.all2all import dp_combine, dp_dispatch
             x, lg, meta = dp_dispatch(x, lg)
         topk_w, topk_ids = self.select_experts(lg)
+        if self.eplb_state is not None:
+            topk_ids = self.eplb_state.map_topk(self.eplb_layer, topk_ids)      # logical -> physical slot
+            self.eplb_state.record(self.eplb_layer, topk_ids)
         if self.expert_map is not None:
             topk_ids = self.expert_map[topk_ids.long()]
         if self.routed_scaling_factor != 1.0:

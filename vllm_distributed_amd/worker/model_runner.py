@@ -132,9 +132,41 @@ class ModelRunner:
                 for n, m in self.drafter.attention_layers().items():
                     m.layer_name = n
                     self.attn_layers[n] = m
+        pc = self.parallel_config
+        if pc.enable_eplb and pc.enable_expert_parallel:
+            self._init_eplb()
         if self.vllm_config.lora_config is not None:
             from ..lora.manager import LoRAManager
             self.lora_manager = LoRAManager(self.model, self.vllm_config, self.device)
+
+    def _init_eplb(self) -> None:
+        from ..layers.moe import FusedMoE
+        from ..parallel.eplb import EplbState
+        from ..parallel.state import get_ep_group
+        layers = [m for m in self.model.modules() if isinstance(m, FusedMoE)]
+        if not layers or get_ep_group().world_size == 1:
+            return
+        pc = self.parallel_config
+        hf = self.model_config.hf_config
+        first = layers[0]
+        self.eplb_state = EplbState(len(layers), first.global_num_experts, first.num_physical_experts,
+                                    get_ep_group().world_size, window=pc.eplb_window_size,
+                                    step_interval=pc.eplb_step_interval,
+                                    num_groups=int(getattr(hf, "n_group", 1) or 1))
+        for i, m in enumerate(layers):
+            m.eplb_state, m.eplb_layer = self.eplb_state, i
+        self._eplb_layers = layers
+        # placement changes are applied eagerly between steps: captured graphs would bake the old maps in
+        self.use_graphs = False
+        logger.info("EPLB on: %d MoE layers, %d logical -> %d physical experts", len(layers),
+                    first.global_num_experts, first.num_physical_experts)
+
+    def _eplb_step(self) -> None:
+        from ..parallel.state import get_ep_group
+        st = self.eplb_state
+        weights = [m.expert_weight_tensors() for m in self._eplb_layers]
+        g = get_ep_group()
+        st.step_done(g.cpu_group, weights, p2p_group=g.device_group if (self.is_gpu and not g.staged) else g.cpu_group)
 
     def get_model(self) -> nn.Module:
         return self.model
@@ -411,6 +443,8 @@ class ModelRunner:
             conn.clear_connector_metadata()
         if self.lora_manager is not None:
             self.lora_manager.clear_active()       # the output head and warm-up runs are not adapted
+        if self.eplb_state is not None:
+            self._eplb_step()
         if tmd is not None and not tmd.is_root:
             # the root samples; everybody applies the same tokens to the persistent batch
             if not pp.is_last_rank:
