@@ -14,6 +14,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     "Qwen2MoeForCausalLM": ("mixtral", "Qwen2MoeForCausalLM"),
     "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
+    "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
     "GPT2LMHeadModel": ("opt", "GPT2LMHeadModel"),
     "LlamaModel": ("pooling", "LlamaEmbeddingModel"),

@@ -1,0 +1,143 @@
+"""Multimodal inputs: registry of per-architecture processors, content hashing, placeholder expansion.
+
+A processor turns ``{"prompt_token_ids": [...], "multi_modal_data": {"image": ...}}`` into
+  * the prompt with every image token expanded to as many placeholder tokens as the encoder emits,
+  * one encoder input per item (pre-processed pixel tensor),
+  * one content hash per item (prefix caching keys and encoder-cache identity),
+  * one ``PlaceholderRange`` per item (where its embeddings land in the prompt).
+Images may be PIL images, ``[H, W, 3]`` uint8 arrays / tensors, or already pre-processed
+``[3, S, S]`` float tensors.
+Reference: vllm/multimodal/{registry.py, processing.py, hasher.py, inputs.py}, vllm/v1/engine/mm_input_cache.py.
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import Any, Callable, Optional
+
+import numpy as np
+import torch
+
+from ..request import PlaceholderRange
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def hash_item(x: Any) -> str:
+    h = hashlib.sha256()
+    if isinstance(x, torch.Tensor):
+        h.update(str((tuple(x.shape), str(x.dtype))).encode())
+        h.update(x.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
+    elif isinstance(x, np.ndarray):
+        h.update(str((x.shape, x.dtype.str)).encode())
+        h.update(np.ascontiguousarray(x).tobytes())
+    elif hasattr(x, "tobytes") and hasattr(x, "size"):        # PIL image
+        h.update(str((x.size, getattr(x, "mode", ""))).encode())
+        h.update(x.tobytes())
+    else:
+        h.update(repr(x).encode())
+    return h.hexdigest()
+
+
+def to_pixel_values(img: Any, size: int, mean=CLIP_MEAN, std=CLIP_STD) -> torch.Tensor:
+    """CLIP-style preprocessing: shortest side to ``size`` (bicubic), centre crop, scale to [0,1], normalise."""
+    if isinstance(img, torch.Tensor) and img.dtype.is_floating_point and img.dim() == 3 and img.shape[0] == 3:
+        return img.float()                                   # already pre-processed
+    if hasattr(img, "convert"):                              # PIL
+        img = np.asarray(img.convert("RGB"))
+    t = torch.as_tensor(np.asarray(img) if not isinstance(img, torch.Tensor) else img)
+    if t.dim() != 3 or t.shape[-1] != 3:
+        raise ValueError(f"image must be [H, W, 3] or a pre-processed [3, S, S] float tensor, got {tuple(t.shape)}")
+    t = t.permute(2, 0, 1).float().unsqueeze(0)
+    H, W = t.shape[-2:]
+    s = size / min(H, W)
+    nh, nw = max(int(round(H * s)), size), max(int(round(W * s)), size)
+    if (nh, nw) != (H, W):
+        t = torch.nn.functional.interpolate(t, size=(nh, nw), mode="bicubic", align_corners=False, antialias=True)
+    top, left = (nh - size) // 2, (nw - size) // 2
+    t = t[0, :, top:top + size, left:left + size].clamp(0, 255) / 255.0
+    m = torch.tensor(mean).view(3, 1, 1)
+    sd = torch.tensor(std).view(3, 1, 1)
+    return (t - m) / sd
+
+
+class MultiModalRegistry:
+    """architecture name -> processor factory; processors are built once per model config."""
+
+    def __init__(self):
+        self._factories: dict[str, Callable] = {}
+        self._cache: dict[int, Any] = {}
+
+    def register_processor(self, arch: str, factory: Callable) -> None:
+        self._factories[arch] = factory
+
+    def supports(self, arch: str) -> bool:
+        return arch in self._factories
+
+    def get_processor(self, vllm_config):
+        key = id(vllm_config.model_config)
+        if key not in self._cache:
+            arch = (vllm_config.model_config.architectures or [""])[0]
+            if arch not in self._factories:
+                raise ValueError(f"{arch} takes no multimodal inputs")
+            self._cache[key] = self._factories[arch](vllm_config)
+        return self._cache[key]
+
+
+MULTIMODAL_REGISTRY = MultiModalRegistry()
+
+
+class ImageTokenProcessor:
+    """Models whose prompt marks each image with ONE special token that the encoder output replaces
+    (LLaVA family)."""
+
+    def __init__(self, image_token_id: int, tokens_per_image: int, image_size: int):
+        self.image_token_id, self.tokens_per_image, self.image_size = image_token_id, tokens_per_image, image_size
+
+    def __call__(self, prompt_token_ids: list[int], mm_data: dict):
+        images = mm_data.get("image")
+        if images is None:
+            raise ValueError("multi_modal_data needs an 'image' entry")
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        spots = [i for i, t in enumerate(prompt_token_ids) if t == self.image_token_id]
+        # prompts may already carry the expanded run of image tokens: collapse runs first
+        runs, prev = [], -2
+        for i in spots:
+            if i != prev + 1:
+                runs.append([i, 1])
+            else:
+                runs[-1][1] += 1
+            prev = i
+        if len(runs) != len(images):
+            raise ValueError(f"prompt has {len(runs)} image placeholders but {len(images)} images were given")
+        out, positions, inputs, hashes = [], [], [], []
+        cur = 0
+        for (start, n), img in zip(runs, images):
+            out.extend(prompt_token_ids[cur:start])
+            positions.append(PlaceholderRange(offset=len(out), length=self.tokens_per_image))
+            out.extend([self.image_token_id] * self.tokens_per_image)
+            cur = start + n
+            inputs.append(to_pixel_values(img, self.image_size))
+            hashes.append(hash_item(img))
+        out.extend(prompt_token_ids[cur:])
+        return out, inputs, hashes, positions
+
+
+def process_multimodal(vllm_config, prompt_token_ids: list[int], mm_data: dict):
+    """(expanded prompt ids, encoder inputs, content hashes, placeholder ranges)."""
+    return MULTIMODAL_REGISTRY.get_processor(vllm_config)(list(prompt_token_ids), mm_data)
+
+
+def _llava_processor(vllm_config):
+    hf = vllm_config.model_config.hf_config
+    vc = hf.vision_config if isinstance(hf.vision_config, dict) else hf.vision_config.to_dict()
+    size, patch = int(vc.get("image_size", 336)), int(vc.get("patch_size", 14))
+    n = (size // patch) ** 2
+    if getattr(hf, "vision_feature_select_strategy", "default") == "full":
+        n += 1
+    return ImageTokenProcessor(int(getattr(hf, "image_token_index", None) or getattr(hf, "image_token_id", 32000)),
+                               n, size)
+
+
+MULTIMODAL_REGISTRY.register_processor("LlavaForConditionalGeneration", _llava_processor)

@@ -83,6 +83,7 @@ class ModelRunner:
         self.kv_connector = None
         self.lora_manager = None
         self.eplb_state = None
+        self.encoder_cache: dict[str, dict[int, torch.Tensor]] = {}     # request -> item index -> embeddings
         self._init_buffers()
 
     # ------------------------------------------------------------------
@@ -366,6 +367,48 @@ class ModelRunner:
         att = (S_l, T_l, nd, ndt, int(seq_l.max()) if S_l else 0, int(n_l.max()) if S_l else 0)
         return tmd, att
 
+    # ---- multimodal -----------------------------------------------------------------------------------
+    def _run_mm_encoder(self, so: SchedulerOutput) -> None:
+        """Run the vision encoder for the items scheduled this step; keep outputs until the scheduler frees them."""
+        ib = self.input_batch
+        for rid in so.finished_req_ids:
+            self.encoder_cache.pop(rid, None)
+        for rid, i in so.free_encoder_input_ids:
+            self.encoder_cache.get(rid, {}).pop(i, None)
+        if not so.scheduled_encoder_inputs:
+            return
+        todo = [(rid, i) for rid, idxs in so.scheduled_encoder_inputs.items() for i in idxs]
+        px = torch.stack([ib.reqs[rid].mm_inputs[i] for rid, i in todo]).to(self.device, self.dtype)
+        emb = self.model.encode_images(px)
+        for (rid, i), e in zip(todo, emb):
+            self.encoder_cache.setdefault(rid, {})[i] = e
+
+    def _gather_mm_embeddings(self, req_ids, rows, n_sched, cu):
+        """Embeddings and the token mask of every placeholder position covered by this step."""
+        ib = self.input_batch
+        parts, idx = [], []
+        for k, rid in enumerate(req_ids):
+            st = ib.reqs[rid]
+            if not st.mm_positions:
+                continue
+            a = int(ib.num_computed[rows[k]])
+            b = a + int(n_sched[k])
+            for i, pos in enumerate(st.mm_positions):
+                lo, hi = max(pos.offset, a), min(pos.offset + pos.length, b)
+                if lo >= hi:
+                    continue
+                e = self.encoder_cache.get(rid, {}).get(i)
+                if e is None:
+                    raise RuntimeError(f"encoder output {i} of request {rid} is missing")
+                parts.append(e[lo - pos.offset: hi - pos.offset])
+                base = int(cu[k]) - a
+                idx.extend(range(base + lo, base + hi))
+        if not parts:
+            return None, None
+        mask = torch.zeros(int(cu[-1]), dtype=torch.bool)
+        mask[idx] = True
+        return torch.cat(parts, dim=0), mask.to(self.device)
+
     def _decode_splits(self, num_seqs: int, max_seq_len: int, fixed: bool) -> int:
         if num_seqs == 0:
             return 1
@@ -401,13 +444,19 @@ class ModelRunner:
         if not so.total_num_scheduled_tokens:
             return self._finish_kv_only(so)
         req_ids, rows, n_sched, cu, S, T, logits_idx, att, tmd = self._prepare_inputs(so)
+        inputs_embeds = None
+        if getattr(self.model, "is_multimodal", False):
+            self._run_mm_encoder(so)
+            mm_e, mm_mask = self._gather_mm_embeddings(req_ids, rows, n_sched, cu)
+            if mm_e is not None:
+                inputs_embeds = self.model.get_input_embeddings(self.input_ids[:T], mm_e, mm_mask)
         S_a, T_a, nd, ndt, max_seq, max_q = att        # what THIS rank attends for (== the batch without TKNP)
         ib = self.input_batch
         pure_decode = nd == S and max_q == 1
         pp = get_pp_group()
         graph_bs = None
         if self.use_graphs and pure_decode and S <= (self.capture_sizes[0] if self.capture_sizes else 0) \
-                and self.graphs and self.lora_manager is None:
+                and self.graphs and self.lora_manager is None and inputs_embeds is None:
             graph_bs = self.vllm_config.pad_for_cudagraph(S)
         if self.lora_manager is not None:
             self.lora_manager.set_active(req_ids, rows, n_sched, ib)
@@ -437,7 +486,7 @@ class ModelRunner:
             with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T):
                 if conn is not None:
                     conn.start_load_kv()
-                hidden = self.model(self.input_ids[:T], self.positions[:T_a], inter, None)
+                hidden = self.model(self.input_ids[:T], self.positions[:T_a], inter, inputs_embeds)
         if conn is not None:
             conn.wait_for_save()
             conn.clear_connector_metadata()
