@@ -9,8 +9,39 @@ _FALLBACK_TEMPLATE = (
     "{% if add_generation_prompt %}<|assistant|>\n{% endif %}")
 
 
+IMAGE_PLACEHOLDER = "<image>"       # replaced by the model's image token string before tokenisation
+
+
+def load_image(url: str):
+    """``data:`` URLs (base64) and local ``file://`` paths; there is no network fetch on purpose."""
+    import base64
+    import io
+
+    from PIL import Image
+    if url.startswith("data:"):
+        head, _, payload = url.partition(",")
+        raw = base64.b64decode(payload) if ";base64" in head else payload.encode()
+        return Image.open(io.BytesIO(raw)).convert("RGB")
+    if url.startswith("file://"):
+        return Image.open(url[len("file://"):]).convert("RGB")
+    raise ValueError("image_url must be a data: URL or a file:// path (remote fetching is disabled)")
+
+
+def load_media(parts: list[dict]) -> dict:
+    """Media content parts -> ``multi_modal_data``."""
+    images = []
+    for part in parts:
+        if part.get("type") == "image_url":
+            u = part["image_url"]
+            images.append(load_image(u["url"] if isinstance(u, dict) else u))
+        else:
+            raise ValueError(f"{part.get('type')} inputs are not supported by this model")
+    return {"image": images} if images else {}
+
+
 def _flatten_content(content: Any) -> tuple[str, list[dict]]:
-    """OpenAI content may be a string or a list of typed parts; returns (text, media parts)."""
+    """OpenAI content may be a string or a list of typed parts; returns (text, media parts).  Each image part
+    leaves ``IMAGE_PLACEHOLDER`` in the text at the position where it occurred."""
     if content is None:
         return "", []
     if isinstance(content, str):
@@ -25,6 +56,8 @@ def _flatten_content(content: Any) -> tuple[str, list[dict]]:
             texts.append(part.get("text", ""))
         elif t in ("image_url", "audio_url", "video_url", "input_audio", "image_embeds"):
             media.append(part)
+            if t == "image_url":
+                texts.append(IMAGE_PLACEHOLDER)
         elif t == "refusal":
             texts.append(part.get("refusal", ""))
         else:

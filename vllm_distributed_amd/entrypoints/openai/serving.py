@@ -361,6 +361,24 @@ class OpenAIServingChat(OpenAIServing):
             prompts = await self._tokenize_prompt(tok, text, request.add_special_tokens,
                                                   request.truncate_prompt_tokens)
             p = prompts[0]
+            from ..chat_utils import load_media, parse_chat_messages
+            _, media = parse_chat_messages(request.messages)
+            mm_data = load_media(media) if media else None
+            if mm_data:
+                img_id = getattr(self.model_config.hf_config, "image_token_index", None) or \
+                    getattr(self.model_config.hf_config, "image_token_id", None)
+                if img_id is None:
+                    raise ValueError("this model takes no image inputs")
+                marker = tok.encode("<image>", add_special_tokens=False)
+                ids, out_ids, i = p["prompt_token_ids"], [], 0
+                while i < len(ids):            # the literal placeholder text -> the model's image token
+                    if marker and ids[i:i + len(marker)] == marker:
+                        out_ids.append(int(img_id))
+                        i += len(marker)
+                    else:
+                        out_ids.append(ids[i])
+                        i += 1
+                p["prompt_token_ids"] = out_ids
             sp = request.to_sampling_params(self.max_model_len - len(p["prompt_token_ids"]), self.default_sampling)
         except Exception as e:   # noqa: BLE001 - template / validation problems are client errors
             logger.debug("chat preprocessing failed", exc_info=True)
@@ -368,8 +386,11 @@ class OpenAIServingChat(OpenAIServing):
         rid = f"chatcmpl-{request.request_id or random_uuid()}"
         trace = extract_trace_headers(raw_request.headers) if raw_request is not None else None
         try:
-            gen = self.engine_client.generate(TokensPrompt(prompt_token_ids=p["prompt_token_ids"]), sp, rid,
-                                              lora_request=lora, trace_headers=trace, priority=request.priority)
+            prompt = TokensPrompt(prompt_token_ids=p["prompt_token_ids"])
+            if mm_data:
+                prompt["multi_modal_data"] = mm_data
+            gen = self.engine_client.generate(prompt, sp, rid, lora_request=lora, trace_headers=trace,
+                                              priority=request.priority)
         except ValueError as e:
             return self.error(str(e))
         model_name = self.models.model_name(lora)
