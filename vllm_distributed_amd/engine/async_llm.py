@@ -31,7 +31,7 @@ logger = init_logger(__name__)
 class AsyncLLM:
     def __init__(self, vllm_config: VllmConfig, executor_class: Optional[type] = None, log_stats: bool = True,
                  log_requests: bool = False, start_engine_loop: bool = True, stat_loggers: Optional[list] = None,
-                 client_index: int = 0):
+                 client_index: int = 0, attach: Optional[dict] = None):
         from ..executor.base import Executor
         self.vllm_config = vllm_config
         self.model_config = vllm_config.model_config
@@ -44,7 +44,9 @@ class AsyncLLM:
                                             lora_enabled=vllm_config.lora_config is not None)
         self.processor = Processor(vllm_config, self.tokenizer)
         self.output_processor = OutputProcessor(self.tokenizer, log_stats)
-        self.engine_core = EngineCoreClient.make_client(True, True, vllm_config, executor_class, log_stats)
+        self.client_index = client_index
+        self.engine_core = EngineCoreClient.make_client(True, True, vllm_config, executor_class, log_stats,
+                                                        attach=attach)
         self.stat_logger = StatLoggerManager(vllm_config, custom=stat_loggers) if log_stats else None
         self.output_handler: Optional[asyncio.Task] = None
         self._errored_with: Optional[BaseException] = None
@@ -57,10 +59,12 @@ class AsyncLLM:
         return cls(vllm_config, **kw)
 
     @classmethod
-    def from_engine_args(cls, engine_args, start_engine_loop: bool = True, usage_context=None, stat_loggers=None):
+    def from_engine_args(cls, engine_args, start_engine_loop: bool = True, usage_context=None, stat_loggers=None,
+                         client_index: int = 0, attach: Optional[dict] = None):
         cfg = engine_args.create_engine_config(usage_context)
         return cls(cfg, log_stats=not engine_args.disable_log_stats,
-                   log_requests=not getattr(engine_args, "disable_log_requests", True), stat_loggers=stat_loggers)
+                   log_requests=not getattr(engine_args, "disable_log_requests", True), stat_loggers=stat_loggers,
+                   client_index=client_index, attach=attach)
 
     def shutdown(self) -> None:
         if self.output_handler is not None:
@@ -88,6 +92,7 @@ class AsyncLLM:
         queue = RequestOutputCollector(kind)
         text, req = self.processor.process_inputs(request_id, prompt, params, arrival_time, lora_request,
                                                   tokenization_kwargs, trace_headers, priority, data_parallel_rank)
+        req.client_index = self.client_index
         n = params.n if isinstance(params, SamplingParams) else 1
         if n == 1:
             self.output_processor.add_request(req, text, None, 0, queue)

@@ -34,7 +34,7 @@ class EngineDeadError(RuntimeError):
 class EngineCoreClient:
     @staticmethod
     def make_client(multiprocess_mode: bool, asyncio_mode: bool, vllm_config: VllmConfig, executor_class: type,
-                    log_stats: bool) -> "EngineCoreClient":
+                    log_stats: bool, attach: Optional[dict] = None) -> "EngineCoreClient":
         if asyncio_mode and not multiprocess_mode:
             raise NotImplementedError("asyncio front ends need the multiprocess engine core")
         if not multiprocess_mode:
@@ -45,9 +45,9 @@ class EngineCoreClient:
         pc = vllm_config.parallel_config
         if pc.data_parallel_size > 1:
             if pc.data_parallel_external_lb:
-                return DPAsyncMPClient(vllm_config, executor_class, log_stats)
-            return DPLBAsyncMPClient(vllm_config, executor_class, log_stats)
-        return AsyncMPClient(vllm_config, executor_class, log_stats)
+                return DPAsyncMPClient(vllm_config, executor_class, log_stats, attach=attach)
+            return DPLBAsyncMPClient(vllm_config, executor_class, log_stats, attach=attach)
+        return AsyncMPClient(vllm_config, executor_class, log_stats, attach=attach)
 
     # sync API
     def get_output(self) -> EngineCoreOutputs: raise NotImplementedError

@@ -34,44 +34,59 @@ HANDSHAKE_TIMEOUT_S = 600
 
 
 class EngineCoreProc(EngineCore):
-    def __init__(self, vllm_config: VllmConfig, executor_class: type, log_stats: bool, address: str,
+    def __init__(self, vllm_config: VllmConfig, executor_class: type, log_stats: bool, address,
                  engine_index: int = 0):
+        """``address``: one front-end address, or a list of them (one per API-server process; the
+        position in the list is the ``client_index`` that requests carry and outputs are routed by)."""
         self.engine_index = engine_index
         self.input_queue: "queue.Queue[tuple]" = queue.Queue()
         self.output_queue: "queue.Queue[Any]" = queue.Queue()
-        self.conn: Connection = connect(address, timeout=HANDSHAKE_TIMEOUT_S)
-        self.conn.send({"status": "HELLO", "engine_index": engine_index, "pid": os.getpid()})
+        addresses = [address] if isinstance(address, str) else list(address)
+        self.conns: list[Connection] = [connect(a, timeout=HANDSHAKE_TIMEOUT_S) for a in addresses]
+        self.conn = self.conns[0]
+        for c in self.conns:
+            c.send({"status": "HELLO", "engine_index": engine_index, "pid": os.getpid()})
         super().__init__(vllm_config, executor_class, log_stats, executor_fail_callback=self._executor_failed)
-        self.conn.send({"status": "READY", "engine_index": engine_index,
-                        "num_gpu_blocks": vllm_config.cache_config.num_gpu_blocks})
+        for c in self.conns:
+            c.send({"status": "READY", "engine_index": engine_index,
+                    "num_gpu_blocks": vllm_config.cache_config.num_gpu_blocks})
         self.engines_running = False
-        self._in_t = threading.Thread(target=self._input_loop, daemon=True, name="core-input")
+        self._live_clients = len(self.conns)
+        self._in_ts = [threading.Thread(target=self._input_loop, args=(i,), daemon=True, name=f"core-input-{i}")
+                       for i in range(len(self.conns))]
         self._out_t = threading.Thread(target=self._output_loop, daemon=True, name="core-output")
-        self._in_t.start()
+        for t in self._in_ts:
+            t.start()
         self._out_t.start()
 
     def _executor_failed(self) -> None:
         self.input_queue.put((EngineCoreRequestType.EXECUTOR_FAILED, None))
 
     # ---- IO threads ---------------------------------------------------------
-    def _input_loop(self) -> None:
+    def _input_loop(self, client: int) -> None:
         try:
             while True:
-                kind, payload = self.conn.recv()
+                kind, payload = self.conns[client].recv()
+                if kind == EngineCoreRequestType.UTILITY:
+                    payload = (*payload, client)
                 self.input_queue.put((kind, payload))
         except (EOFError, OSError):
-            # the client went away: stop the engine
-            self.input_queue.put((None, "client disconnected"))
+            # the engine stops when its last client has gone away
+            self.input_queue.put((EngineCoreRequestType.CLIENT_GONE, client))
 
     def _output_loop(self) -> None:
         while True:
             item = self.output_queue.get()
-            try:
-                if item is None:
-                    return
-                self.conn.send(item)
-            except (EOFError, OSError):
+            if item is None:
                 return
+            client = getattr(item, "_client", 0)
+            targets = self.conns if client < 0 else [self.conns[client]]
+            for c in targets:
+                try:
+                    c.send(item)
+                except (EOFError, OSError):
+                    if len(self.conns) == 1:
+                        return
 
     # ---- busy loop -------------------------------------------------------------
     def run_busy_loop(self) -> None:
@@ -100,6 +115,7 @@ class EngineCoreProc(EngineCore):
         outs, executed = self.step_fn()
         for client_idx, o in (outs.items() if outs else ()):
             o.engine_index = self.engine_index
+            o._client = client_idx if client_idx < len(self.conns) else 0
             self.output_queue.put(o)
         return executed
 
@@ -111,14 +127,21 @@ class EngineCoreProc(EngineCore):
         elif kind == EngineCoreRequestType.ABORT:
             self.abort_requests(payload)
         elif kind == EngineCoreRequestType.UTILITY:
-            call_id, method, args = payload
+            call_id, method, args, *who = payload
             out = UtilityOutput(call_id)
             try:
                 out.result = getattr(self, method)(*args)
             except BaseException as e:   # noqa: BLE001 - reported to the caller
                 logger.exception("utility %s failed", method)
                 out.failure_message = f"{method} failed: {e}\n{traceback.format_exc()}"
-            self.output_queue.put(EngineCoreOutputs(engine_index=self.engine_index, utility_output=out))
+            reply = EngineCoreOutputs(engine_index=self.engine_index, utility_output=out)
+            reply._client = who[0] if who else 0
+            self.output_queue.put(reply)
+        elif kind == EngineCoreRequestType.CLIENT_GONE:
+            self._live_clients -= 1
+            if self._live_clients <= 0:
+                raise SystemExit(0)
+            self.abort_requests([rid for rid, r in self.scheduler.requests.items() if r.client_index == payload])
         elif kind == EngineCoreRequestType.EXECUTOR_FAILED:
             raise RuntimeError("a worker process died")
         elif kind == EngineCoreRequestType.START_DP_WAVE:
@@ -161,16 +184,18 @@ class EngineCoreProc(EngineCore):
         except BaseException:
             logger.exception("engine core crashed")
             if core is not None:
-                try:
-                    core.conn.send(ENGINE_CORE_DEAD)
-                except Exception:
-                    pass
+                for c in core.conns:
+                    try:
+                        c.send(ENGINE_CORE_DEAD)
+                    except Exception:
+                        pass
             else:
-                try:
-                    c = connect(address, timeout=2)
-                    c.send({"status": "FAILED", "engine_index": engine_index, "error": traceback.format_exc()})
-                except Exception:
-                    pass
+                for a in ([address] if isinstance(address, str) else address):
+                    try:
+                        c = connect(a, timeout=2)
+                        c.send({"status": "FAILED", "engine_index": engine_index, "error": traceback.format_exc()})
+                    except Exception:
+                        pass
             raise
         finally:
             if core is not None:

@@ -186,8 +186,12 @@ class DPEngineCoreProc(EngineCoreProc):
             elif not self.engines_running:
                 # the front end still thinks an old wave is running: tell it to wake the others
                 self.engines_running = True
-                self.output_queue.put(EngineCoreOutputs(engine_index=self.engine_index, start_wave=self.current_wave))
+                self._announce(EngineCoreOutputs(engine_index=self.engine_index, start_wave=self.current_wave))
         super().add_request(request)
+
+    def _announce(self, msg: EngineCoreOutputs) -> None:
+        msg._client = -1            # wave state concerns every front end
+        self.output_queue.put(msg)
 
     def _start_wave(self, payload) -> None:
         wave, _origin = payload
@@ -222,7 +226,7 @@ class DPEngineCoreProc(EngineCoreProc):
             self.engines_running = self._agree_unfinished(local_unfinished)
             if not self.engines_running:
                 if self.engine_index == 0:
-                    self.output_queue.put(EngineCoreOutputs(engine_index=0, wave_complete=self.current_wave))
+                    self._announce(EngineCoreOutputs(engine_index=0, wave_complete=self.current_wave))
                 self.current_wave += 1
                 self.step_counter = 0
 

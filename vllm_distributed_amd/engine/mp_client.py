@@ -30,32 +30,26 @@ logger = init_logger(__name__)
 
 
 class CoreEngineProcManager:
-    """Spawns engine-core processes and performs the HELLO/READY handshake."""
+    """Spawns engine-core processes and performs the HELLO/READY handshake.
+
+    Three shapes:
+    * default: listen on a fresh Unix socket, spawn ``num_engines`` cores, wait for all of them;
+    * ``num_remote > 0``: listen on TCP (``listen_address``) instead, so that cores started on other
+      nodes by ``vda serve --headless`` can join; wait for local + remote cores;
+    * ``spawn=False`` (attach): only listen on ``listen_address`` and wait; somebody else (the
+      multi-API-server launcher) starts the cores and tells them about this listener.
+    """
 
     def __init__(self, vllm_config: VllmConfig, executor_class: type, log_stats: bool, num_engines: int = 1,
-                 start_index: int = 0, local_start_index: int = 0, coordinator_address: Optional[str] = None):
-        ctx = get_mp_context()
-        self.listener = Listener(make_ipc_address("engine"))
+                 start_index: int = 0, local_start_index: int = 0, coordinator_address: Optional[str] = None,
+                 listen_address: Optional[str] = None, num_remote: int = 0, spawn: bool = True):
+        self.listener = Listener(listen_address or make_ipc_address("engine"))
         self.procs: list[multiprocessing.Process] = []
         self.conns: dict[int, Connection] = {}
-        for i in range(num_engines):
-            idx = start_index + i
-            p = ctx.Process(target=EngineCoreProc.run_engine_core, name=f"EngineCore_{idx}",
-                            kwargs=dict(vllm_config=vllm_config, executor_class=executor_class, log_stats=log_stats,
-                                        address=self.listener.address, engine_index=idx, dp_rank=idx,
-                                        local_dp_rank=local_start_index + i,
-                                        coordinator_address=coordinator_address))
-            env_patch = {}
-            if vllm_config.parallel_config.data_parallel_size > 1 and \
-                    vllm_config.device_config.device == "cuda":
-                # each DP replica owns a contiguous slice of the node's GPUs
-                ws = vllm_config.parallel_config.world_size
-                lo = (local_start_index + i) * ws
-                env_patch["HIP_VISIBLE_DEVICES"] = ",".join(str(d) for d in range(lo, lo + ws))
-            with _patched_env(env_patch):
-                p.start()
-            self.procs.append(p)
-        self._wait_ready(num_engines)
+        if spawn:
+            self.procs = launch_engine_cores(vllm_config, executor_class, log_stats, self.listener.address,
+                                             num_engines, start_index, local_start_index, coordinator_address)
+        self._wait_ready(num_engines + num_remote)
 
     def _wait_ready(self, n: int) -> None:
         deadline = time.monotonic() + HANDSHAKE_TIMEOUT_S
@@ -109,6 +103,31 @@ class CoreEngineProcManager:
         self.listener.close()
 
 
+def launch_engine_cores(vllm_config: VllmConfig, executor_class: type, log_stats: bool, address,
+                        num_engines: int, start_index: int = 0, local_start_index: int = 0,
+                        coordinator_address: Optional[str] = None) -> list:
+    """Start ``num_engines`` engine-core processes that connect to ``address`` (one front-end address
+    or a list of them).  Engine ``i`` gets global DP rank ``start_index + i``."""
+    ctx = get_mp_context()
+    procs = []
+    for i in range(num_engines):
+        idx = start_index + i
+        p = ctx.Process(target=EngineCoreProc.run_engine_core, name=f"EngineCore_{idx}",
+                        kwargs=dict(vllm_config=vllm_config, executor_class=executor_class, log_stats=log_stats,
+                                    address=address, engine_index=idx, dp_rank=idx,
+                                    local_dp_rank=local_start_index + i, coordinator_address=coordinator_address))
+        env_patch = {}
+        if vllm_config.parallel_config.data_parallel_size > 1 and vllm_config.device_config.device == "cuda":
+            # each DP replica owns a contiguous slice of the node's GPUs
+            ws = vllm_config.parallel_config.world_size
+            lo = (local_start_index + i) * ws
+            env_patch["HIP_VISIBLE_DEVICES"] = ",".join(str(d) for d in range(lo, lo + ws))
+        with _patched_env(env_patch):
+            p.start()
+        procs.append(p)
+    return procs
+
+
 @contextlib.contextmanager
 def _patched_env(patch: dict):
     old = {k: os.environ.get(k) for k in patch}
@@ -125,10 +144,19 @@ def _patched_env(patch: dict):
 
 class MPClient(EngineCoreClient):
     def __init__(self, vllm_config: VllmConfig, executor_class: type, log_stats: bool, num_engines: int = 1,
-                 coordinator_address: Optional[str] = None):
+                 coordinator_address: Optional[str] = None, attach: Optional[dict] = None, num_remote: int = 0,
+                 listen_address: Optional[str] = None):
+        """``attach = {"address": ..., "num_engines": n, "coordinator_address": ...}``: join engine cores
+        that another process launches (one API server of several) instead of spawning them."""
         self.vllm_config = vllm_config
-        self.manager = CoreEngineProcManager(vllm_config, executor_class, log_stats, num_engines,
-                                             coordinator_address=coordinator_address)
+        self.attach = attach
+        if attach is not None:
+            self.manager = CoreEngineProcManager(vllm_config, executor_class, log_stats, attach["num_engines"],
+                                                 listen_address=attach["address"], spawn=False)
+        else:
+            self.manager = CoreEngineProcManager(vllm_config, executor_class, log_stats, num_engines,
+                                                 coordinator_address=coordinator_address,
+                                                 listen_address=listen_address, num_remote=num_remote)
         self.conns = [self.manager.conns[i] for i in sorted(self.manager.conns)]
         self.engine_dead = False
         self._call_id = 0
@@ -250,8 +278,10 @@ class SyncMPClient(MPClient):
 
 class AsyncMPClient(MPClient):
     def __init__(self, vllm_config, executor_class, log_stats, num_engines: int = 1,
-                 coordinator_address: Optional[str] = None):
-        super().__init__(vllm_config, executor_class, log_stats, num_engines, coordinator_address)
+                 coordinator_address: Optional[str] = None, attach: Optional[dict] = None, num_remote: int = 0,
+                 listen_address: Optional[str] = None):
+        super().__init__(vllm_config, executor_class, log_stats, num_engines, coordinator_address, attach,
+                         num_remote, listen_address)
         self.aconns: list[Optional[AsyncConnection]] = [None] * len(self.conns)
         self.outputs: Optional[asyncio.Queue] = None
         self._utility: dict[int, asyncio.Future] = {}
@@ -376,12 +406,30 @@ class DPAsyncMPClient(AsyncMPClient):
     """One engine core per data-parallel rank behind one front end; requests carry the
     engine they were sent to so aborts go to the right place.  Placement: round robin."""
 
-    def __init__(self, vllm_config, executor_class, log_stats):
+    def __init__(self, vllm_config, executor_class, log_stats, attach: Optional[dict] = None):
         pc = vllm_config.parallel_config
-        from .dp import DPCoordinator
-        self.coordinator = DPCoordinator(pc.data_parallel_size)
-        super().__init__(vllm_config, executor_class, log_stats, pc.data_parallel_size_local or pc.data_parallel_size,
-                         coordinator_address=self.coordinator.engine_address)
+        from .dp import CoordinatorSubscription, DPCoordinator
+        self.coordinator = None
+        self.subscription = None
+        if attach is not None:
+            # one API server of several: the launcher owns the coordinator, we read the load it publishes
+            super().__init__(vllm_config, executor_class, log_stats, attach=attach)
+            if attach.get("coordinator_address"):
+                self.subscription = CoordinatorSubscription(attach["coordinator_address"])
+        else:
+            local = pc.data_parallel_size_local or pc.data_parallel_size
+            remote = pc.data_parallel_size - local
+            host, listen = "127.0.0.1", None
+            coord_port = 0
+            if remote > 0:
+                # engines on other nodes find us at the agreed address; the coordinator sits one port above
+                host = pc.data_parallel_master_ip
+                listen = f"tcp://{host}:{pc.data_parallel_rpc_port}"
+                coord_port = pc.data_parallel_rpc_port + 1
+            self.coordinator = DPCoordinator(pc.data_parallel_size, host=host, port=coord_port)
+            super().__init__(vllm_config, executor_class, log_stats, local,
+                             coordinator_address=self.coordinator.engine_address, num_remote=remote,
+                             listen_address=listen)
         self.req_to_engine: dict[str, int] = {}
         self._rr = 0
         self.current_wave = 0
@@ -443,7 +491,10 @@ class DPAsyncMPClient(AsyncMPClient):
 
     def shutdown(self) -> None:
         super().shutdown()
-        self.coordinator.close()
+        if self.coordinator is not None:
+            self.coordinator.close()
+        if self.subscription is not None:
+            self.subscription.close()
 
 
 class DPLBAsyncMPClient(DPAsyncMPClient):
@@ -453,6 +504,11 @@ class DPLBAsyncMPClient(DPAsyncMPClient):
     def _pick(self) -> int:
         best, best_score = 0, None
         n = len(self.conns)
+        sub = self.subscription
+        if sub is not None and len(sub.counts) == n:
+            # several front ends: the published load covers everybody's requests
+            self.counts = [list(c) for c in sub.counts]
+            sub.counts = []
         for k in range(n):
             i = (self._rr + 1 + k) % n
             w, r = self.counts[i]

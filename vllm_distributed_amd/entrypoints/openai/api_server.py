@@ -319,14 +319,15 @@ def build_app(args: argparse.Namespace, engine: AsyncLLM) -> FastAPI:
     return app
 
 
-async def run_server(args: argparse.Namespace, sock: Optional[socket.socket] = None) -> None:
+async def run_server(args: argparse.Namespace, sock: Optional[socket.socket] = None, client_index: int = 0,
+                     attach: Optional[dict] = None, on_ready=None) -> None:
     import uvicorn
     if args.model is None and getattr(args, "model_tag", None):
         args.model = args.model_tag
     if args.model is None:
         raise SystemExit("a model is required (positional tag or --model)")
     engine_args = AsyncEngineArgs.from_cli_args(args)
-    engine = AsyncLLM.from_engine_args(engine_args)
+    engine = AsyncLLM.from_engine_args(engine_args, client_index=client_index, attach=attach)
     app = build_app(args, engine)
     config = uvicorn.Config(app, host=args.host or "0.0.0.0", port=args.port, log_level=args.uvicorn_log_level,
                             timeout_keep_alive=envs.VLLM_HTTP_TIMEOUT_KEEP_ALIVE, ssl_keyfile=args.ssl_keyfile,
@@ -334,6 +335,12 @@ async def run_server(args: argparse.Namespace, sock: Optional[socket.socket] = N
     server = uvicorn.Server(config)
     loop = asyncio.get_running_loop()
     task = loop.create_task(server.serve(sockets=[sock] if sock else None))
+    if on_ready is not None:
+        async def _announce():
+            while not server.started and not task.done():
+                await asyncio.sleep(0.05)
+            on_ready()
+        loop.create_task(_announce())
 
     def stop(*_):
         server.should_exit = True

@@ -175,6 +175,7 @@ class EngineCoreRequestType(enum.Enum):
     START_DP_WAVE = b"\x02"
     UTILITY = b"\x03"
     EXECUTOR_FAILED = b"\x04"
+    CLIENT_GONE = b"\x05"     # internal: a front-end connection closed
 
 
 class Request:
