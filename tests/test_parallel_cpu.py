@@ -58,7 +58,9 @@ def _reference(model):
 
 @pytest.mark.parametrize("kind,kw", [("llama", {"tensor_parallel_size": 2}),
                                      ("opt", {"tensor_parallel_size": 2}),
-                                     ("llama", {"pipeline_parallel_size": 2})])
+                                     ("llama", {"pipeline_parallel_size": 2}),
+                                     ("llama", {"tensor_parallel_size": 2, "compilation_config":
+                                                {"enable_sequence_parallelism": True}})])
 def test_two_rank_matches_single(tmp_path, kind, kw):
     model, _ = _save_tiny(str(tmp_path), kind)
     ref = _reference(model)

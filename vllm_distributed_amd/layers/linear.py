@@ -18,7 +18,8 @@ import torch.nn as nn
 
 from .. import ops
 from ..parallel.state import (get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
-                              tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce)
+                              tensor_model_parallel_all_gather, tensor_model_parallel_all_reduce,
+                              tensor_model_parallel_reduce_scatter)
 from ..parallel.utils import ensure_divisible
 
 
@@ -209,6 +210,20 @@ class QKVParallelLinear(ColumnParallelLinear):
         dst.copy_(src)
 
 
+_SEQUENCE_PARALLEL = False
+
+
+def set_sequence_parallel(active: bool) -> bool:
+    """While active, row-parallel layers end in a reduce-scatter over the token dimension instead of
+    an all-reduce: each rank keeps T/tp rows, the norm that follows runs on those rows only, and the
+    caller all-gathers before the next column-parallel GEMM.  Same bytes on the wire as an all-reduce,
+    1/tp of the norm / residual work.  Returns the previous state.
+    Reference: vllm/compilation/sequence_parallelism.py:87-482 (there an FX graph rewrite)."""
+    global _SEQUENCE_PARALLEL
+    old, _SEQUENCE_PARALLEL = _SEQUENCE_PARALLEL, bool(active)
+    return old
+
+
 class RowParallelLinear(LinearBase):
     def __init__(self, input_size, output_size, bias=True, input_is_parallel=True, params_dtype=None,
                  reduce_results=True, quant_config=None, prefix=""):
@@ -242,5 +257,7 @@ class RowParallelLinear(LinearBase):
         b = self.bias if (self.tp_rank == 0 or self.tp_size == 1) else None
         y = self.quant_method.apply(self, x, b)
         if self.reduce_results and self.tp_size > 1:
+            if _SEQUENCE_PARALLEL:
+                return tensor_model_parallel_reduce_scatter(y, 0)
             y = tensor_model_parallel_all_reduce(y)
         return y

@@ -19,10 +19,12 @@ import torch.nn as nn
 from ..config import VllmConfig
 from ..layers.attention import Attention
 from ..layers.basic import LogitsProcessor, ParallelLMHead, RMSNorm, SiluAndMul, VocabParallelEmbedding
-from ..layers.linear import MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear
+from ..layers.linear import (MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear,
+                             set_sequence_parallel)
 from ..layers.rotary import get_rope
 from ..layers.token_parallel import tknp_metadata, token_parallel_attention
-from ..parallel.state import get_pp_group, get_tensor_model_parallel_world_size
+from ..parallel.state import (get_pp_group, get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
+                              tensor_model_parallel_all_gather)
 from .utils import (IntermediateTensors, PPMissingLayer, load_weights_with_mapping, make_layers, maybe_prefix)
 
 
@@ -131,14 +133,20 @@ class LlamaDecoderLayer(nn.Module):
         return LlamaMLP(config.hidden_size, config.intermediate_size, bool(getattr(config, "mlp_bias", False)),
                         quant_config, prefix)
 
-    def forward(self, positions, hidden_states, residual):
+    def forward(self, positions, hidden_states, residual, sp: bool = False):
+        """With ``sp`` the layer's input, output and residual are this rank's T/tp rows: the norms
+        run on the shard, the GEMMs on all rows (all-gather in front, reduce-scatter behind)."""
         if residual is None:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        if sp:
+            hidden_states = tensor_model_parallel_all_gather(hidden_states, 0)
         hidden_states = self.self_attn(positions, hidden_states)
         hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        if sp:
+            hidden_states = tensor_model_parallel_all_gather(hidden_states, 0)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
@@ -162,6 +170,11 @@ class LlamaModel(nn.Module):
             lambda p: self.layer_cls(config, vllm_config, quant_config, p), f"{prefix}.layers")
         self.norm = RMSNorm(config.hidden_size, getattr(config, "rms_norm_eps", 1e-6)) if pp.is_last_rank \
             else PPMissingLayer()
+        self.tp = get_tensor_model_parallel_world_size()
+        # sequence parallelism: dense Llama-style layers only (the MoE blocks reduce on their own)
+        self.sequence_parallel = bool(vllm_config.compilation_config.enable_sequence_parallelism and self.tp > 1
+                                      and self.layer_cls is LlamaDecoderLayer
+                                      and not vllm_config.parallel_config.enable_token_parallel)
 
     def get_input_embeddings(self, input_ids):
         return self.embed_tokens(input_ids)
@@ -174,8 +187,27 @@ class LlamaModel(nn.Module):
             residual = None
         else:
             hidden, residual = intermediate_tensors["hidden_states"], intermediate_tensors["residual"]
-        for layer in self.layers[self.start_layer:self.end_layer]:
-            hidden, residual = layer(positions, hidden, residual)
+        sp = self.sequence_parallel and hidden.shape[0] % self.tp == 0 and hidden.shape[0] > 0
+        if not sp:
+            for layer in self.layers[self.start_layer:self.end_layer]:
+                hidden, residual = layer(positions, hidden, residual)
+        else:
+            # every stage starts and ends with full rows; in between each rank holds T/tp of them
+            r = get_tensor_model_parallel_rank()
+            hidden = hidden.chunk(self.tp)[r]
+            if residual is not None:
+                residual = residual.chunk(self.tp)[r]
+            old = set_sequence_parallel(True)
+            try:
+                for layer in self.layers[self.start_layer:self.end_layer]:
+                    hidden, residual = layer(positions, hidden, residual, sp=True)
+            finally:
+                set_sequence_parallel(old)
+            if pp.is_last_rank:
+                hidden, _ = self.norm(hidden, residual)
+                return tensor_model_parallel_all_gather(hidden, 0)
+            hidden = tensor_model_parallel_all_gather(hidden, 0)
+            residual = tensor_model_parallel_all_gather(residual, 0)
         if not pp.is_last_rank:
             return IntermediateTensors({"hidden_states": hidden, "residual": residual})
         hidden, _ = self.norm(hidden, residual)

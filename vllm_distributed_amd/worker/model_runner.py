@@ -75,6 +75,9 @@ class ModelRunner:
         self.attn_layers: dict[str, Attention] = {}
         self.input_batch: Optional[InputBatch] = None
         self.graphs: dict[int, tuple] = {}
+        pcfg = vllm_config.parallel_config
+        self.sp_multiple = pcfg.tensor_parallel_size if vllm_config.compilation_config.enable_sequence_parallelism \
+            else 1
         self.graph_pool = None
         self._step = 0
         self._rng = np.random.default_rng(mc.seed)
@@ -483,10 +486,20 @@ class ModelRunner:
             inter = None
             if not pp.is_first_rank:
                 inter = intermediate_tensors
+            T_in, P_in = T, T_a
+            tp = self.sp_multiple
+            if tp > 1 and tmd is None and inputs_embeds is None and T % tp and T + tp <= self.input_ids.shape[0]:
+                # sequence parallelism splits the rows over the TP ranks: pad to a multiple of tp with
+                # rows that attention ignores (they lie beyond num_actual_tokens)
+                T_in = P_in = (T + tp - 1) // tp * tp
+                self.input_ids[T:T_in].zero_()
+                self.positions[T:T_in].zero_()
             with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T):
                 if conn is not None:
                     conn.start_load_kv()
-                hidden = self.model(self.input_ids[:T], self.positions[:T_a], inter, inputs_embeds)
+                hidden = self.model(self.input_ids[:T_in], self.positions[:P_in], inter, inputs_embeds)
+            if T_in > T and torch.is_tensor(hidden):
+                hidden = hidden[:T]
         if conn is not None:
             conn.wait_for_save()
             conn.clear_connector_metadata()
