@@ -13,8 +13,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_custom_allreduce_shared_gpu(world):
+def _run_ranks(world, script):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -22,7 +21,7 @@ def test_custom_allreduce_shared_gpu(world):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", VDA_COMM_SPIN_TIMEOUT_MS="5000")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "scripts", "car_worker.py")], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "scripts", script)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -36,3 +35,14 @@ def test_custom_allreduce_shared_gpu(world):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
     print(outs[0])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_custom_allreduce_shared_gpu(world):
+    _run_ranks(world, "car_worker.py")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_quantised_allreduce_shared_gpu(world):
+    """int8 / int4 two-shot all-reduce: error within the two-rounding-step bound, graph replay."""
+    _run_ranks(world, "qr_worker.py")

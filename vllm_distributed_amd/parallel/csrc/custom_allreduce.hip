@@ -262,3 +262,236 @@ VDA_EXPORT int vda_car_allreduce(void* ctx, const void* in, void* out, size_t nb
 #undef L
   return (int)hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------
+// Quantised two-shot all-reduce ("quick reduce"): the bytes that cross xGMI are int8 or int4
+// with one fp32 scale per 32 values, so a bandwidth-bound all-reduce moves 1.8x / 3.2x less.
+// Both shots carry quantised data: inputs are quantised into the staging half, the reducer
+// dequantises all peers' slices, sums in fp32 and re-quantises its result, the gather phase
+// dequantises into the output.  The error is two rounding steps of absmax/127 (or /7) per group.
+//
+// Unit = 32 values (64 input bytes); unit u belongs to thread (u mod GRID_THREADS) for every call,
+// the reducer of unit (sweep j, block b) is rank (j + b) mod world, and a result lives at the
+// unit's own index in the reducer's result area.  A block therefore only ever touches units of
+// its own block index, on every rank and in every phase, which is the ownership rule that makes
+// the parity-selected staging halves safe (see car_kernel).  The arena of this path is separate
+// from the unquantised one, because the two kernels own elements differently.
+// Role of the reference's csrc/quickreduce (quick_reduce_impl.cuh:543-696, codecs :60-540).
+// ---------------------------------------------------------------------------
+template <int BITS> struct QCodec;
+template <> struct QCodec<8> {
+  static constexpr int DATA_BYTES = 32;
+  static constexpr float QMAX = 127.f;
+  struct Packed { u32x4 d[2]; };
+  __device__ static __forceinline__ Packed encode(const float* v, float inv) {
+    Packed p;
+    uint32_t* w = reinterpret_cast<uint32_t*>(p.d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int q = __float2int_rn(v[i * 4 + k] * inv);
+        q = q < -127 ? -127 : (q > 127 ? 127 : q);
+        x |= (uint32_t)(q & 0xFF) << (8 * k);
+      }
+      w[i] = x;
+    }
+    return p;
+  }
+  __device__ static __forceinline__ void accumulate(float* acc, const Packed& p, float scale) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p.d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[i * 4 + k] += (float)(int8_t)(w[i] >> (8 * k)) * scale;
+  }
+  __device__ static __forceinline__ Packed load(const char* base, size_t unit) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(base + unit * DATA_BYTES);
+    Packed r; r.d[0] = p[0]; r.d[1] = p[1]; return r;
+  }
+  __device__ static __forceinline__ void store(char* base, size_t unit, const Packed& v) {
+    u32x4* p = reinterpret_cast<u32x4*>(base + unit * DATA_BYTES);
+    p[0] = v.d[0]; p[1] = v.d[1];
+  }
+};
+template <> struct QCodec<4> {
+  static constexpr int DATA_BYTES = 16;
+  static constexpr float QMAX = 7.f;
+  struct Packed { u32x4 d; };
+  __device__ static __forceinline__ Packed encode(const float* v, float inv) {
+    Packed p;
+    uint32_t* w = reinterpret_cast<uint32_t*>(&p.d);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int q = __float2int_rn(v[i * 8 + k] * inv);
+        q = q < -7 ? -7 : (q > 7 ? 7 : q);
+        x |= (uint32_t)(q & 0xF) << (4 * k);
+      }
+      w[i] = x;
+    }
+    return p;
+  }
+  __device__ static __forceinline__ void accumulate(float* acc, const Packed& p, float scale) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&p.d);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int q = ((int)(w[i] << (28 - 4 * k))) >> 28;     // sign-extend the nibble
+        acc[i * 8 + k] += (float)q * scale;
+      }
+  }
+  __device__ static __forceinline__ Packed load(const char* base, size_t unit) {
+    Packed r; r.d = reinterpret_cast<const u32x4*>(base + unit * DATA_BYTES)[0]; return r;
+  }
+  __device__ static __forceinline__ void store(char* base, size_t unit, const Packed& v) {
+    reinterpret_cast<u32x4*>(base + unit * DATA_BYTES)[0] = v.d;
+  }
+};
+
+// One staging half of the quantised path: [in data][in scales][result data][result scales], each
+// sized for `cap` units (CarArgs::in_bytes carries cap).
+template <int BITS> struct QLayout {
+  using C = QCodec<BITS>;
+  __host__ __device__ static size_t half_bytes(size_t cap) { return 2 * cap * (C::DATA_BYTES + 4); }
+  __device__ static char* in_data(char* half, size_t) { return half; }
+  __device__ static float* in_scale(char* half, size_t cap) { return reinterpret_cast<float*>(half + cap * C::DATA_BYTES); }
+  __device__ static char* res_data(char* half, size_t cap) { return half + cap * (C::DATA_BYTES + 4); }
+  __device__ static float* res_scale(char* half, size_t cap) {
+    return reinterpret_cast<float*>(half + cap * (C::DATA_BYTES + 4) + cap * C::DATA_BYTES);
+  }
+};
+
+template <typename T> __device__ __forceinline__ void unit_to_float(const u32x4* src, float* v) {
+  // 32 values of a 2-byte type = 4 x 16 bytes
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32x4 raw = src[q];
+    const T* p = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[q * 8 + i] = (float)p[i];
+  }
+}
+
+template <int BITS> __device__ __forceinline__ float group_scale(const float* v, float& inv) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) m = fmaxf(m, fabsf(v[i]));
+  const float scale = m > 0.f ? m / QCodec<BITS>::QMAX : 1.f;
+  inv = 1.f / scale;
+  return scale;
+}
+
+template <typename T, int BITS>
+__global__ __launch_bounds__(512) void qr_kernel(CarArgs a, const u32x4* __restrict__ in, u32x4* __restrict__ out,
+                                                 size_t nunits) {
+  using C = QCodec<BITS>;
+  using L = QLayout<BITS>;
+  Signal* me = a.sig[a.rank];
+  __shared__ uint32_t s_cnt, s_call;
+  if (threadIdx.x == 0) { s_cnt = me->counter[blockIdx.x]; s_call = me->calls[blockIdx.x]; }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;
+  const size_t cap = a.in_bytes;                    // capacity in units
+  const size_t half_off = (size_t)(s_call & 1) * a.half_bytes;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  char* my_half = a.data[a.rank] + half_off;
+
+  // 0) quantise my input into my staging half
+  for (size_t u = tid; u < nunits; u += stride) {
+    float v[32];
+    unit_to_float<T>(in + u * 4, v);
+    float inv;
+    const float sc = group_scale<BITS>(v, inv);
+    C::store(L::in_data(my_half, cap), u, C::encode(v, inv));
+    L::in_scale(my_half, cap)[u] = sc;
+  }
+  bool ok = cross_barrier(a, cnt + 1);
+
+  // 1) reduce the units this rank is responsible for, keep the result quantised
+  if (ok) {
+    size_t j = 0;
+    for (size_t u = tid; u < nunits; u += stride, ++j) {
+      if ((int)((j + blockIdx.x) % a.world) != a.rank) continue;
+      float acc[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int r = 0; r < MAX_RANKS; ++r) {
+        if (r < a.world) {
+          char* half = a.data[(a.rank + r) % a.world] + half_off;
+          const typename C::Packed p = C::load(L::in_data(half, cap), u);
+          const float sc = L::in_scale(half, cap)[u];
+          C::accumulate(acc, p, sc);
+        }
+      }
+      float inv;
+      const float sc = group_scale<BITS>(acc, inv);
+      C::store(L::res_data(my_half, cap), u, C::encode(acc, inv));
+      L::res_scale(my_half, cap)[u] = sc;
+    }
+  }
+  ok = cross_barrier(a, cnt + 2) && ok;
+
+  // 2) gather every unit from its reducer
+  if (ok) {
+    size_t j = 0;
+    for (size_t u = tid; u < nunits; u += stride, ++j) {
+      const int src = (int)((j + blockIdx.x) % a.world);
+      char* half = a.data[src] + half_off;
+      const typename C::Packed p = C::load(L::res_data(half, cap), u);
+      const float sc = L::res_scale(half, cap)[u];
+      float v[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v[i] = 0.f;
+      C::accumulate(v, p, sc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[u * 4 + q] = acc_pack<T>(v + q * 8);
+    }
+  }
+  if (threadIdx.x == 0) { me->counter[blockIdx.x] = cnt + 2; me->calls[blockIdx.x] = s_call + 1; }
+}
+
+// Bytes of one staging half for `max_bytes` of 2-byte input at the given codec width.
+VDA_EXPORT size_t vda_qr_half_bytes(size_t max_bytes, int bits) {
+  const size_t cap = (max_bytes + 63) / 64;
+  return bits == 8 ? QLayout<8>::half_bytes(cap) : QLayout<4>::half_bytes(cap);
+}
+
+// The context is a CarCtx whose in_bytes field holds the capacity in units; arenas and signal
+// blocks come from vda_car_alloc (a separate pair from the unquantised path).
+VDA_EXPORT void* vda_qr_create(int rank, int world, void** peer_data, void** peer_sig, size_t max_bytes, int bits,
+                               unsigned long long spin_limit) {
+  if (world < 2 || world > MAX_RANKS || (bits != 8 && bits != 4)) return nullptr;
+  CarCtx* c = new CarCtx();
+  c->rank = rank; c->world = world;
+  c->in_bytes = (max_bytes + 63) / 64;
+  c->half_bytes = vda_qr_half_bytes(max_bytes, bits);
+  for (int i = 0; i < world; ++i) { c->data[i] = (char*)peer_data[i]; c->sig[i] = (Signal*)peer_sig[i]; }
+  c->spin_limit = spin_limit;
+  return c;
+}
+
+// dtype: 0 bf16, 1 f16.  nbytes: multiple of 64, at most the capacity given at creation.
+VDA_EXPORT int vda_qr_allreduce(void* ctx, const void* in, void* out, size_t nbytes, int dtype, int bits,
+                                hipStream_t st) {
+  CarCtx* c = (CarCtx*)ctx;
+  if (nbytes % 64 || nbytes == 0 || nbytes / 64 > c->in_bytes || dtype < 0 || dtype > 1) return -1;
+  const size_t nunits = nbytes / 64;
+  CarArgs a;
+  for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
+  a.rank = c->rank; a.world = c->world; a.half_bytes = c->half_bytes; a.in_bytes = c->in_bytes;
+  a.spin_limit = c->spin_limit;
+#define L(T, B) hipLaunchKernelGGL((qr_kernel<T, B>), dim3(MAX_BLOCKS), dim3(512), 0, st, a, (const u32x4*)in, \
+                                   (u32x4*)out, nunits)
+  if (bits == 8) { if (dtype == 0) L(bf16_t, 8); else L(f16_t, 8); }
+  else           { if (dtype == 0) L(bf16_t, 4); else L(f16_t, 4); }
+#undef L
+  return (int)hipGetLastError();
+}

@@ -55,6 +55,7 @@ class GroupCoordinator:
         self.device = torch.device(f"cuda:{local_rank}") if backend == "nccl" else \
             (torch.device("cuda:0") if self.staged else torch.device("cpu"))
         self.ca_comm = None       # peer-memory all-reduce
+        self.qr_comm = None       # quantised peer-memory all-reduce (opt-in)
         self.rccl_comm = None     # stream-explicit RCCL (graph capturable)
         self.mq_broadcaster = None
         self.all2all = None
@@ -86,6 +87,13 @@ class GroupCoordinator:
             except Exception as e:
                 logger.warning("peer-memory all-reduce disabled for group %s: %s", self.name, e)
                 self.ca_comm = None
+            if envs.VLLM_ROCM_QUICK_REDUCE_QUANTIZATION not in ("NONE", "FP"):
+                try:
+                    from .custom_allreduce import QuickAllReduce
+                    self.qr_comm = QuickAllReduce.maybe_create(self.cpu_group, self.device)
+                except Exception as e:
+                    logger.warning("quantised all-reduce disabled for group %s: %s", self.name, e)
+                    self.qr_comm = None
 
     # ---- properties --------------------------------------------------------
     @property
@@ -125,6 +133,10 @@ class GroupCoordinator:
         if self.world_size == 1:
             return x
         if x.is_cuda:
+            if self.qr_comm is not None:          # opt-in, lossy, large messages only
+                out = self.qr_comm.all_reduce(x)
+                if out is not None:
+                    return out
             if self.ca_comm is not None:
                 out = self.ca_comm.all_reduce(x)
                 if out is not None:
@@ -353,6 +365,9 @@ class GroupCoordinator:
             yield ctx
 
     def destroy(self) -> None:
+        if self.qr_comm is not None:
+            self.qr_comm.close()
+            self.qr_comm = None
         if self.ca_comm is not None:
             self.ca_comm.close()
             self.ca_comm = None
