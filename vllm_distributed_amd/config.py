@@ -142,6 +142,9 @@ class ModelConfig:
     tokenizer: Optional[str] = None
     #: Skip tokenizer construction; prompts must then be given as token ids.
     skip_tokenizer_init: bool = False
+    #: Allocate weights and KV cache from the address-stable sleep allocator, so that sleep / wake-up
+    #: releases and restores device memory without invalidating captured graphs.
+    enable_sleep_mode: bool = False
     #: "auto" | "slow": prefer the Rust tokenizer or force the Python one.
     tokenizer_mode: str = "auto"
     #: Allow custom code from the checkpoint directory (never executed here; kept for CLI parity).

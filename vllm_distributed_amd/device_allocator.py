@@ -10,6 +10,7 @@ Reference: vllm/device_allocator/cumem.py (CuMemAllocator sleep/wake_up), csrc/c
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import gc
 from typing import Optional
@@ -88,7 +89,103 @@ def open_shared(handle: bytes, nbytes: int, device: torch.device) -> SharedRegio
     return SharedRegion(ptr.value, nbytes, device, handle, owner=False)
 
 
-# ---- sleep mode ---------------------------------------------------------------------------------
+# ---- sleep mode, address-stable (virtual memory management) ---------------------------------------
+def _immortal(obj) -> None:
+    ctypes.pythonapi.Py_IncRef(ctypes.py_object(obj))
+
+
+class SleepAllocator:
+    """Tagged memory pools on the native VMM allocator (parallel/csrc/device_memory.hip).
+
+        alloc = SleepAllocator.get()
+        with alloc.use_memory_pool("weights"):   model = load(...)
+        with alloc.use_memory_pool("kv_cache"):  kv = torch.zeros(...)
+        alloc.sleep(offload_tags=("weights",))   # weights -> pinned host, KV pages discarded
+        alloc.wake_up()                          # same addresses again
+
+    Every allocation made inside ``use_memory_pool`` goes through PyTorch's pluggable-allocator
+    hook into ``vda_vmm_malloc``; the native side keeps the block table, so sleeping and waking are
+    one call each and tensors, views, graph-captured pointers all stay valid.
+    Reference: vllm/device_allocator/cumem.py:113-281."""
+    TAGS = {"weights": 1, "kv_cache": 2}
+    _instance: Optional["SleepAllocator"] = None
+
+    @classmethod
+    def get(cls) -> "SleepAllocator":
+        if cls._instance is None:
+            cls._instance = cls()
+        return cls._instance
+
+    def __init__(self):
+        from . import envs
+        import os
+        lib = _lib()
+        ll = ctypes.c_longlong
+        lib.vda_vmm_set_tag.argtypes = [ctypes.c_int]
+        lib.vda_vmm_sleep.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.vda_vmm_sleep.restype = ll
+        lib.vda_vmm_wake.argtypes = [ctypes.c_int]
+        lib.vda_vmm_wake.restype = ll
+        lib.vda_vmm_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.vda_vmm_bytes.restype = ll
+        self.lib = lib
+        path = envs.VDA_COMM_LIBRARY or os.path.join(os.path.dirname(os.path.abspath(__file__)), "parallel",
+                                                     "libvda_comm.so")
+        self._pluggable = torch.cuda.memory.CUDAPluggableAllocator(path, "vda_vmm_malloc", "vda_vmm_free")
+        # A MemPool keeps only a raw pointer to its allocator, and interpreter shutdown destroys objects
+        # in no useful order: the allocator and the pools are made immortal, the driver reclaims the
+        # memory when the process ends.
+        _immortal(self._pluggable)
+        self._pools: dict[str, "torch.cuda.MemPool"] = {}
+        self.asleep: set[str] = set()
+
+    @contextlib.contextmanager
+    def use_memory_pool(self, tag: str):
+        if tag not in self.TAGS:
+            raise ValueError(f"unknown memory tag {tag!r}")
+        pool = self._pools.get(tag)
+        if pool is None:
+            pool = self._pools[tag] = torch.cuda.MemPool(self._pluggable.allocator())
+            _immortal(pool)
+        self.lib.vda_vmm_set_tag(self.TAGS[tag])
+        try:
+            with torch.cuda.use_mem_pool(pool):
+                yield
+        finally:
+            self.lib.vda_vmm_set_tag(0)
+
+    def bytes(self, tag: str, which: int = 0) -> int:
+        return int(self.lib.vda_vmm_bytes(self.TAGS[tag], which))
+
+    def sleep(self, offload_tags: tuple = ("weights",)) -> int:
+        """Release the physical memory of every pool; pools named in ``offload_tags`` keep their
+        contents in pinned host memory.  Returns bytes released."""
+        torch.cuda.synchronize()
+        total = 0
+        for tag, tid in self.TAGS.items():
+            if tag in self.asleep:
+                continue
+            n = int(self.lib.vda_vmm_sleep(tid, int(tag in offload_tags)))
+            if n < 0:
+                raise RuntimeError(f"releasing the {tag} pool failed with HIP error {self.lib.vda_vmm_last_error()}")
+            total += n
+            self.asleep.add(tag)
+        return total
+
+    def wake_up(self, tags: Optional[list] = None) -> int:
+        total = 0
+        for tag in (tags or list(self.TAGS)):
+            if tag not in self.asleep:
+                continue
+            n = int(self.lib.vda_vmm_wake(self.TAGS[tag]))
+            if n < 0:
+                raise RuntimeError(f"mapping the {tag} pool failed with HIP error {self.lib.vda_vmm_last_error()}")
+            total += n
+            self.asleep.discard(tag)
+        return total
+
+
+# ---- sleep mode without VMM (free and re-create) ------------------------------------------------
 def offload_module(module: nn.Module, keep_copy: bool = True) -> dict[str, Optional[torch.Tensor]]:
     """Release the device memory of every parameter and buffer; with ``keep_copy`` their values are
     kept in pinned host memory.  Tied tensors are stored once."""

@@ -46,6 +46,7 @@ class EngineArgs:
     served_model_name: Optional[Union[str, list[str]]] = None
     tokenizer: Optional[str] = None
     skip_tokenizer_init: bool = False
+    enable_sleep_mode: bool = False
     tokenizer_mode: str = "auto"
     trust_remote_code: bool = False
     dtype: str = "auto"
@@ -187,7 +188,7 @@ class EngineArgs:
     # ---- config --------------------------------------------------------------------
     def create_model_config(self) -> C.ModelConfig:
         return C.ModelConfig(
-            model=self.model, tokenizer=self.tokenizer, skip_tokenizer_init=self.skip_tokenizer_init,
+            model=self.model, tokenizer=self.tokenizer, skip_tokenizer_init=self.skip_tokenizer_init, enable_sleep_mode=self.enable_sleep_mode,
             tokenizer_mode=self.tokenizer_mode, trust_remote_code=self.trust_remote_code, dtype=self.dtype,
             seed=self.seed, max_model_len=self.max_model_len, quantization=self.quantization,
             enforce_eager=self.enforce_eager, max_seq_len_to_capture=self.max_seq_len_to_capture,

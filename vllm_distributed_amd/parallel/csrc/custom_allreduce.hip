@@ -459,8 +459,13 @@ __global__ __launch_bounds__(512) void qr_kernel(CarArgs a, const u32x4* __restr
 }
 
 // Bytes of one staging half for `max_bytes` of 2-byte input at the given codec width.
+static size_t qr_capacity(size_t max_bytes) {
+  // units, rounded up to a multiple of 4 so that every plane of the layout starts 16-byte aligned
+  return ((max_bytes + 63) / 64 + 3) / 4 * 4;
+}
+
 VDA_EXPORT size_t vda_qr_half_bytes(size_t max_bytes, int bits) {
-  const size_t cap = (max_bytes + 63) / 64;
+  const size_t cap = qr_capacity(max_bytes);
   return bits == 8 ? QLayout<8>::half_bytes(cap) : QLayout<4>::half_bytes(cap);
 }
 
@@ -471,7 +476,7 @@ VDA_EXPORT void* vda_qr_create(int rank, int world, void** peer_data, void** pee
   if (world < 2 || world > MAX_RANKS || (bits != 8 && bits != 4)) return nullptr;
   CarCtx* c = new CarCtx();
   c->rank = rank; c->world = world;
-  c->in_bytes = (max_bytes + 63) / 64;
+  c->in_bytes = qr_capacity(max_bytes);
   c->half_bytes = vda_qr_half_bytes(max_bytes, bits);
   for (int i = 0; i < world; ++i) { c->data[i] = (char*)peer_data[i]; c->sig[i] = (Signal*)peer_sig[i]; }
   c->spin_limit = spin_limit;

@@ -75,6 +75,7 @@ class ModelRunner:
         self.attn_layers: dict[str, Attention] = {}
         self.input_batch: Optional[InputBatch] = None
         self.graphs: dict[int, tuple] = {}
+        self.sleep_allocator = None
         pcfg = vllm_config.parallel_config
         self.sp_multiple = pcfg.tensor_parallel_size if vllm_config.compilation_config.enable_sequence_parallelism \
             else 1
@@ -113,12 +114,22 @@ class ModelRunner:
         dst[: t.shape[0]].copy_(t, non_blocking=True)
 
     # ------------------------------------------------------------------
+    def _sleep_pool(self, tag: str):
+        """Allocation context of the address-stable sleep allocator, or a no-op when sleep mode is off."""
+        import contextlib
+        if not (self.is_gpu and self.vllm_config.model_config.enable_sleep_mode):
+            return contextlib.nullcontext()
+        from ..device_allocator import SleepAllocator
+        self.sleep_allocator = SleepAllocator.get()
+        return self.sleep_allocator.use_memory_pool(tag)
+
     def load_model(self) -> None:
         t0 = time.time()
         if self.is_gpu:
             torch.cuda.synchronize()
             before = torch.cuda.memory_allocated(self.device)
-        self.model = get_model(self.vllm_config, self.device)
+        with self._sleep_pool("weights"):
+            self.model = get_model(self.vllm_config, self.device)
         if self.is_gpu:
             self.model_memory = torch.cuda.memory_allocated(self.device) - before
             logger.info("weights take %.2f GiB, loaded in %.1f s", self.model_memory / 2**30, time.time() - t0)
@@ -214,7 +225,8 @@ class ModelRunner:
                 self.kv_regions.append(r)
                 self.kv_chunks.append(r.tensor)
             else:
-                self.kv_chunks.append(torch.zeros(nbytes, dtype=torch.uint8, device=self.device))
+                with self._sleep_pool("kv_cache"):
+                    self.kv_chunks.append(torch.zeros(nbytes, dtype=torch.uint8, device=self.device))
         self.kv_arena = self.kv_chunks[0] if len(self.kv_chunks) == 1 else None
         spec_of = {}
         for g in cfg.kv_cache_groups:

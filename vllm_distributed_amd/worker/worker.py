@@ -217,6 +217,12 @@ class Worker:
             return
         mr = self.model_runner
         free0 = torch.cuda.mem_get_info(self.device)[0]
+        if mr.sleep_allocator is not None and not getattr(mr, "kv_regions", None):
+            # address-stable path: pages go away, tensors / views / captured graphs stay valid
+            n = mr.sleep_allocator.sleep(offload_tags=("weights",) if level == 1 else ())
+            self._sleeping = level
+            logger.info("sleep level %d released %.2f GiB (addresses kept)", level, n / 2**30)
+            return
         from ..device_allocator import offload_module
         self._sleep_saved = offload_module(mr.model, keep_copy=(level == 1))
         # KV cache: drop every view and chunk (exported IPC regions are closed too)
@@ -237,6 +243,11 @@ class Worker:
         if not self._sleeping:
             return
         mr = self.model_runner
+        if mr.sleep_allocator is not None and mr.sleep_allocator.asleep:
+            mr.sleep_allocator.wake_up(tags)
+            if not mr.sleep_allocator.asleep:
+                self._sleeping = 0
+            return
         from ..device_allocator import restore_module
         if tags is None or "weights" in tags:
             restore_module(mr.model, self._sleep_saved, self.device)
