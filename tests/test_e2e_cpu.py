@@ -47,13 +47,37 @@ def _save_tiny(tmp, kind):
                                 num_experts=4, num_experts_per_tok=2, moe_intermediate_size=128, head_dim=64,
                                 decoder_sparse_step=1, norm_topk_prob=True, use_sliding_window=False)
         m = tf.Qwen3MoeForCausalLM(cfg)
+    elif kind in ("deepseek_v2", "deepseek_v2_yarn"):
+        rope = {"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 64, "mscale": 1.0,
+                "mscale_all_dim": 1.0, "beta_fast": 32, "beta_slow": 1, "rope_theta": 10000.0} \
+            if kind.endswith("yarn") else None
+        cfg = tf.DeepseekV2Config(vocab_size=320, hidden_size=128, intermediate_size=256, moe_intermediate_size=64,
+                                  num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                                  n_shared_experts=1, n_routed_experts=4, num_experts_per_tok=2,
+                                  first_k_dense_replace=1, kv_lora_rank=32, q_lora_rank=48, qk_rope_head_dim=16,
+                                  qk_nope_head_dim=32, v_head_dim=32, max_position_embeddings=256,
+                                  topk_method="group_limited_greedy", n_group=2, topk_group=1,
+                                  routed_scaling_factor=2.0, norm_topk_prob=False, rope_parameters=rope)
+        m = tf.DeepseekV2ForCausalLM(cfg)
+    elif kind == "deepseek_v3":
+        cfg = tf.DeepseekV3Config(vocab_size=320, hidden_size=128, intermediate_size=256, moe_intermediate_size=64,
+                                  num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                                  n_shared_experts=1, n_routed_experts=8, num_experts_per_tok=2,
+                                  first_k_dense_replace=1, kv_lora_rank=32, q_lora_rank=None, qk_rope_head_dim=16,
+                                  qk_nope_head_dim=32, v_head_dim=32, max_position_embeddings=256, n_group=2,
+                                  topk_group=1, routed_scaling_factor=2.5, norm_topk_prob=True)
+        m = tf.DeepseekV3ForCausalLM(cfg)
+        with torch.no_grad():
+            for layer in m.model.layers[1:]:
+                layer.mlp.gate.e_score_correction_bias.copy_(torch.randn(8) * 0.1)
     m = m.float().eval()
     path = os.path.join(tmp, kind)
     m.save_pretrained(path, safe_serialization=True)
     return path, m
 
 
-@pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2", "mixtral", "qwen2_moe", "qwen3_moe"])
+@pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2", "mixtral", "qwen2_moe", "qwen3_moe",
+                                  "deepseek_v2", "deepseek_v2_yarn", "deepseek_v3"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

@@ -182,6 +182,11 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is
     elif kind == "yarn":
         orig = rs.get("original_max_position_embeddings", max_position)
         extra = {k: rs[k] for k in ("extrapolation_factor", "attn_factor", "beta_fast", "beta_slow") if k in rs}
+        if rs.get("mscale") and rs.get("mscale_all_dim"):
+            # DeepSeek flavour: the cos/sin magnitude is the ratio of two mscale terms, the rest of
+            # the correction goes into the softmax scale (applied by the attention layer)
+            extra["mscale"] = yarn_mscale(rs["factor"], float(rs["mscale"])) / \
+                yarn_mscale(rs["factor"], float(rs["mscale_all_dim"]))
         rope = YaRNScalingRotaryEmbedding(head_size, rotary_dim, orig, base, is_neox_style, rs["factor"], **extra)
     elif kind in ("longrope", "su"):
         rope = LongRoPEScaledRotaryEmbedding(head_size, rotary_dim, max_position,

@@ -14,6 +14,9 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     "Qwen2MoeForCausalLM": ("mixtral", "Qwen2MoeForCausalLM"),
     "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
+    "DeepseekV2ForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
+    "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
+    "DeepseekForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
     "GPT2LMHeadModel": ("opt", "GPT2LMHeadModel"),
