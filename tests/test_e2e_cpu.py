@@ -70,6 +70,42 @@ def _save_tiny(tmp, kind):
         with torch.no_grad():
             for layer in m.model.layers[1:]:
                 layer.mlp.gate.e_score_correction_bias.copy_(torch.randn(8) * 0.1)
+    elif kind == "gemma":
+        cfg = tf.GemmaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                             num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=256)
+        m = tf.GemmaForCausalLM(cfg)
+    elif kind == "gemma2":
+        cfg = tf.Gemma2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                              num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=256,
+                              query_pre_attn_scalar=32, sliding_window=16, attn_logit_softcapping=20.0,
+                              final_logit_softcapping=10.0)
+        m = tf.Gemma2ForCausalLM(cfg)
+    elif kind == "phi3":
+        cfg = tf.Phi3Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                            num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                            original_max_position_embeddings=256, pad_token_id=0)
+        m = tf.Phi3ForCausalLM(cfg)
+    elif kind == "granite":
+        cfg = tf.GraniteConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                               num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                               embedding_multiplier=6.0, residual_multiplier=0.4, attention_multiplier=0.1,
+                               logits_scaling=4.0, tie_word_embeddings=True)
+        m = tf.GraniteForCausalLM(cfg)
+    elif kind == "gpt_neox":
+        cfg = tf.GPTNeoXConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                               num_attention_heads=2, max_position_embeddings=256, rotary_pct=0.25)
+        m = tf.GPTNeoXForCausalLM(cfg)
+    elif kind == "gptj":
+        cfg = tf.GPTJConfig(vocab_size=320, n_embd=128, n_layer=2, n_head=2, n_positions=256, rotary_dim=32)
+        m = tf.GPTJForCausalLM(cfg)
+    elif kind == "starcoder2":
+        cfg = tf.Starcoder2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                  num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                                  sliding_window=None)
+        m = tf.Starcoder2ForCausalLM(cfg)
+    elif kind == "gpt_bigcode":
+        cfg = tf.GPTBigCodeConfig(vocab_size=320, n_embd=128, n_layer=2, n_head=2, n_positions=256, multi_query=True)
+        m = tf.GPTBigCodeForCausalLM(cfg)
     m = m.float().eval()
     path = os.path.join(tmp, kind)
     m.save_pretrained(path, safe_serialization=True)
@@ -77,7 +113,8 @@ def _save_tiny(tmp, kind):
 
 
 @pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2", "mixtral", "qwen2_moe", "qwen3_moe",
-                                  "deepseek_v2", "deepseek_v2_yarn", "deepseek_v3"])
+                                  "deepseek_v2", "deepseek_v2_yarn", "deepseek_v3", "gemma", "gemma2", "phi3",
+                                  "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

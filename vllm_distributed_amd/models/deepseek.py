@@ -147,6 +147,7 @@ class DeepseekMoE(nn.Module):
 
 
 class DeepseekDecoderLayer(nn.Module):
+    norm_cls = RMSNorm
     def __init__(self, config, vllm_config: VllmConfig, quant_config=None, prefix: str = ""):
         super().__init__()
         idx = int(prefix.split(".")[-1])

@@ -18,7 +18,8 @@ import torch.nn as nn
 
 from ..config import VllmConfig
 from ..layers.attention import Attention
-from ..layers.basic import LogitsProcessor, ParallelLMHead, RMSNorm, SiluAndMul, VocabParallelEmbedding
+from ..layers.basic import (LogitsProcessor, ParallelLMHead, RMSNorm, SiluAndMul, VocabParallelEmbedding,
+                            get_act_and_mul_fn)
 from ..layers.linear import (MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear,
                              set_sequence_parallel)
 from ..layers.rotary import get_rope
@@ -30,13 +31,13 @@ from .utils import (IntermediateTensors, PPMissingLayer, load_weights_with_mappi
 
 class LlamaMLP(nn.Module):
     def __init__(self, hidden_size: int, intermediate_size: int, bias: bool = False, quant_config=None,
-                 prefix: str = "", reduce_results: bool = True):
+                 prefix: str = "", reduce_results: bool = True, act: str = "silu"):
         super().__init__()
         self.gate_up_proj = MergedColumnParallelLinear(hidden_size, [intermediate_size] * 2, bias=bias,
                                                        quant_config=quant_config, prefix=f"{prefix}.gate_up_proj")
         self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=bias, quant_config=quant_config,
                                            reduce_results=reduce_results, prefix=f"{prefix}.down_proj")
-        self.act_fn = SiluAndMul()
+        self.act_fn = SiluAndMul() if act == "silu" else get_act_and_mul_fn(act)
 
     def forward(self, x):
         return self.down_proj(self.act_fn(self.gate_up_proj(x)))
@@ -46,7 +47,8 @@ class LlamaAttention(nn.Module):
     def __init__(self, config, hidden_size: int, num_heads: int, num_kv_heads: int, rope_theta: float,
                  rope_scaling: Optional[dict], max_position: int, bias: bool = False, o_bias: bool = False,
                  sliding_window: Optional[int] = None, quant_config=None, prefix: str = "", qk_norm: bool = False,
-                 cache_dtype: str = "auto", attention_only: bool = False):
+                 cache_dtype: str = "auto", attention_only: bool = False, scale: Optional[float] = None,
+                 logits_soft_cap: Optional[float] = None):
         super().__init__()
         tp = get_tensor_model_parallel_world_size()
         self.total_num_heads, self.total_num_kv_heads = num_heads, num_kv_heads
@@ -60,8 +62,9 @@ class LlamaAttention(nn.Module):
         partial = getattr(config, "partial_rotary_factor", 1.0) or 1.0
         self.rotary_emb = get_rope(self.head_dim, self.head_dim, max_position, rope_theta, True, rope_scaling,
                                    partial)
-        self.attn = Attention(self.num_heads, self.head_dim, self.head_dim ** -0.5, self.num_kv_heads,
-                              sliding_window=sliding_window, prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
+        self.attn = Attention(self.num_heads, self.head_dim, scale if scale is not None else self.head_dim ** -0.5,
+                              self.num_kv_heads, sliding_window=sliding_window, logits_soft_cap=logits_soft_cap,
+                              prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
         self.qk_norm = qk_norm and not attention_only
         if self.qk_norm:
             eps = getattr(config, "rms_norm_eps", 1e-6)
@@ -97,6 +100,13 @@ class LlamaAttention(nn.Module):
 
 
 class LlamaDecoderLayer(nn.Module):
+    norm_cls = RMSNorm
+    supports_sequence_parallel = True      # subclasses with their own forward / MLP turn this off
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        """Per-family keyword arguments for LlamaAttention (softmax scale, soft cap, window...)."""
+        return {}
+
     def __init__(self, config, vllm_config: VllmConfig, quant_config=None, prefix: str = "",
                  attention_only: bool = False):
         super().__init__()
@@ -115,19 +125,20 @@ class LlamaDecoderLayer(nn.Module):
         if window is not None and getattr(config, "max_window_layers", None) is not None \
                 and arch.startswith("Qwen") and layer_idx < config.max_window_layers:
             window = None
+        kw = dict(bias=bias, o_bias=False if arch.startswith("Qwen") else bias, sliding_window=window,
+                  quant_config=quant_config, prefix=f"{prefix}.self_attn", qk_norm=arch.startswith("Qwen3"),
+                  cache_dtype=vllm_config.cache_config.cache_dtype, attention_only=attention_only)
+        kw.update(self._attention_extras(config, layer_idx))
         self.self_attn = LlamaAttention(
             config, config.hidden_size, config.num_attention_heads,
             getattr(config, "num_key_value_heads", None) or config.num_attention_heads,
-            rope_theta, rope_scaling, mc.max_model_len, bias=bias, o_bias=False
-            if arch.startswith("Qwen") else bias, sliding_window=window, quant_config=quant_config,
-            prefix=f"{prefix}.self_attn", qk_norm=arch.startswith("Qwen3"),
-            cache_dtype=vllm_config.cache_config.cache_dtype, attention_only=attention_only)
+            rope_theta, rope_scaling, mc.max_model_len, **kw)
         if attention_only:
             return
         self.mlp = self._make_mlp(config, vllm_config, quant_config, f"{prefix}.mlp")
         eps = getattr(config, "rms_norm_eps", 1e-6)
-        self.input_layernorm = RMSNorm(config.hidden_size, eps)
-        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps)
+        self.input_layernorm = self.norm_cls(config.hidden_size, eps)
+        self.post_attention_layernorm = self.norm_cls(config.hidden_size, eps)
 
     def _make_mlp(self, config, vllm_config, quant_config, prefix):
         return LlamaMLP(config.hidden_size, config.intermediate_size, bool(getattr(config, "mlp_bias", False)),
@@ -153,6 +164,7 @@ class LlamaDecoderLayer(nn.Module):
 
 class LlamaModel(nn.Module):
     layer_cls = LlamaDecoderLayer
+    embed_scale_of = staticmethod(lambda config: 1.0)      # Gemma: sqrt(hidden), Granite: embedding_multiplier
 
     def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
         super().__init__()
@@ -168,12 +180,13 @@ class LlamaModel(nn.Module):
         self.start_layer, self.end_layer, self.layers = make_layers(
             config.num_hidden_layers,
             lambda p: self.layer_cls(config, vllm_config, quant_config, p), f"{prefix}.layers")
-        self.norm = RMSNorm(config.hidden_size, getattr(config, "rms_norm_eps", 1e-6)) if pp.is_last_rank \
-            else PPMissingLayer()
+        self.norm = self.layer_cls.norm_cls(config.hidden_size, getattr(config, "rms_norm_eps", 1e-6)) \
+            if pp.is_last_rank else PPMissingLayer()
+        self.embed_scale = float(self.embed_scale_of(config))
         self.tp = get_tensor_model_parallel_world_size()
         # sequence parallelism: dense Llama-style layers only (the MoE blocks reduce on their own)
         self.sequence_parallel = bool(vllm_config.compilation_config.enable_sequence_parallelism and self.tp > 1
-                                      and self.layer_cls is LlamaDecoderLayer
+                                      and getattr(self.layer_cls, "supports_sequence_parallel", False)
                                       and not vllm_config.parallel_config.enable_token_parallel)
 
     def get_input_embeddings(self, input_ids):
@@ -184,6 +197,8 @@ class LlamaModel(nn.Module):
         pp = get_pp_group()
         if pp.is_first_rank:
             hidden = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
+            if self.embed_scale != 1.0:
+                hidden = hidden * self.embed_scale
             residual = None
         else:
             hidden, residual = intermediate_tensors["hidden_states"], intermediate_tensors["residual"]
@@ -236,10 +251,14 @@ class LlamaForCausalLM(nn.Module):
                                           prefix=maybe_prefix(prefix, "lm_head"))
             if self.tie:
                 self.lm_head.tie_weights(self.model.embed_tokens)
-            self.logits_processor = LogitsProcessor(config.vocab_size, config.vocab_size,
-                                                    getattr(config, "logit_scale", 1.0))
+            self.logits_processor = LogitsProcessor(config.vocab_size, config.vocab_size, self._logit_scale(config),
+                                                    soft_cap=getattr(config, "final_logit_softcapping", None))
         else:
             self.lm_head = PPMissingLayer()
+
+    @staticmethod
+    def _logit_scale(config) -> float:
+        return float(getattr(config, "logit_scale", 1.0) or 1.0)
 
     def get_input_embeddings(self, input_ids):
         return self.model.get_input_embeddings(input_ids)

@@ -59,6 +59,7 @@ class SparseMoeBlock(nn.Module):
 
 
 class MixtralDecoderLayer(LlamaDecoderLayer):
+    supports_sequence_parallel = False
     def _make_mlp(self, config, vllm_config, quant_config, prefix):
         # checkpoint names: model.layers.N.block_sparse_moe.{gate, experts.E.{w1,w2,w3}}
         return SparseMoeBlock(config.hidden_size, config.intermediate_size, _num_experts(config),
@@ -103,6 +104,7 @@ class MixtralForCausalLM(LlamaForCausalLM):
 
 
 class QwenMoeDecoderLayer(LlamaDecoderLayer):
+    supports_sequence_parallel = False
     def _make_mlp(self, config, vllm_config, quant_config, prefix):
         layer_idx = int(prefix.split(".")[-2])
         sparse_step = getattr(config, "decoder_sparse_step", 1) or 1

@@ -14,6 +14,14 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     "Qwen2MoeForCausalLM": ("mixtral", "Qwen2MoeForCausalLM"),
     "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
+    "GemmaForCausalLM": ("llama_family", "GemmaForCausalLM"),
+    "Gemma2ForCausalLM": ("llama_family", "Gemma2ForCausalLM"),
+    "Phi3ForCausalLM": ("llama_family", "Phi3ForCausalLM"),
+    "GraniteForCausalLM": ("llama_family", "GraniteForCausalLM"),
+    "GPTNeoXForCausalLM": ("gpt_family", "GPTNeoXForCausalLM"),
+    "GPTJForCausalLM": ("gpt_family", "GPTJForCausalLM"),
+    "Starcoder2ForCausalLM": ("gpt_family", "Starcoder2ForCausalLM"),
+    "GPTBigCodeForCausalLM": ("gpt_family", "GPTBigCodeForCausalLM"),
     "DeepseekV2ForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
     "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
     "DeepseekForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
