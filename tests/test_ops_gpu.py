@@ -512,3 +512,28 @@ def test_fp8_kv_cache_write_and_attention(dt, Hq, Hkv, D, bs):
         ops.paged_attention_decode(od, qd, kc, vc, bt, sl, qsl1, scale, num_splits=nsplit, k_scale=ks, v_scale=vs)
         wd = R.paged_attention(qd, kc, vc, bt, sl, qsl1, scale, k_scale=ks, v_scale=vs)
         torch.testing.assert_close(od.float(), wd.float(), **tol(dt))
+
+
+# ---- int8 W8A8 --------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H", [128, 4096, 8192, 28672])
+def test_int8_quant_dynamic_and_static(dt, H):
+    x = (torch.randn(37, H, device=DEV) * 3).to(dt)
+    q, s = ops.int8_quant(x)
+    qr, sr = R.int8_quant(x)
+    torch.testing.assert_close(s, sr, rtol=1e-6, atol=0)
+    assert int((q.int() - qr.int()).abs().max()) <= 1          # rounding of values that sit on .5 after the divide
+    assert float((q != qr).float().mean()) < 1e-3
+    st = torch.tensor([0.05], device=DEV)
+    q2, _ = ops.int8_quant(x, st)
+    q2r, _ = R.int8_quant(x, st)
+    assert int((q2.int() - q2r.int()).abs().max()) <= 1
+
+
+@pytest.mark.parametrize("M", [1, 17, 300])
+def test_int8_linear_matches_integer_reference(M):
+    from vllm_distributed_amd.layers.quant import _int8_matmul
+    xq = torch.randint(-127, 128, (M, 1024), device=DEV, dtype=torch.int8)
+    w = torch.randint(-127, 128, (512, 1024), device=DEV, dtype=torch.int8)
+    ref = (xq.cpu().long() @ w.cpu().long().t()).float()
+    torch.testing.assert_close(_int8_matmul(xq, w).cpu(), ref, rtol=1e-6, atol=0.5)

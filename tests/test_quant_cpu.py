@@ -3,6 +3,7 @@ fp8-serialised checkpoint with per-projection scales (fused-layer requantisation
 import json
 import os
 
+import pytest
 import torch
 from safetensors.torch import load_file, save_file
 
@@ -93,3 +94,145 @@ def test_fp8_kv_cache_close_to_16bit(tmp_path):
     b.shutdown()
     for x, y in zip(lp, ref_lp):
         assert abs(x[0] - y[0]) < 0.05
+
+
+# ---- weight-only formats dequantised at load time --------------------------------------------------
+def _pack_rows(v, bits):
+    per = 32 // bits
+    v = v.to(torch.int64).view(v.shape[0] // per, per, v.shape[1])
+    out = torch.zeros(v.shape[0], v.shape[2], dtype=torch.int64)
+    for i in range(per):
+        out |= v[:, i, :] << (bits * i)
+    return out.to(torch.int32) if bits * per < 32 else (out & 0xFFFFFFFF).to(torch.uint32).view(torch.int32)
+
+
+def _pack_cols(v, bits, order=None):
+    per = 32 // bits
+    v = v.to(torch.int64).view(v.shape[0], v.shape[1] // per, per)
+    if order is not None:
+        inv = [order.index(i) for i in range(per)]
+        v = v[:, :, inv]
+    out = torch.zeros(v.shape[0], v.shape[1], dtype=torch.int64)
+    for i in range(per):
+        out |= v[:, :, i] << (bits * i)
+    return (out & 0xFFFFFFFF).to(torch.uint32).view(torch.int32)
+
+
+def _int4_quantise(w, group):
+    """w [N, K] -> q [K, N] in 0..15, zeros [G, N], scales [G, N] and the dequantised [N, K]."""
+    N, K = w.shape
+    wt = w.t().reshape(K // group, group, N)
+    lo, hi = wt.amin(1), wt.amax(1)
+    scales = ((hi - lo) / 15).clamp(min=1e-6).half()
+    zeros = (-lo / scales.float()).round().clamp(0, 15)
+    q = (wt / scales.float().unsqueeze(1) + zeros.unsqueeze(1)).round().clamp(0, 15)
+    deq = ((q - zeros.unsqueeze(1)) * scales.float().unsqueeze(1)).reshape(K, N).t().contiguous()
+    return q.reshape(K, N).to(torch.int32), zeros.to(torch.int32), scales, deq
+
+
+@pytest.mark.parametrize("fmt", ["gptq", "awq", "fp8_block"])
+def test_weight_only_checkpoints_are_dequantised_while_loading(tmp_path, fmt):
+    """A GPTQ / AWQ / block-fp8 checkpoint of the tiny Llama generates the tokens of the HF model
+    that holds the dequantised weights."""
+    import json
+    import os
+
+    from safetensors.torch import load_file, save_file
+
+    from tests.test_e2e_cpu import _save_tiny
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.models.dequant import _AWQ_ORDER
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    out, group = {}, 32
+    for name, t in sd.items():
+        if not (name.endswith("_proj.weight") and t.dim() == 2):
+            out[name] = t
+            continue
+        prefix = name[: -len(".weight")]
+        if fmt == "fp8_block":
+            bn = bk = 32
+            N, K = t.shape
+            blocks = t.view(N // bn, bn, K // bk, bk)
+            s = (blocks.abs().amax(dim=(1, 3)) / 448.0).clamp(min=1e-8)
+            q = (blocks / s[:, None, :, None]).view(N, K).to(torch.float8_e4m3fn)
+            out[name], out[prefix + ".weight_scale_inv"] = q, s.float()
+            deq = (q.float().view(N // bn, bn, K // bk, bk) * s[:, None, :, None]).view(N, K)
+        else:
+            q, zeros, scales, deq = _int4_quantise(t.float(), group)
+            if fmt == "gptq":
+                out[prefix + ".qweight"] = _pack_rows(q, 4)
+                out[prefix + ".qzeros"] = _pack_cols(zeros - 1, 4)          # v1 files store zero - 1
+                out[prefix + ".g_idx"] = (torch.arange(q.shape[0]) // group).to(torch.int32)
+            else:
+                out[prefix + ".qweight"] = _pack_cols(q, 4, _AWQ_ORDER)
+                out[prefix + ".qzeros"] = _pack_cols(zeros, 4, _AWQ_ORDER)
+            out[prefix + ".scales"] = scales
+        mod = hf.get_submodule(prefix)
+        with torch.no_grad():
+            mod.weight.copy_(deq)
+    save_file(out, os.path.join(path, "model.safetensors"))
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    cfg["quantization_config"] = {"gptq": {"quant_method": "gptq", "bits": 4, "group_size": group, "desc_act": False},
+                                  "awq": {"quant_method": "awq", "bits": 4, "group_size": group, "zero_point": True,
+                                          "version": "gemm"},
+                                  "fp8_block": {"quant_method": "fp8", "weight_block_size": [32, 32],
+                                                "activation_scheme": "dynamic"}}[fmt]
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, (fmt, p)
+
+
+@pytest.mark.parametrize("strategy", ["channel", "tensor"])
+def test_int8_w8a8_checkpoint(tmp_path, strategy):
+    """compressed-tensors int8 W8A8 (dynamic per-token activations): the engine's greedy tokens equal a
+    plain PyTorch emulation of the same arithmetic through the HF model."""
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    out = {}
+    for name, t in sd.items():
+        if not (name.endswith("_proj.weight") and t.dim() == 2):
+            out[name] = t
+            continue
+        prefix = name[: -len(".weight")]
+        amax = t.abs().amax(1, keepdim=True) if strategy == "channel" else t.abs().amax().reshape(1)
+        s = (amax / 127.0).clamp(min=1e-8).float()
+        q = torch.round(t / s).clamp(-128, 127).to(torch.int8)
+        out[name], out[prefix + ".weight_scale"] = q, s
+        mod = hf.get_submodule(prefix)
+        wq, ws = q.float(), s.reshape(-1, 1) if strategy == "channel" else s.reshape(1, 1)
+
+        def fwd(x, wq=wq, ws=ws):
+            xs = (x.abs().amax(-1, keepdim=True) / 127.0).clamp(min=1e-10)
+            xq = torch.round(x / xs).clamp(-128, 127)
+            return (xq @ wq.t()) * xs * ws.reshape(1, -1)
+        mod.forward = fwd
+    save_file(out, os.path.join(path, "model.safetensors"))
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    cfg["quantization_config"] = {
+        "quant_method": "compressed-tensors", "format": "int-quantized", "ignore": ["lm_head"],
+        "config_groups": {"group_0": {"targets": ["Linear"],
+                                      "weights": {"num_bits": 8, "type": "int", "symmetric": True, "strategy": strategy},
+                                      "input_activations": {"num_bits": 8, "type": "int", "symmetric": True,
+                                                            "dynamic": True, "strategy": "token"}}}}
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, (strategy, p)

@@ -204,8 +204,11 @@ class ModelConfig:
             qc = hf.get("quantization_config")
             if qc:
                 self.quantization = str(qc.get("quant_method", "")).lower() or None
-        if self.quantization not in (None, "fp8", "compressed-tensors", "quark"):
-            raise ValueError(f"unsupported quantization {self.quantization!r} (supported: fp8)")
+        if self.quantization in ("awq_marlin", "gptq_marlin"):
+            self.quantization = self.quantization.split("_")[0]
+        if self.quantization not in (None, "fp8", "compressed-tensors", "quark", "awq", "gptq"):
+            raise ValueError(f"unsupported quantization {self.quantization!r} "
+                             "(supported: fp8, compressed-tensors, quark, awq, gptq)")
         if self.served_model_name is None:
             self.served_model_name = self.model
         if self.task == "auto":

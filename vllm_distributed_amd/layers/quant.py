@@ -70,8 +70,6 @@ class Fp8Config(QuantizationConfig):
                  ignored_layers: Optional[list[str]] = None, weight_block_size: Optional[list[int]] = None):
         if activation_scheme not in ("static", "dynamic"):
             raise ValueError(f"unsupported activation scheme {activation_scheme!r}")
-        if weight_block_size is not None:
-            raise ValueError("block-wise fp8 weights are not supported; use per-tensor fp8 checkpoints")
         self.is_checkpoint_fp8_serialized = is_checkpoint_fp8_serialized
         self.activation_scheme = activation_scheme
         self.ignored_layers = ignored_layers or []
@@ -95,6 +93,96 @@ class Fp8Config(QuantizationConfig):
         return None
 
 
+class Int8Config(QuantizationConfig):
+    """W8A8 int8 (compressed-tensors): int8 weights with per-channel or per-tensor scales,
+    activations quantised per token on the fly (or with a calibrated static scale)."""
+    name = "int8"
+    FUSED = Fp8Config.FUSED
+
+    def __init__(self, weight_strategy: str = "channel", dynamic_activations: bool = True,
+                 ignored_layers: Optional[list[str]] = None):
+        if weight_strategy not in ("channel", "tensor"):
+            raise ValueError(f"int8: unsupported weight strategy {weight_strategy!r}")
+        self.weight_strategy, self.dynamic = weight_strategy, dynamic_activations
+        self.ignored_layers = ignored_layers or []
+
+    def get_quant_method(self, layer: nn.Module, prefix: str):
+        if isinstance(layer, LinearBase):
+            if _is_ignored(prefix, self.ignored_layers, self.FUSED) or prefix.endswith("lm_head"):
+                return UnquantizedLinearMethod()
+            return Int8LinearMethod(self)
+        return None
+
+
+_INT_MM_OK: Optional[bool] = None
+
+
+def _int8_matmul(xq: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """int8 [M, K] x int8 [N, K]^T -> fp32 [M, N] of exact integer sums (int32 accumulation through
+    the library's int8 GEMM on the GPU; rows are padded to its minimum of 32)."""
+    global _INT_MM_OK
+    M = xq.shape[0]
+    if xq.is_cuda and _INT_MM_OK is not False and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+        try:
+            a = xq
+            if M < 32:
+                a = torch.zeros((32, xq.shape[1]), dtype=torch.int8, device=xq.device)
+                a[:M] = xq
+            y = torch._int_mm(a, w.t())[:M].float()
+            _INT_MM_OK = True
+            return y
+        except RuntimeError:
+            if _INT_MM_OK:
+                raise
+            _INT_MM_OK = False
+    return xq.float() @ w.float().t()
+
+
+class Int8LinearMethod:
+    def __init__(self, cfg: Int8Config):
+        self.cfg = cfg
+
+    def create_weights(self, layer: nn.Module, in_per_rank: int, out_per_rank: int, dtype: torch.dtype) -> None:
+        w = nn.Parameter(torch.empty(out_per_rank, in_per_rank, dtype=torch.int8), requires_grad=False)
+        set_weight_attrs(w, {"input_dim": 1, "output_dim": 0})
+        layer.register_parameter("weight", w)
+        layer.orig_dtype = dtype
+        n_shards = len(getattr(layer, "output_sizes", [0]))
+        layer.logical_widths = [s // getattr(layer, "tp_size", 1) for s in layer.output_sizes] \
+            if hasattr(layer, "output_sizes") else [out_per_rank]
+        if self.cfg.weight_strategy == "channel":
+            ws = nn.Parameter(torch.ones(out_per_rank, 1, dtype=torch.float32), requires_grad=False)
+            set_weight_attrs(ws, {"output_dim": 0})
+        else:
+            ws = nn.Parameter(torch.ones(n_shards, dtype=torch.float32), requires_grad=False)
+            set_weight_attrs(ws, {"per_shard_scalar": n_shards > 1})
+        layer.register_parameter("weight_scale", ws)
+        if not self.cfg.dynamic:
+            ins = nn.Parameter(torch.ones(n_shards, dtype=torch.float32), requires_grad=False)
+            set_weight_attrs(ins, {"per_shard_scalar": n_shards > 1})
+            layer.register_parameter("input_scale", ins)
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        ws = layer.weight_scale.data.float()
+        if self.cfg.weight_strategy == "tensor":
+            ws = torch.cat([ws.reshape(-1)[i].expand(w) for i, w in enumerate(layer.logical_widths)]) \
+                if ws.numel() > 1 else ws.reshape(1).expand(layer.weight.shape[0])
+        layer.weight_scale = nn.Parameter(ws.reshape(1, -1).contiguous(), requires_grad=False)     # [1, N]
+        ins = getattr(layer, "input_scale", None)
+        layer.input_scale = nn.Parameter(ins.data.float().max().reshape(1), requires_grad=False) \
+            if ins is not None else None
+
+    def apply(self, layer: nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        xq, xs = ops.int8_quant(x2, getattr(layer, "input_scale", None))
+        acc = _int8_matmul(xq, layer.weight)
+        y = acc * (xs.float().reshape(-1, 1) if xs.numel() > 1 else xs.float().reshape(1, 1)) * layer.weight_scale
+        if bias is not None:
+            y = y + bias.float()
+        return y.to(x.dtype).view(*shape[:-1], -1)
+
+
 def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
     mc = vllm_config.model_config
     q = mc.quantization
@@ -102,15 +190,29 @@ def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
         return None
     hf_q = mc.hf_config.get("quantization_config") if hasattr(mc.hf_config, "get") else \
         getattr(mc.hf_config, "quantization_config", None)
+    if q in ("awq", "gptq") or (q == "fp8" and hf_q and hf_q.get("weight_block_size")):
+        # weight-only formats without a kernel of their own: dequantised while the checkpoint loads
+        from ..models.dequant import LoadTimeDequant
+        return LoadTimeDequant(q, dict(hf_q or {}))
     if q == "fp8":
         return Fp8Config.from_config(hf_q) if hf_q else Fp8Config(False, "dynamic")
     if q in ("compressed-tensors", "quark"):
         # accept only the plain per-tensor fp8 flavour of these container formats
         groups = (hf_q or {}).get("config_groups") or {}
+        kinds = {(str(g.get("weights", {}).get("type", "")), int(g.get("weights", {}).get("num_bits", 8)))
+                 for g in groups.values()}
+        if groups and kinds == {("int", 8)}:
+            g0 = next(iter(groups.values()))
+            act = g0.get("input_activations") or {}
+            if int(act.get("num_bits", 8)) != 8 or not act.get("symmetric", True) \
+                    or not g0["weights"].get("symmetric", True):
+                raise ValueError(f"{q}: only symmetric W8A8 int8 schemes are supported")
+            return Int8Config(str(g0["weights"].get("strategy", "channel")), bool(act.get("dynamic", True)),
+                              (hf_q or {}).get("ignore"))
         ok = all(str(g.get("weights", {}).get("type", "")).startswith("float") and
                  int(g.get("weights", {}).get("num_bits", 8)) == 8 for g in groups.values())
         if not groups or not ok:
-            raise ValueError(f"{q}: only per-tensor fp8 weight schemes are supported")
+            raise ValueError(f"{q}: only per-tensor fp8 and symmetric int8 W8A8 weight schemes are supported")
         dyn = any(g.get("input_activations", {}).get("dynamic", True) for g in groups.values())
         return Fp8Config(True, "dynamic" if dyn else "static", (hf_q or {}).get("ignore"))
     raise ValueError(f"unsupported quantization {q!r}")

@@ -1,0 +1,122 @@
+"""Load-time dequantisation of weight-only checkpoint formats.
+
+GPTQ and AWQ (4/8-bit integers with group scales and zero points) and block-wise fp8
+(``weight_scale_inv`` per 128x128 block, DeepSeek-V3 style) checkpoints are turned into 16-bit
+weights while the checkpoint streams in: the iterator below pairs every packed tensor with its
+scales / zero points and yields the ordinary ``<module>.weight``.  The model then runs with the
+exact values of the quantised model on the bf16 GEMM path; the memory saving of the format is
+not kept.
+Reference: vllm/model_executor/layers/quantization/gptq.py, awq.py (tensor layouts),
+utils/fp8_utils.py (block scales).
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, Optional
+
+import torch
+
+_AWQ_ORDER = [0, 4, 1, 5, 2, 6, 3, 7]        # nibble j of a packed word holds column _AWQ_ORDER^-1
+
+
+def _unpack_rows(packed: torch.Tensor, bits: int) -> torch.Tensor:
+    """int32 [R, C] with 32/bits values per word along dim 0 (low bits first) -> int32 [R*32/bits, C]."""
+    per = 32 // bits
+    shifts = torch.arange(0, 32, bits, dtype=torch.int32).view(1, per, 1)
+    v = (packed.to(torch.int32).unsqueeze(1) >> shifts) & ((1 << bits) - 1)
+    return v.reshape(packed.shape[0] * per, packed.shape[1])
+
+
+def _unpack_cols(packed: torch.Tensor, bits: int) -> torch.Tensor:
+    """int32 [R, C] with 32/bits values per word along dim 1 -> int32 [R, C*32/bits]."""
+    per = 32 // bits
+    shifts = torch.arange(0, 32, bits, dtype=torch.int32).view(1, 1, per)
+    v = (packed.to(torch.int32).unsqueeze(2) >> shifts) & ((1 << bits) - 1)
+    return v.reshape(packed.shape[0], packed.shape[1] * per)
+
+
+def dequantize_gptq(qweight, qzeros, scales, g_idx: Optional[torch.Tensor], bits: int, zero_offset: int,
+                    dtype: torch.dtype) -> torch.Tensor:
+    """-> [N, K].  qweight [K*bits/32, N], qzeros [G, N*bits/32], scales [G, N], g_idx [K]."""
+    q = _unpack_rows(qweight, bits)                       # [K, N]
+    z = _unpack_cols(qzeros, bits) + zero_offset          # [G, N]
+    K = q.shape[0]
+    if g_idx is None:
+        g_idx = torch.arange(K, dtype=torch.int64) // (K // scales.shape[0])
+    g = g_idx.to(torch.int64)
+    w = (q - z[g]).to(torch.float32) * scales.to(torch.float32)[g]
+    return w.t().contiguous().to(dtype)
+
+
+def dequantize_awq(qweight, qzeros, scales, bits: int, dtype: torch.dtype) -> torch.Tensor:
+    """-> [N, K].  qweight [K, N*bits/32], qzeros [G, N*bits/32], scales [G, N]; 4-bit words are
+    interleaved (columns 0,2,4,6,1,3,5,7)."""
+    def cols(p):
+        v = _unpack_cols(p, bits)
+        if bits == 4:
+            v = v.view(v.shape[0], -1, 8)[:, :, _AWQ_ORDER].reshape(v.shape[0], -1)
+        return v
+    q, z = cols(qweight), cols(qzeros)
+    K, G = q.shape[0], scales.shape[0]
+    g = torch.arange(K, dtype=torch.int64) // (K // G)
+    w = (q - z[g]).to(torch.float32) * scales.to(torch.float32)[g]
+    return w.t().contiguous().to(dtype)
+
+
+def dequantize_block_fp8(weight, scale_inv, block: tuple[int, int], dtype: torch.dtype) -> torch.Tensor:
+    N, K = weight.shape
+    s = scale_inv.to(torch.float32).repeat_interleave(block[0], 0)[:N].repeat_interleave(block[1], 1)[:, :K]
+    return (weight.to(torch.float32) * s).to(dtype)
+
+
+class LoadTimeDequant:
+    """What the loader needs to know about a weight-only format; carries no layer methods, so the
+    model is built with ordinary 16-bit layers."""
+
+    def __init__(self, method: str, cfg: dict):
+        self.method = method
+        self.bits = int(cfg.get("bits", cfg.get("w_bit", 4)) or 4)
+        self.block = tuple(cfg.get("weight_block_size") or (128, 128))
+        # AutoGPTQ v1 files store zero - 1
+        self.zero_offset = 0 if str(cfg.get("checkpoint_format", "gptq")) == "gptq_v2" else 1
+        if method in ("gptq", "awq") and self.bits not in (2, 4, 8):
+            raise ValueError(f"{method}: {self.bits}-bit weights are not supported (2, 4, 8)")
+
+    def get_quant_method(self, layer, prefix):
+        return None
+
+    def wrap(self, weights: Iterable[tuple[str, torch.Tensor]], dtype: torch.dtype) -> Iterator[tuple[str, torch.Tensor]]:
+        pending: dict[str, dict[str, torch.Tensor]] = {}
+        parts = ("qweight", "qzeros", "scales", "g_idx", "weight_scale_inv")
+
+        def finish(prefix: str, d: dict) -> Optional[torch.Tensor]:
+            if self.method == "fp8":
+                if "weight" in d and "weight_scale_inv" in d:
+                    return dequantize_block_fp8(d["weight"], d["weight_scale_inv"], self.block, dtype)
+                return None
+            if not all(k in d for k in ("qweight", "qzeros", "scales")):
+                return None
+            if self.method == "awq":
+                return dequantize_awq(d["qweight"], d["qzeros"], d["scales"], self.bits, dtype)
+            return dequantize_gptq(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), self.bits,
+                                   self.zero_offset, dtype)
+
+        for name, t in weights:
+            prefix, _, leaf = name.rpartition(".")
+            held = leaf in parts or (self.method == "fp8" and leaf == "weight" and t.dtype == torch.float8_e4m3fn)
+            if not held:
+                yield name, t
+                continue
+            d = pending.setdefault(prefix, {})
+            d[leaf] = t
+            # GPTQ: g_idx may come last, so integer formats are completed at the end unless it is here
+            ready = self.method in ("fp8", "awq") or "g_idx" in d
+            if ready:
+                w = finish(prefix, d)
+                if w is not None:
+                    del pending[prefix]
+                    yield f"{prefix}.weight", w
+        for prefix, d in pending.items():
+            w = finish(prefix, d)
+            if w is None:
+                raise ValueError(f"{prefix}: incomplete {self.method} tensors in the checkpoint ({sorted(d)})")
+            yield f"{prefix}.weight", w

@@ -159,8 +159,13 @@ class DefaultModelLoader(BaseModelLoader):
         return safetensors_iterator(files) if is_st else pt_iterator(files)
 
     def load_weights(self, model: nn.Module, vllm_config: VllmConfig) -> None:
-        loaded = model.load_weights(self.get_all_weights(vllm_config))
-        if loaded is not None and vllm_config.model_config.quantization is None:
+        from .dequant import LoadTimeDequant
+        weights = self.get_all_weights(vllm_config)
+        qc = getattr(vllm_config, "quant_config", None)
+        if isinstance(qc, LoadTimeDequant):
+            weights = qc.wrap(weights, vllm_config.model_config.dtype)
+        loaded = model.load_weights(weights)
+        if loaded is not None and (vllm_config.model_config.quantization is None or isinstance(qc, LoadTimeDequant)):
             # strict: every parameter must have come from the checkpoint
             missing = {n for n, _ in model.named_parameters()} - set(loaded)
             if missing:

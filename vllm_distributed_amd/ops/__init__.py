@@ -321,6 +321,20 @@ def per_token_fp8_quant(x: torch.Tensor, scale_ub: Optional[torch.Tensor] = None
     return out.view(x.shape), scales.view(*x.shape[:-1], 1)
 
 
+def int8_quant(x: torch.Tensor, scale: Optional[torch.Tensor] = None):
+    """Symmetric int8 quantisation of the last dimension's rows: per-token dynamic scales
+    ([..., 1] fp32, absmax / 127) when ``scale`` is None, the given scalar otherwise."""
+    if not _dev(x) or x.shape[-1] % 8 or x.shape[-1] > 65536:
+        return R.int8_quant(x, scale)
+    H = x.shape[-1]
+    x2 = _contig_last(x).view(-1, H)
+    out = torch.empty(x2.shape, dtype=torch.int8, device=x.device)
+    scales = torch.empty((x2.shape[0], 1), dtype=torch.float32, device=x.device) if scale is None else scale
+    N.call("vda_int8_quant", out.data_ptr(), scales.data_ptr(), x2.data_ptr(), N.ptr(scale), x2.shape[0], H,
+           x2.stride(0), out.stride(0), N.dt(x.dtype), N.stream())
+    return out.view(x.shape), (scales.view(*x.shape[:-1], 1) if scale is None else scale)
+
+
 def fp8_dequant(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype):
     if not _dev(q) or q.numel() % 8:
         return R.fp8_dequant(q, scale, dtype)

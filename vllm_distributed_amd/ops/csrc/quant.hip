@@ -136,6 +136,80 @@ VDA_EXPORT int vda_per_token_fp8_quant(void* out, float* scales, const void* in,
   return 0;
 }
 
+// int8: one workgroup per token row.  Dynamic: scale[row] = max(|row|)/127 and the scale is written
+// out; static: the given scale is used for every row.  Values are rounded to nearest and saturated.
+// Role of the reference's csrc/quantization/compressed_tensors/int8_quant_kernels.cu:109-338
+// (symmetric forms; the asymmetric zero-point forms are not built).
+template <typename T, int MAXV>
+__global__ __launch_bounds__(1024) void quant_int8_kernel(int8_t* __restrict__ out, float* __restrict__ scales,
+                                                          const T* __restrict__ in, const float* static_scale,
+                                                          int H, long in_stride, long out_stride) {
+  using V8 = typename Vec<T>::v8;
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const int nvec = H >> 3;
+  V8 x[MAXV];
+  float m = 0.f;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int i = threadIdx.x + v * blockDim.x;
+    if (i < nvec) {
+      x[v] = ld16<V8>(in + row * in_stride + 8 * i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)x[v][j]));
+    }
+  }
+  float sc;
+  if (static_scale) {
+    sc = *static_scale;
+  } else {
+    m = block_max(m, red);
+    sc = fmaxf(m / 127.f, 1e-10f);
+    if (threadIdx.x == 0) scales[row] = sc;
+  }
+  const float inv = 1.f / sc;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int i = threadIdx.x + v * blockDim.x;
+    if (i < nvec) {
+      u32x2 pk;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int q = __float2int_rn((float)x[v][h * 4 + j] * inv);
+          q = q < -128 ? -128 : (q > 127 ? 127 : q);
+          w |= (uint32_t)(q & 0xFF) << (8 * j);
+        }
+        pk[h] = w;
+      }
+      *reinterpret_cast<u32x2*>(out + row * out_stride + 8 * i) = pk;
+    }
+  }
+}
+
+// scales: [rows] written when static_scale is null, ignored otherwise.
+VDA_EXPORT int vda_int8_quant(void* out, float* scales, const void* in, const float* static_scale, int rows, int H,
+                              long in_stride, long out_stride, int dtype, hipStream_t st) {
+  if (H % 8) return -1;
+  if (rows == 0) return 0;
+  const int nvec = H / 8;
+  int threads = ((nvec + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  const int need = (nvec + threads - 1) / threads;
+  if (need > 8) return -2;
+  dim3 grid(rows), block(threads);
+#define L(TT, MV) hipLaunchKernelGGL((quant_int8_kernel<TT, MV>), grid, block, 0, st, (int8_t*)out, scales, \
+                                     (const TT*)in, static_scale, H, in_stride, out_stride)
+#define BY(TT) do { if (need <= 1) L(TT, 1); else if (need <= 2) L(TT, 2); else if (need <= 4) L(TT, 4); else L(TT, 8); } while (0)
+  if (dtype == VDA_BF16) BY(bf16_t); else if (dtype == VDA_F16) BY(f16_t); else return -3;
+#undef BY
+#undef L
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
 VDA_EXPORT int vda_fp8_dequant(void* out, const void* in, const float* scale, long n, int dtype, hipStream_t st) {
   if (n % 8) return -1;
   if (n == 0) return 0;

@@ -47,6 +47,7 @@ _SIGS = {
     "vda_apply_penalties": [P, P, P, P, P, P, I, I, L, P],
     "vda_scaled_fp8_quant": [P, P, P, L, I, I, P],
     "vda_per_token_fp8_quant": [P, P, P, P, I, I, L, L, I, P],
+    "vda_int8_quant": [P, P, P, P, I, I, L, L, I, P],
     "vda_fp8_dequant": [P, P, P, L, I, P],
     "vda_skinny_gemm": [P, P, P, P, P, I, I, I, L, L, L, I, I, P],
     "vda_moe_topk_softmax": [P, P, P, I, I, I, I, L, I, P],

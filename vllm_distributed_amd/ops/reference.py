@@ -296,3 +296,13 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
         act = (torch.nn.functional.silu(h[:, :I]) * h[:, I:]).to(x.dtype).float()
         out.index_add_(0, tok, (act @ b.t()) * topk_w[tok, slot].float().unsqueeze(1))
     return out.to(x.dtype)
+
+
+def int8_quant(x, scale=None):
+    xf = x.float()
+    if scale is None:
+        s = (xf.abs().amax(-1, keepdim=True) / 127.0).clamp(min=1e-10)
+    else:
+        s = scale.float().reshape(())
+    q = torch.round(xf / s).clamp(-128, 127).to(torch.int8)
+    return q, (s if scale is None else scale)
