@@ -784,6 +784,14 @@ class ModelRunner:
             return
         t0 = time.time()
         free0 = torch.cuda.mem_get_info(self.device)[0]
+        with torch.inference_mode(False):
+            # The first capture of a process creates the default generator's capture-state tensors, and
+            # every later capture updates them in place.  Created inside inference mode they would make
+            # any capture outside it (user code sharing the process) fail, so create them here.
+            probe = torch.zeros(1, device=self.device)
+            with torch.cuda.graph(torch.cuda.CUDAGraph()):
+                probe.add_(1)
+            del probe
         self.graph_pool = torch.cuda.graph_pool_handle()
         with graph_capture(self.device) as cap:
             for bs in sorted(self.capture_sizes, reverse=True):
