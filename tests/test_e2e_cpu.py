@@ -106,6 +106,21 @@ def _save_tiny(tmp, kind):
     elif kind == "gpt_bigcode":
         cfg = tf.GPTBigCodeConfig(vocab_size=320, n_embd=128, n_layer=2, n_head=2, n_positions=256, multi_query=True)
         m = tf.GPTBigCodeForCausalLM(cfg)
+    elif kind in ("mamba", "falcon_mamba", "mamba2"):
+        if kind == "mamba":
+            m = tf.MambaForCausalLM(tf.MambaConfig(vocab_size=320, hidden_size=64, state_size=16, num_hidden_layers=2,
+                                                   conv_kernel=4, expand=2, use_bias=True))
+        elif kind == "falcon_mamba":
+            m = tf.FalconMambaForCausalLM(tf.FalconMambaConfig(vocab_size=320, hidden_size=64, state_size=16,
+                                                               num_hidden_layers=2, conv_kernel=4, expand=2))
+        else:
+            m = tf.Mamba2ForCausalLM(tf.Mamba2Config(vocab_size=320, hidden_size=64, state_size=32, num_heads=8,
+                                                     head_dim=16, n_groups=2, num_hidden_layers=2, conv_kernel=4,
+                                                     expand=2, chunk_size=8, tie_word_embeddings=True))
+        with torch.no_grad():      # the default initialisation is so small that greedy decoding repeats one token
+            for n, p in m.named_parameters():
+                if p.dim() >= 2 and "A_log" not in n:
+                    p.mul_(4.0)
     m = m.float().eval()
     path = os.path.join(tmp, kind)
     m.save_pretrained(path, safe_serialization=True)
@@ -114,12 +129,15 @@ def _save_tiny(tmp, kind):
 
 @pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2", "mixtral", "qwen2_moe", "qwen3_moe",
                                   "deepseek_v2", "deepseek_v2_yarn", "deepseek_v3", "gemma", "gemma2", "phi3",
-                                  "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode"])
+                                  "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
+                                  "falcon_mamba", "mamba2"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]
+    # transformers' eager Mamba-2 normalises the gated output over the whole width, not per group
+    extra = {"hf_overrides": {"gated_norm_groups": 1}} if kind == "mamba2" else {}
     llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
-              max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16)
+              max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16, **extra)
     outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=12,
                                                                                    ignore_eos=True))
     for p, o in zip(prompts, outs):

@@ -537,3 +537,77 @@ def test_int8_linear_matches_integer_reference(M):
     w = torch.randint(-127, 128, (512, 1024), device=DEV, dtype=torch.int8)
     ref = (xq.cpu().long() @ w.cpu().long().t()).float()
     torch.testing.assert_close(_int8_matmul(xq, w).cpu(), ref, rtol=1e-6, atol=0.5)
+
+
+# ---- state-space kernels ---------------------------------------------------------------------------
+def _ragged(lens, computed):
+    """Batch description shared by the state-space kernels: qsl, seq_lens, block table (slot in column 0)."""
+    S = len(lens)
+    qsl = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    seq = torch.tensor([l + c if l else 0 for l, c in zip(lens, computed)], dtype=torch.int32, device=DEV)
+    bt = torch.zeros((S, 4), dtype=torch.int32, device=DEV)
+    bt[:, 0] = torch.randperm(S + 3, device=DEV)[:S].int()
+    return qsl, seq, bt
+
+
+@pytest.mark.parametrize("dt", DTYPES + [torch.float32])
+@pytest.mark.parametrize("W", [2, 3, 4])
+@pytest.mark.parametrize("lens,computed", [([1, 1, 1, 1], [5, 0, 9, 1]), ([7, 150, 1, 2], [0, 0, 3, 2]),
+                                           ([200], [64]), ([3, 1, 70], [1, 0, 0])])
+def test_causal_conv1d(dt, W, lens, computed):
+    C = 328
+    T = sum(lens)
+    qsl, seq, bt = _ragged(lens, computed)
+    x = torch.randn(T, 2 * C, device=DEV, dtype=dt)[:, :C]          # strided rows, like a slice of in_proj's output
+    w = torch.randn(C, W, device=DEV, dtype=dt) * 0.5
+    b = torch.randn(C, device=DEV, dtype=dt)
+    st = torch.randn(len(lens) + 3, C, W - 1, device=DEV, dtype=dt)
+    st_ref = st.clone()
+    y = ops.causal_conv1d(x, w, b, st, qsl, seq, bt, max(lens))
+    y_ref = R.causal_conv1d(x, w, b, st_ref, qsl, seq, bt)
+    torch.testing.assert_close(y.float(), y_ref.float(), **tol(dt if dt != torch.float32 else torch.float16))
+    torch.testing.assert_close(st.float(), st_ref.float(), atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("variant", ["mamba1", "mamba2"])
+@pytest.mark.parametrize("lens,computed", [([1, 1, 1], [4, 0, 30]), ([9, 33, 1], [0, 5, 2]), ([64], [0])])
+def test_selective_scan(dt, variant, lens, computed):
+    T = sum(lens)
+    qsl, seq, bt = _ragged(lens, computed)
+    if variant == "mamba1":
+        Ch, N, E, G = 192, 16, 192, 1
+        A = -torch.rand(Ch, N, device=DEV) * 2
+    else:
+        Ch, N, E, G = 256, 128, 8, 2           # 8 heads of 32 channels, 2 B/C groups
+        A = -torch.rand(E, device=DEV) * 2
+    u = torch.randn(T, Ch, device=DEV, dtype=dt)
+    z = torch.randn(T, Ch, device=DEV, dtype=dt)
+    delta = torch.randn(T, E, device=DEV, dtype=dt) * 0.5
+    bc = torch.randn(T, 2 * G * N + 5, device=DEV, dtype=dt) * 0.3
+    B, C = bc[:, :G * N], bc[:, G * N:2 * G * N]
+    D = torch.randn(E, device=DEV)
+    db = torch.randn(E, device=DEV) * 0.2
+    st = torch.randn(len(lens) + 3, Ch, N, device=DEV)
+    st_ref = st.clone()
+    y = ops.selective_scan(u, delta, A, B, C, D, z, db, st, qsl, seq, bt, num_groups=G)
+    y_ref = R.selective_scan(u, delta, A, B, C, D, z, db, st_ref, qsl, seq, bt, num_groups=G)
+    torch.testing.assert_close(y.float(), y_ref.float(), atol=6e-2 if dt == torch.bfloat16 else 2e-2, rtol=3e-2)
+    torch.testing.assert_close(st, st_ref, atol=2e-3, rtol=2e-3)
+
+
+def test_state_space_kernels_skip_padded_rows():
+    """Rows with seq_len 0 (graph padding) neither read nor write state."""
+    qsl = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV)
+    seq = torch.tensor([3, 0], dtype=torch.int32, device=DEV)
+    bt = torch.tensor([[1], [2]], dtype=torch.int32, device=DEV)
+    C, W, N = 64, 4, 16
+    x = torch.randn(2, C, device=DEV, dtype=torch.bfloat16)
+    cs = torch.randn(4, C, W - 1, device=DEV, dtype=torch.bfloat16)
+    ss = torch.randn(4, C, N, device=DEV)
+    cs0, ss0 = cs.clone(), ss.clone()
+    ops.causal_conv1d(x, torch.randn(C, W, device=DEV, dtype=torch.bfloat16), None, cs, qsl, seq, bt, 1)
+    ops.selective_scan(x, x, -torch.rand(C, N, device=DEV), torch.randn(2, N, device=DEV, dtype=torch.bfloat16),
+                       torch.randn(2, N, device=DEV, dtype=torch.bfloat16), None, None, None, ss, qsl, seq, bt)
+    assert torch.equal(cs[2], cs0[2]) and torch.equal(ss[2], ss0[2])
+    assert not torch.equal(cs[1], cs0[1]) and not torch.equal(ss[1], ss0[1])

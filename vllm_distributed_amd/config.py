@@ -261,7 +261,15 @@ class ModelConfig:
     def get_vocab_size(self) -> int:
         return self.hf_config.vocab_size
 
+    @property
+    def is_attention_free(self) -> bool:
+        """State-space models: no attention layers, one fixed-size state per request instead of a KV cache."""
+        return any(a in ("MambaForCausalLM", "FalconMambaForCausalLM", "Mamba2ForCausalLM")
+                   for a in self.architectures)
+
     def get_total_num_attention_heads(self) -> int:
+        if self.is_attention_free:
+            return 1
         return self.hf_config.get("num_attention_heads") or self.hf_config.get("n_head")
 
     def get_total_num_kv_heads(self) -> int:
@@ -822,6 +830,8 @@ class VllmConfig:
         if sc.enable_chunked_prefill is False and sc.max_num_batched_tokens < mc.max_model_len:
             sc.max_num_batched_tokens = mc.max_model_len
         cc.sliding_window = mc.get_sliding_window()
+        if mc.is_attention_free:
+            cc.enable_prefix_caching = False      # recurrent state cannot be shared by prefix
         if self.lora_config is not None:
             sc.max_loras = self.lora_config.max_loras
         if self.speculative_config is not None and not self.speculative_config.enabled:

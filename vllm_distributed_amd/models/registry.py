@@ -26,6 +26,9 @@ _MODELS: dict[str, tuple[str, str]] = {
     "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
     "DeepseekForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
+    "MambaForCausalLM": ("mamba", "MambaForCausalLM"),
+    "FalconMambaForCausalLM": ("mamba", "FalconMambaForCausalLM"),
+    "Mamba2ForCausalLM": ("mamba", "Mamba2ForCausalLM"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
     "GPT2LMHeadModel": ("opt", "GPT2LMHeadModel"),
     "LlamaModel": ("pooling", "LlamaEmbeddingModel"),

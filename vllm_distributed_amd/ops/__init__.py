@@ -453,3 +453,52 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
            sorted_ids.data_ptr(), offsets.data_ptr(), E, H, I, max_pairs, N.dt(x.dtype), wd, st)
     N.call("vda_moe_sum", out.data_ptr(), out2.data_ptr(), ids.data_ptr(), T, H, k, out.stride(0), N.dt(x.dtype), st)
     return out
+
+
+# ---- state-space layers (Mamba / Mamba-2) ------------------------------------------------------------
+def causal_conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], conv_state: torch.Tensor,
+                  query_start_loc: torch.Tensor, seq_lens: torch.Tensor, block_table: torch.Tensor,
+                  max_query_len: int, activation: bool = True) -> torch.Tensor:
+    """Depthwise causal convolution over a ragged batch.  x [T, C] (row stride arbitrary), weight [C, W],
+    conv_state [slots, C, W-1] holds the last W-1 inputs of every request and is rolled forward in place;
+    sequence s uses slot ``block_table[s, 0]``, and rows with ``seq_lens[s] == 0`` are skipped."""
+    S = seq_lens.shape[0]
+    if not _dev(x):
+        return R.causal_conv1d(x, weight, bias, conv_state, query_start_loc, seq_lens, block_table, activation)
+    T, C = x.shape
+    out = torch.empty((T, C), dtype=x.dtype, device=x.device)
+    assert x.stride(1) == 1 and weight.is_contiguous() and conv_state.is_contiguous()
+    assert conv_state.shape[1] == C and conv_state.shape[2] == weight.shape[1] - 1 and conv_state.dtype == x.dtype
+    N.call("vda_causal_conv1d", out.data_ptr(), x.data_ptr(), weight.data_ptr(), N.ptr(bias), conv_state.data_ptr(),
+           query_start_loc.data_ptr(), seq_lens.data_ptr(), block_table.data_ptr(), block_table.stride(0), S, C,
+           weight.shape[1], max(int(max_query_len), 1), x.stride(0), out.stride(0), int(activation), N.dt(x.dtype),
+           N.stream())
+    return out
+
+
+def selective_scan(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
+                   D: Optional[torch.Tensor], z: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor],
+                   ssm_state: torch.Tensor, query_start_loc: torch.Tensor, seq_lens: torch.Tensor,
+                   block_table: torch.Tensor, softplus: bool = True, num_groups: int = 1) -> torch.Tensor:
+    """Selective state-space scan over a ragged batch with carried state.
+    u, z [T, Ch]; delta [T, Ch] (Mamba) or [T, heads] (Mamba-2: one step size per head);
+    A fp32 [Ch, N] or [heads]; B, C [T, groups * N]; D, delta_bias fp32 with delta's width;
+    ssm_state fp32 [slots, Ch, N], updated in place.  Returns y * silu(z) (y when z is None)."""
+    if not _dev(u):
+        return R.selective_scan(u, delta, A, B, C, D, z, delta_bias, ssm_state, query_start_loc, seq_lens,
+                                block_table, softplus, num_groups)
+    T, Ch = u.shape
+    Nst = ssm_state.shape[2]
+    E = delta.shape[1]
+    assert Ch % E == 0 and Ch % num_groups == 0 and ssm_state.shape[1] == Ch and ssm_state.dtype == torch.float32
+    assert A.dtype == torch.float32 and A.is_contiguous() and ssm_state.is_contiguous()
+    assert B.shape[1] == num_groups * Nst and C.shape[1] == num_groups * Nst
+    for t in (u, delta, B, C) + ((z,) if z is not None else ()):
+        assert t.stride(1) == 1 and t.dtype == u.dtype
+    out = torch.empty((T, Ch), dtype=u.dtype, device=u.device)
+    N.call("vda_selective_scan", out.data_ptr(), u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(),
+           C.data_ptr(), N.ptr(D), N.ptr(z), N.ptr(delta_bias), ssm_state.data_ptr(), query_start_loc.data_ptr(),
+           seq_lens.data_ptr(), block_table.data_ptr(), block_table.stride(0), seq_lens.shape[0], Ch, Nst,
+           u.stride(0), delta.stride(0), B.stride(0), C.stride(0), z.stride(0) if z is not None else 0, out.stride(0),
+           Ch // E, int(A.dim() == 1), Ch // num_groups, int(softplus), N.dt(u.dtype), N.stream())
+    return out

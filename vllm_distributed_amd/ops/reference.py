@@ -306,3 +306,67 @@ def int8_quant(x, scale=None):
         s = scale.float().reshape(())
     q = torch.round(xf / s).clamp(-128, 127).to(torch.int8)
     return q, (s if scale is None else scale)
+
+
+# ---- state-space layers ---------------------------------------------------------------------------
+def causal_conv1d(x, weight, bias, conv_state, qsl, seq_lens, block_table, activation=True):
+    T, C = x.shape
+    W = weight.shape[1]
+    out = torch.zeros((T, C), dtype=x.dtype, device=x.device)
+    w = weight.float()
+    for s in range(seq_lens.shape[0]):
+        sl = int(seq_lens[s])
+        if sl <= 0:
+            continue
+        t0, t1 = int(qsl[s]), int(qsl[s + 1])
+        L = t1 - t0
+        slot = int(block_table[s, 0])
+        prev = conv_state[slot].float() if sl - L > 0 else torch.zeros((C, W - 1), device=x.device)
+        seq = torch.cat([prev.t(), x[t0:t1].float()], dim=0)              # [W-1+L, C]
+        win = seq.unfold(0, W, 1)                                           # [L, C, W]
+        y = (win * w.unsqueeze(0)).sum(-1)
+        if bias is not None:
+            y = y + bias.float()
+        if activation:
+            y = torch.nn.functional.silu(y)
+        out[t0:t1] = y.to(x.dtype)
+        conv_state[slot] = seq[-(W - 1):].t().to(conv_state.dtype)
+    return out
+
+
+def selective_scan(u, delta, A, B, C, D, z, delta_bias, ssm_state, qsl, seq_lens, block_table, softplus=True,
+                   num_groups=1):
+    T, Ch = u.shape
+    Nst = ssm_state.shape[2]
+    E = delta.shape[1]
+    rep = Ch // E
+    out = torch.zeros((T, Ch), dtype=u.dtype, device=u.device)
+    A_full = (A.float().repeat_interleave(rep).unsqueeze(1).expand(Ch, Nst) if A.dim() == 1 else A.float())
+    Dv = D.float().repeat_interleave(rep) if D is not None else None
+    gch = Ch // num_groups
+    for s in range(seq_lens.shape[0]):
+        sl = int(seq_lens[s])
+        if sl <= 0:
+            continue
+        t0, t1 = int(qsl[s]), int(qsl[s + 1])
+        slot = int(block_table[s, 0])
+        h = ssm_state[slot].float().clone() if sl - (t1 - t0) > 0 else torch.zeros((Ch, Nst), device=u.device)
+        for t in range(t0, t1):
+            dt = delta[t].float()
+            if delta_bias is not None:
+                dt = dt + delta_bias.float()
+            if softplus:
+                dt = torch.nn.functional.softplus(dt)
+            dt = dt.repeat_interleave(rep)                                   # [Ch]
+            x = u[t].float()
+            Bt = B[t].float().view(num_groups, Nst).repeat_interleave(gch, dim=0)   # [Ch, N]
+            Ct = C[t].float().view(num_groups, Nst).repeat_interleave(gch, dim=0)
+            h = torch.exp(dt.unsqueeze(1) * A_full) * h + (dt * x).unsqueeze(1) * Bt
+            y = (h * Ct).sum(-1)
+            if Dv is not None:
+                y = y + Dv * x
+            if z is not None:
+                y = y * torch.nn.functional.silu(z[t].float())
+            out[t] = y.to(u.dtype)
+        ssm_state[slot] = h
+    return out

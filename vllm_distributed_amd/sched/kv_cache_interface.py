@@ -77,22 +77,29 @@ class SlidingWindowSpec(AttentionSpec):
 
 @dataclass(frozen=True)
 class MambaSpec(KVCacheSpec):
+    """Recurrent state of one request: several tensors (conv window, SSM state) that may differ in dtype."""
     shapes: tuple = ()
     dtype: torch.dtype = torch.float32
+    dtypes: tuple = ()          # per shape; empty = ``dtype`` for all
 
     @property
     def type_id(self) -> str:
-        return f"mamba_{self.shapes}_{self.dtype}"
+        return f"mamba_{self.shapes}_{self.dtypes or self.dtype}"
 
-    @property
-    def page_size_bytes(self) -> int:
-        n = 0
-        for s in self.shapes:
+    def part_bytes(self) -> list[int]:
+        """Bytes of each state tensor of one request, rounded up to 16 so parts stay aligned."""
+        out = []
+        for i, s in enumerate(self.shapes):
             k = 1
             for d in s:
                 k *= d
-            n += k
-        return n * _dtype_size(self.dtype)
+            k *= _dtype_size(self.dtypes[i] if self.dtypes else self.dtype)
+            out.append((k + 15) // 16 * 16)
+        return out
+
+    @property
+    def page_size_bytes(self) -> int:
+        return sum(self.part_bytes())
 
     def max_memory_usage_bytes(self, max_model_len: int, max_num_batched_tokens: int) -> int:
         return self.page_size_bytes   # one state per request, independent of length

@@ -32,7 +32,7 @@ from ..models.loader import get_model
 from ..models.utils import IntermediateTensors
 from ..parallel.state import get_pp_group, get_tknp_group, get_tp_group, graph_capture
 from ..request import LogprobsLists
-from ..sched.kv_cache_interface import KVCacheConfig, KVCacheSpec
+from ..sched.kv_cache_interface import KVCacheConfig, KVCacheSpec, MambaSpec
 from ..sched.output import EMPTY_MODEL_RUNNER_OUTPUT, ModelRunnerOutput, SchedulerOutput
 from .input_batch import InputBatch
 
@@ -133,7 +133,9 @@ class ModelRunner:
         if self.is_gpu:
             self.model_memory = torch.cuda.memory_allocated(self.device) - before
             logger.info("weights take %.2f GiB, loaded in %.1f s", self.model_memory / 2**30, time.time() - t0)
-        self.attn_layers = {n: m for n, m in self.model.named_modules() if isinstance(m, Attention)}
+        # every layer that owns per-request cache memory: attention layers and state-space mixers
+        self.attn_layers = {n: m for n, m in self.model.named_modules()
+                            if isinstance(m, Attention) or getattr(m, "is_state_space_layer", False)}
         for n, m in self.attn_layers.items():
             m.layer_name = n
         spec = self.vllm_config.speculative_config
@@ -241,6 +243,25 @@ class ModelRunner:
             for t in g:
                 raw = self.kv_chunks[ci][off: off + t.size]
                 sp = spec_of[t.shared_by[0]]
+                if isinstance(sp, MambaSpec):
+                    # one region per state tensor, each [num_blocks, *shape]; a request's slot is its block id
+                    parts, o2 = [], 0
+                    for i, (shape, pb) in enumerate(zip(sp.shapes, sp.part_bytes())):
+                        dt_i = sp.dtypes[i] if sp.dtypes else sp.dtype
+                        numel = 1
+                        for d in shape:
+                            numel *= d
+                        if pb != numel * dt_i.itemsize:
+                            raise ValueError(f"state tensor of {numel * dt_i.itemsize} bytes per request is not "
+                                             "a multiple of 16 bytes")
+                        parts.append(raw[o2: o2 + nb * pb].view(dt_i).view(nb, *shape))
+                        o2 += nb * pb
+                    for n in t.shared_by:
+                        self.attn_layers[n].bind_kv_cache(*parts)
+                        self.kv_layer_loc[n] = (ci, off, t.size)
+                    self.kv_caches.append(tuple(parts))
+                    off += t.size
+                    continue
                 half = t.size // 2
                 k = raw[:half].view(sp.dtype).view(nb, sp.num_kv_heads, sp.block_size, sp.head_size)
                 v = raw[half:].view(sp.dtype).view(nb, sp.num_kv_heads, sp.head_size, sp.block_size)
