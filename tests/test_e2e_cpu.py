@@ -120,7 +120,7 @@ def _save_tiny(tmp, kind):
         with torch.no_grad():      # the default initialisation is so small that greedy decoding repeats one token
             for n, p in m.named_parameters():
                 if p.dim() >= 2 and "A_log" not in n:
-                    p.mul_(4.0)
+                    p.mul_(1.5)
     m = m.float().eval()
     path = os.path.join(tmp, kind)
     m.save_pretrained(path, safe_serialization=True)

@@ -60,8 +60,15 @@ def _reference(model):
                                      ("opt", {"tensor_parallel_size": 2}),
                                      ("llama", {"pipeline_parallel_size": 2}),
                                      ("llama", {"tensor_parallel_size": 2, "compilation_config":
-                                                {"enable_sequence_parallelism": True}})])
-def test_two_rank_matches_single(tmp_path, kind, kw):
+                                                {"enable_sequence_parallelism": True}}),
+                                     ("llama", {"tensor_parallel_size": 2, "compilation_config":
+                                                {"enable_async_tp": True}}),
+                                     ("llama", {"tensor_parallel_size": 2, "pipeline_parallel_size": 1,
+                                                "max_num_batched_tokens": 256, "compilation_config":
+                                                {"enable_async_tp": True}})])
+def test_two_rank_matches_single(tmp_path, kind, kw, monkeypatch):
+    # async TP: every step of at least 8 tokens runs as two micro-batches (mixed decode + chunked prefill)
+    monkeypatch.setenv("VDA_ASYNC_TP_MIN_TOKENS", "8")
     model, _ = _save_tiny(str(tmp_path), kind)
     ref = _reference(model)
     got = _launch(2, model, str(tmp_path / "out"), kw)

@@ -83,6 +83,8 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VLLM_DISABLE_CUSTOM_ALL_REDUCE": (_bool, False),
     "VDA_CUSTOM_AR_MAX_BYTES": (int, 16 * 1024 * 1024),
     "VDA_CUSTOM_AR_ONESHOT_BYTES": (int, 512 * 1024),
+    "VDA_CUSTOM_AR_CHUNKED": (_bool, False),     # messages beyond one arena: chunk through it instead of RCCL
+    "VDA_ASYNC_TP_MIN_TOKENS": (int, 2048),      # async TP: batches of at least this many tokens run as 2 micro-batches
     "VDA_COMM_SPIN_TIMEOUT_MS": (int, 20000),
     "VLLM_ROCM_QUICK_REDUCE_QUANTIZATION": (str.upper, "NONE"),
     "VLLM_ROCM_QUICK_REDUCE_CAST_BF16_TO_FP16": (_bool, False),

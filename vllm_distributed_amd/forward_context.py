@@ -69,9 +69,20 @@ class DPMetadata:
 
 
 @dataclass
+class MicroBatch:
+    """A run of whole sequences of the step's batch: token rows [start, end) and their own metadata
+    (query offsets rebased to the first row).  Two of them let TP collectives of one overlap with the
+    GEMMs of the other."""
+    start: int
+    end: int
+    attn_metadata: AttentionMetadata
+
+
+@dataclass
 class ForwardContext:
     attn_metadata: Optional[AttentionMetadata]
     tknp: Optional[TokenParallelMetadata] = None
+    micro_batches: Optional[list] = None
     dp: Optional[DPMetadata] = None
     kv_connector: Any = None
     extra: dict = field(default_factory=dict)
@@ -93,11 +104,12 @@ def has_forward_context() -> bool:
 
 
 @contextlib.contextmanager
-def set_forward_context(attn_metadata, tknp=None, dp=None, kv_connector=None, num_tokens: int = 0):
+def set_forward_context(attn_metadata, tknp=None, dp=None, kv_connector=None, num_tokens: int = 0,
+                        micro_batches=None):
     global _ctx, _last_log
     track = envs.VLLM_LOG_BATCHSIZE_INTERVAL >= 0 and num_tokens > 0
     t0 = time.perf_counter() if track else 0.0
-    prev, _ctx = _ctx, ForwardContext(attn_metadata, tknp, dp, kv_connector)
+    prev, _ctx = _ctx, ForwardContext(attn_metadata, tknp, micro_batches, dp, kv_connector)
     try:
         yield _ctx
     finally:

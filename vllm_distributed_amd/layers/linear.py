@@ -224,6 +224,18 @@ def set_sequence_parallel(active: bool) -> bool:
     return old
 
 
+_DEFER_REDUCE = False
+
+
+def set_defer_reduce(active: bool) -> bool:
+    """While active, row-parallel layers return their partial sums and the caller owns the reduction
+    (the micro-batched forward starts it on the communication stream and overlaps it with the other
+    micro-batch's GEMMs).  Returns the previous state."""
+    global _DEFER_REDUCE
+    old, _DEFER_REDUCE = _DEFER_REDUCE, bool(active)
+    return old
+
+
 class RowParallelLinear(LinearBase):
     def __init__(self, input_size, output_size, bias=True, input_is_parallel=True, params_dtype=None,
                  reduce_results=True, quant_config=None, prefix=""):
@@ -256,7 +268,7 @@ class RowParallelLinear(LinearBase):
         # bias only once: on rank 0 before the sum
         b = self.bias if (self.tp_rank == 0 or self.tp_size == 1) else None
         y = self.quant_method.apply(self, x, b)
-        if self.reduce_results and self.tp_size > 1:
+        if self.reduce_results and self.tp_size > 1 and not _DEFER_REDUCE:
             if _SEQUENCE_PARALLEL:
                 return tensor_model_parallel_reduce_scatter(y, 0)
             y = tensor_model_parallel_all_reduce(y)

@@ -20,12 +20,13 @@ from ..config import VllmConfig
 from ..layers.attention import Attention
 from ..layers.basic import (LogitsProcessor, ParallelLMHead, RMSNorm, SiluAndMul, VocabParallelEmbedding,
                             get_act_and_mul_fn)
+from ..forward_context import get_forward_context, has_forward_context
 from ..layers.linear import (MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear,
-                             set_sequence_parallel)
+                             set_defer_reduce, set_sequence_parallel)
 from ..layers.rotary import get_rope
 from ..layers.token_parallel import tknp_metadata, token_parallel_attention
 from ..parallel.state import (get_pp_group, get_tensor_model_parallel_rank, get_tensor_model_parallel_world_size,
-                              tensor_model_parallel_all_gather)
+                              get_tp_group, tensor_model_parallel_all_gather)
 from .utils import (IntermediateTensors, PPMissingLayer, load_weights_with_mapping, make_layers, maybe_prefix)
 
 
@@ -161,6 +162,19 @@ class LlamaDecoderLayer(nn.Module):
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
+    # The two halves of ``forward``, split where the TP reductions sit (used with deferred reductions).
+    def attention_phase(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        return self.self_attn(positions, hidden_states), residual
+
+    def mlp_phase(self, hidden_states, residual):
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.mlp(hidden_states), residual
+
 
 class LlamaModel(nn.Module):
     layer_cls = LlamaDecoderLayer
@@ -203,7 +217,10 @@ class LlamaModel(nn.Module):
         else:
             hidden, residual = intermediate_tensors["hidden_states"], intermediate_tensors["residual"]
         sp = self.sequence_parallel and hidden.shape[0] % self.tp == 0 and hidden.shape[0] > 0
-        if not sp:
+        mbs = get_forward_context().micro_batches if (self.tp > 1 and has_forward_context()) else None
+        if mbs and not sp and getattr(self.layer_cls, "supports_sequence_parallel", False):
+            hidden, residual = self._forward_micro_batched(positions, hidden, residual, mbs)
+        elif not sp:
             for layer in self.layers[self.start_layer:self.end_layer]:
                 hidden, residual = layer(positions, hidden, residual)
         else:
@@ -227,6 +244,47 @@ class LlamaModel(nn.Module):
             return IntermediateTensors({"hidden_states": hidden, "residual": residual})
         hidden, _ = self.norm(hidden, residual)
         return hidden
+
+
+def _forward_micro_batched(self, positions, hidden, residual, mbs):
+    """Async tensor parallelism for large (prefill) batches: the batch runs as micro-batches of whole
+    sequences, and every TP all-reduce is started on the communication stream while this stream goes
+    on with the other micro-batch, so xGMI traffic hides behind GEMMs instead of adding to them:
+
+        A.attn -> AR(A) | B.attn -> AR(B) | A.mlp -> AR(A') | B.mlp -> AR(B') | next layer A.attn ...
+
+    Every rank issues the collectives in this same order.  Role of the reference's collective-fusion
+    pass (vllm/compilation/collective_fusion.py), done at run time instead of by graph rewriting."""
+    ctx = get_forward_context()
+    tp = get_tp_group()
+    full_md = ctx.attn_metadata
+    n = len(mbs)
+    pos = [positions[m.start:m.end] for m in mbs]
+    h = [hidden[m.start:m.end] for m in mbs]
+    res = [None if residual is None else residual[m.start:m.end] for m in mbs]
+    pending = [None] * n
+    old = set_defer_reduce(True)
+    try:
+        for layer in self.layers[self.start_layer:self.end_layer]:
+            for i, m in enumerate(mbs):
+                ctx.attn_metadata = m.attn_metadata
+                x = pending[i].wait() if pending[i] is not None else h[i]
+                o, res[i] = layer.attention_phase(pos[i], x, res[i])
+                pending[i] = tp.all_reduce_async(o)
+            for i in range(n):
+                y, res[i] = layer.mlp_phase(pending[i].wait(), res[i])
+                pending[i] = tp.all_reduce_async(y)
+    finally:
+        set_defer_reduce(old)
+        ctx.attn_metadata = full_md
+    h = [pending[i].wait() if pending[i] is not None else h[i] for i in range(n)]
+    tail = hidden[mbs[-1].end:]          # padding rows beyond the scheduled tokens, if any
+    if tail.shape[0]:
+        h, res = h + [tail], res + [tail]
+    return torch.cat(h, dim=0), torch.cat(res, dim=0)
+
+
+LlamaModel._forward_micro_batched = _forward_micro_batched
 
 
 class LlamaForCausalLM(nn.Module):

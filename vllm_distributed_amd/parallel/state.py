@@ -36,6 +36,22 @@ class GraphCaptureContext:
     stream: Any
 
 
+class AsyncWork:
+    """Result of ``GroupCoordinator.all_reduce_async``: ``wait()`` orders the caller's current stream
+    after the collective and hands out the reduced tensor."""
+
+    def __init__(self, out: torch.Tensor, done):
+        self.out, self.done = out, done
+
+    def wait(self) -> torch.Tensor:
+        if self.done is not None:
+            cur = torch.cuda.current_stream(self.out.device)
+            cur.wait_event(self.done)
+            self.out.record_stream(cur)    # allocated on the comm stream, consumed (and freed) on this one
+            self.done = None
+        return self.out
+
+
 class GroupCoordinator:
     def __init__(self, ranks: Sequence[int], rank: int, local_rank: int, backend: str, name: str,
                  use_device_comm: bool = False, use_message_queue: bool = False):
@@ -59,6 +75,7 @@ class GroupCoordinator:
         self.rccl_comm = None     # stream-explicit RCCL (graph capturable)
         self.mq_broadcaster = None
         self.all2all = None
+        self._comm_stream = None  # side stream of all_reduce_async
         self._use_device_comm = use_device_comm and backend in ("nccl", "gloo+hip")
         self._use_mq = use_message_queue
 
@@ -137,7 +154,10 @@ class GroupCoordinator:
                 out = self.qr_comm.all_reduce(x)
                 if out is not None:
                     return out
-            if self.ca_comm is not None:
+            if self.ca_comm is not None and (self.rccl_comm is None or envs.VDA_CUSTOM_AR_CHUNKED
+                                             or x.numel() * x.element_size() <= self.ca_comm.max_bytes):
+                # latency-bound sizes (decode) take the peer-memory kernel; messages beyond one arena
+                # (prefill chunks, 100+ MiB) are bandwidth bound and go to RCCL
                 out = self.ca_comm.all_reduce(x)
                 if out is not None:
                     return out
@@ -148,6 +168,27 @@ class GroupCoordinator:
         if h is not x:
             x.copy_(h)
         return x
+
+    def all_reduce_async(self, x: torch.Tensor) -> "AsyncWork":
+        """Start the all-reduce of ``x`` on this group's communication stream and return at once; the
+        caller keeps issuing independent kernels on its own stream and calls ``wait()`` where the sum is
+        needed.  All ranks must start their collectives in the same order.  On the host path (and for
+        groups of one) the work is finished before this returns."""
+        if self.world_size == 1 or not x.is_cuda:
+            return AsyncWork(self.all_reduce(x), None)
+        cur = torch.cuda.current_stream(x.device)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=x.device)
+        comm = self._comm_stream
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        comm.wait_event(ready)
+        x.record_stream(comm)              # produced on the caller's stream, consumed on the comm stream
+        with torch.cuda.stream(comm):
+            out = self.all_reduce(x)
+            done = torch.cuda.Event()
+            done.record(comm)
+        return AsyncWork(out, done)
 
     def all_gather(self, x: torch.Tensor, dim: int = -1) -> torch.Tensor:
         if self.world_size == 1:

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from .. import envs, ops
 from ..config import VllmConfig
-from ..forward_context import AttentionMetadata, TokenParallelMetadata, set_forward_context
+from ..forward_context import AttentionMetadata, MicroBatch, TokenParallelMetadata, set_forward_context
 from ..layers.attention import Attention
 from ..layers.sampler import Sampler, SamplingMetadata
 from ..logger import init_logger
@@ -79,6 +79,10 @@ class ModelRunner:
         pcfg = vllm_config.parallel_config
         self.sp_multiple = pcfg.tensor_parallel_size if vllm_config.compilation_config.enable_sequence_parallelism \
             else 1
+        # async tensor parallelism: large eager batches run as two micro-batches whose all-reduces
+        # overlap with each other's GEMMs (models/llama.py::_forward_micro_batched)
+        self.async_tp = bool(vllm_config.compilation_config.enable_async_tp
+                             and pcfg.tensor_parallel_size > 1 and self.tknp_size == 1 and self.sp_multiple == 1)
         self.graph_pool = None
         self._step = 0
         self._rng = np.random.default_rng(mc.seed)
@@ -104,6 +108,8 @@ class ModelRunner:
         self.query_start_loc = torch.zeros(Spad + 1, dtype=torch.int32, device=dev)
         self.prefill_qsl = torch.zeros(Spad + 1, dtype=torch.int32, device=dev)
         self.logits_indices = torch.zeros(Tpad, dtype=torch.int64, device=dev)
+        self.mb_qsl = torch.zeros(Spad + 1, dtype=torch.int32, device=dev)          # second micro-batch, rebased
+        self.mb_prefill_qsl = torch.zeros(Spad + 1, dtype=torch.int32, device=dev)
         self.pin = self.is_gpu
         self.intermediate: Optional[IntermediateTensors] = None
 
@@ -472,6 +478,43 @@ class ModelRunner:
             max_query_len=max_q, max_seq_len=max_seq, max_decode_query_len=self.max_decode_q,
             decode_num_splits=nsplit, decode_workspace=self._workspace(max(ndt, 1), nsplit))
 
+    def _make_micro_batches(self, rows, n_sched, cu, S, T, nd) -> Optional[list]:
+        """Split the step's sequences into two runs of about equal token count (None when one sequence
+        dominates).  The first run reuses the step's own device arrays; the second gets its query
+        offsets rebased to its first row."""
+        if S < 2:
+            return None
+        k = int(np.argmin(np.abs(cu[1:S].astype(np.int64) - T // 2))) + 1
+        if min(int(cu[k]), T - int(cu[k])) * 4 < T:
+            return None
+        ib = self.input_batch
+        seq_lens = (ib.num_computed[rows] + n_sched).astype(np.int64)
+        out = []
+        for a, b in ((0, k), (k, S)):
+            nd_u = min(max(nd - a, 0), b - a)
+            t0, t1 = int(cu[a]), int(cu[b])
+            ndt_u = int(cu[a + nd_u]) - t0
+            if a == 0:
+                qsl, pqsl = self.query_start_loc[: b + 1], self.prefill_qsl[: b - nd_u + 1]
+            else:
+                self._to_dev(self.mb_qsl, (cu[a: b + 1] - cu[a]).astype(np.int32))
+                qsl = self.mb_qsl[: b - a + 1]
+                p = a + nd_u
+                self._to_dev(self.mb_prefill_qsl, (cu[p: b + 1] - cu[p]).astype(np.int32))
+                pqsl = self.mb_prefill_qsl[: b - p + 1]
+            max_seq = int(seq_lens[a:b].max())
+            nsplit = self._decode_splits(nd_u, max_seq, False)
+            md = AttentionMetadata(
+                num_actual_tokens=t1 - t0, num_decode_seqs=nd_u, num_decode_tokens=ndt_u,
+                num_prefill_seqs=b - a - nd_u, num_prefill_tokens=t1 - t0 - ndt_u,
+                slot_mapping=self.slot_mapping[t0:], block_table=self.block_table[a:b], seq_lens=self.seq_lens[a:b],
+                query_start_loc=qsl, prefill_query_start_loc=pqsl if nd_u < b - a else None,
+                max_query_len=int(n_sched[a:b].max()), max_seq_len=max_seq,
+                max_decode_query_len=self.max_decode_q, decode_num_splits=nsplit,
+                decode_workspace=self._workspace(max(ndt_u, 1), nsplit))
+            out.append(MicroBatch(t0, t1, md))
+        return out
+
     # ------------------------------------------------------------------
     @torch.inference_mode()
     def execute_model(self, so: SchedulerOutput, intermediate_tensors: Optional[IntermediateTensors] = None
@@ -527,7 +570,11 @@ class ModelRunner:
                 T_in = P_in = (T + tp - 1) // tp * tp
                 self.input_ids[T:T_in].zero_()
                 self.positions[T:T_in].zero_()
-            with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T):
+            mbs = None
+            if self.async_tp and T >= envs.VDA_ASYNC_TP_MIN_TOKENS and conn is None and self.lora_manager is None \
+                    and inputs_embeds is None and T_in == T:
+                mbs = self._make_micro_batches(rows, n_sched, cu, S, T, nd)
+            with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T, micro_batches=mbs):
                 if conn is not None:
                     conn.start_load_kv()
                 hidden = self.model(self.input_ids[:T_in], self.positions[:P_in], inter, inputs_embeds)
