@@ -44,14 +44,19 @@ def _launch(world, model, out, kw, extra_env):
     return [json.load(open(f"{out}.{r}")) for r in range(world)], logs
 
 
-@pytest.mark.parametrize("eager", [True, False])
-def test_tp2_on_one_gpu(tmp_path, eager):
+@pytest.mark.parametrize("eager,async_tp", [(True, False), (False, False), (False, True)])
+def test_tp2_on_one_gpu(tmp_path, eager, async_tp):
     from tests.test_e2e_cpu import _save_tiny
     model, _ = _save_tiny(str(tmp_path), "llama")
     kw = dict(device="cuda", dtype="bfloat16", gpu_memory_utilization=0.03, enforce_eager=eager, max_num_seqs=8)
     single, _ = _launch(1, model, str(tmp_path / "one"), kw, {})
-    got, logs = _launch(2, model, str(tmp_path / "two"), dict(kw, tensor_parallel_size=2),
-                        {"VDA_REHEARSE_ON_ONE_GPU": "1", "VLLM_LOGGING_LEVEL": "INFO"})
+    env = {"VDA_REHEARSE_ON_ONE_GPU": "1", "VLLM_LOGGING_LEVEL": "INFO"}
+    if async_tp:
+        # prefill steps run as two micro-batches with their all-reduces on the communication stream,
+        # decode steps replay graphs
+        kw = dict(kw, compilation_config={"enable_async_tp": True})
+        env["VDA_ASYNC_TP_MIN_TOKENS"] = "8"
+    got, logs = _launch(2, model, str(tmp_path / "two"), dict(kw, tensor_parallel_size=2), env)
     assert got[0] == got[1], "tensor-parallel ranks disagree"
     assert any("peer-memory all-reduce enabled" in l for l in logs), logs[0][-2000:]
     # bf16 sums are reassociated across ranks, so allow a few near-tie flips but not a different model
