@@ -36,6 +36,7 @@ def main() -> None:
     ap.add_argument("--output-len", type=int, default=128)
     ap.add_argument("--max-num-batched-tokens", type=int, default=16384)
     ap.add_argument("--enforce-eager", action="store_true")
+    ap.add_argument("--no-async-tp", action="store_true", help="keep TP all-reduces on the compute stream")
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
     a = ap.parse_args()
 
@@ -54,6 +55,9 @@ def main() -> None:
     kw = {}
     if world > 1:
         kw["distributed_executor_backend"] = "external_launcher"
+        if not a.no_async_tp:
+            # prefill chunks run as two micro-batches whose TP all-reduces overlap with each other's GEMMs
+            kw["compilation_config"] = {"enable_async_tp": True}
     llm = LLM(model=a.model, load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16",
               tensor_parallel_size=a.gpus, max_model_len=a.input_len + a.output_len + 16,
               max_num_seqs=max(a.batch, 8), max_num_batched_tokens=a.max_num_batched_tokens,
