@@ -611,3 +611,21 @@ def test_state_space_kernels_skip_padded_rows():
                        torch.randn(2, N, device=DEV, dtype=torch.bfloat16), None, None, None, ss, qsl, seq, bt)
     assert torch.equal(cs[2], cs0[2]) and torch.equal(ss[2], ss0[2])
     assert not torch.equal(cs[1], cs0[1]) and not torch.equal(ss[1], ss0[1])
+
+
+# ---- 4-bit weights ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K,G", [(1, 4096, 4096, 128), (7, 1024, 8192, 64), (33, 512, 1024, 32),
+                                     (64, 6144, 4096, 128), (200, 256, 512, 128)])
+def test_w4_linear(dt, M, N, K, G):
+    q = torch.randint(0, 16, (N, K), device=DEV)
+    qw = ops.w4_pack(q)
+    scales = (torch.rand(N, K // G, device=DEV) * 0.02 + 0.005).to(dt)
+    zeros = torch.randint(0, 17, (N, K // G), device=DEV).to(dt)
+    x = torch.randn(M, K, device=DEV, dtype=dt)
+    b = torch.randn(N, device=DEV, dtype=dt)
+    w_ref = R.w4_dequant(qw, scales, zeros, G, torch.float32)
+    torch.testing.assert_close(ops.w4_dequant(qw, scales, zeros, G, dt).float(), w_ref, atol=2e-3, rtol=1e-2)
+    y = ops.w4_linear(x, qw, scales, zeros, G, b)
+    y_ref = x.float() @ w_ref.t() + b.float()
+    torch.testing.assert_close(y.float(), y_ref, atol=0.15 if dt == torch.bfloat16 else 0.03, rtol=2e-2)

@@ -130,11 +130,14 @@ def _int4_quantise(w, group):
     return q.reshape(K, N).to(torch.int32), zeros.to(torch.int32), scales, deq
 
 
-@pytest.mark.parametrize("fmt", ["gptq", "awq", "fp8_block"])
-def test_weight_only_checkpoints_are_dequantised_while_loading(tmp_path, fmt):
+@pytest.mark.parametrize("fmt,packed", [("gptq", True), ("gptq", False), ("awq", True), ("awq", False),
+                                        ("fp8_block", False)])
+def test_weight_only_checkpoints_are_dequantised_while_loading(tmp_path, fmt, packed, monkeypatch):
     """A GPTQ / AWQ / block-fp8 checkpoint of the tiny Llama generates the tokens of the HF model
-    that holds the dequantised weights."""
+    that holds the dequantised weights, with the 4-bit weights kept packed (W4A16 layers) or expanded
+    while loading."""
     import json
+    monkeypatch.setenv("VDA_INT4_WEIGHTS", "1" if packed else "0")
     import os
 
     from safetensors.torch import load_file, save_file
@@ -184,6 +187,9 @@ def test_weight_only_checkpoints_are_dequantised_while_loading(tmp_path, fmt):
               max_num_batched_tokens=64)
     outs = llm.generate(prompt_token_ids=prompts,
                         sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    names = {n for n, _ in llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+             .named_parameters()}
+    assert any(n.endswith("qkv_proj.qweight") for n in names) == packed
     llm.shutdown()
     for p, o in zip(prompts, outs):
         with torch.no_grad():

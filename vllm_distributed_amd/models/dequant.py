@@ -62,15 +62,73 @@ def dequantize_awq(qweight, qzeros, scales, bits: int, dtype: torch.dtype) -> to
     return w.t().contiguous().to(dtype)
 
 
+def gptq_to_packed4(qweight, qzeros, scales, zero_offset: int, dtype: torch.dtype):
+    """GPTQ 4-bit tensors -> (packed int32 [N, K/8], scales [N, G], zero points [N, G]) for ops.w4_linear."""
+    from ..ops import w4_pack
+    q = _unpack_rows(qweight, 4).t().contiguous()                     # [N, K]
+    z = (_unpack_cols(qzeros, 4) + zero_offset).t().contiguous()      # [N, G]
+    return w4_pack(q), scales.t().contiguous().to(dtype), z.to(dtype)
+
+
+def awq_to_packed4(qweight, qzeros, scales, dtype: torch.dtype):
+    from ..ops import w4_pack
+
+    def cols(p):
+        v = _unpack_cols(p, 4)
+        return v.view(v.shape[0], -1, 8)[:, :, _AWQ_ORDER].reshape(v.shape[0], -1)
+    q = cols(qweight).t().contiguous()                                # [N, K]
+    z = cols(qzeros).t().contiguous()                                 # [N, G]
+    return w4_pack(q), scales.t().contiguous().to(dtype), z.to(dtype)
+
+
 def dequantize_block_fp8(weight, scale_inv, block: tuple[int, int], dtype: torch.dtype) -> torch.Tensor:
     N, K = weight.shape
     s = scale_inv.to(torch.float32).repeat_interleave(block[0], 0)[:N].repeat_interleave(block[1], 1)[:, :K]
     return (weight.to(torch.float32) * s).to(dtype)
 
 
+class Int4LinearMethod:
+    """Linear layer over packed 4-bit weights with group scales and zero points (W4A16): decode-sized
+    batches stream a quarter of the bytes through the MFMA skinny kernel (ops/csrc/w4.hip).
+    Reference: vllm/model_executor/layers/quantization/gptq.py:GPTQLinearMethod, awq.py:AWQLinearMethod."""
+
+    def __init__(self, group_size: int):
+        self.group_size = group_size
+
+    def create_weights(self, layer, in_per_rank: int, out_per_rank: int, dtype: torch.dtype) -> None:
+        import torch.nn as nn
+        from ..layers.linear import set_weight_attrs
+        total_in = getattr(layer, "input_size", in_per_rank)
+        G = self.group_size if self.group_size > 0 else total_in
+        whole = G >= total_in                    # one group spans all of K: scales are not split by row-parallel TP
+        g_per_rank = 1 if whole else in_per_rank // G
+        if in_per_rank % 8 or (not whole and in_per_rank % G):
+            raise ValueError(f"{getattr(layer, 'prefix', '')}: {in_per_rank} input features per rank do not "
+                             f"divide into groups of {G}")
+        layer.w4_group = in_per_rank if whole else G
+        qw = nn.Parameter(torch.zeros(out_per_rank, in_per_rank // 8, dtype=torch.int32), requires_grad=False)
+        set_weight_attrs(qw, {"input_dim": 1, "output_dim": 0})
+        layer.register_parameter("qweight", qw)
+        for name in ("scales", "qzeros"):
+            p = nn.Parameter(torch.zeros(out_per_rank, g_per_rank, dtype=dtype), requires_grad=False)
+            set_weight_attrs(p, {"output_dim": 0} if whole else {"input_dim": 1, "output_dim": 0})
+            layer.register_parameter(name, p)
+
+    def process_weights_after_loading(self, layer) -> None:
+        pass
+
+    def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        from .. import ops
+        shape = x.shape
+        y = ops.w4_linear(x.reshape(-1, shape[-1]), layer.qweight, layer.scales, layer.qzeros, layer.w4_group, bias)
+        return y.view(*shape[:-1], -1)
+
+
 class LoadTimeDequant:
-    """What the loader needs to know about a weight-only format; carries no layer methods, so the
-    model is built with ordinary 16-bit layers."""
+    """What the loader needs to know about a weight-only format.  4-bit GPTQ / AWQ linear layers without
+    activation reordering keep their 4-bit weights (repacked for the W4A16 kernel, ``Int4LinearMethod``);
+    everything else (2/8-bit, act-order, expert weights, block fp8) is expanded to 16 bit while loading,
+    so those layers are ordinary ones."""
 
     def __init__(self, method: str, cfg: dict):
         self.method = method
@@ -80,25 +138,48 @@ class LoadTimeDequant:
         self.zero_offset = 0 if str(cfg.get("checkpoint_format", "gptq")) == "gptq_v2" else 1
         if method in ("gptq", "awq") and self.bits not in (2, 4, 8):
             raise ValueError(f"{method}: {self.bits}-bit weights are not supported (2, 4, 8)")
+        from .. import envs
+        self.group_size = int(cfg.get("group_size", cfg.get("q_group_size", 128)) or 128)
+        self.skip = list(cfg.get("modules_to_not_convert") or [])
+        self.pack4 = (method in ("gptq", "awq") and self.bits == 4 and not cfg.get("desc_act", False)
+                      and envs.VDA_INT4_WEIGHTS and (self.group_size == -1 or self.group_size % 32 == 0))
+
+    def _packed(self, prefix: str) -> bool:
+        return self.pack4 and ".experts." not in prefix and not prefix.endswith("lm_head") \
+            and not any(s and s in prefix for s in self.skip)
 
     def get_quant_method(self, layer, prefix):
+        from ..layers.linear import LinearBase
+        if isinstance(layer, LinearBase) and self._packed(prefix):
+            return Int4LinearMethod(self.group_size)
         return None
 
     def wrap(self, weights: Iterable[tuple[str, torch.Tensor]], dtype: torch.dtype) -> Iterator[tuple[str, torch.Tensor]]:
         pending: dict[str, dict[str, torch.Tensor]] = {}
         parts = ("qweight", "qzeros", "scales", "g_idx", "weight_scale_inv")
 
-        def finish(prefix: str, d: dict) -> Optional[torch.Tensor]:
+        def finish(prefix: str, d: dict):
             if self.method == "fp8":
                 if "weight" in d and "weight_scale_inv" in d:
                     return dequantize_block_fp8(d["weight"], d["weight_scale_inv"], self.block, dtype)
                 return None
             if not all(k in d for k in ("qweight", "qzeros", "scales")):
                 return None
+            if self._packed(prefix):
+                qw, sc, z = (awq_to_packed4(d["qweight"], d["qzeros"], d["scales"], dtype) if self.method == "awq"
+                             else gptq_to_packed4(d["qweight"], d["qzeros"], d["scales"], self.zero_offset, dtype))
+                return {"qweight": qw, "scales": sc, "qzeros": z}
             if self.method == "awq":
                 return dequantize_awq(d["qweight"], d["qzeros"], d["scales"], self.bits, dtype)
             return dequantize_gptq(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), self.bits,
                                    self.zero_offset, dtype)
+
+        def emit(prefix: str, w):
+            if isinstance(w, dict):
+                for leaf, t in w.items():
+                    yield f"{prefix}.{leaf}", t
+            else:
+                yield f"{prefix}.weight", w
 
         for name, t in weights:
             prefix, _, leaf = name.rpartition(".")
@@ -114,9 +195,9 @@ class LoadTimeDequant:
                 w = finish(prefix, d)
                 if w is not None:
                     del pending[prefix]
-                    yield f"{prefix}.weight", w
+                    yield from emit(prefix, w)
         for prefix, d in pending.items():
             w = finish(prefix, d)
             if w is None:
                 raise ValueError(f"{prefix}: incomplete {self.method} tensors in the checkpoint ({sorted(d)})")
-            yield f"{prefix}.weight", w
+            yield from emit(prefix, w)

@@ -372,6 +372,46 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return torch.nn.functional.linear(x, w, bias)
 
 
+# ---- 4-bit weight-only linear (GPTQ / AWQ) ------------------------------------------------------
+def w4_pack(q: torch.Tensor) -> torch.Tensor:
+    """Integer weights [N, K] with values 0..15 -> the kernel's packed form, int32 [N, K/8]: element e
+    of every 8 sits in nibble 2*(e%4) + e//4 (see ops/csrc/w4.hip)."""
+    N_, K = q.shape
+    v = q.to(torch.int64).view(N_, K // 8, 8)
+    word = torch.zeros((N_, K // 8), dtype=torch.int64, device=q.device)
+    for e in range(8):
+        word |= (v[:, :, e] & 0xF) << (4 * (2 * (e % 4) + e // 4))
+    return word.to(torch.uint32).view(torch.int32) if hasattr(torch, "uint32") else word.to(torch.int32)
+
+
+def w4_dequant(qw: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, group: int,
+               dtype: torch.dtype) -> torch.Tensor:
+    """Packed 4-bit weights -> [N, K] in ``dtype``: (q - zero) * scale per group of ``group`` K elements."""
+    N_, K = qw.shape[0], qw.shape[1] * 8
+    if not _dev(qw) or dtype not in (torch.bfloat16, torch.float16):
+        return R.w4_dequant(qw, scales, zeros, group, dtype)
+    out = torch.empty((N_, K), dtype=dtype, device=qw.device)
+    N.call("vda_w4_dequant", out.data_ptr(), qw.data_ptr(), scales.data_ptr(), zeros.data_ptr(), N_, K, group,
+           N.dt(dtype), N.stream())
+    return out
+
+
+def w4_linear(x: torch.Tensor, qw: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, group: int,
+              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ dequant(qw).T (+ bias).  Up to 64 rows stream the packed weights once through the MFMA
+    skinny kernel (a quarter of the bytes of 16-bit weights); more rows expand them and use the
+    library GEMM."""
+    M, K = x.shape
+    N_ = qw.shape[0]
+    if _dev(x) and M <= 64 and N_ % 16 == 0 and K % 128 == 0 and group % 32 == 0 and x.stride(1) == 1 \
+            and x.dtype in (torch.bfloat16, torch.float16) and scales.dtype == x.dtype:
+        y = torch.empty((M, N_), dtype=x.dtype, device=x.device)
+        N.call("vda_w4_skinny_gemm", y.data_ptr(), x.data_ptr(), qw.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+               N.ptr(bias), M, N_, K, group, x.stride(0), y.stride(0), N.dt(x.dtype), N.stream())
+        return y
+    return torch.nn.functional.linear(x, w4_dequant(qw, scales, zeros, group, x.dtype), bias)
+
+
 # ---- mixture of experts ------------------------------------------------------------------------
 def moe_topk_softmax(logits: torch.Tensor, k: int, renormalize: bool = True):
     """Router: softmax over experts then top-k.  Returns (weights f32 [T,k], ids i32 [T,k])."""

@@ -370,3 +370,18 @@ def selective_scan(u, delta, A, B, C, D, z, delta_bias, ssm_state, qsl, seq_lens
             out[t] = y.to(u.dtype)
         ssm_state[slot] = h
     return out
+
+
+# ---- 4-bit weights -----------------------------------------------------------------------------------
+def w4_unpack(qw: torch.Tensor) -> torch.Tensor:
+    """int32 [N, K/8] in the kernel's nibble order -> int64 [N, K] of values 0..15."""
+    w = qw.to(torch.int64) & 0xFFFFFFFF
+    cols = [(w >> (4 * (2 * (e % 4) + e // 4))) & 0xF for e in range(8)]
+    return torch.stack(cols, dim=-1).reshape(qw.shape[0], -1)
+
+
+def w4_dequant(qw, scales, zeros, group, dtype):
+    q = w4_unpack(qw).float()
+    s = scales.float().repeat_interleave(group, dim=1)
+    z = zeros.float().repeat_interleave(group, dim=1)
+    return ((q - z) * s).to(dtype)
