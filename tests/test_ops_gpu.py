@@ -629,3 +629,19 @@ def test_w4_linear(dt, M, N, K, G):
     y = ops.w4_linear(x, qw, scales, zeros, G, b)
     y_ref = x.float() @ w_ref.t() + b.float()
     torch.testing.assert_close(y.float(), y_ref, atol=0.15 if dt == torch.bfloat16 else 0.03, rtol=2e-2)
+
+
+# ---- multi-LoRA ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T,K,N,Rk", [(1, 4096, 4096, 16), (37, 1024, 3072, 8), (256, 2048, 512, 64)])
+def test_lora_update(dt, T, K, N, Rk):
+    slots = 4
+    x = torch.randn(T, K, device=DEV, dtype=dt)
+    y = torch.randn(T, N, device=DEV, dtype=dt)
+    A = torch.randn(slots, Rk, K, device=DEV, dtype=dt) * (K ** -0.5)
+    B = torch.randn(slots, N, Rk, device=DEV, dtype=dt) * 0.3
+    ts = torch.randint(-1, slots, (T,), device=DEV, dtype=torch.int32)
+    y_ref = y.clone()
+    R.lora_update(y_ref, x, A, B, ts)
+    ops.lora_update(y, x, A, B, ts)
+    torch.testing.assert_close(y.float(), y_ref.float(), **tol(dt))

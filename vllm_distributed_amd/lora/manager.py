@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from ..layers.linear import (ColumnParallelLinear, LinearBase, MergedColumnParallelLinear, QKVParallelLinear,
                              RowParallelLinear)
+from .. import envs, ops
 from ..logger import init_logger
 
 logger = init_logger(__name__)
@@ -97,6 +98,13 @@ class _LoRALinearMethod:
         A, B = layer.lora_A, layer.lora_B
         x2 = x.reshape(-1, x.shape[-1])
         y2 = y.view(-1, y.shape[-1])
+        ts = self.manager.token_slots
+        if ts is not None and x2.shape[0] <= envs.VDA_LORA_KERNEL_MAX_TOKENS and ops.lora_update_ok(x2, A, B) \
+                and ts.shape[0] == x2.shape[0]:
+            # decode-sized batch: one shrink + one expand launch for all adapters (slots without weights
+            # for this layer hold zeros)
+            ops.lora_update(y2, x2 if x2.stride(1) == 1 else x2.contiguous(), A, B, ts)
+            return y
         for slot, idx in groups:
             if not layer.lora_has[slot]:
                 continue
@@ -123,6 +131,7 @@ class LoRAManager:
         self.slot_of: "OrderedDict[int, int]" = OrderedDict()        # adapter id -> device slot (LRU order)
         self.free_slots = list(range(self.max_loras))
         self.active_groups: list[tuple[int, Optional[torch.Tensor]]] = []
+        self.token_slots: Optional[torch.Tensor] = None       # int32 [T] adapter slot of every token row (-1: none)
         self.layers: dict[str, LinearBase] = {}
         for name, m in model.named_modules():
             if isinstance(m, LinearBase) and "lm_head" not in name and isinstance(
@@ -210,6 +219,9 @@ class LoRAManager:
             layer.lora_has[slot] = any(p is not None for p in parts)
             if layer.lora_has[slot]:
                 self._shard_into(layer, slot, parts)
+            else:                                   # the fused kernel reads every slot: no stale weights
+                layer.lora_A[slot].zero_()
+                layer.lora_B[slot].zero_()
         self.slot_of[lora.id] = slot
         return slot
 
@@ -256,6 +268,7 @@ class LoRAManager:
     def set_active(self, req_ids: list[str], rows: np.ndarray, n_sched: np.ndarray, ib) -> None:
         ids = ib.lora_id[rows]
         self.active_groups = []
+        self.token_slots = None
         if not (ids > 0).any():
             return
         busy = set(int(i) for i in np.unique(ids) if i > 0)
@@ -268,6 +281,7 @@ class LoRAManager:
                 self.add_adapter(ib.reqs[rid].lora_request)
             slot_by_id[lid] = self._activate(self.cpu_cache[lid], busy)
         tok_slot = np.repeat(np.array([slot_by_id.get(int(i), -1) for i in ids], dtype=np.int64), n_sched)
+        self.token_slots = torch.from_numpy(tok_slot.astype(np.int32)).to(self.device, non_blocking=True)
         for slot in sorted(set(slot_by_id.values())):
             idx = np.nonzero(tok_slot == slot)[0]
             if len(idx) == len(tok_slot):
@@ -277,3 +291,4 @@ class LoRAManager:
 
     def clear_active(self) -> None:
         self.active_groups = []
+        self.token_slots = None

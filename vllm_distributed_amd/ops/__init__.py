@@ -412,6 +412,28 @@ def w4_linear(x: torch.Tensor, qw: torch.Tensor, scales: torch.Tensor, zeros: to
     return torch.nn.functional.linear(x, w4_dequant(qw, scales, zeros, group, x.dtype), bias)
 
 
+# ---- multi-LoRA ----------------------------------------------------------------------------------
+def lora_update_ok(x: torch.Tensor, A: torch.Tensor, B: torch.Tensor) -> bool:
+    return (_dev(x) and x.dtype in (torch.bfloat16, torch.float16) and A.dtype == x.dtype and B.dtype == x.dtype
+            and x.shape[-1] % 8 == 0 and B.shape[1] % 8 == 0 and A.shape[1] % 8 == 0 and A.shape[1] <= 256)
+
+
+def lora_update(y: torch.Tensor, x: torch.Tensor, A: torch.Tensor, B: torch.Tensor, tok_slot: torch.Tensor) -> None:
+    """y[t] += B[s] @ (A[s] @ x[t]) with s = tok_slot[t] (rows with s < 0 untouched), in place.
+    x [T, K], y [T, N], A [slots, R, K], B [slots, N, R], tok_slot int32 [T]."""
+    T, K = x.shape
+    R_, N_ = A.shape[1], B.shape[1]
+    if not lora_update_ok(x, A, B):
+        return R.lora_update(y, x, A, B, tok_slot)
+    assert x.stride(1) == 1 and y.stride(1) == 1 and A.is_contiguous() and B.is_contiguous()
+    h = torch.empty((T, R_), dtype=torch.float32, device=x.device)
+    st = N.stream()
+    N.call("vda_lora_shrink", h.data_ptr(), x.data_ptr(), A.data_ptr(), tok_slot.data_ptr(), T, R_, K, x.stride(0),
+           N.dt(x.dtype), st)
+    N.call("vda_lora_expand", y.data_ptr(), h.data_ptr(), B.data_ptr(), tok_slot.data_ptr(), T, R_, N_, y.stride(0),
+           N.dt(x.dtype), st)
+
+
 # ---- mixture of experts ------------------------------------------------------------------------
 def moe_topk_softmax(logits: torch.Tensor, k: int, renormalize: bool = True):
     """Router: softmax over experts then top-k.  Returns (weights f32 [T,k], ids i32 [T,k])."""

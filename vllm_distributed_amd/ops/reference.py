@@ -385,3 +385,13 @@ def w4_dequant(qw, scales, zeros, group, dtype):
     s = scales.float().repeat_interleave(group, dim=1)
     z = zeros.float().repeat_interleave(group, dim=1)
     return ((q - z) * s).to(dtype)
+
+
+# ---- multi-LoRA --------------------------------------------------------------------------------------
+def lora_update(y, x, A, B, tok_slot):
+    for s in torch.unique(tok_slot).tolist():
+        if s < 0:
+            continue
+        idx = torch.nonzero(tok_slot == s).squeeze(1)
+        d = (x[idx].float() @ A[s].float().t()) @ B[s].float().t()
+        y[idx] = (y[idx].float() + d).to(y.dtype)
