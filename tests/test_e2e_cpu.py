@@ -47,6 +47,15 @@ def _save_tiny(tmp, kind):
                                 num_experts=4, num_experts_per_tok=2, moe_intermediate_size=128, head_dim=64,
                                 decoder_sparse_step=1, norm_topk_prob=True, use_sliding_window=False)
         m = tf.Qwen3MoeForCausalLM(cfg)
+    elif kind == "deepseek_v2_mla":
+        # latent sizes the GPU MLA kernel is built for (kv_lora_rank 64 + rope 32)
+        cfg = tf.DeepseekV2Config(vocab_size=320, hidden_size=128, intermediate_size=256, moe_intermediate_size=64,
+                                  num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                                  n_shared_experts=1, n_routed_experts=4, num_experts_per_tok=2,
+                                  first_k_dense_replace=1, kv_lora_rank=64, q_lora_rank=48, qk_rope_head_dim=32,
+                                  qk_nope_head_dim=32, v_head_dim=32, max_position_embeddings=256,
+                                  topk_method="greedy", n_group=1, topk_group=1, norm_topk_prob=False)
+        m = tf.DeepseekV2ForCausalLM(cfg)
     elif kind in ("deepseek_v2", "deepseek_v2_yarn"):
         rope = {"rope_type": "yarn", "factor": 4.0, "original_max_position_embeddings": 64, "mscale": 1.0,
                 "mscale_all_dim": 1.0, "beta_fast": 32, "beta_slow": 1, "rope_theta": 10000.0} \
@@ -128,7 +137,7 @@ def _save_tiny(tmp, kind):
 
 
 @pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2", "mixtral", "qwen2_moe", "qwen3_moe",
-                                  "deepseek_v2", "deepseek_v2_yarn", "deepseek_v3", "gemma", "gemma2", "phi3",
+                                  "deepseek_v2", "deepseek_v2_yarn", "deepseek_v2_mla", "deepseek_v3", "gemma", "gemma2", "phi3",
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2"])
 def test_greedy_matches_hf(tmp_path, kind):
@@ -161,4 +170,23 @@ def test_chunked_prefill_prefix_cache_and_preemption_same_tokens(tmp_path):
               max_num_seqs=16, max_num_batched_tokens=48, enable_prefix_caching=True, num_gpu_blocks_override=24)
     got = [list(o.outputs[0].token_ids) for o in llm.generate(prompt_token_ids=prompts, sampling_params=sp)]
     assert got == ref
+    llm.shutdown()
+
+
+def test_deepseek_expanded_heads_path_still_matches_hf(tmp_path, monkeypatch):
+    """VDA_MLA=0 keeps the per-head K/V cache (padded heads) instead of the latent cache."""
+    monkeypatch.setenv("VDA_MLA", "0")
+    path, hf = _save_tiny(str(tmp_path), "deepseek_v2")
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 40]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+              max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False)
+    mr = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+    assert not any(getattr(m, "is_mla", False) for m in mr.attn_layers.values())
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=8,
+                                                                                   ignore_eos=True))
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref
     llm.shutdown()

@@ -20,7 +20,7 @@ def _llm(path, **kw):
     return LLM(model=path, **base)
 
 
-@pytest.mark.parametrize("kind", ["llama", "qwen2", "mixtral", "mamba", "mamba2"])
+@pytest.mark.parametrize("kind", ["llama", "qwen2", "mixtral", "mamba", "mamba2", "deepseek_v2_mla"])
 def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     import transformers as tf
     from vllm_distributed_amd import SamplingParams
@@ -30,6 +30,9 @@ def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     extra = {"hf_overrides": {"gated_norm_groups": 1}} if kind == "mamba2" else {}
     a = _llm(path, **extra)                          # hipGraph decode
     outs_g = a.generate(prompt_token_ids=PROMPTS, sampling_params=sp)
+    if kind == "deepseek_v2_mla":      # the latent-cache kernel, not the expanded-head fallback, must be what ran
+        mr = a.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+        assert all(getattr(m, "is_mla", False) for m in mr.attn_layers.values())
     a.shutdown()
     b = _llm(path, enforce_eager=True, **extra)
     outs_e = b.generate(prompt_token_ids=PROMPTS, sampling_params=sp)

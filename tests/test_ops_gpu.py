@@ -645,3 +645,46 @@ def test_lora_update(dt, T, K, N, Rk):
     R.lora_update(y_ref, x, A, B, ts)
     ops.lora_update(y, x, A, B, ts)
     torch.testing.assert_close(y.float(), y_ref.float(), **tol(dt))
+
+
+# ---- multi-head latent attention -------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("DK,DV", [(96, 64), (576, 512), (160, 128)])
+@pytest.mark.parametrize("H,lens,computed,nsplit", [(16, [1, 1, 1], [37, 700, 5], 1), (16, [1, 1], [1500, 90], 4),
+                                                    (4, [9, 40, 1], [0, 13, 100], 1), (128, [2, 1], [300, 64], 2),
+                                                    (8, [130], [0], 1)])
+def test_mla_attention(dt, DK, DV, H, lens, computed, nsplit):
+    BS, S = 16, len(lens)
+    T = sum(lens)
+    total = [l + c for l, c in zip(lens, computed)]
+    nblocks = sum((t + BS - 1) // BS for t in total) + 4
+    kc = torch.zeros(nblocks, BS, DK, device=DEV, dtype=dt)
+    vt = torch.zeros(nblocks, DV, BS, device=DEV, dtype=dt)
+    kc_ref, vt_ref = kc.clone(), vt.clone()
+    perm = torch.randperm(nblocks - 1, device=DEV) + 1
+    maxb = max((t + BS - 1) // BS for t in total)
+    bt = torch.zeros((S, maxb), dtype=torch.int32, device=DEV)
+    used = 0
+    for s, t in enumerate(total):
+        nb = (t + BS - 1) // BS
+        bt[s, :nb] = perm[used:used + nb].int()
+        used += nb
+    # fill the caches through the write kernel, one call with every token of every sequence
+    all_c = torch.randn(sum(total), DV, device=DEV, dtype=dt)
+    all_pe = torch.randn(sum(total), DK - DV, device=DEV, dtype=dt)
+    slots, o = [], 0
+    for s, t in enumerate(total):
+        pos = torch.arange(t, device=DEV)
+        slots.append(bt[s, pos // BS].long() * BS + pos % BS)
+    slots = torch.cat(slots)
+    slots[3] = -1                                   # skipped token
+    ops.mla_cache_write(all_c, all_pe, kc, vt, slots)
+    R.mla_cache_write(all_c, all_pe, kc_ref, vt_ref, slots)
+    assert torch.equal(kc, kc_ref) and torch.equal(vt, vt_ref)
+    qsl = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    seq = torch.tensor(total, dtype=torch.int32, device=DEV)
+    q = torch.randn(T, H, DK, device=DEV, dtype=dt) * 0.5
+    out = torch.empty(T, H, DV, device=DEV, dtype=dt)
+    ops.mla_attention(out, q, kc, vt, bt, seq, qsl, DK ** -0.5, max(lens), nsplit)
+    ref = R.mla_attention(q, kc, vt, bt, seq, qsl, DK ** -0.5)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))

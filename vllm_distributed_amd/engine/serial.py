@@ -150,7 +150,7 @@ def _register_engine_types() -> None:
         wire_struct(i)(cls)
     from ..sched import kv_cache_interface as K
     for i, cls in enumerate((K.FullAttentionSpec, K.SlidingWindowSpec, K.MambaSpec, K.KVCacheTensor,
-                             K.KVCacheGroupSpec, K.KVCacheConfig), start=40):
+                             K.KVCacheGroupSpec, K.KVCacheConfig, K.MLASpec), start=40):
         wire_struct(i)(cls)
     wire_custom(100, SamplingParams, SamplingParams.to_wire, SamplingParams.from_wire)
     wire_custom(101, PoolingParams, PoolingParams.to_wire, PoolingParams.from_wire)

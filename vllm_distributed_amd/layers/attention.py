@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..forward_context import AttentionMetadata, get_forward_context
-from ..sched.kv_cache_interface import FullAttentionSpec, KVCacheSpec, SlidingWindowSpec
+from ..sched.kv_cache_interface import FullAttentionSpec, KVCacheSpec, MLASpec, SlidingWindowSpec
 
 
 class Attention(nn.Module):
@@ -99,3 +99,61 @@ class Attention(nn.Module):
         if conn is not None:
             conn.save_kv_layer(self.layer_name, (self.k_cache, self.v_cache), md)
         return out.view(T, qs)
+
+
+class MLAAttention(nn.Module):
+    """Multi-head latent attention over a latent KV cache (DeepSeek-V2 / V3).
+
+    The cache keeps one row per token: the normalised latent ``c_kv`` followed by the rotated shared key
+    ``k_pe`` (plus a transposed copy of the latent for the P.V product).  Queries arrive with the key
+    up-projection already absorbed (``q_abs = q_nope . W_UK``), so all heads attend over the same rows, and
+    the output stays in latent space for the caller's value up-projection.  One kernel serves decode and
+    (chunked) prefill.
+    Reference: vllm/v1/attention/backends/mla/common.py (the "absorbed" decode formulation, :200-330),
+    csrc/cache_kernels.cu::concat_and_cache_mla.
+    """
+    is_mla = True
+
+    def __init__(self, num_heads: int, kv_lora_rank: int, rope_dim: int, scale: float, prefix: str = ""):
+        super().__init__()
+        self.num_heads, self.kv_lora_rank, self.rope_dim = num_heads, kv_lora_rank, rope_dim
+        self.dk, self.dv = kv_lora_rank + rope_dim, kv_lora_rank
+        self.scale = float(scale)
+        self.layer_name = prefix
+        from ..config import get_current_vllm_config_or_none
+        cfg = get_current_vllm_config_or_none()
+        self.max_model_len = cfg.model_config.max_model_len if cfg is not None else 4096
+        self.k_cache: Optional[torch.Tensor] = None       # [blocks, BS, dk]
+        self.v_cache: Optional[torch.Tensor] = None       # [blocks, dv, BS]
+
+    def get_kv_cache_spec(self, block_size: int, dtype: torch.dtype) -> KVCacheSpec:
+        if dtype == torch.float8_e4m3fn:
+            raise ValueError("the latent KV cache is 16-bit (fp8 is not supported for MLA)")
+        return MLASpec(block_size=block_size, num_kv_heads=1, head_size=self.dk, dtype=dtype, use_mla=True,
+                       v_size=self.dv)
+
+    def bind_kv_cache(self, k_cache: torch.Tensor, v_cache: torch.Tensor) -> None:
+        self.k_cache, self.v_cache = k_cache, v_cache
+
+    def forward(self, q: torch.Tensor, kv_c: torch.Tensor, k_pe: torch.Tensor) -> torch.Tensor:
+        """q [T, H, dk] (absorbed nope part, then rotated rope part); kv_c [T, kv_lora_rank] normalised;
+        k_pe [T, rope_dim] rotated.  Returns [T, H, kv_lora_rank]."""
+        md: Optional[AttentionMetadata] = get_forward_context().attn_metadata
+        T = q.shape[0]
+        out = torch.empty((T, self.num_heads, self.dv), dtype=q.dtype, device=q.device)
+        if md is None or self.k_cache is None:
+            return out.zero_()
+        n = md.num_actual_tokens
+        ops.mla_cache_write(kv_c[:n], k_pe[:n], self.k_cache, self.v_cache, md.slot_mapping[:n])
+        if n < T:
+            out[n:].zero_()
+        S = md.num_decode_seqs + md.num_prefill_seqs
+        # few query tokens per sequence: split the keys further so the launch fills the chip.  The factor
+        # depends on the batch size and the model's maximum length only, so eager steps and captured
+        # graphs of one batch size compute identical sums.
+        nsplit = 1
+        if md.max_query_len <= 4:
+            nsplit = ops.decode_num_splits(S * max(self.num_heads // 16, 1), 1, self.max_model_len)
+        ops.mla_attention(out[:n], q[:n], self.k_cache, self.v_cache, md.block_table[:S], md.seq_lens[:S],
+                          md.query_start_loc[:S + 1], self.scale, md.max_query_len, nsplit)
+        return out

@@ -19,7 +19,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..config import VllmConfig
-from ..layers.attention import Attention
+from .. import envs, ops
+from ..layers.attention import Attention, MLAAttention
 from ..layers.basic import RMSNorm
 from ..layers.linear import ColumnParallelLinear, ReplicatedLinear, RowParallelLinear
 from ..layers.moe import FusedMoE
@@ -80,11 +81,56 @@ class DeepseekAttention(nn.Module):
         # the rotary pairs are interleaved (x0,x1),(x2,x3),... in these checkpoints
         self.rotary_emb = get_rope(self.rope_dim, self.rope_dim, vllm_config.model_config.max_model_len, theta, False,
                                    rope_cfg)
+        # Latent cache + absorbed projections when the kernel is built for these sizes and kv_b_proj keeps
+        # 16-bit weights (its two halves become W_UK and W_UV); expanded, padded heads otherwise.
+        on_dev = vllm_config.device_config.device != "cpu"
+        self.use_mla = bool(envs.VDA_MLA and quant_config is None
+                            and vllm_config.cache_config.cache_dtype == "auto"
+                            and vllm_config.kv_transfer_config is None
+                            and ops.mla_supported(self.kv_lora_rank + self.rope_dim, self.kv_lora_rank,
+                                                  vllm_config.model_config.dtype, on_dev))
+        if self.use_mla:
+            self.attn = MLAAttention(self.num_heads, self.kv_lora_rank, self.rope_dim, scale, prefix=f"{prefix}.attn")
+            self._w_uk = self._w_uv = None
+            return
         self.pad = _padded_head_size(max(self.qk_dim, self.v_dim))
         self.attn = Attention(self.num_heads, self.pad, scale, self.num_heads, prefix=f"{prefix}.attn",
                               cache_dtype=vllm_config.cache_config.cache_dtype)
 
+    def _absorbed_weights(self):
+        """kv_b_proj's weight [H * (nope + v), R] seen as W_UK [H, nope, R] and W_UV^T [H, R, v]."""
+        w = self.kv_b_proj.weight
+        if self._w_uk is None or self._w_uk.data_ptr() != w.data_ptr():
+            w3 = w.view(self.num_heads, self.nope + self.v_dim, self.kv_lora_rank)
+            self._w_uk = w3[:, : self.nope, :]                                  # view: shares kv_b_proj's storage
+            self._w_uv_t = w3[:, self.nope:, :].transpose(1, 2).contiguous()    # [H, R, v]
+        return self._w_uk, self._w_uv_t
+
+    def _forward_mla(self, positions: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        T, H = x.shape[0], self.num_heads
+        if self.q_lora_rank:
+            q = self.q_b_proj(self.q_a_layernorm(self.q_a_proj(x)))
+        else:
+            q = self.q_proj(x)
+        q = q.view(T, H, self.qk_dim)
+        latent = self.kv_a_proj_with_mqa(x)
+        kv_c = self.kv_a_layernorm(latent[:, : self.kv_lora_rank].contiguous())
+        k_pe = latent[:, self.kv_lora_rank:].contiguous()
+        q_pe = q[:, :, self.nope:].contiguous().view(T, H * self.rope_dim)
+        n = min(positions.shape[0], T)
+        self.rotary_emb(positions[:n], q_pe[:n], k_pe[:n])
+        w_uk, w_uv_t = self._absorbed_weights()
+        qf = torch.empty((T, H, self.kv_lora_rank + self.rope_dim), dtype=q.dtype, device=q.device)
+        # q_abs[t, h] = q_nope[t, h] . W_UK[h]: one batched GEMM over the heads
+        torch.bmm(q[:, :, : self.nope].transpose(0, 1), w_uk, out=qf[:, :, : self.kv_lora_rank].transpose(0, 1))
+        qf[:, :, self.kv_lora_rank:] = q_pe.view(T, H, self.rope_dim)
+        o_lat = self.attn(qf, kv_c, k_pe)                                        # [T, H, R]
+        o = torch.bmm(o_lat.transpose(0, 1), w_uv_t).transpose(0, 1)             # [T, H, v]
+        return self.o_proj(o.reshape(T, H * self.v_dim))
+
     def forward(self, positions: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        if self.use_mla:
+            return self._forward_mla(positions, x)
         T, H, P = x.shape[0], self.num_heads, self.pad
         if self.q_lora_rank:
             q = self.q_b_proj(self.q_a_layernorm(self.q_a_proj(x)))

@@ -250,6 +250,49 @@ def merge_attn_states(prefix, prefix_lse, suffix, suffix_lse, return_lse: bool =
     return (out, lse) if return_lse else out
 
 
+# ---- multi-head latent attention ------------------------------------------------------------
+def mla_supported(dk: int, dv: int, dtype: torch.dtype, on_device: bool) -> bool:
+    """Latent sizes the MLA kernel is built for (DeepSeek-V2/V3: 576 / 512, plus two small ones)."""
+    if not on_device or envs.VDA_FORCE_TORCH_OPS:
+        return True
+    return dtype in (torch.bfloat16, torch.float16) and (dk, dv) in ((576, 512), (96, 64), (160, 128))
+
+
+def mla_cache_write(kv_c: torch.Tensor, k_pe: torch.Tensor, kc: torch.Tensor, vt: torch.Tensor,
+                    slot_mapping: torch.Tensor) -> None:
+    """Write the normalised latent kv_c [T, R] and the rotated shared key k_pe [T, rope] of every token
+    into the latent cache: kc [blocks, BS, R + rope] and the transposed copy vt [blocks, R, BS]."""
+    if not _dev(kv_c):
+        return R.mla_cache_write(kv_c, k_pe, kc, vt, slot_mapping)
+    T, Rk = kv_c.shape
+    assert kv_c.stride(1) == 1 and k_pe.stride(1) == 1 and kc.is_contiguous() and vt.is_contiguous()
+    N.call("vda_mla_cache_write", kv_c.data_ptr(), k_pe.data_ptr(), kc.data_ptr(), vt.data_ptr(),
+           slot_mapping.data_ptr(), T, Rk, k_pe.shape[1], kc.shape[1], kv_c.stride(0), k_pe.stride(0),
+           N.dt(kv_c.dtype), N.stream())
+
+
+def mla_attention(out: torch.Tensor, q: torch.Tensor, kc: torch.Tensor, vt: torch.Tensor, block_table: torch.Tensor,
+                  seq_lens: torch.Tensor, q_start_loc: torch.Tensor, scale: float, max_query_len: int,
+                  num_splits: int = 1) -> torch.Tensor:
+    """Causal multi-query attention of q [T, H, DK] over the latent cache; out [T, H, DV] stays in latent
+    space (the caller applies the value up-projection).  Decode and (chunked) prefill are one path."""
+    T, H, DK = q.shape
+    DV = vt.shape[1]
+    if not _dev(q):
+        out.copy_(R.mla_attention(q, kc, vt, block_table, seq_lens, q_start_loc, scale))
+        return out
+    part_out = part_lse = None
+    if num_splits > 1:
+        part_out = torch.empty((T, H, num_splits, DV), dtype=torch.float32, device=q.device)
+        part_lse = torch.empty((T, H, num_splits), dtype=torch.float32, device=q.device)
+    assert q.stride(2) == 1 and q.stride(1) == DK and out.stride(2) == 1 and out.stride(1) == DV
+    N.call("vda_mla_attention", out.data_ptr(), q.data_ptr(), kc.data_ptr(), vt.data_ptr(), block_table.data_ptr(),
+           seq_lens.data_ptr(), q_start_loc.data_ptr(), N.ptr(part_out), N.ptr(part_lse), seq_lens.shape[0], T, H, DK,
+           DV, kc.shape[1], block_table.stride(0), num_splits, max(int(max_query_len), 1), q.stride(0),
+           out.stride(0), scale, N.dt(q.dtype), N.stream())
+    return out
+
+
 # ---- sampling --------------------------------------------------------------------------
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     if not _dev(logits):

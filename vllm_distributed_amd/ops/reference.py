@@ -395,3 +395,40 @@ def lora_update(y, x, A, B, tok_slot):
         idx = torch.nonzero(tok_slot == s).squeeze(1)
         d = (x[idx].float() @ A[s].float().t()) @ B[s].float().t()
         y[idx] = (y[idx].float() + d).to(y.dtype)
+
+
+# ---- multi-head latent attention -----------------------------------------------------------------------
+def mla_cache_write(kv_c, k_pe, kc, vt, slot_mapping):
+    BS = kc.shape[1]
+    Rk = kv_c.shape[1]
+    for t in range(kv_c.shape[0]):
+        slot = int(slot_mapping[t])
+        if slot < 0:
+            continue
+        b, o = slot // BS, slot % BS
+        kc[b, o, :Rk] = kv_c[t].to(kc.dtype)
+        kc[b, o, Rk:] = k_pe[t].to(kc.dtype)
+        vt[b, :, o] = kv_c[t].to(vt.dtype)
+
+
+def mla_attention(q, kc, vt, block_table, seq_lens, q_start_loc, scale):
+    T, H, DK = q.shape
+    DV, BS = vt.shape[1], kc.shape[1]
+    out = torch.zeros((T, H, DV), dtype=q.dtype, device=q.device)
+    for s in range(seq_lens.shape[0]):
+        L = int(seq_lens[s])
+        a, b = int(q_start_loc[s]), int(q_start_loc[s + 1])
+        if L <= 0 or b <= a:
+            continue
+        nblk = (L + BS - 1) // BS
+        blocks = block_table[s, :nblk].long()
+        K = kc[blocks].reshape(-1, DK)[:L].float()                         # [L, DK]
+        V = vt[blocks].permute(0, 2, 1).reshape(-1, DV)[:L].float()        # [L, DV]
+        qs = q[a:b].float()                                                # [n, H, DK]
+        n = b - a
+        sc = torch.einsum("nhd,ld->nhl", qs, K) * scale
+        pos = torch.arange(L, device=q.device).view(1, 1, L)
+        lim = (L - n + torch.arange(n, device=q.device) + 1).view(n, 1, 1)
+        sc = sc.masked_fill(pos >= lim, float("-inf"))
+        out[a:b] = torch.einsum("nhl,ld->nhd", torch.softmax(sc, dim=-1), V).to(q.dtype)
+    return out

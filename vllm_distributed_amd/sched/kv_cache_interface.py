@@ -62,6 +62,22 @@ class FullAttentionSpec(AttentionSpec):
 
 
 @dataclass(frozen=True)
+class MLASpec(FullAttentionSpec):
+    """Latent cache of multi-head latent attention: per token one row of ``head_size`` = kv_lora_rank +
+    rope_dim elements (what queries dot against) plus a transposed copy of its first ``v_size`` =
+    kv_lora_rank elements (what the P.V MFMA reads); num_kv_heads is 1."""
+    v_size: int = 0
+
+    @property
+    def type_id(self) -> str:
+        return f"mla_{self.block_size}_{self.page_size_bytes}"
+
+    @property
+    def page_size_bytes(self) -> int:
+        return self.block_size * (self.head_size + self.v_size) * _dtype_size(self.dtype)
+
+
+@dataclass(frozen=True)
 class SlidingWindowSpec(AttentionSpec):
     sliding_window: int = 0
 

@@ -23,7 +23,7 @@ from ..logger import init_logger
 from ..metrics.stats import PrefixCacheStats
 from ..parallel.utils import cdiv
 from .block_pool import BlockPool, KVCacheBlock
-from .kv_cache_interface import (FullAttentionSpec, KVCacheConfig, KVCacheSpec, MambaSpec,
+from .kv_cache_interface import (FullAttentionSpec, KVCacheConfig, KVCacheSpec, MLASpec, MambaSpec,
                                  SlidingWindowSpec)
 from .kv_cache_utils import BlockHash, extend_block_hashes, get_hash_fn
 
@@ -211,7 +211,8 @@ class MambaManager(SingleTypeManager):
         return new
 
 
-_MANAGERS = {FullAttentionSpec: FullAttentionManager, SlidingWindowSpec: SlidingWindowManager,
+_MANAGERS = {FullAttentionSpec: FullAttentionManager, MLASpec: FullAttentionManager,
+             SlidingWindowSpec: SlidingWindowManager,
              MambaSpec: MambaManager}
 
 

@@ -32,7 +32,7 @@ from ..models.loader import get_model
 from ..models.utils import IntermediateTensors
 from ..parallel.state import get_pp_group, get_tknp_group, get_tp_group, graph_capture
 from ..request import LogprobsLists
-from ..sched.kv_cache_interface import KVCacheConfig, KVCacheSpec, MambaSpec
+from ..sched.kv_cache_interface import KVCacheConfig, KVCacheSpec, MLASpec, MambaSpec
 from ..sched.output import EMPTY_MODEL_RUNNER_OUTPUT, ModelRunnerOutput, SchedulerOutput
 from .input_batch import InputBatch
 
@@ -141,7 +141,8 @@ class ModelRunner:
             logger.info("weights take %.2f GiB, loaded in %.1f s", self.model_memory / 2**30, time.time() - t0)
         # every layer that owns per-request cache memory: attention layers and state-space mixers
         self.attn_layers = {n: m for n, m in self.model.named_modules()
-                            if isinstance(m, Attention) or getattr(m, "is_state_space_layer", False)}
+                            if isinstance(m, Attention) or getattr(m, "is_state_space_layer", False)
+                    or getattr(m, "is_mla", False)}
         for n, m in self.attn_layers.items():
             m.layer_name = n
         spec = self.vllm_config.speculative_config
@@ -266,6 +267,16 @@ class ModelRunner:
                         self.attn_layers[n].bind_kv_cache(*parts)
                         self.kv_layer_loc[n] = (ci, off, t.size)
                     self.kv_caches.append(tuple(parts))
+                    off += t.size
+                    continue
+                if isinstance(sp, MLASpec):
+                    kb = nb * sp.block_size * sp.head_size * sp.dtype.itemsize
+                    k = raw[:kb].view(sp.dtype).view(nb, sp.block_size, sp.head_size)
+                    v = raw[kb:].view(sp.dtype).view(nb, sp.v_size, sp.block_size)
+                    for n in t.shared_by:
+                        self.attn_layers[n].bind_kv_cache(k, v)
+                        self.kv_layer_loc[n] = (ci, off, t.size)
+                    self.kv_caches.append((k, v))
                     off += t.size
                     continue
                 half = t.size // 2
