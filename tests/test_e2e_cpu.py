@@ -49,7 +49,7 @@ def _save_tiny(tmp, kind):
         m = tf.Qwen3MoeForCausalLM(cfg)
     elif kind == "deepseek_v2_mla":
         # latent sizes the GPU MLA kernel is built for (kv_lora_rank 64 + rope 32)
-        cfg = tf.DeepseekV2Config(vocab_size=320, hidden_size=128, intermediate_size=256, moe_intermediate_size=64,
+        cfg = tf.DeepseekV2Config(vocab_size=320, hidden_size=128, intermediate_size=256, moe_intermediate_size=128,
                                   num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
                                   n_shared_experts=1, n_routed_experts=4, num_experts_per_tok=2,
                                   first_k_dense_replace=1, kv_lora_rank=64, q_lora_rank=48, qk_rope_head_dim=32,
