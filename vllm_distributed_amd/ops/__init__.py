@@ -441,12 +441,13 @@ def w4_dequant(qw: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, grou
 
 def w4_linear(x: torch.Tensor, qw: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, group: int,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ dequant(qw).T (+ bias).  Up to 64 rows stream the packed weights once through the MFMA
-    skinny kernel (a quarter of the bytes of 16-bit weights); more rows expand them and use the
-    library GEMM."""
+    """y = x @ dequant(qw).T (+ bias).  Decode-sized batches (``VDA_W4_SKINNY_MAX_M`` rows, 64 at most)
+    stream the packed weights once through the MFMA skinny kernel (a quarter of the bytes of 16-bit
+    weights); more rows expand them and use the library GEMM."""
     M, K = x.shape
     N_ = qw.shape[0]
-    if _dev(x) and M <= 64 and N_ % 16 == 0 and K % 128 == 0 and group % 32 == 0 and x.stride(1) == 1 \
+    if _dev(x) and M <= envs.VDA_W4_SKINNY_MAX_M and N_ % 16 == 0 and K % 128 == 0 and group % 32 == 0 \
+            and x.stride(1) == 1 \
             and x.dtype in (torch.bfloat16, torch.float16) and scales.dtype == x.dtype:
         y = torch.empty((M, N_), dtype=x.dtype, device=x.device)
         N.call("vda_w4_skinny_gemm", y.data_ptr(), x.data_ptr(), qw.data_ptr(), scales.data_ptr(), zeros.data_ptr(),

@@ -57,20 +57,49 @@ __global__ __launch_bounds__(256) void w4_skinny_gemm_kernel(T* __restrict__ y, 
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0, 0, 0, 0};
 
   const int nchunk = K >> 7;
-  for (int c = wave; c < nchunk; c += 4) {
+  // UN chunks per iteration: their weight, scale and zero loads are all issued before the first
+  // widening, so a lane keeps UN x 16 bytes of packed weights in flight (the loop is latency bound
+  // otherwise: one 16-byte load per lane per trip)
+  constexpr int UN = 4;
+  int c = wave;
+  for (; c + 4 * (UN - 1) < nchunk; c += 4 * UN) {
+    u32x4 raw[UN];
+    float sv[UN], nz[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int cc = c + 4 * u;
+      raw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (long)cc * 16));
+      const int grp = (cc * 128 + g * 32) / G;
+      sv[u] = (float)srow[grp];
+      nz[u] = (float)zrow[grp];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int cc = c + 4 * u;
+      const float nzs = -nz[u] * sv[u];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const V8 wa = w4_expand<T>(raw[u][q], sv[u], nzs);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)cc * 128 + 8 * q) : V8{};
+          acc[mt] = mfma16(wa, xa, acc[mt]);
+        }
+      }
+    }
+  }
+  for (; c < nchunk; c += 4) {
     const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (long)c * 16));
     const int grp = (c * 128 + g * 32) / G;
     const float s = (float)srow[grp];
     const float nzs = -(float)zrow[grp] * s;
-    V8 wa[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wa[q] = w4_expand<T>(raw[q], s, nzs);
+    for (int q = 0; q < 4; ++q) {
+      const V8 wa = w4_expand<T>(raw[q], s, nzs);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int mt = 0; mt < MT; ++mt) {
         const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)c * 128 + 8 * q) : V8{};
-        acc[mt] = mfma16(wa[q], xa, acc[mt]);
+        acc[mt] = mfma16(wa, xa, acc[mt]);
       }
     }
   }
