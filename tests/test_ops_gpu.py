@@ -571,7 +571,8 @@ def test_causal_conv1d(dt, W, lens, computed):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("variant", ["mamba1", "mamba2"])
-@pytest.mark.parametrize("lens,computed", [([1, 1, 1], [4, 0, 30]), ([9, 33, 1], [0, 5, 2]), ([64], [0])])
+@pytest.mark.parametrize("lens,computed", [([1, 1, 1], [4, 0, 30]), ([9, 33, 1], [0, 5, 2]), ([64], [0]),
+                                           ([600, 3, 260], [0, 5, 40])])      # last: chunk-parallel passes
 def test_selective_scan(dt, variant, lens, computed):
     T = sum(lens)
     qsl, seq, bt = _ragged(lens, computed)
@@ -590,7 +591,7 @@ def test_selective_scan(dt, variant, lens, computed):
     db = torch.randn(E, device=DEV) * 0.2
     st = torch.randn(len(lens) + 3, Ch, N, device=DEV)
     st_ref = st.clone()
-    y = ops.selective_scan(u, delta, A, B, C, D, z, db, st, qsl, seq, bt, num_groups=G)
+    y = ops.selective_scan(u, delta, A, B, C, D, z, db, st, qsl, seq, bt, num_groups=G, max_query_len=max(lens))
     y_ref = R.selective_scan(u, delta, A, B, C, D, z, db, st_ref, qsl, seq, bt, num_groups=G)
     torch.testing.assert_close(y.float(), y_ref.float(), atol=6e-2 if dt == torch.bfloat16 else 2e-2, rtol=3e-2)
     torch.testing.assert_close(st, st_ref, atol=2e-3, rtol=2e-3)

@@ -119,7 +119,7 @@ class MambaMixer(StateSpaceLayer):
             dt_low, B, C = self._norm(dt_low), self._norm(B), self._norm(C)
         dt = self.dt_proj(dt_low.contiguous())
         y = ops.selective_scan(xc, dt, self.A, B, C, self.D, z, self.dt_bias, self.ssm_state, md.query_start_loc,
-                               md.seq_lens, md.block_table, softplus=True)
+                               md.seq_lens, md.block_table, softplus=True, max_query_len=md.max_query_len)
         return self.out_proj(y)
 
 
@@ -197,7 +197,8 @@ class Mamba2Mixer(StateSpaceLayer):
             dt = torch.nn.functional.softplus(dt.float() + self.dt_bias).clamp(*self.dt_limit).to(x.dtype)
             bias, softplus = None, False
         y = ops.selective_scan(xs, dt, self.A, B, C, self.D, gate, bias, self.ssm_state, md.query_start_loc,
-                               md.seq_lens, md.block_table, softplus=softplus, num_groups=self.n_groups)
+                               md.seq_lens, md.block_table, softplus=softplus, num_groups=self.n_groups,
+                               max_query_len=md.max_query_len)
         return self.out_proj(self._gated_norm(y))
 
 

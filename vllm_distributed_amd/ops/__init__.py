@@ -585,7 +585,8 @@ def causal_conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
 def selective_scan(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
                    D: Optional[torch.Tensor], z: Optional[torch.Tensor], delta_bias: Optional[torch.Tensor],
                    ssm_state: torch.Tensor, query_start_loc: torch.Tensor, seq_lens: torch.Tensor,
-                   block_table: torch.Tensor, softplus: bool = True, num_groups: int = 1) -> torch.Tensor:
+                   block_table: torch.Tensor, softplus: bool = True, num_groups: int = 1,
+                   max_query_len: int = 1) -> torch.Tensor:
     """Selective state-space scan over a ragged batch with carried state.
     u, z [T, Ch]; delta [T, Ch] (Mamba) or [T, heads] (Mamba-2: one step size per head);
     A fp32 [Ch, N] or [heads]; B, C [T, groups * N]; D, delta_bias fp32 with delta's width;
@@ -602,9 +603,22 @@ def selective_scan(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: tor
     for t in (u, delta, B, C) + ((z,) if z is not None else ()):
         assert t.stride(1) == 1 and t.dtype == u.dtype
     out = torch.empty((T, Ch), dtype=u.dtype, device=u.device)
+    # long prefills: chunks of the sequence run in parallel (summary, combine, output passes); the
+    # chunk length keeps the two fp32 workspaces of [S, chunks, Ch, N] within ~1 GiB
+    S = seq_lens.shape[0]
+    chunk, nchunks, ws_p, ws_h = 0, 1, None, None
+    if max_query_len >= envs.VDA_SCAN_CHUNK_MIN_TOKENS:
+        chunk = 64
+        while chunk < max_query_len and S * -(-max_query_len // chunk) * Ch * Nst * 8 > (1 << 30):
+            chunk *= 2
+        nchunks = -(-max_query_len // chunk)
+        if nchunks > 1:
+            ws_p = torch.empty((S, nchunks, Ch, Nst), dtype=torch.float32, device=u.device)
+            ws_h = torch.empty_like(ws_p)
     N.call("vda_selective_scan", out.data_ptr(), u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(),
            C.data_ptr(), N.ptr(D), N.ptr(z), N.ptr(delta_bias), ssm_state.data_ptr(), query_start_loc.data_ptr(),
            seq_lens.data_ptr(), block_table.data_ptr(), block_table.stride(0), seq_lens.shape[0], Ch, Nst,
            u.stride(0), delta.stride(0), B.stride(0), C.stride(0), z.stride(0) if z is not None else 0, out.stride(0),
-           Ch // E, int(A.dim() == 1), Ch // num_groups, int(softplus), N.dt(u.dtype), N.stream())
+           Ch // E, int(A.dim() == 1), Ch // num_groups, int(softplus), chunk, nchunks, N.ptr(ws_p), N.ptr(ws_h),
+           N.dt(u.dtype), N.stream())
     return out

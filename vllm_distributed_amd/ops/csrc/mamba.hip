@@ -89,19 +89,24 @@ VDA_EXPORT int vda_causal_conv1d(void* out, const void* x, const void* weight, c
 // ---- selective scan ----------------------------------------------------------------------------
 // h[c, n] <- exp(dt * A[c, n]) * h[c, n] + dt * B[t, n] * u[t, c];  y[t, c] = sum_n C[t, n] h[c, n] + D[c] u[t, c]
 // NL = N / 16 lanes share one channel (16 states each, y summed with shuffles), so Mamba (N = 16) uses one
-// lane per channel and Mamba-2 (N = 128) eight.  Tokens of a sequence are walked in order; channels,
-// sequences and state slices supply the parallelism.
+// lane per channel and Mamba-2 (N = 128) eight.
 //   dt_div      channels per dt / A / D entry (1: per channel; head_dim for Mamba-2 heads)
 //   a_scalar    A holds one value per dt entry instead of [C, N]
 //   group_ch    channels per B / C group (B, C are [T, groups * N])
-template <typename T, int N>
+// MODE 0  whole sequences in one pass (decode, short chunks): tokens walked in order, state read and written.
+// Long prefills are cut into chunks of `chunk` tokens (grid.z) and run in three passes, since the
+// recurrence is linear in h:  h_end = P * h_start + H_loc  with P = prod exp(dt A), H_loc = chunk result from 0.
+// MODE 1  per chunk: P and H_loc into the workspace (no output)
+//         (then scan_combine_kernel walks the chunks of a sequence: start state of every chunk, final state)
+// MODE 2  per chunk: outputs, starting from the chunk's start state in the workspace
+template <typename T, int N, int MODE>
 __global__ __launch_bounds__(256) void selective_scan_kernel(
     T* __restrict__ out, const T* __restrict__ u, const T* __restrict__ delta, const float* __restrict__ A,
     const T* __restrict__ Bm, const T* __restrict__ Cm, const float* __restrict__ D, const T* __restrict__ z,
     const float* __restrict__ delta_bias, float* __restrict__ ssm_state, const int* __restrict__ qsl,
     const int* __restrict__ seq_lens, const int* __restrict__ block_table, long bt_stride, int C, long u_stride,
     long d_stride, long b_stride, long c_stride, long z_stride, long o_stride, int dt_div, int a_scalar,
-    int group_ch, int softplus) {
+    int group_ch, int softplus, int chunk, float* __restrict__ ws_p, float* __restrict__ ws_h) {
   constexpr int NL = N / 16;
   const int s = blockIdx.y;
   const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -111,18 +116,29 @@ __global__ __launch_bounds__(256) void selective_scan_kernel(
   if (sl <= 0) return;
   const int t0 = qsl[s], L = qsl[s + 1] - t0;
   const bool has_init = sl - L > 0;
+  int ta = t0, tb = t0 + L;
+  long ws_off = 0;
+  if (MODE != 0) {
+    ta = t0 + blockIdx.z * chunk;
+    if (ta >= tb) return;
+    tb = min(tb, ta + chunk);
+    ws_off = ((((long)s * gridDim.z + blockIdx.z) * C + c) * N) + part * 16;
+  }
   float* hp = ssm_state + ((long)block_table[s * bt_stride] * C + c) * N + part * 16;
   const int e = c / dt_div;
-  float a[16], h[16];
+  float a[16], h[16], pr[16];
 #pragma unroll
   for (int n = 0; n < 16; ++n) {
     a[n] = a_scalar ? A[e] : A[(long)c * N + part * 16 + n];
-    h[n] = has_init ? hp[n] : 0.f;
+    if (MODE == 0) h[n] = has_init ? hp[n] : 0.f;
+    else if (MODE == 1) h[n] = 0.f;
+    else h[n] = ws_p[ws_off + n];            // start state left there by the combine pass
+    pr[n] = 1.f;
   }
   const float dv = D ? D[e] : 0.f;
   const float db = delta_bias ? delta_bias[e] : 0.f;
   const long bc_off = (long)(c / group_ch) * N + part * 16;
-  for (int t = t0; t < t0 + L; ++t) {
+  for (int t = ta; t < tb; ++t) {
     float dt = (float)delta[(long)t * d_stride + e] + db;
     if (softplus) dt = softplus_f(dt);
     const float x = (float)u[(long)t * u_stride + c];
@@ -132,19 +148,54 @@ __global__ __launch_bounds__(256) void selective_scan_kernel(
     float y = 0.f;
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-      h[n] = __expf(dt * a[n]) * h[n] + dx * (float)bp[n];
-      y += (float)cp[n] * h[n];
+      const float dec = __expf(dt * a[n]);
+      h[n] = dec * h[n] + dx * (float)bp[n];
+      if (MODE == 1) pr[n] *= dec;
+      else y += (float)cp[n] * h[n];
     }
+    if (MODE != 1) {
 #pragma unroll
-    for (int o = NL / 2; o > 0; o >>= 1) y += __shfl_xor(y, o, 64);
-    if (part == 0) {
-      y += dv * x;
-      if (z) y *= silu_f((float)z[(long)t * z_stride + c]);
-      out[(long)t * o_stride + c] = (T)y;
+      for (int o = NL / 2; o > 0; o >>= 1) y += __shfl_xor(y, o, 64);
+      if (part == 0) {
+        y += dv * x;
+        if (z) y *= silu_f((float)z[(long)t * z_stride + c]);
+        out[(long)t * o_stride + c] = (T)y;
+      }
     }
   }
+  if (MODE == 0) {
 #pragma unroll
-  for (int n = 0; n < 16; ++n) hp[n] = h[n];
+    for (int n = 0; n < 16; ++n) hp[n] = h[n];
+  } else if (MODE == 1) {
+#pragma unroll
+    for (int n = 0; n < 16; ++n) { ws_p[ws_off + n] = pr[n]; ws_h[ws_off + n] = h[n]; }
+  }
+}
+
+// One thread per (sequence, channel, state): walk the sequence's chunks, replace every chunk's P by the
+// state the chunk starts from, and leave the final state in the request's slot.
+__global__ __launch_bounds__(256) void scan_combine_kernel(float* __restrict__ ws_p, const float* __restrict__ ws_h,
+                                                           float* __restrict__ ssm_state,
+                                                           const int* __restrict__ qsl,
+                                                           const int* __restrict__ seq_lens,
+                                                           const int* __restrict__ block_table, long bt_stride,
+                                                           long CN, int chunk, int nchunks) {
+  const int s = blockIdx.y;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= CN) return;
+  const int sl = seq_lens[s];
+  if (sl <= 0) return;
+  const int L = qsl[s + 1] - qsl[s];
+  float* hp = ssm_state + (long)block_table[s * bt_stride] * CN + i;
+  float h = (sl - L > 0) ? *hp : 0.f;
+  const int nc = (L + chunk - 1) / chunk;
+  for (int k = 0; k < nc; ++k) {
+    const long off = ((long)s * nchunks + k) * CN + i;
+    const float p = ws_p[off];
+    ws_p[off] = h;
+    h = p * h + ws_h[off];
+  }
+  *hp = h;
 }
 
 VDA_EXPORT int vda_selective_scan(void* out, const void* u, const void* delta, const float* A, const void* Bm,
@@ -152,22 +203,31 @@ VDA_EXPORT int vda_selective_scan(void* out, const void* u, const void* delta, c
                                   float* ssm_state, const int* qsl, const int* seq_lens, const int* block_table,
                                   long bt_stride, int S, int C, int N, long u_stride, long d_stride, long b_stride,
                                   long c_stride, long z_stride, long o_stride, int dt_div, int a_scalar, int group_ch,
-                                  int softplus, int dtype, hipStream_t st) {
+                                  int softplus, int chunk, int nchunks, float* ws_p, float* ws_h, int dtype,
+                                  hipStream_t st) {
   if (S <= 0 || C <= 0) return 0;
   if (N != 16 && N != 32 && N != 64 && N != 128 && N != 256) return -1;
   if (dt_div < 1 || group_ch < 1) return -2;
+  const bool chunked = nchunks > 1;
+  if (chunked && (!ws_p || !ws_h || chunk < 1)) return -4;
   const long threads = (long)C * (N / 16);
-  dim3 block(256), grid((unsigned)((threads + 255) / 256), S);
-#define L(TT, NN) hipLaunchKernelGGL((selective_scan_kernel<TT, NN>), grid, block, 0, st, (TT*)out, (const TT*)u,      \
-    (const TT*)delta, A, (const TT*)Bm, (const TT*)Cm, D, (const TT*)z, delta_bias, ssm_state, qsl, seq_lens,           \
-    block_table, bt_stride, C, u_stride, d_stride, b_stride, c_stride, z_stride, o_stride, dt_div, a_scalar, group_ch, \
-    softplus)
-#define BYN(TT) do { if (N == 16) L(TT, 16); else if (N == 32) L(TT, 32); else if (N == 64) L(TT, 64); \
-                     else if (N == 128) L(TT, 128); else L(TT, 256); } while (0)
-  if (dtype == VDA_BF16) BYN(bf16_t);
-  else if (dtype == VDA_F16) BYN(f16_t);
-  else if (dtype == VDA_F32) BYN(float);
+  dim3 block(256), grid((unsigned)((threads + 255) / 256), S, chunked ? nchunks : 1);
+#define L(TT, NN, MODE) hipLaunchKernelGGL((selective_scan_kernel<TT, NN, MODE>), grid, block, 0, st, (TT*)out,             (const TT*)u, (const TT*)delta, A, (const TT*)Bm, (const TT*)Cm, D, (const TT*)z, delta_bias, ssm_state, qsl,           seq_lens, block_table, bt_stride, C, u_stride, d_stride, b_stride, c_stride, z_stride, o_stride, dt_div, a_scalar,      group_ch, softplus, chunk, ws_p, ws_h)
+#define BYN(TT, MODE) do { if (N == 16) L(TT, 16, MODE); else if (N == 32) L(TT, 32, MODE);                                    else if (N == 64) L(TT, 64, MODE); else if (N == 128) L(TT, 128, MODE);                             else L(TT, 256, MODE); } while (0)
+#define RUN(TT) do {                                                                                                   \
+    if (!chunked) { BYN(TT, 0); }                                                                                      \
+    else {                                                                                                             \
+      BYN(TT, 1);                                                                                                      \
+      const long CN = (long)C * N;                                                                                     \
+      hipLaunchKernelGGL(scan_combine_kernel, dim3((unsigned)((CN + 255) / 256), S), block, 0, st, ws_p, ws_h,         \
+                         ssm_state, qsl, seq_lens, block_table, bt_stride, CN, chunk, nchunks);                        \
+      BYN(TT, 2);                                                                                                      \
+    } } while (0)
+  if (dtype == VDA_BF16) RUN(bf16_t);
+  else if (dtype == VDA_F16) RUN(f16_t);
+  else if (dtype == VDA_F32) RUN(float);
   else return -3;
+#undef RUN
 #undef BYN
 #undef L
   VDA_CHECK_LAUNCH();
