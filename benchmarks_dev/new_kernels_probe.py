@@ -26,7 +26,7 @@ def timeit(fn, reps=20):
 
 
 print("== W4A16 skinny GEMM (Llama-3-70B shapes, group 128) vs bf16 skinny / library GEMM")
-for M in (1, 16, 64):
+for M in (1, 8, 16, 32):
     for N, K in ((10240, 8192), (57344, 8192), (8192, 28672)):
         qw = torch.randint(-2**31, 2**31 - 1, (N, K // 8), device=DEV, dtype=torch.int32)
         sc = (torch.rand(N, K // 128, device=DEV) * 0.01).to(DT)
@@ -77,7 +77,7 @@ for S, Lq in ((256, 1), (4, 2048)):
     B = torch.randn(T, 16, device=DEV, dtype=DT)
     Cm = torch.randn(T, 16, device=DEV, dtype=DT)
     ss = torch.zeros(S, C, 16, device=DEV)
-    t = timeit(lambda: ops.selective_scan(x, dl, A, B, Cm, None, x, None, ss, qsl, seq, bt))
+    t = timeit(lambda: ops.selective_scan(x, dl, A, B, Cm, None, x, None, ss, qsl, seq, bt, max_query_len=Lq))
     print(f"scan-1  S={S:3d} L={Lq:4d}: {t * 1e6:8.1f} us  ({(4 * T * C * 2 + 2 * S * C * 16 * 4) / t / 1e12:5.2f} TB/s)")
     C2, Hh, N2 = 8192, 128, 128
     x2 = torch.randn(T, C2, device=DEV, dtype=DT)
@@ -85,7 +85,7 @@ for S, Lq in ((256, 1), (4, 2048)):
     A2 = -torch.rand(Hh, device=DEV)
     B2 = torch.randn(T, N2, device=DEV, dtype=DT)
     ss2 = torch.zeros(S, C2, N2, device=DEV)
-    t = timeit(lambda: ops.selective_scan(x2, d2, A2, B2, B2, None, x2, None, ss2, qsl, seq, bt))
+    t = timeit(lambda: ops.selective_scan(x2, d2, A2, B2, B2, None, x2, None, ss2, qsl, seq, bt, max_query_len=Lq))
     print(f"scan-2  S={S:3d} L={Lq:4d}: {t * 1e6:8.1f} us  ({(3 * T * C2 * 2 + 2 * S * C2 * N2 * 4) / t / 1e12:5.2f} TB/s)")
 
 print("== multi-LoRA update, rank 16, 4 adapters")

@@ -603,15 +603,17 @@ def selective_scan(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: tor
     for t in (u, delta, B, C) + ((z,) if z is not None else ()):
         assert t.stride(1) == 1 and t.dtype == u.dtype
     out = torch.empty((T, Ch), dtype=u.dtype, device=u.device)
-    # long prefills: chunks of the sequence run in parallel (summary, combine, output passes); the
-    # chunk length keeps the two fp32 workspaces of [S, chunks, Ch, N] within ~1 GiB
+    # Long prefills of few sequences leave the chip idle when every (sequence, channel) walks its tokens
+    # alone, so the tokens are cut into chunks that run in parallel (summary, combine, output passes).
+    # The passes cost workspace traffic of 6 x Ch x N floats per chunk, so only as many chunks are made
+    # as it takes to reach ~8 waves per CU; wide states (Mamba-2) fill the chip without chunking.
     S = seq_lens.shape[0]
     chunk, nchunks, ws_p, ws_h = 0, 1, None, None
     if max_query_len >= envs.VDA_SCAN_CHUNK_MIN_TOKENS:
-        chunk = 64
-        while chunk < max_query_len and S * -(-max_query_len // chunk) * Ch * Nst * 8 > (1 << 30):
-            chunk *= 2
-        nchunks = -(-max_query_len // chunk)
+        want = -(-131072 // (S * Ch * (Nst // 16)))
+        if want > 1:
+            chunk = max(64, -(-(-(-max_query_len // want)) // 64) * 64)
+            nchunks = -(-max_query_len // chunk)
         if nchunks > 1:
             ws_p = torch.empty((S, nchunks, Ch, Nst), dtype=torch.float32, device=u.device)
             ws_h = torch.empty_like(ws_p)
