@@ -111,6 +111,31 @@ def test_chat_completion(server):
     _run(server, f)
 
 
+def test_responses_api_and_invocations(server):
+    async def f(c):
+        chat = (await c.post("/v1/chat/completions", json={"model": "tiny", "max_tokens": 5, "temperature": 0,
+                                                           "messages": [{"role": "user", "content": "w7 w8"}]})).json()
+        r = (await c.post("/v1/responses", json={"model": "tiny", "input": "w7 w8", "max_output_tokens": 5,
+                                                 "temperature": 0})).json()
+        assert r["object"] == "response" and r["status"] == "incomplete"         # 5 tokens hit the limit
+        text = r["output"][-1]["content"][0]["text"]
+        assert text == chat["choices"][0]["message"]["content"] and r["usage"]["output_tokens"] == 5
+        got = (await c.get(f"/v1/responses/{r['id']}")).json()
+        assert got["id"] == r["id"]
+        # a follow-up turn sees the first exchange
+        r2 = (await c.post("/v1/responses", json={"input": [{"role": "user", "content": [{"type": "input_text",
+                                                                                           "text": "w9"}]}],
+                                                  "previous_response_id": r["id"], "max_output_tokens": 3,
+                                                  "temperature": 0})).json()
+        assert r2["previous_response_id"] == r["id"] and r2["usage"]["input_tokens"] > r["usage"]["input_tokens"]
+        assert (await c.get("/v1/responses/resp_missing")).status_code == 404
+        inv = (await c.post("/invocations", json={"model": "tiny", "prompt": "w1 w2", "max_tokens": 3,
+                                                  "temperature": 0})).json()
+        assert inv["object"] == "text_completion" and inv["usage"]["completion_tokens"] == 3
+        assert (await c.post("/rerank", json={"query": "w1", "documents": ["w2"]})).status_code >= 400   # not a pooling model
+    _run(server, f)
+
+
 def test_metrics_endpoint(server):
     async def f(c):
         await c.post("/v1/completions", json={"prompt": "w1", "max_tokens": 2})

@@ -39,3 +39,56 @@ def test_embedding_and_classification_match_hf(tmp_path):
         with torch.no_grad():
             ref = torch.softmax(cls_hf(torch.tensor([p])).logits[0], dim=-1)
         torch.testing.assert_close(torch.tensor(o.outputs.probs), ref, atol=1e-4, rtol=1e-3)
+
+
+def test_pooling_rerank_and_classify_endpoints(tmp_path):
+    """/pooling, /rerank and /classify through the FastAPI app (in-process engine, ASGI transport)."""
+    import asyncio
+
+    import httpx
+    import transformers as tf
+
+    from tests.test_openai_server_cpu import _add_tokenizer
+    from vllm_distributed_amd.engine.arg_utils import AsyncEngineArgs
+    from vllm_distributed_amd.engine.async_llm import AsyncLLM
+    from vllm_distributed_amd.entrypoints.openai.api_server import build_app, make_arg_parser
+    torch.manual_seed(0)
+    cfg = tf.LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256, head_dim=64,
+                         num_labels=3, pad_token_id=0, id2label={0: "neg", 1: "neu", 2: "pos"},
+                         label2id={"neg": 0, "neu": 1, "pos": 2})
+    results = {}
+    for task, cls in (("embed", tf.LlamaModel), ("classify", tf.LlamaForSequenceClassification)):
+        path = os.path.join(tmp_path, task)
+        cls(cfg).float().eval().save_pretrained(path, safe_serialization=True)
+        _add_tokenizer(path)
+        args = make_arg_parser().parse_args(["--model", path, "--dtype", "float32", "--device", "cpu", "--task", task,
+                                             "--max-model-len", "256", "--max-num-seqs", "8",
+                                             "--max-num-batched-tokens", "256", "--served-model-name", "tiny"])
+        engine = AsyncLLM.from_engine_args(AsyncEngineArgs.from_cli_args(args))
+        app = build_app(args, engine)
+        loop = asyncio.new_event_loop()
+
+        async def go():
+            async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://t") as c:
+                if task == "embed":
+                    pool = (await c.post("/pooling", json={"model": "tiny", "input": ["w1 w2 w3", "w4"]})).json()
+                    emb = (await c.post("/v1/embeddings", json={"input": ["w1 w2 w3", "w4"]})).json()
+                    rr = (await c.post("/v1/rerank", json={"query": "w1 w2 w3", "documents": ["w9 w8", "w1 w2 w3", "w4"],
+                                                           "top_n": 2})).json()
+                    return pool, emb, rr
+                return (await c.post("/classify", json={"input": ["w1 w2 w3", "w4 w5"]})).json()
+        try:
+            results[task] = loop.run_until_complete(asyncio.wait_for(go(), timeout=120))
+        finally:
+            engine.shutdown()
+            loop.close()
+    pool, emb, rr = results["embed"]
+    assert len(pool["data"]) == 2 and len(pool["data"][0]["data"]) == 128
+    torch.testing.assert_close(torch.tensor(pool["data"][0]["data"]), torch.tensor(emb["data"][0]["embedding"]),
+                               atol=1e-5, rtol=1e-4)
+    assert len(rr["results"]) == 2 and rr["results"][0]["index"] == 1          # the identical document ranks first
+    assert rr["results"][0]["relevance_score"] > 0.999 >= rr["results"][1]["relevance_score"]
+    cl = results["classify"]
+    assert len(cl["data"]) == 2 and cl["data"][0]["num_classes"] == 3
+    assert abs(sum(cl["data"][0]["probs"]) - 1.0) < 1e-3 and cl["data"][0]["label"] in ("neg", "neu", "pos")

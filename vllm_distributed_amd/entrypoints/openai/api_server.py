@@ -31,10 +31,11 @@ from ...engine.async_llm import AsyncLLM
 from ...engine.core_client import EngineDeadError
 from ...logger import init_logger
 from ...version import __version__
-from .protocol import (ChatCompletionRequest, CompletionRequest, DetokenizeRequest, EmbeddingRequest, ErrorResponse,
-                       LoadLoRAAdapterRequest, ScoreRequest, TokenizeRequest, UnloadLoRAAdapterRequest)
+from .protocol import (ChatCompletionRequest, ClassificationRequest, CompletionRequest, DetokenizeRequest,
+                       EmbeddingRequest, ErrorResponse, LoadLoRAAdapterRequest, PoolingRequest, RerankRequest,
+                       ResponsesRequest, ScoreRequest, TokenizeRequest, UnloadLoRAAdapterRequest)
 from .serving import (OpenAIServingChat, OpenAIServingCompletion, OpenAIServingEmbedding, OpenAIServingModels,
-                      OpenAIServingScores, OpenAIServingTokenization)
+                      OpenAIServingPooling, OpenAIServingResponses, OpenAIServingScores, OpenAIServingTokenization)
 
 logger = init_logger(__name__)
 
@@ -144,6 +145,9 @@ def build_app(args: argparse.Namespace, engine: AsyncLLM) -> FastAPI:
                                 response_role=args.response_role, **common) if gen else None
     st.embedding = OpenAIServingEmbedding(engine, mc, models, **common) if not gen else None
     st.score = OpenAIServingScores(engine, mc, models, embedding=st.embedding, **common) if not gen else None
+    st.pooling = OpenAIServingPooling(engine, mc, models, embedding=st.embedding, scores=st.score, **common) \
+        if not gen else None
+    st.responses = OpenAIServingResponses(engine, mc, models, chat=st.chat, **common) if gen else None
     st.tokenization = OpenAIServingTokenization(engine, mc, models, chat_template=template, **common)
     st.server_load = 0
 
@@ -253,6 +257,56 @@ def build_app(args: argparse.Namespace, engine: AsyncLLM) -> FastAPI:
     async def score(request: ScoreRequest, raw: Request):
         e = _need(st.score, "the Score API")
         return _resp(e) if e else await _tracked(st.score.create_score, request, raw)
+
+    @app.post("/pooling")
+    async def pooling(request: PoolingRequest, raw: Request):
+        e = _need(st.pooling, "the Pooling API")
+        return _resp(e) if e else await _tracked(st.pooling.create_pooling, request, raw)
+
+    @app.post("/classify")
+    async def classify(request: ClassificationRequest, raw: Request):
+        e = _need(st.pooling, "the Classification API")
+        return _resp(e) if e else await _tracked(st.pooling.create_classify, request, raw)
+
+    @app.post("/rerank")
+    @app.post("/v1/rerank")
+    @app.post("/v2/rerank")
+    async def rerank(request: RerankRequest, raw: Request):
+        e = _need(st.pooling, "the Rerank API")
+        return _resp(e) if e else await _tracked(st.pooling.create_rerank, request, raw)
+
+    @app.post("/v1/responses")
+    async def responses(request: ResponsesRequest, raw: Request):
+        e = _need(st.responses, "the Responses API")
+        return _resp(e) if e else await _tracked(st.responses.create_responses, request, raw)
+
+    @app.get("/v1/responses/{response_id}")
+    async def get_response(response_id: str):
+        e = _need(st.responses, "the Responses API")
+        return _resp(e) if e else _resp(await st.responses.retrieve_responses(response_id))
+
+    @app.post("/v1/responses/{response_id}/cancel")
+    async def cancel_response(response_id: str):
+        e = _need(st.responses, "the Responses API")
+        return _resp(e) if e else _resp(await st.responses.cancel_responses(response_id))
+
+    @app.post("/invocations")
+    async def invocations(raw: Request):
+        """SageMaker-style single entry point: the body's fields pick the API."""
+        body = await raw.json()
+        if "messages" in body:
+            return await chat_completions(ChatCompletionRequest(**body), raw)
+        if "prompt" in body:
+            return await completions(CompletionRequest(**body), raw)
+        if "query" in body and "documents" in body:
+            return await rerank(RerankRequest(**body), raw)
+        if "text_1" in body:
+            return await score(ScoreRequest(**body), raw)
+        if "input" in body:
+            if st.embedding is not None:
+                return await embeddings(EmbeddingRequest(**body), raw)
+            return await responses(ResponsesRequest(**body), raw)
+        return JSONResponse({"error": "cannot tell which API this body is for"}, status_code=400)
 
     @app.post("/tokenize")
     async def tokenize(request: TokenizeRequest, raw: Request):

@@ -445,6 +445,130 @@ class RerankRequest(OpenAIBaseModel):
     top_n: int = 0
 
 
+class RerankDocument(OpenAIBaseModel):
+    text: str
+
+
+class RerankResult(OpenAIBaseModel):
+    index: int
+    document: RerankDocument
+    relevance_score: float
+
+
+class RerankUsage(OpenAIBaseModel):
+    total_tokens: int
+
+
+class RerankResponse(OpenAIBaseModel):
+    id: str = Field(default_factory=lambda: random_id("rerank"))
+    model: str
+    usage: RerankUsage
+    results: list[RerankResult]
+
+
+class PoolingRequest(EmbeddingRequest):
+    """Raw pooler output of a pooling model (reference: /pooling)."""
+
+
+class PoolingResponseData(OpenAIBaseModel):
+    index: int
+    object: str = "pooling"
+    data: Any
+
+
+class PoolingResponse(OpenAIBaseModel):
+    id: str = Field(default_factory=lambda: random_id("pool"))
+    object: str = "list"
+    created: int = Field(default_factory=lambda: int(time.time()))
+    model: str
+    data: list[PoolingResponseData]
+    usage: UsageInfo
+
+
+class ClassificationRequest(OpenAIBaseModel):
+    model: Optional[str] = None
+    input: Union[str, list[str]]
+    truncate_prompt_tokens: Optional[int] = None
+    priority: int = 0
+
+
+class ClassificationData(OpenAIBaseModel):
+    index: int
+    label: Optional[str] = None
+    probs: list[float]
+    num_classes: int
+
+
+class ClassificationResponse(OpenAIBaseModel):
+    id: str = Field(default_factory=lambda: random_id("classify"))
+    object: str = "list"
+    created: int = Field(default_factory=lambda: int(time.time()))
+    model: str
+    data: list[ClassificationData]
+    usage: UsageInfo
+
+
+# ---- Responses API ---------------------------------------------------------------------------
+class ResponsesRequest(OpenAIBaseModel):
+    model: Optional[str] = None
+    input: Union[str, list[dict[str, Any]]]
+    instructions: Optional[str] = None
+    max_output_tokens: Optional[int] = None
+    temperature: Optional[float] = None
+    top_p: Optional[float] = None
+    stream: bool = False
+    store: bool = True
+    background: bool = False
+    metadata: Optional[dict[str, Any]] = None
+    previous_response_id: Optional[str] = None
+    user: Optional[str] = None
+    priority: int = 0
+
+
+class ResponseOutputText(OpenAIBaseModel):
+    type: str = "output_text"
+    text: str
+    annotations: list = Field(default_factory=list)
+
+
+class ResponseOutputMessage(OpenAIBaseModel):
+    id: str = Field(default_factory=lambda: random_id("msg"))
+    type: str = "message"
+    role: str = "assistant"
+    status: str = "completed"
+    content: list[ResponseOutputText]
+
+
+class ResponseReasoningItem(OpenAIBaseModel):
+    id: str = Field(default_factory=lambda: random_id("rs"))
+    type: str = "reasoning"
+    summary: list = Field(default_factory=list)
+    content: list[dict[str, Any]] = Field(default_factory=list)
+
+
+class ResponseUsage(OpenAIBaseModel):
+    input_tokens: int
+    output_tokens: int
+    total_tokens: int
+
+
+class ResponsesResponse(OpenAIBaseModel):
+    id: str = Field(default_factory=lambda: random_id("resp"))
+    object: str = "response"
+    created_at: int = Field(default_factory=lambda: int(time.time()))
+    status: str = "completed"
+    model: str
+    output: list[Any]
+    instructions: Optional[str] = None
+    metadata: Optional[dict[str, Any]] = None
+    temperature: Optional[float] = None
+    top_p: Optional[float] = None
+    max_output_tokens: Optional[int] = None
+    previous_response_id: Optional[str] = None
+    usage: Optional[ResponseUsage] = None
+    incomplete_details: Optional[dict[str, Any]] = None
+
+
 # ---- tokenizer ---------------------------------------------------------------------------
 class TokenizeRequest(OpenAIBaseModel):
     model: Optional[str] = None

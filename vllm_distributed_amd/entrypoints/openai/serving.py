@@ -580,6 +580,164 @@ class OpenAIServingScores(OpenAIServing):
         return ScoreResponse(model=er.model, data=data, usage=er.usage)
 
 
+class OpenAIServingPooling(OpenAIServing):
+    """/pooling (raw pooler output), /classify (class probabilities) and /rerank (query vs documents).
+    Reference: vllm/entrypoints/openai/serving_pooling.py, serving_classification.py, serving_score.py."""
+
+    def __init__(self, *a, embedding: OpenAIServingEmbedding = None, scores: "OpenAIServingScores" = None, **kw):
+        super().__init__(*a, **kw)
+        self.embedding, self.scores = embedding, scores
+
+    async def _pool(self, texts, params, rid, priority=0, truncate=None):
+        tok = await self.tokenizer()
+        prompts = await self._tokenize_prompt(tok, texts, True, truncate)
+        gens = [self.engine_client.encode(TokensPrompt(prompt_token_ids=p["prompt_token_ids"]), params, f"{rid}-{i}",
+                                          priority=priority) for i, p in enumerate(prompts)]
+        finals = [None] * len(prompts)
+        async for i, res in merge_async_iterators(*gens):
+            finals[i] = res
+        return finals
+
+    async def create_pooling(self, request, raw_request=None):
+        from .protocol import PoolingResponse, PoolingResponseData
+        err = self.check_model(request)
+        if err:
+            return err
+        if self.model_config.runner_type != "pooling":
+            return self.error("the served model is not a pooling model")
+        rid = f"pool-{random_uuid()}"
+        try:
+            finals = await self._pool(request.input, request.to_pooling_params(), rid, request.priority,
+                                      request.truncate_prompt_tokens)
+        except ValueError as e:
+            return self.error(str(e))
+        ntok = sum(len(f.prompt_token_ids) for f in finals)
+        data = [PoolingResponseData(index=i, data=f.outputs.data.float().tolist()) for i, f in enumerate(finals)]
+        return PoolingResponse(id=rid, model=self.models.model_name(), data=data,
+                               usage=UsageInfo(prompt_tokens=ntok, total_tokens=ntok))
+
+    async def create_classify(self, request, raw_request=None):
+        import torch
+        from ...sampling_params import PoolingParams
+        from .protocol import ClassificationData, ClassificationResponse
+        err = self.check_model(request)
+        if err:
+            return err
+        if self.model_config.runner_type != "pooling":
+            return self.error("the served model is not a classification model (start with --task classify)")
+        rid = f"classify-{random_uuid()}"
+        texts = [request.input] if isinstance(request.input, str) else list(request.input)
+        try:
+            finals = await self._pool(texts, PoolingParams(task="classify"), rid, request.priority,
+                                      request.truncate_prompt_tokens)
+        except ValueError as e:
+            return self.error(str(e))
+        id2label = getattr(self.model_config.hf_config, "id2label", None) or {}
+        data, ntok = [], 0
+        for i, f in enumerate(finals):
+            probs = f.outputs.data.float().flatten()
+            if probs.numel() > 1 and not torch.isclose(probs.sum(), torch.tensor(1.0), atol=1e-3):
+                probs = torch.softmax(probs, dim=-1)
+            k = int(probs.argmax())
+            label = id2label.get(k, id2label.get(str(k))) if hasattr(id2label, "get") else None
+            data.append(ClassificationData(index=i, label=label, probs=probs.tolist(), num_classes=probs.numel()))
+            ntok += len(f.prompt_token_ids)
+        return ClassificationResponse(id=rid, model=self.models.model_name(), data=data,
+                                      usage=UsageInfo(prompt_tokens=ntok, total_tokens=ntok))
+
+    async def create_rerank(self, request, raw_request=None):
+        from .protocol import RerankDocument, RerankResponse, RerankResult, RerankUsage
+        sr = await self.scores.create_score(ScoreRequest(model=request.model, text_1=request.query,
+                                                         text_2=list(request.documents)))
+        if isinstance(sr, ErrorResponse):
+            return sr
+        rows = sorted(sr.data, key=lambda d: -d.score)
+        if request.top_n and request.top_n > 0:
+            rows = rows[: request.top_n]
+        return RerankResponse(model=sr.model, usage=RerankUsage(total_tokens=sr.usage.total_tokens),
+                              results=[RerankResult(index=d.index, document=RerankDocument(text=request.documents[d.index]),
+                                                    relevance_score=d.score) for d in rows])
+
+
+class OpenAIServingResponses(OpenAIServing):
+    """OpenAI Responses API on top of the chat pipeline: ``input`` (text or message items) and
+    ``instructions`` become chat messages; the reply is returned as response output items, with the
+    reasoning parser's output as a reasoning item.  Stored responses can be fetched, cancelled and chained
+    through ``previous_response_id``.  Reference: vllm/entrypoints/openai/serving_responses.py."""
+
+    def __init__(self, *a, chat: "OpenAIServingChat" = None, **kw):
+        super().__init__(*a, **kw)
+        self.chat = chat
+        self.store: dict[str, tuple[Any, list[dict]]] = {}
+
+    @staticmethod
+    def _messages(request, history: list[dict]) -> list[dict]:
+        msgs = list(history)
+        if request.instructions and not history:
+            msgs.append({"role": "system", "content": request.instructions})
+        if isinstance(request.input, str):
+            msgs.append({"role": "user", "content": request.input})
+        else:
+            for item in request.input:
+                content = item.get("content", "")
+                if isinstance(content, list):       # input_text / output_text parts
+                    content = "".join(p.get("text", "") for p in content if isinstance(p, dict))
+                msgs.append({"role": item.get("role", "user"), "content": content})
+        return msgs
+
+    async def create_responses(self, request, raw_request=None):
+        from .protocol import (ResponseOutputMessage, ResponseOutputText, ResponseReasoningItem, ResponsesResponse,
+                               ResponseUsage)
+        if request.stream:
+            return self.error("streaming responses are not supported; use /v1/chat/completions for streaming")
+        history: list[dict] = []
+        if request.previous_response_id:
+            prev = self.store.get(request.previous_response_id)
+            if prev is None:
+                return self.error(f"response {request.previous_response_id} not found", "NotFoundError",
+                                  HTTPStatus.NOT_FOUND)
+            history = prev[1]
+        msgs = self._messages(request, history)
+        kw = {"model": request.model, "messages": msgs, "priority": request.priority}
+        for src, dst in (("max_output_tokens", "max_completion_tokens"), ("temperature", "temperature"),
+                         ("top_p", "top_p")):
+            if getattr(request, src) is not None:
+                kw[dst] = getattr(request, src)
+        res = await self.chat.create_chat_completion(ChatCompletionRequest(**kw), raw_request)
+        if isinstance(res, ErrorResponse):
+            return res
+        msg = res.choices[0].message
+        out: list[Any] = []
+        if getattr(msg, "reasoning_content", None):
+            out.append(ResponseReasoningItem(content=[{"type": "reasoning_text", "text": msg.reasoning_content}]))
+        out.append(ResponseOutputMessage(content=[ResponseOutputText(text=msg.content or "")]))
+        length = res.choices[0].finish_reason == "length"
+        resp = ResponsesResponse(
+            model=res.model, output=out, instructions=request.instructions, metadata=request.metadata,
+            temperature=request.temperature, top_p=request.top_p, max_output_tokens=request.max_output_tokens,
+            previous_response_id=request.previous_response_id, status="incomplete" if length else "completed",
+            incomplete_details={"reason": "max_output_tokens"} if length else None,
+            usage=ResponseUsage(input_tokens=res.usage.prompt_tokens, output_tokens=res.usage.completion_tokens or 0,
+                                total_tokens=res.usage.total_tokens))
+        if request.store:
+            self.store[resp.id] = (resp, msgs + [{"role": "assistant", "content": msg.content or ""}])
+            while len(self.store) > 1024:
+                self.store.pop(next(iter(self.store)))
+        return resp
+
+    async def retrieve_responses(self, response_id: str):
+        hit = self.store.get(response_id)
+        if hit is None:
+            return self.error(f"response {response_id} not found", "NotFoundError", HTTPStatus.NOT_FOUND)
+        return hit[0]
+
+    async def cancel_responses(self, response_id: str):
+        hit = self.store.get(response_id)
+        if hit is None:
+            return self.error(f"response {response_id} not found", "NotFoundError", HTTPStatus.NOT_FOUND)
+        return hit[0]          # responses run in the foreground here: nothing is left to cancel
+
+
 class OpenAIServingTokenization(OpenAIServing):
     def __init__(self, *a, chat_template: Optional[str] = None, **kw):
         super().__init__(*a, **kw)

@@ -100,7 +100,7 @@ class IterationStats:
         n_new = len(output.new_token_ids)
         self.num_generation_tokens += n_new
         if is_prefilling:
-            assert n_new > 0
+            # generation requests emit their first token here; pooling requests finish without tokens
             self.num_prompt_tokens += prompt_len
             self.time_to_first_tokens_iter.append(self._since_arrival(req_stats.arrival_time))
         req_stats.num_generation_tokens += n_new
