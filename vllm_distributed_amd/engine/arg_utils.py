@@ -197,6 +197,8 @@ class EngineArgs:
             disable_sliding_window=self.disable_sliding_window, limit_mm_per_prompt=self.limit_mm_per_prompt)
 
     def create_engine_config(self, usage_context=None) -> C.VllmConfig:
+        from ..plugins import load_general_plugins
+        load_general_plugins()               # plugins may register model architectures the config names
         mc = self.create_model_config()
         device = C.DeviceConfig(self.device)
         on_gpu = device.device == "cuda"

@@ -29,6 +29,8 @@ logger = init_logger(__name__)
 class EngineCore:
     def __init__(self, vllm_config: VllmConfig, executor_class: type, log_stats: bool,
                  executor_fail_callback: Optional[Callable] = None):
+        from ..plugins import load_general_plugins
+        load_general_plugins()
         self.vllm_config = vllm_config
         self.log_stats = log_stats
         logger.info("initialising engine core: %s", vllm_config)

@@ -28,6 +28,11 @@ class LLMEngine:
         self.model_config = vllm_config.model_config
         self.log_stats = log_stats
         executor_class = executor_class or Executor.get_class(vllm_config)
+        from ..usage import UsageContext, usage_message
+        usage_message.report_usage((self.model_config.architectures or ["unknown"])[0], UsageContext.ENGINE_CONTEXT,
+                                   {"dtype": str(self.model_config.dtype),
+                                    "tensor_parallel_size": vllm_config.parallel_config.tensor_parallel_size,
+                                    "quantization": self.model_config.quantization})
         self.tokenizer: Optional[TokenizerGroup] = None
         if not self.model_config.skip_tokenizer_init:
             self.tokenizer = TokenizerGroup(

@@ -74,3 +74,85 @@ def get_ip() -> str:
 
 def get_distributed_init_method(ip: str, port: int) -> str:
     return f"tcp://[{ip}]:{port}" if ":" in ip else f"tcp://{ip}:{port}"
+
+
+class StatelessProcessGroup:
+    """A process group that leaves ``torch.distributed``'s global state alone: ranks meet on a TCPStore
+    and exchange msgpack-encoded objects through it.  Used for control-plane agreement between
+    processes that are not part of the engine's own world (data-parallel replicas, prefill/decode
+    pairs) and to hand a unique id to a dedicated RCCL communicator (``RcclCommunicator`` accepts it).
+    Keys are consumed in order, so broadcasts and gathers from different call sites cannot mix.
+    Reference: vllm/distributed/utils.py:137-340 (StatelessProcessGroup)."""
+
+    def __init__(self, rank: int, world_size: int, store, data_expiration_seconds: int = 3600):
+        import time as _time
+        self.rank, self.world_size, self.store = rank, world_size, store
+        self.expire = data_expiration_seconds
+        self._time = _time
+        self.send_dst_counter = {i: 0 for i in range(world_size)}
+        self.recv_src_counter = {i: 0 for i in range(world_size)}
+        self.broadcast_send_counter = 0
+        self.broadcast_recv_src_counter = {i: 0 for i in range(world_size)}
+        self._sent: list[tuple[str, float]] = []
+
+    @classmethod
+    def create(cls, host: str, port: int, rank: int, world_size: int, data_expiration_seconds: int = 3600,
+               store_timeout: int = 300) -> "StatelessProcessGroup":
+        import datetime
+
+        from torch.distributed import TCPStore
+        store = TCPStore(host_name=host, port=port, world_size=world_size, is_master=(rank == 0),
+                         timeout=datetime.timedelta(seconds=store_timeout))
+        return cls(rank, world_size, store, data_expiration_seconds)
+
+    @staticmethod
+    def _enc(obj) -> bytes:
+        from ..engine.serial import decode as _d, encode as _e  # noqa: F401  (registered wire types)
+        return _e(obj)
+
+    @staticmethod
+    def _dec(raw: bytes):
+        from ..engine.serial import decode
+        return decode(raw)
+
+    def _expire(self) -> None:
+        now = self._time.time()
+        while self._sent and now - self._sent[0][1] > self.expire:
+            key, _ = self._sent.pop(0)
+            try:
+                self.store.delete_key(key)
+            except Exception:
+                pass
+
+    def send_obj(self, obj, dst: int) -> None:
+        self._expire()
+        key = f"send_to/{dst}/{self.send_dst_counter[dst]}"
+        self.store.set(key, self._enc(obj))
+        self.send_dst_counter[dst] += 1
+        self._sent.append((key, self._time.time()))
+
+    def recv_obj(self, src: int):
+        obj = self._dec(self.store.get(f"send_to/{self.rank}/{self.recv_src_counter[src]}"))
+        self.recv_src_counter[src] += 1
+        return obj
+
+    def broadcast_obj(self, obj, src: int):
+        if self.rank == src:
+            self._expire()
+            key = f"broadcast_from/{src}/{self.broadcast_send_counter}"
+            self.store.set(key, self._enc(obj))
+            self.broadcast_send_counter += 1
+            self._sent.append((key, self._time.time()))
+            return obj
+        key = f"broadcast_from/{src}/{self.broadcast_recv_src_counter[src]}"
+        self.broadcast_recv_src_counter[src] += 1
+        return self._dec(self.store.get(key))
+
+    def all_gather_obj(self, obj) -> list:
+        out = []
+        for i in range(self.world_size):
+            out.append(self.broadcast_obj(obj if i == self.rank else None, src=i))
+        return out
+
+    def barrier(self) -> None:
+        self.all_gather_obj(self.rank)

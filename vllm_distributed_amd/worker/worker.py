@@ -52,6 +52,8 @@ class Worker:
 
     # ------------------------------------------------------------------
     def init_device(self) -> None:
+        from ..plugins import load_general_plugins
+        load_general_plugins()               # worker processes need the same registrations as the front end
         dc = self.vllm_config.device_config
         pc = self.parallel_config
         if dc.device == "cuda":
