@@ -445,7 +445,7 @@ class ParallelConfig:
     enable_token_parallel: bool = False
     #: Number of token-parallel ranks.
     token_parallel_size: int = 1
-    #: mp | uni | external_launcher | ray (ray is not available here).
+    #: mp | uni | external_launcher | ray (ray only when the package is installed).
     distributed_executor_backend: Optional[str] = None
     #: Use only RCCL for all-reduce (disable the peer-memory kernels).
     disable_custom_all_reduce: bool = False
@@ -483,9 +483,11 @@ class ParallelConfig:
         if self.distributed_executor_backend is None:
             self.distributed_executor_backend = "mp" if self.world_size > 1 else "uni"
         if self.distributed_executor_backend == "ray":
-            raise ValueError("the ray executor is not available in this build; use 'mp' or "
-                             "'external_launcher'")
-        if self.distributed_executor_backend not in ("mp", "uni", "external_launcher"):
+            from .executor.ray_executor import ray_is_available
+            if not ray_is_available():
+                raise ValueError("distributed_executor_backend='ray' needs the `ray` package, which is not "
+                                 "installed; use 'mp' or 'external_launcher'")
+        if self.distributed_executor_backend not in ("mp", "uni", "external_launcher", "ray"):
             raise ValueError(f"unknown executor backend {self.distributed_executor_backend!r}")
         if self.distributed_executor_backend == "uni" and self.world_size > 1:
             raise ValueError("the uni executor runs exactly one rank")

@@ -33,6 +33,9 @@ class Executor:
         if backend == "external_launcher":
             from .uniproc import ExternalLauncherExecutor
             return ExternalLauncherExecutor
+        if backend == "ray":
+            from .ray_executor import RayDistributedExecutor
+            return RayDistributedExecutor
         raise ValueError(f"unknown executor backend {backend!r}")
 
     def __init__(self, vllm_config: VllmConfig):
