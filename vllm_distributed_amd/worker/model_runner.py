@@ -37,6 +37,7 @@ from ..sched.output import EMPTY_MODEL_RUNNER_OUTPUT, ModelRunnerOutput, Schedul
 from .input_batch import InputBatch
 
 logger = init_logger(__name__)
+_CAPTURE_STATE_ANCHOR = None      # see ModelRunner.capture_model
 
 
 class ModelRunner:
@@ -863,14 +864,19 @@ class ModelRunner:
             return
         t0 = time.time()
         free0 = torch.cuda.mem_get_info(self.device)[0]
-        with torch.inference_mode(False):
-            # The first capture of a process creates the default generator's capture-state tensors, and
-            # every later capture updates them in place.  Created inside inference mode they would make
-            # any capture outside it (user code sharing the process) fail, so create them here.
-            probe = torch.zeros(1, device=self.device)
-            with torch.cuda.graph(torch.cuda.CUDAGraph()):
-                probe.add_(1)
-            del probe
+        global _CAPTURE_STATE_ANCHOR
+        if _CAPTURE_STATE_ANCHOR is None:
+            with torch.inference_mode(False):
+                # The default generator creates its capture-state tensors when the first graph registers
+                # with it and drops them when the last one is destroyed; every capture updates them in
+                # place.  Created inside inference mode they would make a capture outside it (user code
+                # sharing the process) fail, so a tiny graph captured here, outside inference mode, is
+                # kept for the life of the process: the tensors are made once and stay ordinary ones.
+                probe = torch.zeros(1, device=self.device)
+                anchor = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(anchor):
+                    probe.add_(1)
+                _CAPTURE_STATE_ANCHOR = (anchor, probe)
         self.graph_pool = torch.cuda.graph_pool_handle()
         with graph_capture(self.device) as cap:
             for bs in sorted(self.capture_sizes, reverse=True):
