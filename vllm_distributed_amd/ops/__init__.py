@@ -606,11 +606,11 @@ def selective_scan(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: tor
     # Long prefills of few sequences leave the chip idle when every (sequence, channel) walks its tokens
     # alone, so the tokens are cut into chunks that run in parallel (summary, combine, output passes).
     # The passes cost workspace traffic of 6 x Ch x N floats per chunk, so only as many chunks are made
-    # as it takes to reach ~8 waves per CU; wide states (Mamba-2) fill the chip without chunking.
+    # as it takes to reach ~32 waves per CU; wide states (Mamba-2) fill the chip almost without chunking.
     S = seq_lens.shape[0]
     chunk, nchunks, ws_p, ws_h = 0, 1, None, None
     if max_query_len >= envs.VDA_SCAN_CHUNK_MIN_TOKENS:
-        want = -(-131072 // (S * Ch * (Nst // 16)))
+        want = -(-524288 // (S * Ch * (Nst // 16)))
         if want > 1:
             chunk = max(64, -(-(-(-max_query_len // want)) // 64) * 64)
             nchunks = -(-max_query_len // chunk)
