@@ -194,6 +194,7 @@ class DeepseekMoE(nn.Module):
 
 class DeepseekDecoderLayer(nn.Module):
     norm_cls = RMSNorm
+    make_norm = classmethod(lambda cls, config: cls.norm_cls(config.hidden_size, getattr(config, "rms_norm_eps", 1e-6)))
     def __init__(self, config, vllm_config: VllmConfig, quant_config=None, prefix: str = ""):
         super().__init__()
         idx = int(prefix.split(".")[-1])

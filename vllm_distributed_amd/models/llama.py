@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ..config import VllmConfig
 from ..layers.attention import Attention
-from ..layers.basic import (LogitsProcessor, ParallelLMHead, RMSNorm, SiluAndMul, VocabParallelEmbedding,
+from ..layers.basic import (GemmaRMSNorm, LogitsProcessor, ParallelLMHead, RMSNorm, SiluAndMul, VocabParallelEmbedding,
                             get_act_and_mul_fn)
 from ..forward_context import get_forward_context, has_forward_context
 from ..layers.linear import (MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear,
@@ -49,9 +49,11 @@ class LlamaAttention(nn.Module):
                  rope_scaling: Optional[dict], max_position: int, bias: bool = False, o_bias: bool = False,
                  sliding_window: Optional[int] = None, quant_config=None, prefix: str = "", qk_norm: bool = False,
                  cache_dtype: str = "auto", attention_only: bool = False, scale: Optional[float] = None,
-                 logits_soft_cap: Optional[float] = None):
+                 logits_soft_cap: Optional[float] = None, neox_style: bool = True,
+                 qkv_clip: Optional[float] = None, alibi_slopes: Optional[list] = None, use_rope: bool = True):
         super().__init__()
         tp = get_tensor_model_parallel_world_size()
+        self.qkv_clip = qkv_clip
         self.total_num_heads, self.total_num_kv_heads = num_heads, num_kv_heads
         self.num_heads = num_heads // tp
         self.num_kv_heads = max(1, num_kv_heads // tp)
@@ -60,17 +62,28 @@ class LlamaAttention(nn.Module):
         self.attention_only = attention_only
         if not attention_only:
             self._make_projections(hidden_size, num_heads, num_kv_heads, bias, o_bias, quant_config, prefix)
-        partial = getattr(config, "partial_rotary_factor", 1.0) or 1.0
-        self.rotary_emb = get_rope(self.head_dim, self.head_dim, max_position, rope_theta, True, rope_scaling,
-                                   partial)
+        partial = getattr(config, "partial_rotary_factor", None) or \
+            (getattr(config, "rope_parameters", None) or {}).get("partial_rotary_factor") or 1.0
+        self.rotary_emb = get_rope(self.head_dim, self.head_dim, max_position, rope_theta, neox_style, rope_scaling,
+                                   partial) if use_rope else None
+        if alibi_slopes is not None:       # this rank's heads
+            r = get_tensor_model_parallel_rank()
+            alibi_slopes = list(alibi_slopes)[r * self.num_heads:(r + 1) * self.num_heads]
         self.attn = Attention(self.num_heads, self.head_dim, scale if scale is not None else self.head_dim ** -0.5,
-                              self.num_kv_heads, sliding_window=sliding_window, logits_soft_cap=logits_soft_cap,
-                              prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
-        self.qk_norm = qk_norm and not attention_only
+                              self.num_kv_heads, alibi_slopes=alibi_slopes, sliding_window=sliding_window,
+                              logits_soft_cap=logits_soft_cap, prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
+        # True: RMSNorm per head (Qwen3); "gemma": the (1 + w) form per head; "full": one RMSNorm over the
+        # whole q / k projection (OLMo-2)
+        self.qk_norm = qk_norm if not attention_only else False
         if self.qk_norm:
             eps = getattr(config, "rms_norm_eps", 1e-6)
-            self.q_norm = RMSNorm(self.head_dim, eps)
-            self.k_norm = RMSNorm(self.head_dim, eps)
+            if self.qk_norm == "full":
+                self.q_norm = RMSNorm(num_heads * self.head_dim, eps)
+                self.k_norm = RMSNorm(num_kv_heads * self.head_dim, eps)
+            else:
+                cls = GemmaRMSNorm if self.qk_norm == "gemma" else RMSNorm
+                self.q_norm = cls(self.head_dim, eps)
+                self.k_norm = cls(self.head_dim, eps)
 
     def _make_projections(self, hidden_size, num_heads, num_kv_heads, bias, o_bias, quant_config, prefix):
         self.qkv_proj = QKVParallelLinear(hidden_size, self.head_dim, num_heads, num_kv_heads, bias=bias,
@@ -84,9 +97,26 @@ class LlamaAttention(nn.Module):
         token_parallel_attention(self.attn, self.rotary_emb, None, positions, md, self.q_size + 2 * self.kv_size,
                                  self.q_size, dtype, positions.device)
 
+    def _full_width_qk_norm(self, qkv: torch.Tensor) -> None:
+        """RMSNorm over all heads of q (and of k) at once; with TP the other ranks' heads are gathered first."""
+        tp = get_tensor_model_parallel_world_size()
+        r = get_tensor_model_parallel_rank()
+        for lo, size, norm in ((0, self.q_size, self.q_norm), (self.q_size, self.kv_size, self.k_norm)):
+            x = qkv[:, lo:lo + size].contiguous()
+            if tp > 1:
+                x = tensor_model_parallel_all_gather(x, -1)
+            if x.shape[-1] != norm.weight.shape[0]:
+                raise ValueError("full-width q/k norm needs num_key_value_heads to be a multiple of the TP size")
+            y = norm(x)
+            qkv[:, lo:lo + size] = y[:, r * size:(r + 1) * size] if tp > 1 else y
+
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
         qkv = self.qkv_proj(hidden_states)
-        if self.qk_norm:
+        if self.qkv_clip is not None:
+            qkv.clamp_(-self.qkv_clip, self.qkv_clip)
+        if self.qk_norm == "full":
+            self._full_width_qk_norm(qkv)
+        elif self.qk_norm:
             T = qkv.shape[0]
             q = qkv[:, : self.q_size].reshape(T * self.num_heads, self.head_dim)
             k = qkv[:, self.q_size: self.q_size + self.kv_size].reshape(T * self.num_kv_heads, self.head_dim)
@@ -137,9 +167,13 @@ class LlamaDecoderLayer(nn.Module):
         if attention_only:
             return
         self.mlp = self._make_mlp(config, vllm_config, quant_config, f"{prefix}.mlp")
-        eps = getattr(config, "rms_norm_eps", 1e-6)
-        self.input_layernorm = self.norm_cls(config.hidden_size, eps)
-        self.post_attention_layernorm = self.norm_cls(config.hidden_size, eps)
+        self.input_layernorm = self.make_norm(config)
+        self.post_attention_layernorm = self.make_norm(config)
+
+    @classmethod
+    def make_norm(cls, config) -> nn.Module:
+        """The block's normalisation layer (families with LayerNorm or other epsilon names override)."""
+        return cls.norm_cls(config.hidden_size, getattr(config, "rms_norm_eps", 1e-6))
 
     def _make_mlp(self, config, vllm_config, quant_config, prefix):
         return LlamaMLP(config.hidden_size, config.intermediate_size, bool(getattr(config, "mlp_bias", False)),
@@ -194,8 +228,7 @@ class LlamaModel(nn.Module):
         self.start_layer, self.end_layer, self.layers = make_layers(
             config.num_hidden_layers,
             lambda p: self.layer_cls(config, vllm_config, quant_config, p), f"{prefix}.layers")
-        self.norm = self.layer_cls.norm_cls(config.hidden_size, getattr(config, "rms_norm_eps", 1e-6)) \
-            if pp.is_last_rank else PPMissingLayer()
+        self.norm = self.layer_cls.make_norm(config) if pp.is_last_rank else PPMissingLayer()
         self.embed_scale = float(self.embed_scale_of(config))
         self.tp = get_tensor_model_parallel_world_size()
         # sequence parallelism: dense Llama-style layers only (the MoE blocks reduce on their own)
