@@ -115,6 +115,63 @@ def _save_tiny(tmp, kind):
     elif kind == "gpt_bigcode":
         cfg = tf.GPTBigCodeConfig(vocab_size=320, n_embd=128, n_layer=2, n_head=2, n_positions=256, multi_query=True)
         m = tf.GPTBigCodeForCausalLM(cfg)
+    elif kind == "stablelm":
+        cfg = tf.StableLmConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                                use_qkv_bias=True)
+        m = tf.StableLmForCausalLM(cfg)
+    elif kind == "olmo":
+        cfg = tf.OlmoConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                            num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256, clip_qkv=0.5)
+        m = tf.OlmoForCausalLM(cfg)
+    elif kind == "olmo2":
+        cfg = tf.Olmo2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                             num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256)
+        m = tf.Olmo2ForCausalLM(cfg)
+    elif kind == "cohere":
+        cfg = tf.CohereConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                              num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                              logit_scale=0.25)
+        m = tf.CohereForCausalLM(cfg)
+    elif kind == "nemotron":
+        cfg = tf.NemotronConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                                head_dim=64)
+        m = tf.NemotronForCausalLM(cfg)
+    elif kind == "glm":
+        cfg = tf.GlmConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                           num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256, head_dim=64,
+                           pad_token_id=0)
+        m = tf.GlmForCausalLM(cfg)
+    elif kind == "glm4":
+        cfg = tf.Glm4Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                            num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256, head_dim=64,
+                            pad_token_id=0)
+        m = tf.Glm4ForCausalLM(cfg)
+    elif kind == "gemma3":
+        cfg = tf.Gemma3TextConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                                  num_attention_heads=2, num_key_value_heads=1, head_dim=64,
+                                  max_position_embeddings=256, query_pre_attn_scalar=32, sliding_window=16,
+                                  layer_types=["sliding_attention", "sliding_attention", "full_attention"])
+        m = tf.Gemma3ForCausalLM(cfg)
+    elif kind in ("falcon_new", "falcon_mq", "falcon_alibi"):
+        kw = {"falcon_new": dict(new_decoder_architecture=True, num_kv_heads=1),
+              "falcon_mq": dict(new_decoder_architecture=False, multi_query=True, parallel_attn=True),
+              "falcon_alibi": dict(new_decoder_architecture=False, multi_query=False, parallel_attn=False,
+                                   alibi=True, bias=True)}[kind]
+        cfg = tf.FalconConfig(vocab_size=320, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                              max_position_embeddings=256, **kw)
+        m = tf.FalconForCausalLM(cfg)
+    elif kind == "bloom":
+        cfg = tf.BloomConfig(vocab_size=320, hidden_size=128, n_layer=2, n_head=2)
+        m = tf.BloomForCausalLM(cfg)
+    elif kind == "mpt":
+        cfg = tf.MptConfig(vocab_size=320, d_model=128, n_layers=2, n_heads=2, max_seq_len=256)
+        m = tf.MptForCausalLM(cfg)
+    elif kind == "phi":
+        cfg = tf.PhiConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                           num_attention_heads=2, max_position_embeddings=256)
+        m = tf.PhiForCausalLM(cfg)
     elif kind in ("mamba", "falcon_mamba", "mamba2"):
         if kind == "mamba":
             m = tf.MambaForCausalLM(tf.MambaConfig(vocab_size=320, hidden_size=64, state_size=16, num_hidden_layers=2,
@@ -139,7 +196,9 @@ def _save_tiny(tmp, kind):
 @pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2", "mixtral", "qwen2_moe", "qwen3_moe",
                                   "deepseek_v2", "deepseek_v2_yarn", "deepseek_v2_mla", "deepseek_v3", "gemma", "gemma2", "phi3",
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
-                                  "falcon_mamba", "mamba2"])
+                                  "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
+                                  "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
+                                  "mpt", "phi"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]
@@ -189,4 +248,112 @@ def test_deepseek_expanded_heads_path_still_matches_hf(tmp_path, monkeypatch):
             ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
                               eos_token_id=None)[0, len(p):].tolist()
         assert list(o.outputs[0].token_ids) == ref
+    llm.shutdown()
+
+
+def _write_checkpoint(path, state, config: dict):
+    import json
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    save_file({k: v.contiguous() for k, v in state.items()}, os.path.join(path, "model.safetensors"))
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(config, f)
+
+
+def test_internlm2_layout_equals_llama(tmp_path):
+    """InternLM2 is not in transformers: the same weights as a tiny HF Llama, renamed and with q/k/v
+    interleaved per KV head the way InternLM2 checkpoints store them, must decode the same tokens."""
+    _, hf = _save_tiny(str(tmp_path), "llama")
+    c = hf.config
+    H, KV, D = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+    g = H // KV
+    names = {"self_attn.o_proj": "attention.wo", "input_layernorm": "attention_norm",
+             "post_attention_layernorm": "ffn_norm", "mlp.gate_proj": "feed_forward.w1",
+             "mlp.up_proj": "feed_forward.w3", "mlp.down_proj": "feed_forward.w2"}
+    state, sd = {}, hf.state_dict()
+    for k, v in sd.items():
+        if ".q_proj." in k:
+            q, kk, vv = v, sd[k.replace("q_proj", "k_proj")], sd[k.replace("q_proj", "v_proj")]
+            fused = torch.cat([q.view(KV, g, D, -1), kk.view(KV, 1, D, -1), vv.view(KV, 1, D, -1)], dim=1)
+            state[k.replace("self_attn.q_proj", "attention.wqkv")] = fused.reshape((H + 2 * KV) * D, -1)
+            continue
+        if ".k_proj." in k or ".v_proj." in k:
+            continue
+        k = k.replace("model.embed_tokens", "model.tok_embeddings").replace("lm_head.", "output.")
+        for a, b in names.items():
+            k = k.replace(a, b)
+        state[k] = v
+    cfg = c.to_dict()
+    cfg.update(architectures=["InternLM2ForCausalLM"], model_type="internlm2", rope_theta=10000.0)
+    path = str(tmp_path / "internlm2")
+    _write_checkpoint(path, state, cfg)
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 40]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+              max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=10,
+                                                                                   ignore_eos=True))
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=10, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref
+    llm.shutdown()
+
+
+def test_baichuan_alibi_matches_plain_torch(tmp_path):
+    """Baichuan is not in transformers either: a random checkpoint in its layout (W_pack, ALiBi, no
+    rotary) against a plain PyTorch forward written here.  Parity with the original code is unpinned."""
+    from vllm_distributed_amd.models.llama_variants import alibi_slopes
+    torch.manual_seed(1)
+    V, d, H, L, F = 320, 128, 2, 2, 256
+    D = d // H
+    w = {"model.embed_tokens.weight": torch.randn(V, d) * 0.5, "model.norm.weight": torch.rand(d) + 0.5,
+         "lm_head.weight": torch.randn(V, d) * 0.2}
+    for i in range(L):
+        p = f"model.layers.{i}."
+        w[p + "self_attn.W_pack.weight"] = torch.randn(3 * d, d) * 0.15
+        w[p + "self_attn.o_proj.weight"] = torch.randn(d, d) * 0.1
+        w[p + "mlp.gate_proj.weight"] = torch.randn(F, d) * 0.1
+        w[p + "mlp.up_proj.weight"] = torch.randn(F, d) * 0.1
+        w[p + "mlp.down_proj.weight"] = torch.randn(d, F) * 0.1
+        w[p + "input_layernorm.weight"] = torch.rand(d) + 0.5
+        w[p + "post_attention_layernorm.weight"] = torch.rand(d) + 0.5
+    cfg = dict(architectures=["BaiChuanForCausalLM"], model_type="baichuan", vocab_size=V, hidden_size=d,
+               intermediate_size=F, num_hidden_layers=L, num_attention_heads=H, rms_norm_eps=1e-6,
+               model_max_length=256, max_position_embeddings=256, tie_word_embeddings=False, torch_dtype="float32")
+    path = str(tmp_path / "baichuan")
+    _write_checkpoint(path, w, cfg)
+
+    def rms(x, g):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * g
+
+    slopes = torch.tensor(alibi_slopes(H))
+
+    def forward(ids):
+        x = w["model.embed_tokens.weight"][ids]
+        T = len(ids)
+        pos = torch.arange(T)
+        bias = slopes[:, None, None] * (pos[None, :] - pos[:, None])[None].float()
+        mask = torch.full((T, T), float("-inf")).triu(1)
+        for i in range(L):
+            p = f"model.layers.{i}."
+            q, k, v = (rms(x, w[p + "input_layernorm.weight"]) @ w[p + "self_attn.W_pack.weight"].T).chunk(3, -1)
+            q, k, v = (t.view(T, H, D).transpose(0, 1) for t in (q, k, v))
+            a = torch.softmax(q @ k.transpose(1, 2) * D ** -0.5 + bias + mask, -1) @ v
+            x = x + a.transpose(0, 1).reshape(T, d) @ w[p + "self_attn.o_proj.weight"].T
+            h = rms(x, w[p + "post_attention_layernorm.weight"])
+            x = x + (torch.nn.functional.silu(h @ w[p + "mlp.gate_proj.weight"].T) *
+                     (h @ w[p + "mlp.up_proj.weight"].T)) @ w[p + "mlp.down_proj.weight"].T
+        return rms(x, w["model.norm.weight"])[-1] @ w["lm_head.weight"].T
+
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+              max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=8,
+                                                                                   ignore_eos=True))
+    for p, o in zip(prompts, outs):
+        ids = list(p)
+        for _ in range(8):
+            ids.append(int(forward(torch.tensor(ids)).argmax()))
+        assert list(o.outputs[0].token_ids) == ids[len(p):]
     llm.shutdown()

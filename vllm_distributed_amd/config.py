@@ -270,10 +270,15 @@ class ModelConfig:
     def get_total_num_attention_heads(self) -> int:
         if self.is_attention_free:
             return 1
-        return self.hf_config.get("num_attention_heads") or self.hf_config.get("n_head")
+        return self.hf_config.get("num_attention_heads") or self.hf_config.get("n_head") or \
+            self.hf_config.get("n_heads")
 
     def get_total_num_kv_heads(self) -> int:
         hf = self.hf_config
+        if hf.get("model_type") in ("falcon", "RefinedWeb", "RefinedWebModel") \
+                and not hf.get("new_decoder_architecture"):
+            # the first two Falcon generations: one shared KV head with multi_query, else one per head
+            return 1 if hf.get("multi_query", True) else self.get_total_num_attention_heads()
         for k in ("num_key_value_heads", "n_head_kv", "num_kv_heads", "multi_query_group_num"):
             if hf.get(k) is not None:
                 return hf.get(k)
@@ -293,7 +298,8 @@ class ModelConfig:
         return max(1, self.get_total_num_kv_heads() // pc.tensor_parallel_size)
 
     def get_total_num_hidden_layers(self) -> int:
-        return self.hf_config.get("num_hidden_layers") or self.hf_config.get("n_layer")
+        return self.hf_config.get("num_hidden_layers") or self.hf_config.get("n_layer") or \
+            self.hf_config.get("n_layers")
 
     def get_num_layers(self, pc: "ParallelConfig", pp_rank: Optional[int] = None) -> int:
         from .parallel.utils import get_pp_indices

@@ -138,21 +138,26 @@ class LlamaDecoderLayer(nn.Module):
         """Per-family keyword arguments for LlamaAttention (softmax scale, soft cap, window...)."""
         return {}
 
-    def __init__(self, config, vllm_config: VllmConfig, quant_config=None, prefix: str = "",
-                 attention_only: bool = False):
-        super().__init__()
-        mc = vllm_config.model_config
+    def _rope_of(self, config, layer_idx: int) -> tuple[float, Optional[dict]]:
+        """(theta, scaling dict or None) of this layer's rotary embedding."""
         rope_scaling = getattr(config, "rope_scaling", None) or getattr(config, "rope_parameters", None)
         # newer HF configs keep theta inside rope_parameters
         rope_theta = getattr(config, "rope_theta", None) or (rope_scaling or {}).get("rope_theta") or 10000.0
         if rope_scaling and "rope_type" not in rope_scaling and "type" not in rope_scaling:
             rope_scaling = None
+        return float(rope_theta), rope_scaling
+
+    def __init__(self, config, vllm_config: VllmConfig, quant_config=None, prefix: str = "",
+                 attention_only: bool = False):
+        super().__init__()
+        mc = vllm_config.model_config
+        layer_idx = int(prefix.split(".")[-1])
+        rope_theta, rope_scaling = self._rope_of(config, layer_idx)
         bias = bool(getattr(config, "attention_bias", False) or getattr(config, "bias", False))
         arch = (mc.architectures or [""])[0]
         if arch.startswith("Qwen2"):
             bias = True
         window = mc.get_sliding_window()
-        layer_idx = int(prefix.split(".")[-1])
         if window is not None and getattr(config, "max_window_layers", None) is not None \
                 and arch.startswith("Qwen") and layer_idx < config.max_window_layers:
             window = None

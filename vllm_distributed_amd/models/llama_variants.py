@@ -1,0 +1,404 @@
+"""More decoder families built from the Llama block: StableLM, OLMo, OLMo-2, Cohere (Command-R),
+Nemotron, GLM / GLM-4, Gemma-3 (text), InternLM2 and Baichuan.  Each differs from Llama in its
+normalisation layer, the residual wiring, the rotary convention or the checkpoint layout only, so
+they share the fused QKV / gate-up projections, the fused RoPE + cache-write kernel and the paged
+attention kernels.
+Reference: vllm/model_executor/models/{stablelm,olmo,olmo2,commandr,nemotron,glm,glm4,gemma3,
+internlm2,baichuan}.py.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..layers.basic import GemmaRMSNorm, LayerNorm, RMSNorm, get_act_fn
+from ..layers.linear import ColumnParallelLinear, RowParallelLinear
+from .llama import LlamaDecoderLayer, LlamaForCausalLM, LlamaMLP, LlamaModel
+from .llama_family import Gemma2DecoderLayer, GemmaModel
+from .utils import load_weights_with_mapping
+
+
+class ResidualLayerNorm(LayerNorm):
+    """LayerNorm with the (x, residual) -> (norm(x + residual), x + residual) form the Llama block uses."""
+
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        if residual is None:
+            return super().forward(x)
+        residual.add_(x)
+        return super().forward(residual), residual
+
+
+class PlainLayerNorm(nn.Module):
+    """LayerNorm without learnable scale or shift (OLMo)."""
+
+    def __init__(self, hidden_size: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(hidden_size), persistent=False)
+
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        if residual is None:
+            return ops.layer_norm(x, self.weight, None, self.eps)
+        residual.add_(x)
+        return ops.layer_norm(residual, self.weight, None, self.eps), residual
+
+
+def alibi_slopes(num_heads: int, alibi_bias_max: float = 8.0) -> list[float]:
+    """Geometric head slopes of ALiBi (Press et al.); heads beyond a power of two take every other slope
+    of the next power."""
+    p = 2 ** math.floor(math.log2(num_heads))
+    base = 2.0 ** (-(2.0 ** -(math.log2(p) - math.log2(alibi_bias_max))))
+    slopes = [base ** (i + 1) for i in range(p)]
+    if p != num_heads:
+        extra = 2.0 ** (-(2.0 ** -(math.log2(2 * p) - math.log2(alibi_bias_max))))
+        slopes += [extra ** (i + 1) for i in range(0, 2 * (num_heads - p), 2)]
+    return slopes
+
+
+# ---- StableLM ----------------------------------------------------------------------------------------
+class StableLmDecoderLayer(LlamaDecoderLayer):
+    supports_sequence_parallel = False
+
+    @classmethod
+    def make_norm(cls, config):
+        return ResidualLayerNorm(config.hidden_size, getattr(config, "layer_norm_eps", 1e-5))
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        if getattr(config, "qk_layernorm", False):
+            raise ValueError("StableLM checkpoints with per-head q/k LayerNorm are not supported")
+        if getattr(config, "use_parallel_residual", False):
+            raise ValueError("StableLM checkpoints with parallel residual blocks are not supported")
+        return {"bias": bool(getattr(config, "use_qkv_bias", False)), "o_bias": False}
+
+
+class StableLmModel(LlamaModel):
+    layer_cls = StableLmDecoderLayer
+
+
+class StableLmForCausalLM(LlamaForCausalLM):
+    model_cls = StableLmModel
+
+
+StablelmForCausalLM = StableLmForCausalLM
+
+
+# ---- OLMo --------------------------------------------------------------------------------------------
+class OlmoDecoderLayer(LlamaDecoderLayer):
+    supports_sequence_parallel = False
+
+    @classmethod
+    def make_norm(cls, config):
+        return PlainLayerNorm(config.hidden_size, 1e-5)
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        return {"qkv_clip": getattr(config, "clip_qkv", None)}
+
+
+class OlmoModel(LlamaModel):
+    layer_cls = OlmoDecoderLayer
+
+
+class OlmoForCausalLM(LlamaForCausalLM):
+    model_cls = OlmoModel
+
+
+# ---- OLMo-2 ------------------------------------------------------------------------------------------
+class Olmo2DecoderLayer(LlamaDecoderLayer):
+    """Norms sit behind the attention and the MLP (x + norm(f(x))); q and k are normalised over their
+    whole width before the rotary embedding."""
+    supports_sequence_parallel = False
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        return {"qk_norm": "full"}
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = "", attention_only: bool = False):
+        super().__init__(config, vllm_config, quant_config, prefix, attention_only)
+        if attention_only:
+            return
+        del self.input_layernorm
+        self.post_feedforward_layernorm = self.make_norm(config)
+
+    def forward(self, positions, hidden_states, residual):
+        # ``residual`` is unused: the stream itself is carried in hidden_states
+        h = hidden_states + self.post_attention_layernorm(self.self_attn(positions, hidden_states))
+        return h + self.post_feedforward_layernorm(self.mlp(h)), None
+
+
+class _NoResidualFinalNorm(LlamaModel):
+    """Blocks that keep the whole stream in hidden_states hand ``None`` as residual to the last norm."""
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None):
+        from ..parallel.state import get_pp_group
+        from .utils import IntermediateTensors
+        pp = get_pp_group()
+        if pp.is_first_rank:
+            hidden = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
+            if self.embed_scale != 1.0:
+                hidden = hidden * self.embed_scale
+        else:
+            hidden = intermediate_tensors["hidden_states"]
+        for layer in self.layers[self.start_layer:self.end_layer]:
+            hidden, _ = layer(positions, hidden, None)
+        if not pp.is_last_rank:
+            return IntermediateTensors({"hidden_states": hidden, "residual": torch.zeros_like(hidden[:0])})
+        return self.norm(hidden)
+
+
+class Olmo2Model(_NoResidualFinalNorm):
+    layer_cls = Olmo2DecoderLayer
+
+
+class Olmo2ForCausalLM(LlamaForCausalLM):
+    model_cls = Olmo2Model
+    supports_pp = False
+
+
+# ---- Cohere (Command-R) ------------------------------------------------------------------------------
+class CohereDecoderLayer(LlamaDecoderLayer):
+    """One LayerNorm (scale only) feeds attention and MLP side by side: x + attn(n(x)) + mlp(n(x)).
+    Rotary pairs are interleaved."""
+    supports_sequence_parallel = False
+
+    @classmethod
+    def make_norm(cls, config):
+        return LayerNorm(config.hidden_size, getattr(config, "layer_norm_eps", 1e-5), bias=False)
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        if getattr(config, "use_qk_norm", False):
+            raise ValueError("Cohere checkpoints with per-head q/k LayerNorm are not supported")
+        return {"neox_style": False}
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = "", attention_only: bool = False):
+        super().__init__(config, vllm_config, quant_config, prefix, attention_only)
+        if not attention_only:
+            del self.post_attention_layernorm
+
+    def forward(self, positions, hidden_states, residual):
+        n = self.input_layernorm(hidden_states)
+        return hidden_states + self.self_attn(positions, n) + self.mlp(n), None
+
+
+class CohereModel(_NoResidualFinalNorm):
+    layer_cls = CohereDecoderLayer
+
+
+class CohereForCausalLM(LlamaForCausalLM):
+    model_cls = CohereModel
+    supports_pp = False
+
+
+# ---- Nemotron ----------------------------------------------------------------------------------------
+def _plus_one_loader(param, tensor):
+    param.data.copy_(tensor.to(param.dtype) + 1.0)
+
+
+class NemotronLayerNorm(ResidualLayerNorm):
+    """LayerNorm whose stored scale is (w - 1); the loader adds the one back."""
+
+    def __init__(self, hidden_size, eps):
+        super().__init__(hidden_size, eps)
+        self.weight.weight_loader = _plus_one_loader
+
+
+class NemotronMLP(nn.Module):
+    def __init__(self, hidden: int, inter: int, bias: bool, act: str, quant_config, prefix: str):
+        super().__init__()
+        self.up_proj = ColumnParallelLinear(hidden, inter, bias=bias, quant_config=quant_config,
+                                            prefix=f"{prefix}.up_proj")
+        self.down_proj = RowParallelLinear(inter, hidden, bias=bias, quant_config=quant_config,
+                                           prefix=f"{prefix}.down_proj")
+        self.act = get_act_fn(act)
+
+    def forward(self, x):
+        return self.down_proj(self.act(self.up_proj(x)))
+
+
+class NemotronDecoderLayer(LlamaDecoderLayer):
+    supports_sequence_parallel = False
+
+    @classmethod
+    def make_norm(cls, config):
+        return NemotronLayerNorm(config.hidden_size, getattr(config, "norm_eps", 1e-5))
+
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        return NemotronMLP(config.hidden_size, config.intermediate_size, bool(getattr(config, "mlp_bias", False)),
+                           config.hidden_act, quant_config, prefix)
+
+
+class NemotronModel(LlamaModel):
+    layer_cls = NemotronDecoderLayer
+
+
+class NemotronForCausalLM(LlamaForCausalLM):
+    model_cls = NemotronModel
+    stacked_params_mapping = LlamaForCausalLM.stacked_params_mapping[:3]
+    packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"]}
+
+
+# ---- GLM / GLM-4 -------------------------------------------------------------------------------------
+class GlmDecoderLayer(LlamaDecoderLayer):
+    """Llama block with interleaved rotary pairs over half of each head; gate and up projections are
+    stored fused in the checkpoint."""
+    supports_sequence_parallel = False
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        return {"neox_style": False, "bias": bool(getattr(config, "attention_bias", False)), "o_bias": False}
+
+
+class GlmModel(LlamaModel):
+    layer_cls = GlmDecoderLayer
+
+
+class GlmForCausalLM(LlamaForCausalLM):
+    model_cls = GlmModel
+    stacked_params_mapping = LlamaForCausalLM.stacked_params_mapping[:3]
+    packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"], "gate_up_proj": ["gate_up_proj"]}
+
+
+class Glm4DecoderLayer(GlmDecoderLayer):
+    """GLM block with a second norm behind the attention and behind the MLP (sandwich norms)."""
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = "", attention_only: bool = False):
+        super().__init__(config, vllm_config, quant_config, prefix, attention_only)
+        if attention_only:
+            return
+        self.post_self_attn_layernorm = self.make_norm(config)
+        self.post_mlp_layernorm = self.make_norm(config)
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.post_self_attn_layernorm(self.self_attn(positions, hidden_states))
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.post_mlp_layernorm(self.mlp(hidden_states)), residual
+
+
+class Glm4Model(LlamaModel):
+    layer_cls = Glm4DecoderLayer
+
+
+class Glm4ForCausalLM(GlmForCausalLM):
+    model_cls = Glm4Model
+
+
+# ---- Gemma-3 (text) ----------------------------------------------------------------------------------
+class Gemma3DecoderLayer(Gemma2DecoderLayer):
+    """Gemma-2 block plus per-head (1 + w) RMSNorm on q and k, and a rotary base of its own for the
+    sliding-window layers."""
+
+    @staticmethod
+    def _is_sliding(config, layer_idx: int) -> bool:
+        kinds = getattr(config, "layer_types", None)
+        if kinds:
+            return kinds[layer_idx] == "sliding_attention"
+        pattern = getattr(config, "sliding_window_pattern", 6)
+        return (layer_idx + 1) % pattern != 0
+
+    def _rope_of(self, config, layer_idx: int):
+        rp = getattr(config, "rope_parameters", None) or {}
+        sliding = self._is_sliding(config, layer_idx)
+        if "full_attention" in rp or "sliding_attention" in rp:
+            d = dict(rp.get("sliding_attention" if sliding else "full_attention") or {})
+            theta = float(d.get("rope_theta") or 10000.0)
+            return theta, (d if d.get("rope_type", "default") != "default" else None)
+        if sliding:
+            return float(getattr(config, "rope_local_base_freq", 10000.0)), None
+        return super()._rope_of(config, layer_idx)
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        return {"scale": float(config.query_pre_attn_scalar) ** -0.5,
+                "logits_soft_cap": getattr(config, "attn_logit_softcapping", None),
+                "sliding_window": getattr(config, "sliding_window", None) if self._is_sliding(config, layer_idx)
+                else None,
+                "qk_norm": "gemma"}
+
+
+class Gemma3Model(GemmaModel):
+    layer_cls = Gemma3DecoderLayer
+
+
+class Gemma3ForCausalLM(LlamaForCausalLM):
+    model_cls = Gemma3Model
+
+
+# ---- InternLM2 ---------------------------------------------------------------------------------------
+class InternLM2ForCausalLM(LlamaForCausalLM):
+    """Llama weights under other names; ``wqkv`` stores, per KV head, its query heads followed by the
+    key and the value head."""
+    packed_modules_mapping = {"qkv_proj": ["wqkv"], "gate_up_proj": ["w1", "w3"]}
+
+    def load_weights(self, weights):
+        c = self.config
+        H, KV = c.num_attention_heads, getattr(c, "num_key_value_heads", None) or c.num_attention_heads
+        D = getattr(c, "head_dim", None) or c.hidden_size // H
+        g = H // KV
+        table = (("tok_embeddings", "embed_tokens"), (".attention.wo.", ".self_attn.o_proj."),
+                 (".attention_norm.", ".input_layernorm."), (".ffn_norm.", ".post_attention_layernorm."),
+                 (".feed_forward.w1.", ".mlp.gate_proj."), (".feed_forward.w3.", ".mlp.up_proj."),
+                 (".feed_forward.w2.", ".mlp.down_proj."))
+
+        def fix(items):
+            for name, t in items:
+                if name.startswith("output."):
+                    name = "lm_head." + name[len("output."):]
+                for a, b in table:
+                    name = name.replace(a, b)
+                if ".attention.wqkv." in name:
+                    base = name.replace(".attention.wqkv.", ".self_attn.{}.")
+                    t = t.view(KV, g + 2, D, *t.shape[1:])
+                    yield base.format("q_proj"), t[:, :g].reshape(H * D, *t.shape[3:])
+                    yield base.format("k_proj"), t[:, g].reshape(KV * D, *t.shape[3:])
+                    yield base.format("v_proj"), t[:, g + 1].reshape(KV * D, *t.shape[3:])
+                    continue
+                yield name, t
+
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)
+
+
+# ---- Baichuan ----------------------------------------------------------------------------------------
+class BaichuanDecoderLayer(LlamaDecoderLayer):
+    """Llama block; every size but the 7B one (hidden 4096) uses ALiBi instead of rotary embeddings."""
+    supports_sequence_parallel = False
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        if config.hidden_size == 4096:
+            return {}
+        return {"use_rope": False, "alibi_slopes": alibi_slopes(config.num_attention_heads)}
+
+
+class BaichuanModel(LlamaModel):
+    layer_cls = BaichuanDecoderLayer
+
+
+class BaichuanForCausalLM(LlamaForCausalLM):
+    """``W_pack`` is q, k and v stacked; Baichuan-2 normalises the rows of the LM head."""
+    model_cls = BaichuanModel
+    packed_modules_mapping = {"qkv_proj": ["W_pack"], "gate_up_proj": ["gate_proj", "up_proj"]}
+
+    def load_weights(self, weights):
+        c = self.config
+        d = c.hidden_size
+        norm_head = getattr(c, "vocab_size", 0) == 125696       # Baichuan-2 releases
+
+        def fix(items):
+            for name, t in items:
+                if ".W_pack." in name:
+                    base = name.replace(".W_pack.", ".{}.")
+                    for i, proj in enumerate(("q_proj", "k_proj", "v_proj")):
+                        yield base.format(proj), t[i * d:(i + 1) * d]
+                    continue
+                if name == "lm_head.weight" and norm_head:
+                    t = torch.nn.functional.normalize(t.float()).to(t.dtype)
+                yield name, t
+
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)
+
+
+BaiChuanForCausalLM = BaichuanForCausalLM

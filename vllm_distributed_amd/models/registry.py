@@ -18,6 +18,29 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Gemma2ForCausalLM": ("llama_family", "Gemma2ForCausalLM"),
     "Phi3ForCausalLM": ("llama_family", "Phi3ForCausalLM"),
     "GraniteForCausalLM": ("llama_family", "GraniteForCausalLM"),
+    "StableLmForCausalLM": ("llama_variants", "StableLmForCausalLM"),
+    "StableLMEpochForCausalLM": ("llama_variants", "StableLmForCausalLM"),
+    "OlmoForCausalLM": ("llama_variants", "OlmoForCausalLM"),
+    "Olmo2ForCausalLM": ("llama_variants", "Olmo2ForCausalLM"),
+    "CohereForCausalLM": ("llama_variants", "CohereForCausalLM"),
+    "NemotronForCausalLM": ("llama_variants", "NemotronForCausalLM"),
+    "GlmForCausalLM": ("llama_variants", "GlmForCausalLM"),
+    "Glm4ForCausalLM": ("llama_variants", "Glm4ForCausalLM"),
+    "Gemma3ForCausalLM": ("llama_variants", "Gemma3ForCausalLM"),
+    "InternLM2ForCausalLM": ("llama_variants", "InternLM2ForCausalLM"),
+    "InternLM3ForCausalLM": ("llama", "LlamaForCausalLM"),
+    "BaichuanForCausalLM": ("llama_variants", "BaichuanForCausalLM"),
+    "BaiChuanForCausalLM": ("llama_variants", "BaichuanForCausalLM"),
+    "AquilaForCausalLM": ("llama", "LlamaForCausalLM"),
+    "AquilaModel": ("llama", "LlamaForCausalLM"),
+    "XverseForCausalLM": ("llama", "LlamaForCausalLM"),
+    "SolarForCausalLM": ("llama", "LlamaForCausalLM"),
+    "FalconForCausalLM": ("classic_decoders", "FalconForCausalLM"),
+    "RWForCausalLM": ("classic_decoders", "FalconForCausalLM"),
+    "BloomForCausalLM": ("classic_decoders", "BloomForCausalLM"),
+    "MptForCausalLM": ("classic_decoders", "MptForCausalLM"),
+    "MPTForCausalLM": ("classic_decoders", "MptForCausalLM"),
+    "PhiForCausalLM": ("classic_decoders", "PhiForCausalLM"),
     "GPTNeoXForCausalLM": ("gpt_family", "GPTNeoXForCausalLM"),
     "GPTJForCausalLM": ("gpt_family", "GPTJForCausalLM"),
     "Starcoder2ForCausalLM": ("gpt_family", "Starcoder2ForCausalLM"),
