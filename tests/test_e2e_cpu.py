@@ -357,3 +357,32 @@ def test_baichuan_alibi_matches_plain_torch(tmp_path):
             ids.append(int(forward(torch.tensor(ids)).argmax()))
         assert list(o.outputs[0].token_ids) == ids[len(p):]
     llm.shutdown()
+
+
+def test_cascade_attention_same_tokens(tmp_path, monkeypatch):
+    """Requests that share a cached prefix take the shared-prefix + suffix + merge path; tokens must
+    equal those of the ordinary path."""
+    from vllm_distributed_amd.layers.attention import Attention
+    monkeypatch.setenv("VDA_CASCADE_MIN_PREFIX", "32")
+    monkeypatch.setenv("VDA_CASCADE_MIN_SEQS", "2")
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    prefix = [(i * 13) % 300 + 1 for i in range(70)]
+    prompts = [prefix + [5 + i, 9, 11 + 2 * i] * (i + 1) for i in range(4)]
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    calls = []
+    orig = Attention._cascade
+    monkeypatch.setattr(Attention, "_cascade", lambda self, *a, **k: (calls.append(a[2].cascade_prefix_len),
+                                                                      orig(self, *a, **k))[1])
+    res = {}
+    for name, off in (("cascade", False), ("plain", True)):
+        llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+                  max_num_seqs=8, max_num_batched_tokens=128, enable_prefix_caching=True, block_size=16,
+                  disable_cascade_attn=off)
+        llm.generate(prompt_token_ids=[prefix + [1, 2]], sampling_params=SamplingParams(temperature=0, max_tokens=1))
+        n0 = len(calls)
+        res[name] = [list(o.outputs[0].token_ids) for o in llm.generate(prompt_token_ids=prompts, sampling_params=sp)]
+        res[name + "_calls"] = len(calls) - n0
+        llm.shutdown()
+    assert res["cascade_calls"] > 0 and res["plain_calls"] == 0
+    assert all(p == 64 for p in calls)              # four whole blocks of the 70-token prefix
+    assert res["cascade"] == res["plain"]

@@ -20,7 +20,8 @@ def _llm(path, **kw):
     return LLM(model=path, **base)
 
 
-@pytest.mark.parametrize("kind", ["llama", "qwen2", "mixtral", "mamba", "mamba2", "deepseek_v2_mla"])
+@pytest.mark.parametrize("kind", ["llama", "qwen2", "mixtral", "mamba", "mamba2", "deepseek_v2_mla", "bloom", "cohere",
+                                  "gemma3", "olmo2", "falcon_new"])
 def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     import transformers as tf
     from vllm_distributed_amd import SamplingParams
@@ -126,3 +127,35 @@ def test_lora_fused_kernels_match_grouped_gemms(tmp_path, monkeypatch):
     assert runs["fused"][0] != runs["base"][0] and runs["fused"][2] != runs["base"][2]
     same = sum(a == b for x, y in zip(runs["fused"], runs["grouped"]) for a, b in zip(x, y))
     assert same >= 0.8 * sum(len(x) for x in runs["fused"]), (runs["fused"], runs["grouped"])
+
+
+def test_cascade_attention_on_gpu(tmp_path, monkeypatch):
+    """Shared cached prefix: the cascade path (bidirectional prefix pass + shifted suffix pass + merge
+    kernels) against the ordinary kernels, first-token log-probabilities within bf16 tolerance."""
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.layers.attention import Attention
+    monkeypatch.setenv("VDA_CASCADE_MIN_PREFIX", "32")
+    monkeypatch.setenv("VDA_CASCADE_MIN_SEQS", "2")
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    prefix = [(i * 13) % 300 + 1 for i in range(150)]
+    prompts = [prefix + [5 + i, 9, 11 + 2 * i] * (i + 1) for i in range(6)]
+    sp = SamplingParams(temperature=0, max_tokens=8, ignore_eos=True, logprobs=0)
+    calls = []
+    orig = Attention._cascade
+    monkeypatch.setattr(Attention, "_cascade", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    res = {}
+    for name, off in (("cascade", False), ("plain", True)):
+        llm = _llm(path, enforce_eager=True, enable_prefix_caching=True, disable_cascade_attn=off)
+        llm.generate(prompt_token_ids=[prefix + [1, 2]], sampling_params=SamplingParams(temperature=0, max_tokens=1))
+        n0 = len(calls)
+        res[name] = llm.generate(prompt_token_ids=prompts, sampling_params=sp)
+        res[name + "_calls"] = len(calls) - n0
+        llm.shutdown()
+    assert res["cascade_calls"] > 0 and res["plain_calls"] == 0
+    same = 0
+    for a, b in zip(res["cascade"], res["plain"]):
+        ta, tb = list(a.outputs[0].token_ids), list(b.outputs[0].token_ids)
+        same += ta == tb
+        if ta[0] == tb[0]:
+            assert abs(a.outputs[0].logprobs[0][ta[0]].logprob - b.outputs[0].logprobs[0][tb[0]].logprob) < 0.05
+    assert same >= 4

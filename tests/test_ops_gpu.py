@@ -217,6 +217,42 @@ def test_paged_attention_prefill_window():
     torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (12, 12, 64), (4, 1, 256)])
+def test_paged_attention_prefill_bidirectional_and_lse(dt, Hq, Hkv, D):
+    seq_lens = [5, 130, 300, 33]
+    q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, seq_lens, Hq, Hkv, D, 16, dt)
+    scale = 1.0 / math.sqrt(D)
+    for causal in (False, True):
+        out = torch.full_like(q, float("nan"))
+        _, lse = ops.paged_attention_prefill(out, q, kc, vc, bt, sl, qsl, scale, causal=causal, return_lse=True)
+        ref, lref = R.paged_attention(q, kc, vc, bt, sl, qsl, scale, return_lse=True, causal=causal)
+        torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+        torch.testing.assert_close(lse, lref, atol=2e-2, rtol=2e-2)
+
+
+def test_cascade_composition_equals_plain_attention():
+    """Shared prefix of P keys attended once by every query token (one bidirectional pseudo-sequence),
+    per-sequence suffixes through a block table that starts behind the prefix, merged by log-sum-exp:
+    the result must equal ordinary causal attention over prefix + suffix."""
+    dt, Hq, Hkv, D, bs = torch.bfloat16, 8, 2, 128, 16
+    P = 10 * bs
+    seq_lens, q_lens = [P + 40, P + 1, P + 300, P + 17], [40, 1, 100, 1]
+    q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, q_lens, Hq, Hkv, D, bs, dt)
+    bt[:, :P // bs] = bt[0, :P // bs]            # every sequence shares the first P // bs blocks
+    scale = 1.0 / math.sqrt(D)
+    ref = R.paged_attention(q, kc, vc, bt, sl, qsl, scale)
+    T = q.shape[0]
+    pre = torch.empty_like(q)
+    one = torch.tensor([0, T], dtype=torch.int32, device=DEV)
+    _, pre_lse = ops.paged_attention_prefill(pre, q, kc, vc, bt[:1], torch.tensor([P], dtype=torch.int32, device=DEV),
+                                             one, scale, causal=False, return_lse=True)
+    suf = torch.empty_like(q)
+    _, suf_lse = ops.paged_attention_prefill(suf, q, kc, vc, bt[:, P // bs:], sl - P, qsl, scale, return_lse=True)
+    out = ops.merge_attn_states(pre, pre_lse, suf, suf_lse)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
 def test_attention_online_softmax_rescale_path():
     """One key far larger than the rest late in the sequence forces the running-max rescale."""
     dt, Hq, Hkv, D, bs = torch.bfloat16, 8, 2, 128, 16

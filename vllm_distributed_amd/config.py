@@ -175,6 +175,8 @@ class ModelConfig:
     override_pooler_config: Optional[dict] = None
     #: Skip sliding-window layers' window (treat as full attention).
     disable_sliding_window: bool = False
+    #: Never use cascade attention (shared-prefix pass + per-request suffix pass) for batches with a long common prefix.
+    disable_cascade_attn: bool = False
     #: Per-modality item limits for multimodal prompts.
     limit_mm_per_prompt: Optional[dict] = None
     #: Default sampling parameters source: "auto" reads generation_config.json.

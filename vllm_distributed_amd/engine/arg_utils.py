@@ -61,6 +61,7 @@ class EngineArgs:
     task: str = "auto"
     generation_config: str = "auto"
     disable_sliding_window: bool = False
+    disable_cascade_attn: bool = False
     # load
     load_format: str = "auto"
     download_dir: Optional[str] = None
@@ -194,7 +195,8 @@ class EngineArgs:
             enforce_eager=self.enforce_eager, max_seq_len_to_capture=self.max_seq_len_to_capture,
             max_logprobs=self.max_logprobs, served_model_name=self.served_model_name, revision=self.revision,
             hf_overrides=self.hf_overrides, task=self.task, generation_config=self.generation_config,
-            disable_sliding_window=self.disable_sliding_window, limit_mm_per_prompt=self.limit_mm_per_prompt)
+            disable_sliding_window=self.disable_sliding_window, disable_cascade_attn=self.disable_cascade_attn,
+            limit_mm_per_prompt=self.limit_mm_per_prompt)
 
     def create_engine_config(self, usage_context=None) -> C.VllmConfig:
         from ..plugins import load_general_plugins

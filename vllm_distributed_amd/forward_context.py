@@ -41,6 +41,12 @@ class AttentionMetadata:
     max_decode_query_len: int = 1
     decode_num_splits: int = 1
     decode_workspace: Optional[tuple] = None
+    # cascade attention (eager steps whose sequences all start with the same cached blocks): the first
+    # ``cascade_prefix_len`` keys are attended once by all query tokens, the rest per sequence
+    cascade_prefix_len: int = 0
+    cascade_seq_len: Optional[torch.Tensor] = None        # int32 [1] = cascade_prefix_len
+    cascade_query_start_loc: Optional[torch.Tensor] = None   # int32 [2] = (0, T)
+    cascade_suffix_seq_lens: Optional[torch.Tensor] = None   # int32 [S] = seq_lens - cascade_prefix_len
     # host copies for connectors / debugging
     seq_lens_cpu: Any = None
     query_start_loc_cpu: Any = None

@@ -84,21 +84,51 @@ class Attention(nn.Module):
                                   self.k_cache, self.v_cache, md.slot_mapping[:n], ksc, vsc)
         q = qkv[:, :qs].view(T, Hq, D)
         nd, ndt = md.num_decode_seqs, md.num_decode_tokens
-        if nd > 0:
-            ops.paged_attention_decode(out[:ndt], q[:ndt], self.k_cache, self.v_cache, md.block_table[:nd],
-                                       md.seq_lens[:nd], md.query_start_loc[:nd + 1], self.scale,
-                                       num_splits=md.decode_num_splits, max_q_len=md.max_decode_query_len,
-                                       window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
-                                       workspace=md.decode_workspace, k_scale=ksc, v_scale=vsc)
-        if md.num_prefill_seqs > 0:
-            e = ndt + md.num_prefill_tokens
-            ops.paged_attention_prefill(out[ndt:e], q[ndt:e], self.k_cache, self.v_cache, md.block_table[nd:],
-                                        md.seq_lens[nd:], md.prefill_query_start_loc, self.scale,
-                                        window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
-                                        k_scale=ksc, v_scale=vsc)
+        if md.cascade_prefix_len and not self.sliding_window:
+            self._cascade(out, q, md, n, ksc, vsc)
+        else:
+            if nd > 0:
+                ops.paged_attention_decode(out[:ndt], q[:ndt], self.k_cache, self.v_cache, md.block_table[:nd],
+                                           md.seq_lens[:nd], md.query_start_loc[:nd + 1], self.scale,
+                                           num_splits=md.decode_num_splits, max_q_len=md.max_decode_query_len,
+                                           window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
+                                           workspace=md.decode_workspace, k_scale=ksc, v_scale=vsc)
+            if md.num_prefill_seqs > 0:
+                e = ndt + md.num_prefill_tokens
+                ops.paged_attention_prefill(out[ndt:e], q[ndt:e], self.k_cache, self.v_cache, md.block_table[nd:],
+                                            md.seq_lens[nd:], md.prefill_query_start_loc, self.scale,
+                                            window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
+                                            k_scale=ksc, v_scale=vsc)
         if conn is not None:
             conn.save_kv_layer(self.layer_name, (self.k_cache, self.v_cache), md)
         return out.view(T, qs)
+
+
+def _cascade(self, out, q, md: AttentionMetadata, n: int, ksc: float, vsc: float) -> None:
+    """Cascade attention: every sequence of the step begins with the same ``P`` cached keys.  They are
+    read once for all query tokens (one bidirectional pseudo-sequence over the shared blocks) instead
+    of once per sequence; each sequence's remaining keys are attended through its block table
+    shifted behind the prefix, and the two partial results are merged by their log-sum-exp.
+    Reference: vllm/v1/attention/backends/flash_attn.py (cascade_attention, use_cascade_attention)."""
+    P = md.cascade_prefix_len
+    bs = self.k_cache.shape[2]
+    S = md.num_decode_seqs + md.num_prefill_seqs
+    kw = dict(softcap=self.softcap, k_scale=ksc, v_scale=vsc, return_lse=True)
+    pre = torch.empty_like(out[:n])
+    _, pre_lse = ops.paged_attention_prefill(pre, q[:n], self.k_cache, self.v_cache, md.block_table[:1],
+                                             md.cascade_seq_len, md.cascade_query_start_loc, self.scale,
+                                             causal=False, **kw)
+    suf = torch.empty_like(out[:n])
+    # ALiBi is relative to each query's own position: in the suffix pass the shift cancels; in the
+    # prefix pass every key lies before every query, so the kernel's (key - last key) form would be
+    # wrong -- sequences with ALiBi never take this path (see the runner's test)
+    _, suf_lse = ops.paged_attention_prefill(suf, q[:n], self.k_cache, self.v_cache, md.block_table[:S, P // bs:],
+                                             md.cascade_suffix_seq_lens, md.query_start_loc[:S + 1], self.scale,
+                                             causal=True, **kw)
+    out[:n] = ops.merge_attn_states(pre, pre_lse, suf, suf_lse)
+
+
+Attention._cascade = _cascade
 
 
 class MLAAttention(nn.Module):

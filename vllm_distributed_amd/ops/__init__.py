@@ -225,17 +225,25 @@ def paged_attention_decode(out, q, k_cache, v_cache, block_table, seq_lens, q_st
 
 def paged_attention_prefill(out, q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale: float,
                             window: int = 0, softcap: float = 0.0, alibi: Optional[torch.Tensor] = None,
-                            k_scale: float = 1.0, v_scale: float = 1.0):
+                            k_scale: float = 1.0, v_scale: float = 1.0, causal: bool = True,
+                            return_lse: bool = False):
+    """Varlen attention of new tokens against the paged cache.  ``causal=False``: every query token sees
+    all ``seq_lens[s]`` keys of its sequence (encoder models, the shared-prefix pass of cascade
+    attention).  ``return_lse``: also return the log-sum-exp [Hq, T] (natural log) of every row."""
     T, Hq, D = q.shape
     if not _dev(q):
-        out.copy_(R.paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, window,
-                                    softcap, alibi, k_scale=k_scale, v_scale=v_scale))
-        return out
+        o, lse = R.paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, window,
+                                   softcap, alibi, return_lse=True, k_scale=k_scale, v_scale=v_scale,
+                                   causal=causal)
+        out.copy_(o)
+        return (out, lse) if return_lse else out
+    lse = torch.full((Hq, T), float("-inf"), dtype=torch.float32, device=q.device) if return_lse else None
     N.call("vda_paged_attention_prefill", out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
            block_table.data_ptr(), seq_lens.data_ptr(), q_start_loc.data_ptr(), N.ptr(alibi), seq_lens.shape[0], T,
            Hq, k_cache.shape[1], D, k_cache.shape[2], block_table.stride(0), q.stride(0), out.stride(0), scale,
-           softcap, window, N.dt(q.dtype), _kv_fp8(k_cache), k_scale, v_scale, N.stream())
-    return out
+           softcap, window, N.dt(q.dtype), _kv_fp8(k_cache), k_scale, v_scale, int(bool(causal)), N.ptr(lse),
+           N.stream())
+    return (out, lse) if return_lse else out
 
 
 def merge_attn_states(prefix, prefix_lse, suffix, suffix_lse, return_lse: bool = False):

@@ -39,6 +39,9 @@ struct AttnParams {
   float v_scale;            // V-cache scale (1 for 16-bit caches)
   int window;               // sliding window size, 0 = none
   int q_tile;               // query tokens per workgroup (prefill form)
+  int causal;               // 1: query token i sees keys up to its own position; 0: every key of the sequence
+  int num_tokens;           // T (row length of lse_out)
+  float* lse_out;           // [Hq, T] natural-log log-sum-exp per (head, token), or nullptr (prefill form)
 };
 
 template <typename T, int D, int BS, int NCT, bool SPLIT, bool F8>
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
     const int qt = q0 + ti;
     const int qt_end = SPLIT ? q_len : min(q_len, q0 + p.q_tile);
     const bool valid = qt < qt_end && (SPLIT ? c < COLS : true);
-    limit[ct] = valid ? ctx + qt + 1 : 0;
+    limit[ct] = valid ? (p.causal ? ctx + qt + 1 : seq_len) : 0;
     lower[ct] = (valid && p.window > 0) ? max(0, limit[ct] - p.window) : 0;
     const int head = kvh * G + h;
     slope[ct] = (p.alibi && valid) ? p.alibi[head] : 0.f;
@@ -238,6 +241,9 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
         for (int i = 0; i < 4; ++i) o[i] = (T)(acc[ct][n][i] * inv);
         *reinterpret_cast<V4*>(op + 16 * n) = o;
       }
+      if (p.lse_out && g == 0)
+        p.lse_out[(long)head * p.num_tokens + col_off[ct]] =
+            l[ct] > 0.f ? (m[ct] + log2f(l[ct])) * 0.6931471805599453f : -INFINITY;
     }
     return;
   } else {
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
     const int ti = c / G, h = c % G;
     const int qt = q0 + ti;
     const bool valid = qt < qt_end;
-    limit[ct] = valid ? ctx + qt + 1 : 0;
+    limit[ct] = valid ? (p.causal ? ctx + qt + 1 : seq_len) : 0;
     lower[ct] = (valid && p.window > 0) ? max(0, limit[ct] - p.window) : 0;
     const int head = kvh * G + h;
     slope[ct] = (p.alibi && valid) ? p.alibi[head] : 0.f;
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
     wave_lo = min(wave_lo, __shfl_xor(wave_lo, o, 64));
   }
   // workgroup-uniform key range (all waves take part in every tile copy)
-  const int wg_hi = ctx + qt_end;
+  const int wg_hi = p.causal ? ctx + qt_end : seq_len;
   const int wg_lo = p.window > 0 ? max(0, ctx + q0 + 1 - p.window) : 0;
   const int step_lo = wg_lo / 32, step_hi = (wg_hi + 31) / 32;
 
@@ -556,6 +562,9 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
       for (int i = 0; i < 4; ++i) o[i] = (T)(acc[ct][n][i] * inv);
       *reinterpret_cast<V4*>(op + 16 * n) = o;
     }
+    if (p.lse_out && g == 0)
+      p.lse_out[(long)head * p.num_tokens + col_off[ct]] =
+          l[ct] > 0.f ? (m[ct] + log2f(l[ct])) * 0.6931471805599453f : -INFINITY;
   }
 }
 
@@ -692,7 +701,7 @@ VDA_EXPORT int vda_paged_attention_decode(
   if (cols > 32 || (cols > 16 && D > 128)) return -4;
   AttnParams p{q, k_cache, v_cache, out, part_out, part_lse, block_table, seq_lens, q_start_loc, alibi,
                num_seqs, Hq, Hkv, max_blocks, nsplit, q_stride, out_stride, scale * (kv_fp8 ? k_scale : 1.f), softcap,
-               kv_fp8 ? v_scale : 1.f, window, 0};
+               kv_fp8 ? v_scale : 1.f, window, 0, 1, num_tokens, nullptr};
   const int form = cols <= 16 ? 0 : 1;
   int rc = dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, form, num_seqs, st, kv_fp8)
                              : dispatch_d<f16_t>(p, D, block_size, form, num_seqs, st, kv_fp8);
@@ -716,21 +725,25 @@ VDA_EXPORT int vda_paged_attention_decode(
 static int g_prefill_variant = 1;
 VDA_EXPORT int vda_set_prefill_variant(int v) { g_prefill_variant = v; return 0; }
 
-// Varlen causal attention of new tokens against the paged cache (the new tokens'
-// own K/V must already be in the cache).  q_tile = 128 / (Hq/Hkv) query tokens
+// Varlen attention of new tokens against the paged cache (the new tokens' own K/V must already be in
+// the cache): causal, or bidirectional within each sequence (encoder models; the shared-prefix pass of
+// cascade attention, where one pseudo-sequence holds every query token of the batch).  lse_out, when
+// given, receives the log-sum-exp of every (head, token) for merging with another pass.  q_tile = 128 / (Hq/Hkv) query tokens
 // per workgroup; the grid over-allocates one tile per sequence.
 VDA_EXPORT int vda_paged_attention_prefill(
     void* out, const void* q, const void* k_cache, const void* v_cache, const int* block_table,
     const int* seq_lens, const int* q_start_loc, const float* alibi, int num_seqs, int num_tokens,
     int Hq, int Hkv, int D, int block_size, int max_blocks, long q_stride, long out_stride, float scale,
-    float softcap, int window, int dtype, int kv_fp8, float k_scale, float v_scale, hipStream_t st) {
+    float softcap, int window, int dtype, int kv_fp8, float k_scale, float v_scale, int causal, float* lse_out,
+    hipStream_t st) {
   if (Hq % Hkv) return -1;
   const int G = Hq / Hkv;
   if (G > 128) return -4;
+  if (!causal && window > 0) return -5;
   const int q_tile = 128 / G;     // 4 waves x 32 columns
   AttnParams p{q, k_cache, v_cache, out, nullptr, nullptr, block_table, seq_lens, q_start_loc, alibi,
                num_seqs, Hq, Hkv, max_blocks, 1, q_stride, out_stride, scale * (kv_fp8 ? k_scale : 1.f), softcap,
-               kv_fp8 ? v_scale : 1.f, window, q_tile};
+               kv_fp8 ? v_scale : 1.f, window, q_tile, causal, num_tokens, lse_out};
   const int grid_x = num_tokens / q_tile + num_seqs;
   const int form = g_prefill_variant == 0 ? 2 : 3;
   return dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, form, grid_x, st, kv_fp8)

@@ -38,7 +38,8 @@ _SIGS = {
     "vda_transfer_blocks": [P, P, P, P, I, L, P],
     "vda_gather_cache": [P, P, P, P, P, I, I, I, I, I, P],
     "vda_paged_attention_decode": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, P],
-    "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, P],
+    "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, I, P,
+                                    P],
     "vda_set_prefill_variant": [I],
     "vda_merge_attn_states": [P, P, P, P, P, P, I, I, I, I, P],
     "vda_argmax": [P, P, I, I, L, I, P],

@@ -129,9 +129,9 @@ def transfer_blocks(dst, src, dst_ids, src_ids):
 # ---- attention -------------------------------------------------------------------
 def paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale,
                     window: int = 0, softcap: float = 0.0, alibi=None, return_lse: bool = False,
-                    k_scale: float = 1.0, v_scale: float = 1.0):
-    """Causal attention of the new tokens of every sequence against its paged
-    K/V (which already contain the new tokens).  q: [T, Hq, D] -> [T, Hq, D]."""
+                    k_scale: float = 1.0, v_scale: float = 1.0, causal: bool = True):
+    """Attention of the new tokens of every sequence against its paged K/V (which already contain
+    the new tokens); causal, or over every key of the sequence.  q: [T, Hq, D] -> [T, Hq, D]."""
     T, Hq, D = q.shape
     Hkv, bs = k_cache.shape[1], k_cache.shape[2]
     G = Hq // Hkv
@@ -159,7 +159,7 @@ def paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, sca
         key = torch.arange(sl, device=q.device)[None, :]
         if alibi is not None:
             sc = sc + alibi.float()[:, None, None] * (key - pos)[None].float()
-        mask = key <= pos
+        mask = (key <= pos) if causal else torch.ones((ql, sl), dtype=torch.bool, device=q.device)
         if window > 0:
             mask &= key > pos - window
         sc = sc.masked_fill(~mask[None], float("-inf"))

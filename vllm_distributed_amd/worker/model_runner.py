@@ -111,6 +111,9 @@ class ModelRunner:
         self.logits_indices = torch.zeros(Tpad, dtype=torch.int64, device=dev)
         self.mb_qsl = torch.zeros(Spad + 1, dtype=torch.int32, device=dev)          # second micro-batch, rebased
         self.mb_prefill_qsl = torch.zeros(Spad + 1, dtype=torch.int32, device=dev)
+        self.cascade_seq_len = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cascade_qsl = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.cascade_suffix_lens = torch.zeros(Spad, dtype=torch.int32, device=dev)
         self.pin = self.is_gpu
         self.intermediate: Optional[IntermediateTensors] = None
 
@@ -490,6 +493,26 @@ class ModelRunner:
             max_query_len=max_q, max_seq_len=max_seq, max_decode_query_len=self.max_decode_q,
             decode_num_splits=nsplit, decode_workspace=self._workspace(max(ndt, 1), nsplit))
 
+    def _cascade_prefix_len(self, so: SchedulerOutput, rows, n_sched, S: int) -> int:
+        """Number of leading keys shared by every sequence of this step that is worth a shared attention
+        pass (0: attend the ordinary way).  Reference: gpu_model_runner.py (_compute_cascade_attn_prefix_len)."""
+        if self.vllm_config.model_config.disable_cascade_attn or S < envs.VDA_CASCADE_MIN_SEQS \
+                or not so.num_common_prefix_blocks or self.tknp_size > 1:
+            return 0
+        blocks = int(so.num_common_prefix_blocks[0])
+        if blocks * self.block_size < envs.VDA_CASCADE_MIN_PREFIX:
+            return 0
+        if getattr(self, "_cascade_ok", None) is None:
+            from ..layers.attention import Attention as _A
+            self._cascade_ok = all(isinstance(m, _A) and m.alibi_slopes is None for m in self.attn_layers.values()) \
+                and len(so.num_common_prefix_blocks) == 1
+        if not self._cascade_ok:
+            return 0
+        # every query token must lie behind the shared keys
+        P = min(blocks * self.block_size, int(self.input_batch.num_computed[rows].min()))
+        P = P // self.block_size * self.block_size
+        return P if P >= envs.VDA_CASCADE_MIN_PREFIX else 0
+
     def _make_micro_batches(self, rows, n_sched, cu, S, T, nd) -> Optional[list]:
         """Split the step's sequences into two runs of about equal token count (None when one sequence
         dominates).  The first run reuses the step's own device arrays; the second gets its query
@@ -571,6 +594,14 @@ class ModelRunner:
         else:
             nsplit = self._decode_splits(nd, max_seq, False)
             md = self._build_attn_metadata(S_a, T_a, nd, ndt, max_seq, max_q, nsplit)
+            P = self._cascade_prefix_len(so, rows, n_sched, S) if tmd is None else 0
+            if P:
+                self._to_dev(self.cascade_seq_len, np.array([P], dtype=np.int32))
+                self._to_dev(self.cascade_qsl, np.array([0, T], dtype=np.int32))
+                self._to_dev(self.cascade_suffix_lens, (ib.num_computed[rows] + n_sched - P).astype(np.int32))
+                md.cascade_prefix_len = P
+                md.cascade_seq_len, md.cascade_query_start_loc = self.cascade_seq_len, self.cascade_qsl
+                md.cascade_suffix_seq_lens = self.cascade_suffix_lens[:S]
             inter = None
             if not pp.is_first_rank:
                 inter = intermediate_tensors
@@ -584,7 +615,7 @@ class ModelRunner:
                 self.positions[T:T_in].zero_()
             mbs = None
             if self.async_tp and T >= envs.VDA_ASYNC_TP_MIN_TOKENS and conn is None and self.lora_manager is None \
-                    and inputs_embeds is None and T_in == T:
+                    and inputs_embeds is None and T_in == T and not P:
                 mbs = self._make_micro_batches(rows, n_sched, cu, S, T, nd)
             with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T, micro_batches=mbs):
                 if conn is not None:
