@@ -2,6 +2,8 @@
 (modelled on tests/models/language/pooling)."""
 import os
 
+import pytest
+
 import torch
 
 from vllm_distributed_amd import LLM
@@ -92,3 +94,62 @@ def test_pooling_rerank_and_classify_endpoints(tmp_path):
     cl = results["classify"]
     assert len(cl["data"]) == 2 and cl["data"][0]["num_classes"] == 3
     assert abs(sum(cl["data"][0]["probs"]) - 1.0) < 1e-3 and cl["data"][0]["label"] in ("neg", "neu", "pos")
+
+
+def _tiny_encoder(tmp, kind):
+    import transformers as tf
+    torch.manual_seed(0)
+    kw = dict(vocab_size=320, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+              max_position_embeddings=128)
+    if kind == "bert":
+        m = tf.BertModel(tf.BertConfig(type_vocab_size=2, **kw))
+    elif kind == "roberta":
+        m = tf.RobertaModel(tf.RobertaConfig(type_vocab_size=1, pad_token_id=1, **kw))
+    elif kind == "bert_cls":
+        m = tf.BertForSequenceClassification(tf.BertConfig(type_vocab_size=2, num_labels=1, **kw))
+    else:
+        m = tf.RobertaForSequenceClassification(tf.RobertaConfig(type_vocab_size=1, pad_token_id=1, num_labels=3,
+                                                                 **kw))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+    m = m.float().eval()
+    path = os.path.join(tmp, kind)
+    m.save_pretrained(path, safe_serialization=True)
+    return path, m
+
+
+@pytest.mark.parametrize("kind", ["bert", "roberta"])
+def test_encoder_only_embeddings_match_hf(tmp_path, kind):
+    """Bidirectional attention through the paged cache: [CLS] embeddings equal transformers'."""
+    path, hf = _tiny_encoder(str(tmp_path), kind)
+    prompts = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 11, [2, 3]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128,
+              max_num_seqs=8, block_size=16)
+    outs = llm.embed(None, prompt_token_ids=prompts)
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf(torch.tensor([p])).last_hidden_state[0, 0]
+        ref = torch.nn.functional.normalize(ref, dim=-1)
+        torch.testing.assert_close(torch.as_tensor(o.outputs.embedding), ref, atol=2e-4, rtol=1e-3)
+    llm.shutdown()
+
+
+@pytest.mark.parametrize("kind", ["bert_cls", "roberta_cls"])
+def test_encoder_only_classifiers_match_hf(tmp_path, kind):
+    from vllm_distributed_amd.sampling_params import PoolingParams
+    path, hf = _tiny_encoder(str(tmp_path), kind)
+    prompts = [[5, 17, 99, 3, 250, 11, 4, 4], [7, 8, 9] * 7]
+    types = [[0, 0, 0, 0, 1, 1, 1, 1], [0] * 10 + [1] * 11]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128,
+              max_num_seqs=8, block_size=16)
+    for p, t in zip(prompts, types):
+        pp = PoolingParams(token_type_ids=t) if kind == "bert_cls" else PoolingParams()
+        out = llm.encode(None, pooling_params=pp, prompt_token_ids=[p])[0]
+        with torch.no_grad():
+            kw = {"token_type_ids": torch.tensor([t])} if kind == "bert_cls" else {}
+            logits = hf(torch.tensor([p]), **kw).logits[0]
+        ref = torch.sigmoid(logits) if logits.numel() == 1 else torch.softmax(logits, -1)
+        torch.testing.assert_close(out.outputs.data.float().flatten(), ref, atol=2e-4, rtol=1e-3)
+    llm.shutdown()

@@ -328,6 +328,11 @@ class ModelConfig:
     def runner_type(self) -> str:
         return "generate" if self.task == "generate" else "pooling"
 
+    @property
+    def is_encoder_only(self) -> bool:
+        """Bidirectional encoders: a prompt runs in one step and its KV blocks are never reused."""
+        return any(a.startswith(("Bert", "Roberta", "XLMRoberta")) for a in self.architectures)
+
     def verify_with_parallel_config(self, pc: "ParallelConfig") -> None:
         heads = self.get_total_num_attention_heads()
         if heads % pc.tensor_parallel_size:

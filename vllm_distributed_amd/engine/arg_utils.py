@@ -207,6 +207,10 @@ class EngineArgs:
         prefix = self.enable_prefix_caching
         if prefix is None:
             prefix = mc.runner_type == "generate"
+        if mc.is_encoder_only:
+            if prefix or self.enable_chunked_prefill:
+                raise ValueError("encoder-only models attend in both directions: prefix caching and chunked "
+                                 "prefill cannot be used with them")
         cache = C.CacheConfig(
             block_size=self.block_size, gpu_memory_utilization=self.gpu_memory_utilization,
             swap_space=self.swap_space, cache_dtype=self.kv_cache_dtype,

@@ -193,6 +193,9 @@ class LLM:
             a = a * len(b)
         if len(a) != len(b):
             raise ValueError("score() needs 1-to-N or N-to-N inputs")
+        mc = self.llm_engine.model_config
+        if any(x.endswith("ForSequenceClassification") for x in mc.architectures):
+            return self._cross_encoder_score(a, b, **kw)
         embs = self.encode(a + b, **kw)
         out = []
         for i in range(len(a)):
@@ -200,6 +203,22 @@ class LLM:
             s = torch.nn.functional.cosine_similarity(x, y, dim=0).item()
             out.append(ScoringRequestOutput(f"{embs[i].request_id}_{embs[len(a) + i].request_id}", ScoringOutput(s),
                                             embs[i].prompt_token_ids + embs[len(a) + i].prompt_token_ids, True))
+        return out
+
+    def _cross_encoder_score(self, a: list, b: list, **kw) -> list[ScoringRequestOutput]:
+        """Sequence-classification models score a pair in one pass: both texts in one prompt, joined the
+        way the tokenizer joins pairs, the second text marked by token type ids where the model has them.
+        Reference: vllm/entrypoints/llm.py (_cross_encoding_score)."""
+        tok = self.get_tokenizer()
+        if tok is None:
+            raise ValueError("scoring text pairs with a cross-encoder needs the tokenizer")
+        out = []
+        for x, y in zip(a, b):
+            enc = tok(x, y, truncation=True, max_length=self.llm_engine.model_config.max_model_len)
+            pp = PoolingParams(token_type_ids=list(enc["token_type_ids"]) if "token_type_ids" in enc else None)
+            o = self.encode(None, pooling_params=pp, prompt_token_ids=[list(enc["input_ids"])], **kw)[0]
+            out.append(ScoringRequestOutput(o.request_id, ScoringOutput(float(o.outputs.data.float().flatten()[0])),
+                                            o.prompt_token_ids, True))
         return out
 
     # ---- engine utilities -------------------------------------------------------------------

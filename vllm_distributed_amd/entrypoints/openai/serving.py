@@ -571,6 +571,8 @@ class OpenAIServingScores(OpenAIServing):
             a = a * len(b)
         if len(a) != len(b):
             return self.error("score needs 1-to-N or N-to-N inputs")
+        if any(x.endswith("ForSequenceClassification") for x in self.model_config.architectures):
+            return await self._cross_encoder_scores(request, a, b)
         er = await self.embedding.create_embedding(EmbeddingRequest(model=request.model, input=a + b))
         if isinstance(er, ErrorResponse):
             return er
@@ -578,6 +580,31 @@ class OpenAIServingScores(OpenAIServing):
         data = [ScoreResponseData(index=i, score=float(torch.nn.functional.cosine_similarity(
             vecs[i], vecs[len(a) + i], dim=0))) for i in range(len(a))]
         return ScoreResponse(model=er.model, data=data, usage=er.usage)
+
+
+async def _cross_encoder_scores(self, request, a: list, b: list):
+    """Sequence-classification models: each pair is one prompt (the tokenizer's pair encoding, token type
+    ids where the model has them); the class-0 output is the score."""
+    from ...sampling_params import PoolingParams
+    tok = await self.tokenizer()
+    rid = f"score-{random_uuid()}"
+    gens, ntok = [], 0
+    for i, (x, y) in enumerate(zip(a, b)):
+        enc = tok(x, y, truncation=True, max_length=self.model_config.max_model_len)
+        ntok += len(enc["input_ids"])
+        pp = PoolingParams(token_type_ids=list(enc["token_type_ids"]) if "token_type_ids" in enc else None)
+        gens.append(self.engine_client.encode(TokensPrompt(prompt_token_ids=list(enc["input_ids"])), pp,
+                                              f"{rid}-{i}"))
+    finals = [None] * len(gens)
+    async for i, res in merge_async_iterators(*gens):
+        finals[i] = res
+    data = [ScoreResponseData(index=i, score=float(f.outputs.data.float().flatten()[0]))
+            for i, f in enumerate(finals)]
+    return ScoreResponse(model=self.models.model_name(), data=data,
+                         usage=UsageInfo(prompt_tokens=ntok, total_tokens=ntok))
+
+
+OpenAIServingScores._cross_encoder_scores = _cross_encoder_scores
 
 
 class OpenAIServingPooling(OpenAIServing):

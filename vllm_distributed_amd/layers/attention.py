@@ -21,9 +21,11 @@ from ..sched.kv_cache_interface import FullAttentionSpec, KVCacheSpec, MLASpec, 
 class Attention(nn.Module):
     def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
                  alibi_slopes: Optional[list[float]] = None, sliding_window: Optional[int] = None,
-                 logits_soft_cap: Optional[float] = None, prefix: str = "", cache_dtype: str = "auto"):
+                 logits_soft_cap: Optional[float] = None, prefix: str = "", cache_dtype: str = "auto",
+                 causal: bool = True):
         super().__init__()
         self.num_heads, self.head_size, self.scale = num_heads, head_size, float(scale)
+        self.causal = causal          # False: encoder models, every token sees its whole sequence
         self.num_kv_heads = num_kv_heads or num_heads
         self.sliding_window = sliding_window or 0
         self.softcap = float(logits_soft_cap or 0.0)
@@ -84,7 +86,7 @@ class Attention(nn.Module):
                                   self.k_cache, self.v_cache, md.slot_mapping[:n], ksc, vsc)
         q = qkv[:, :qs].view(T, Hq, D)
         nd, ndt = md.num_decode_seqs, md.num_decode_tokens
-        if md.cascade_prefix_len and not self.sliding_window:
+        if md.cascade_prefix_len and not self.sliding_window and self.causal:
             self._cascade(out, q, md, n, ksc, vsc)
         else:
             if nd > 0:
@@ -98,7 +100,7 @@ class Attention(nn.Module):
                 ops.paged_attention_prefill(out[ndt:e], q[ndt:e], self.k_cache, self.v_cache, md.block_table[nd:],
                                             md.seq_lens[nd:], md.prefill_query_start_loc, self.scale,
                                             window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
-                                            k_scale=ksc, v_scale=vsc)
+                                            k_scale=ksc, v_scale=vsc, causal=self.causal)
         if conn is not None:
             conn.save_kv_layer(self.layer_name, (self.k_cache, self.v_cache), md)
         return out.view(T, qs)

@@ -54,6 +54,14 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Mamba2ForCausalLM": ("mamba", "Mamba2ForCausalLM"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
     "GPT2LMHeadModel": ("opt", "GPT2LMHeadModel"),
+    "BertModel": ("bert", "BertEmbeddingModel"),
+    "BertForMaskedLM": ("bert", "BertEmbeddingModel"),
+    "BertForSequenceClassification": ("bert", "BertForSequenceClassification"),
+    "RobertaModel": ("bert", "RobertaEmbeddingModel"),
+    "RobertaForMaskedLM": ("bert", "RobertaEmbeddingModel"),
+    "XLMRobertaModel": ("bert", "RobertaEmbeddingModel"),
+    "RobertaForSequenceClassification": ("bert", "RobertaForSequenceClassification"),
+    "XLMRobertaForSequenceClassification": ("bert", "RobertaForSequenceClassification"),
     "LlamaModel": ("pooling", "LlamaEmbeddingModel"),
     "LlamaForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
     "Qwen2ForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),

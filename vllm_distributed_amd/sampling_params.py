@@ -254,13 +254,15 @@ class PoolingParams:
     task: Optional[str] = None
     additional_data: Optional[Any] = None
     output_kind: RequestOutputKind = RequestOutputKind.FINAL_ONLY
+    #: Segment id of every prompt token (BERT cross-encoders: 0 for the first text, 1 for the second).
+    token_type_ids: Optional[list[int]] = None
 
     def clone(self) -> "PoolingParams":
         return copy.deepcopy(self)
 
     def to_wire(self) -> dict:
         return {"dimensions": self.dimensions, "normalize": self.normalize,
-                "softmax": self.softmax, "task": self.task}
+                "softmax": self.softmax, "task": self.task, "token_type_ids": self.token_type_ids}
 
     @classmethod
     def from_wire(cls, d: dict) -> "PoolingParams":

@@ -493,6 +493,21 @@ class ModelRunner:
             max_query_len=max_q, max_seq_len=max_seq, max_decode_query_len=self.max_decode_q,
             decode_num_splits=nsplit, decode_workspace=self._workspace(max(ndt, 1), nsplit))
 
+    def _token_type_ids(self, req_ids, n_sched, T: int) -> Optional[torch.Tensor]:
+        """Segment ids of the step's tokens (requests that carry none are all zero); None when no request has any."""
+        ib = self.input_batch
+        if not any(getattr(ib.reqs[r].pooling_params, "token_type_ids", None) for r in req_ids):
+            return None
+        tt = np.zeros(T, dtype=np.int64)
+        o = 0
+        for r, n in zip(req_ids, n_sched):
+            ids = getattr(ib.reqs[r].pooling_params, "token_type_ids", None)
+            if ids:
+                a = int(ib.num_computed[ib.reqs[r].row])
+                tt[o:o + int(n)] = np.asarray(ids[a:a + int(n)], dtype=np.int64)
+            o += int(n)
+        return torch.from_numpy(tt).to(self.device)
+
     def _cascade_prefix_len(self, so: SchedulerOutput, rows, n_sched, S: int) -> int:
         """Number of leading keys shared by every sequence of this step that is worth a shared attention
         pass (0: attend the ordinary way).  Reference: gpu_model_runner.py (_compute_cascade_attn_prefix_len)."""
@@ -620,7 +635,10 @@ class ModelRunner:
             with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T, micro_batches=mbs):
                 if conn is not None:
                     conn.start_load_kv()
-                hidden = self.model(self.input_ids[:T_in], self.positions[:P_in], inter, inputs_embeds)
+                extra = {}
+                if getattr(self.model, "uses_token_type_ids", False):
+                    extra["token_type_ids"] = self._token_type_ids(req_ids, n_sched, T_in)
+                hidden = self.model(self.input_ids[:T_in], self.positions[:P_in], inter, inputs_embeds, **extra)
             if T_in > T and torch.is_tensor(hidden):
                 hidden = hidden[:T]
         if conn is not None:
