@@ -133,3 +133,92 @@ class Qwen2MoeForCausalLM(MixtralForCausalLM):
 
 class Qwen3MoeForCausalLM(Qwen2MoeForCausalLM):
     pass
+
+
+# ---- OLMoE -------------------------------------------------------------------------------------------
+class OlmoeDecoderLayer(LlamaDecoderLayer):
+    """Llama attention with full-width RMSNorm on q and k; every MLP is a routed expert block.
+    Reference: vllm/model_executor/models/olmoe.py."""
+    supports_sequence_parallel = False
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        return {"qk_norm": "full", "qkv_clip": getattr(config, "clip_qkv", None)}
+
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        return SparseMoeBlock(config.hidden_size, config.intermediate_size, _num_experts(config),
+                              config.num_experts_per_tok, bool(getattr(config, "norm_topk_prob", False)),
+                              quant_config, prefix)
+
+
+class OlmoeModel(LlamaModel):
+    layer_cls = OlmoeDecoderLayer
+
+
+class OlmoeForCausalLM(Qwen2MoeForCausalLM):
+    model_cls = OlmoeModel
+
+
+# ---- Granite-MoE -------------------------------------------------------------------------------------
+class GraniteMoeDecoderLayer(LlamaDecoderLayer):
+    """Granite block (attention / residual multipliers) with a routed expert MLP.
+    Reference: vllm/model_executor/models/granitemoe.py."""
+    supports_sequence_parallel = False
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        return {"scale": float(getattr(config, "attention_multiplier", None) or
+                               (config.hidden_size // config.num_attention_heads) ** -0.5)}
+
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        return SparseMoeBlock(config.hidden_size, config.intermediate_size, _num_experts(config),
+                              config.num_experts_per_tok, True, quant_config,
+                              prefix.replace(".mlp", ".block_sparse_moe"))
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = ""):
+        super().__init__(config, vllm_config, quant_config, prefix)
+        self.block_sparse_moe = self.mlp
+        del self.mlp
+        self.residual_multiplier = float(getattr(config, "residual_multiplier", 1.0) or 1.0)
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states) * self.residual_multiplier
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.block_sparse_moe(hidden_states) * self.residual_multiplier, residual
+
+
+class GraniteMoeModel(LlamaModel):
+    layer_cls = GraniteMoeDecoderLayer
+    embed_scale_of = staticmethod(lambda config: float(getattr(config, "embedding_multiplier", 1.0) or 1.0))
+
+
+class GraniteMoeForCausalLM(MixtralForCausalLM):
+    """The checkpoint stacks all experts: input_linear [E, 2I, H] (gate rows, then up rows) and
+    output_linear [E, H, I]; they are dealt out per expert while loading."""
+    model_cls = GraniteMoeModel
+
+    @staticmethod
+    def _logit_scale(config) -> float:
+        return 1.0 / float(getattr(config, "logits_scaling", 1.0) or 1.0)
+
+    def load_weights(self, weights):
+        def fix(items):
+            for name, t in items:
+                if name.endswith(".block_sparse_moe.input_linear.weight"):
+                    base = name[: -len("input_linear.weight")]
+                    half = t.shape[1] // 2
+                    for e in range(t.shape[0]):
+                        yield f"{base}experts.{e}.w1.weight", t[e, :half]
+                        yield f"{base}experts.{e}.w3.weight", t[e, half:]
+                elif name.endswith(".block_sparse_moe.output_linear.weight"):
+                    base = name[: -len("output_linear.weight")]
+                    for e in range(t.shape[0]):
+                        yield f"{base}experts.{e}.w2.weight", t[e]
+                elif name.endswith(".block_sparse_moe.router.layer.weight"):
+                    yield name.replace(".router.layer.", ".gate."), t
+                else:
+                    yield name, t
+        return super().load_weights(fix(weights))
