@@ -45,6 +45,14 @@ LIBS = {
 }
 
 
+# Per-file additions to the device flags.  attention.hip: keep MFMA accumulators in ordinary VGPRs; with
+# the accumulator-register form the compiler copied all 64 output registers out and back around the
+# conditional rescale of every key tile (~130 of ~470 vector instructions per tile).
+EXTRA_FLAGS = {
+    "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+}
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -95,7 +103,8 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
         cc = (shutil.which("g++") or "g++") if host else None
         fl = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DNDEBUG"] if host else flags
         with ThreadPoolExecutor(jobs) as ex:
-            for src, did in ex.map(lambda a: _compile_one(a[0], a[1], fl, force, cc), zip(srcs, objs)):
+            for src, did in ex.map(lambda a: _compile_one(a[0], a[1], fl + ([] if host else EXTRA_FLAGS.get(
+                    os.path.basename(a[0]), [])), force, cc), zip(srcs, objs)):
                 changed |= did
                 if verbose and did:
                     print(f"[build] compiled {os.path.relpath(src, PKG)}", flush=True)

@@ -22,6 +22,11 @@
 // Nothing goes through LDS except the final cross-wave merge of the decode form.
 #include "common.h"
 
+// 2^x as the bare v_exp_f32 instruction.  fexp2() wraps it in a range check and a rescale for results
+// below the smallest normal float (seven instructions instead of one); softmax terms that small are
+// zero for every purpose here.
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 struct AttnParams {
   const void* q;            // [T, Hq, D]
   const void* k_cache;
@@ -194,13 +199,13 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m[ct], mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f(m[ct] - m_use);
+      const float alpha = fexp2(m[ct] - m_use);
       m[ct] = m_new;
       float ps = 0.f;
       V8 pb;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float e = exp2f(sv[j] - m_use);
+        const float e = fexp2(sv[j] - m_use);
         ps += e;
         pb[j] = (T)e;
       }
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
           const float m2 = s_ml[wave][ct][0][lane], l2 = s_ml[wave][ct][1][lane];
           const float M = fmaxf(m[ct], m2);
           const float Mu = (M == -INFINITY) ? 0.f : M;
-          const float f1 = exp2f(m[ct] - Mu), f2 = exp2f(m2 - Mu);
+          const float f1 = fexp2(m[ct] - Mu), f2 = fexp2(m2 - Mu);
           l[ct] = l[ct] * f1 + l2 * f2;
           m[ct] = M;
 #pragma unroll
@@ -320,8 +325,14 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
 // every wave then reads its MFMA operands from LDS.  16-byte pieces are XOR-swizzled so that the eight
 // lanes served per LDS cycle hit eight different bank groups for both the row-per-lane K reads and the
 // d-row-per-lane V reads.
+#ifndef PREFILL_REG_STAGES
+#define PREFILL_REG_STAGES 1
+#endif
+#ifndef PREFILL_WGS_PER_CU
+#define PREFILL_WGS_PER_CU 2
+#endif
 template <typename T, int D, int BS, bool F8>
-__global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_kernel(AttnParams p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   using CT = typename KVElem<T, F8>::type;
@@ -400,7 +411,14 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
 
   // Two register stages: tile t+2 is requested from memory while tile t is consumed and tile t+1 (requested one
   // iteration earlier) moves from registers into the other LDS buffer -- a full iteration of latency cover.
-  V8 rkA[KPT], rvA[VPT], rkB[KPT], rvB[VPT];
+  V8 rkA[KPT], rvA[VPT];
+#if PREFILL_REG_STAGES == 2
+  V8 rkB[KPT], rvB[VPT];
+#endif
+  // Address arithmetic kept in 32 bits except for the one block-number x block-stride product (a single
+  // v_mad_u64_u32): offsets inside a block fit 32 bits by construction.
+  const unsigned blk_stride = (unsigned)p.Hkv * BS * D;          // elements per cache block (K and V alike)
+  const unsigned k_head = (unsigned)kvh * BS * D, v_head = (unsigned)kvh * D * BS;
   auto gload = [&](int step, V8 (&rk)[KPT], V8 (&rv)[VPT]) {
     const int tb = step * 32;
 #pragma unroll
@@ -408,16 +426,18 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
       const int pi = tid + 256 * i;
       const int key = pi / KCH, ch = pi % KCH;
       const int tok = tb + key;
-      const long blk = bt[max(min(tok / BS, nblk_valid - 1), 0)];
-      rk[i] = KVLoad<T, F8>::ld(kc + ((blk * p.Hkv + kvh) * BS + (tok % BS)) * (long)D + ch * 8);
+      const unsigned blk = (unsigned)bt[max(min(tok / BS, nblk_valid - 1), 0)];
+      const unsigned off = k_head + (unsigned)(tok % BS) * D + ch * 8;
+      rk[i] = KVLoad<T, F8>::ld(kc + (size_t)blk * blk_stride + off);
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const int pi = tid + 256 * i;
       const int d = pi >> 2, c = pi & 3;
       const int tok = tb + 8 * c;
-      const long blk = bt[max(min(tok / BS, nblk_valid - 1), 0)];
-      rv[i] = KVLoad<T, F8>::ld(vc + ((blk * p.Hkv + kvh) * (long)D + d) * BS + (tok % BS));
+      const unsigned blk = (unsigned)bt[max(min(tok / BS, nblk_valid - 1), 0)];
+      const unsigned off = v_head + (unsigned)d * BS + (tok % BS);
+      rv[i] = KVLoad<T, F8>::ld(vc + (size_t)blk * blk_stride + off);
     }
   };
   auto sstore = [&](int buf, const V8 (&rk)[KPT], const V8 (&rv)[VPT]) {
@@ -480,11 +500,11 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
       float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
       float mx = -INFINITY;
       if (fast) {
+        // raw scores: the scale (positive) is applied to the maximum once and folded into the fma that
+        // feeds the exponential, so a score costs max + fma + exp + add
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          sv[j] *= sl2;
-          mx = fmaxf(mx, sv[j]);
-        }
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, sv[j]);
+        mx *= sl2;
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -502,13 +522,14 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m[ct], mx);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f(m[ct] - m_use);
+      const float alpha = fexp2(m[ct] - m_use);
       m[ct] = m_new;
       float ps = 0.f;
       V8 pb;
+      const float mul = fast ? sl2 : 1.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float e = exp2f(sv[j] - m_use);
+        const float e = fexp2(fmaf(sv[j], mul, -m_use));
         ps += e;
         pb[j] = (T)e;
       }
@@ -522,6 +543,7 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
     }
   };
 
+#if PREFILL_REG_STAGES == 2
   // prologue: tile 0 -> LDS buffer 0, tile 1 -> register stage A
   if (step_lo < step_hi) {
     gload(step_lo, rkA, rvA);
@@ -542,6 +564,24 @@ __global__ __launch_bounds__(256) void paged_prefill_lds_kernel(AttnParams p) {
     if (step + 2 < step_hi) sstore(0, rkB, rvB);
     __syncthreads();
   }
+#else
+  // One register stage (16 fewer registers: two workgroups fit a CU, so one wave's global-load and
+  // softmax latency is covered by the other wave of its SIMD rather than by a deeper software pipeline).
+  // Tile t+1 sits in registers while tile t is consumed, then moves to the other LDS buffer and tile t+2
+  // is requested.
+  if (step_lo < step_hi) {
+    gload(step_lo, rkA, rvA);
+    sstore(0, rkA, rvA);
+    if (step_lo + 1 < step_hi) gload(step_lo + 1, rkA, rvA);
+  }
+  __syncthreads();
+  for (int step = step_lo, buf = 0; step < step_hi; ++step, buf ^= 1) {
+    compute(step, buf);
+    if (step + 1 < step_hi) sstore(buf ^ 1, rkA, rvA);
+    if (step + 2 < step_hi) gload(step + 2, rkA, rvA);
+    __syncthreads();
+  }
+#endif
 
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
@@ -584,7 +624,7 @@ __global__ __launch_bounds__(64) void attn_reduce_kernel(T* out, const float* pa
   for (int i = 0; i < PER; ++i) o[i] = 0.f;
   float W = 0.f;
   for (int s = 0; s < nsplit; ++s) {
-    const float w = exp2f(lse[s] - Mu);
+    const float w = fexp2(lse[s] - Mu);
     W += w;
     const float* po = part_out + (th * nsplit + s) * D;
 #pragma unroll

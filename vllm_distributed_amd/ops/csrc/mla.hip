@@ -18,6 +18,9 @@
 // (vllm/v1/attention/backends/mla/*, vllm/attention/ops/triton_decode_attention.py).
 #include "common.h"
 
+// 2^x as the bare v_exp_f32 instruction (fexp2() adds a range check and rescale for sub-normal results)
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // ---- cache write -----------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void mla_cache_write_kernel(const T* __restrict__ kv_c, const T* __restrict__ k_pe,
@@ -149,13 +152,13 @@ __global__ __launch_bounds__(256) void mla_attention_kernel(MlaParams p) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m - m_use);
+    const float alpha = fexp2(m - m_use);
     m = m_new;
     float ps = 0.f;
     V8 pb;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float e = exp2f(sv[j] - m_use);
+      const float e = fexp2(sv[j] - m_use);
       ps += e;
       pb[j] = (T)e;
     }
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void mla_attention_kernel(MlaParams p) {
       const float m2 = s_ml[0][lane], l2 = s_ml[1][lane];
       const float M = fmaxf(m, m2);
       const float Mu = (M == -INFINITY) ? 0.f : M;
-      const float f1 = exp2f(m - Mu), f2 = exp2f(m2 - Mu);
+      const float f1 = fexp2(m - Mu), f2 = fexp2(m2 - Mu);
       l = l * f1 + l2 * f2;
       m = M;
 #pragma unroll
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(64) void mla_reduce_kernel(T* out, const float* par
   for (int i = 0; i < PER; ++i) o[i] = 0.f;
   float W = 0.f;
   for (int s = 0; s < nsplit; ++s) {
-    const float w = exp2f(lse[s] - Mu);
+    const float w = fexp2(lse[s] - Mu);
     W += w;
     const float* po = part_out + (th * nsplit + s) * DV;
 #pragma unroll
