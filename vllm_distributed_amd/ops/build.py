@@ -45,12 +45,13 @@ LIBS = {
 }
 
 
-# Per-file additions to the device flags.  attention.hip: keep MFMA accumulators in ordinary VGPRs; with
-# the accumulator-register form the compiler copied all 64 output registers out and back around the
-# conditional rescale of every key tile (~130 of ~470 vector instructions per tile).
-EXTRA_FLAGS = {
-    "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-}
+# Per-file additions to the device flags.  The online-softmax kernels keep their MFMA accumulators in
+# ordinary VGPRs: with the accumulator-register form the compiler copied every output register out and
+# back around the conditional rescale (attention.hip: ~130 of ~470 vector instructions per key tile;
+# mla.hip: 3296 accumulator moves in six kernels, 400 -> 269 registers).  Measured neutral on the
+# memory-bound skinny GEMMs, which therefore keep the default.
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+EXTRA_FLAGS = {f: _VGPR_FORM for f in ("attention.hip", "mla.hip")}
 
 
 def _hipcc() -> str:
