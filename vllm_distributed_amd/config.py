@@ -119,6 +119,14 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
     if os.path.isfile(path):
         with open(path) as f:
             d = json.load(f)
+    elif model.endswith(".gguf") and os.path.isfile(model):
+        from .models.gguf import config_from_gguf
+        sidecar = os.path.join(os.path.dirname(model), "config.json")
+        if os.path.isfile(sidecar):
+            with open(sidecar) as f:
+                d = json.load(f)
+        else:
+            d = config_from_gguf(model)
     else:
         key = model.rstrip("/").split("/")[-1].lower()
         if key not in PRESETS:

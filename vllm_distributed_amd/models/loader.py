@@ -155,6 +155,9 @@ class BaseModelLoader:
 class DefaultModelLoader(BaseModelLoader):
     def get_all_weights(self, vllm_config: VllmConfig) -> Iterable[tuple[str, torch.Tensor]]:
         folder = vllm_config.model_config.model
+        if folder.endswith(".gguf") and os.path.isfile(folder):
+            from .gguf import gguf_weights_iterator
+            return gguf_weights_iterator(folder, vllm_config.model_config.dtype)
         files, is_st = find_weight_files(folder, self.load_config.load_format, self.load_config.ignore_patterns)
         return safetensors_iterator(files) if is_st else pt_iterator(files)
 
