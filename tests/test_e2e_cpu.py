@@ -126,6 +126,17 @@ def _save_tiny(tmp, kind):
                                   num_local_experts=4, num_experts_per_tok=2, embedding_multiplier=6.0,
                                   residual_multiplier=0.4, attention_multiplier=0.1, logits_scaling=4.0)
         m = tf.GraniteMoeForCausalLM(cfg)
+    elif kind == "jamba":
+        cfg = tf.JambaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=4,
+                             num_attention_heads=2, num_key_value_heads=1, attn_layer_period=2, attn_layer_offset=1,
+                             expert_layer_period=2, expert_layer_offset=1, num_experts=4, num_experts_per_tok=2,
+                             mamba_d_state=16, mamba_d_conv=4, mamba_expand=2, mamba_dt_rank=8,
+                             use_mamba_kernels=False, max_position_embeddings=256)
+        m = tf.JambaForCausalLM(cfg)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() >= 2 and "A_log" not in n:
+                    p.mul_(1.5)
     elif kind == "stablelm":
         cfg = tf.StableLmConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
                                 num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -209,7 +220,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe"])
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

@@ -277,6 +277,12 @@ class ModelConfig:
         return any(a in ("MambaForCausalLM", "FalconMambaForCausalLM", "Mamba2ForCausalLM")
                    for a in self.architectures)
 
+    @property
+    def is_hybrid(self) -> bool:
+        """Attention and state-space layers in one stack: paged KV for the former, one state slot per
+        request for the latter; recurrent state rules out prefix reuse."""
+        return any(a in ("JambaForCausalLM",) for a in self.architectures)
+
     def get_total_num_attention_heads(self) -> int:
         if self.is_attention_free:
             return 1
@@ -853,7 +859,7 @@ class VllmConfig:
         if sc.enable_chunked_prefill is False and sc.max_num_batched_tokens < mc.max_model_len:
             sc.max_num_batched_tokens = mc.max_model_len
         cc.sliding_window = mc.get_sliding_window()
-        if mc.is_attention_free:
+        if mc.is_attention_free or mc.is_hybrid:
             cc.enable_prefix_caching = False      # recurrent state cannot be shared by prefix
         if self.lora_config is not None:
             sc.max_loras = self.lora_config.max_loras

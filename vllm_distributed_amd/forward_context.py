@@ -41,6 +41,9 @@ class AttentionMetadata:
     max_decode_query_len: int = 1
     decode_num_splits: int = 1
     decode_workspace: Optional[tuple] = None
+    # hybrid attention + state-space models: int32 [S, 1], the state slot of every sequence (None: the
+    # slot is column 0 of the block table, as in attention-free models)
+    state_table: Optional[torch.Tensor] = None
     # cascade attention (eager steps whose sequences all start with the same cached blocks): the first
     # ``cascade_prefix_len`` keys are attended once by all query tokens, the rest per sequence
     cascade_prefix_len: int = 0

@@ -1,0 +1,145 @@
+"""Jamba: a hybrid stack of Mamba-1 mixers and (rotary-free) attention layers, each followed by a dense
+or a routed-expert MLP.  Attention layers use the paged KV cache; the Mamba layers keep one recurrent
+state per request in slots the model runner allocates beside the weights (worker/model_runner.py,
+``_init_hybrid_state``), so both kinds of per-request memory live under one scheduler.
+Reference: vllm/model_executor/models/jamba.py.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Iterable
+
+import torch
+import torch.nn as nn
+
+from ..config import VllmConfig
+from ..layers.basic import LogitsProcessor, ParallelLMHead, RMSNorm, VocabParallelEmbedding
+from .llama import LlamaAttention, LlamaMLP
+from .mamba import MambaMixer
+from .mixtral import SparseMoeBlock
+from .utils import load_weights_with_mapping, maybe_prefix
+
+
+def _layer_kinds(config) -> list[str]:
+    kinds = getattr(config, "layers_block_type", None)
+    if kinds:
+        return list(kinds)
+    p, o = config.attn_layer_period, config.attn_layer_offset
+    return ["attention" if i % p == o else "mamba" for i in range(config.num_hidden_layers)]
+
+
+def _layer_experts(config) -> list[int]:
+    n = getattr(config, "layers_num_experts", None)
+    if n:
+        return list(n)
+    p, o = config.expert_layer_period, config.expert_layer_offset
+    return [config.num_experts if i % p == o else 1 for i in range(config.num_hidden_layers)]
+
+
+class JambaLayer(nn.Module):
+    def __init__(self, config, vllm_config: VllmConfig, kind: str, num_experts: int, prefix: str):
+        super().__init__()
+        quant_config = getattr(vllm_config, "quant_config", None)
+        d = config.hidden_size
+        eps = config.rms_norm_eps
+        self.kind = kind
+        if kind == "attention":
+            self.self_attn = LlamaAttention(
+                config, d, config.num_attention_heads, config.num_key_value_heads, 10000.0, None,
+                vllm_config.model_config.max_model_len, quant_config=quant_config, prefix=f"{prefix}.self_attn",
+                cache_dtype=vllm_config.cache_config.cache_dtype, use_rope=False)
+        else:
+            inner = int(config.mamba_expand * d)
+            shim = SimpleNamespace(hidden_size=d, intermediate_size=inner, state_size=config.mamba_d_state,
+                                   conv_kernel=config.mamba_d_conv, time_step_rank=config.mamba_dt_rank,
+                                   use_bias=bool(config.mamba_proj_bias), use_conv_bias=bool(config.mamba_conv_bias))
+            self.mamba = MambaMixer(shim, f"{prefix}.mamba", rms_eps=eps, learned_norms=True)
+        if num_experts > 1:
+            # softmax over all experts, top-k, no renormalisation
+            self.feed_forward = SparseMoeBlock(d, config.intermediate_size, num_experts, config.num_experts_per_tok,
+                                               False, quant_config, f"{prefix}.feed_forward")
+        else:
+            self.feed_forward = LlamaMLP(d, config.intermediate_size, False, quant_config, f"{prefix}.feed_forward")
+        self.input_layernorm = RMSNorm(d, eps)
+        self.pre_ff_layernorm = RMSNorm(d, eps)
+
+    def forward(self, positions, hidden, residual):
+        if residual is None:
+            residual = hidden
+            hidden = self.input_layernorm(hidden)
+        else:
+            hidden, residual = self.input_layernorm(hidden, residual)
+        hidden = self.self_attn(positions, hidden) if self.kind == "attention" else self.mamba(hidden)
+        hidden, residual = self.pre_ff_layernorm(hidden, residual)
+        return self.feed_forward(hidden), residual
+
+
+class JambaForCausalLM(nn.Module):
+    supports_pp = False
+    supports_lora = False
+    packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"], "gate_up_proj": ["gate_proj", "up_proj"]}
+    stacked_params_mapping = [
+        (".qkv_proj", ".q_proj", "q"), (".qkv_proj", ".k_proj", "k"), (".qkv_proj", ".v_proj", "v"),
+        (".gate_up_proj", ".gate_proj", 0), (".gate_up_proj", ".up_proj", 1),
+    ]
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__()
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        kinds, experts = _layer_kinds(config), _layer_experts(config)
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([JambaLayer(config, vllm_config, kinds[i], experts[i], f"model.layers.{i}")
+                                     for i in range(config.num_hidden_layers)])
+        self.final_layernorm = RMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.tie = bool(getattr(config, "tie_word_embeddings", False))
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
+        if self.tie:
+            self.lm_head.tie_weights(self.embed_tokens)
+        self.logits_processor = LogitsProcessor(config.vocab_size)
+
+    def get_input_embeddings(self, ids):
+        return self.embed_tokens(ids)
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None):
+        hidden = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
+        residual = None
+        for layer in self.layers:
+            hidden, residual = layer(positions, hidden, residual)
+        hidden, _ = self.final_layernorm(hidden, residual)
+        return hidden
+
+    def compute_logits(self, hidden):
+        return self.logits_processor(self.lm_head, hidden)
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        from ..layers.moe import FusedMoE
+        n_exp = max(_layer_experts(self.config))
+        experts = FusedMoE.make_expert_params_mapping("gate_proj", "down_proj", "up_proj", n_exp) if n_exp > 1 else []
+        mamba_names = {".mamba.conv1d.weight": ".mamba.conv_weight", ".mamba.conv1d.bias": ".mamba.conv_bias",
+                       ".mamba.A_log": ".mamba.A", ".mamba.dt_proj.bias": ".mamba.dt_bias"}
+
+        def fix(items):
+            for name, t in items:
+                name = name.removeprefix("model.")
+                for a, b in mamba_names.items():
+                    if name.endswith(a):
+                        name = name[: -len(a)] + b
+                if name.endswith(".feed_forward.router.weight"):
+                    name = name.replace(".router.", ".gate.")
+                if name.endswith(".feed_forward.experts.gate_up_proj"):
+                    # recent transformers store all experts stacked: [E, 2I, H] (gate rows, then up rows)
+                    base, half = name[: -len("gate_up_proj")], t.shape[1] // 2
+                    for e in range(t.shape[0]):
+                        yield f"{base}{e}.gate_proj.weight", t[e, :half]
+                        yield f"{base}{e}.up_proj.weight", t[e, half:]
+                    continue
+                if name.endswith(".feed_forward.experts.down_proj"):
+                    base = name[: -len("down_proj")]
+                    for e in range(t.shape[0]):
+                        yield f"{base}{e}.down_proj.weight", t[e]
+                    continue
+                yield name, t
+
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie,
+                                         expert_mapping=experts)

@@ -63,14 +63,24 @@ class StateSpaceLayer(nn.Module):
     def bind_kv_cache(self, conv_state: torch.Tensor, ssm_state: torch.Tensor) -> None:
         self.conv_state, self.ssm_state = conv_state, ssm_state
 
+    @staticmethod
+    def slot_table(md) -> torch.Tensor:
+        """[S, >=1] int32 whose column 0 is each sequence's state slot."""
+        return md.state_table if md.state_table is not None else md.block_table
+
 
 class MambaMixer(StateSpaceLayer):
     """Mamba-1 block: in_proj -> causal conv -> (dt, B, C) projections -> selective scan -> out_proj.
     TP shards the inner channels; x_proj is row-parallel (one small all-reduce per layer)."""
 
-    def __init__(self, config, prefix: str, rms_eps: Optional[float] = None):
+    def __init__(self, config, prefix: str, rms_eps: Optional[float] = None, learned_norms: bool = False):
         super().__init__()
         tp, rank = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        self.learned_norms = learned_norms      # Jamba: RMSNorm with learned scales on dt, B and C
+        if learned_norms:
+            self.dt_layernorm = RMSNorm(int(config.time_step_rank), rms_eps or 1e-6)
+            self.b_layernorm = RMSNorm(int(config.state_size), rms_eps or 1e-6)
+            self.c_layernorm = RMSNorm(int(config.state_size), rms_eps or 1e-6)
         self.hidden = config.hidden_size
         self.d_inner = int(config.intermediate_size)
         self.d_state = int(config.state_size)
@@ -110,16 +120,20 @@ class MambaMixer(StateSpaceLayer):
             p = self.x_proj(xs.contiguous())
             dt = self.dt_proj(p[:, :self.dt_rank].contiguous())
             return self.out_proj(dt * z)
+        tbl = self.slot_table(md)
         xc = ops.causal_conv1d(xs, self.conv_weight, self.conv_bias, self.conv_state, md.query_start_loc,
-                               md.seq_lens, md.block_table, md.max_query_len)
+                               md.seq_lens, tbl, md.max_query_len)
         p = self.x_proj(xc)
         R, N = self.dt_rank, self.d_state
         dt_low, B, C = p[:, :R], p[:, R:R + N], p[:, R + N:]
-        if self.rms_eps is not None:
+        if self.learned_norms:
+            dt_low, B, C = self.dt_layernorm(dt_low.contiguous()), self.b_layernorm(B.contiguous()), \
+                self.c_layernorm(C.contiguous())
+        elif self.rms_eps is not None:
             dt_low, B, C = self._norm(dt_low), self._norm(B), self._norm(C)
         dt = self.dt_proj(dt_low.contiguous())
         y = ops.selective_scan(xc, dt, self.A, B, C, self.D, z, self.dt_bias, self.ssm_state, md.query_start_loc,
-                               md.seq_lens, md.block_table, softplus=True, max_query_len=md.max_query_len)
+                               md.seq_lens, tbl, softplus=True, max_query_len=md.max_query_len)
         return self.out_proj(y)
 
 
@@ -188,8 +202,9 @@ class Mamba2Mixer(StateSpaceLayer):
         gate, xbc, dt = p[:, :di], p[:, di:di + cd], p[:, di + cd:]
         if md is None or self.conv_state is None:
             return self.out_proj(self._gated_norm(xbc[:, :di] * gate))
+        tbl = self.slot_table(md)
         xbc = ops.causal_conv1d(xbc, self.conv_weight, self.conv_bias, self.conv_state, md.query_start_loc,
-                                md.seq_lens, md.block_table, md.max_query_len)
+                                md.seq_lens, tbl, md.max_query_len)
         gn = self.n_groups * self.d_state
         xs, B, C = xbc[:, :di], xbc[:, di:di + gn], xbc[:, di + gn:]
         bias, softplus = self.dt_bias, True
@@ -197,7 +212,7 @@ class Mamba2Mixer(StateSpaceLayer):
             dt = torch.nn.functional.softplus(dt.float() + self.dt_bias).clamp(*self.dt_limit).to(x.dtype)
             bias, softplus = None, False
         y = ops.selective_scan(xs, dt, self.A, B, C, self.D, gate, bias, self.ssm_state, md.query_start_loc,
-                               md.seq_lens, md.block_table, softplus=softplus, num_groups=self.n_groups,
+                               md.seq_lens, tbl, softplus=softplus, num_groups=self.n_groups,
                                max_query_len=md.max_query_len)
         return self.out_proj(self._gated_norm(y))
 

@@ -51,6 +51,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
     "DeepseekForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
+    "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "MambaForCausalLM": ("mamba", "MambaForCausalLM"),
     "FalconMambaForCausalLM": ("mamba", "FalconMambaForCausalLM"),
     "Mamba2ForCausalLM": ("mamba", "Mamba2ForCausalLM"),

@@ -74,6 +74,7 @@ class ModelRunner:
         self.kv_caches: list[tuple[torch.Tensor, torch.Tensor]] = []
         self.kv_arena: Optional[torch.Tensor] = None
         self.attn_layers: dict[str, Attention] = {}
+        self.state_table: Optional[torch.Tensor] = None      # hybrid models only, see _init_hybrid_state
         self.input_batch: Optional[InputBatch] = None
         self.graphs: dict[int, tuple] = {}
         self.sleep_allocator = None
@@ -149,6 +150,7 @@ class ModelRunner:
                     or getattr(m, "is_mla", False)}
         for n, m in self.attn_layers.items():
             m.layer_name = n
+        self._init_hybrid_state()
         spec = self.vllm_config.speculative_config
         if spec is not None and get_pp_group().is_last_rank:
             from ..spec_decode import make_proposer
@@ -166,6 +168,30 @@ class ModelRunner:
         if self.vllm_config.lora_config is not None:
             from ..lora.manager import LoRAManager
             self.lora_manager = LoRAManager(self.model, self.vllm_config, self.device)
+
+    def _init_hybrid_state(self) -> None:
+        """Hybrid models (attention and state-space layers in one stack, e.g. Jamba): the paged KV cache
+        serves the attention layers only.  Every state-space layer gets one state slot per batch row,
+        allocated here next to the weights (so memory profiling counts it), and a sequence's slot is its
+        row of the persistent batch + 1; slot 0 absorbs the padding rows of captured decode graphs."""
+        self.state_table: Optional[torch.Tensor] = None
+        ss = {n: m for n, m in self.attn_layers.items() if getattr(m, "is_state_space_layer", False)}
+        if not ss or len(ss) == len(self.attn_layers):
+            return
+        nslots = max(self.max_num_reqs, max(self.capture_sizes, default=0)) + 1
+        total = 0
+        with self._sleep_pool("kv_cache"):
+            for n, m in ss.items():
+                conv_shape, ssm_shape = m.state_shapes()
+                conv = torch.zeros((nslots, *conv_shape), dtype=m.conv_dtype, device=self.device)
+                ssm = torch.zeros((nslots, *ssm_shape), dtype=torch.float32, device=self.device)
+                m.bind_kv_cache(conv, ssm)
+                total += conv.numel() * conv.element_size() + ssm.numel() * 4
+                del self.attn_layers[n]
+            self.state_table = torch.zeros((nslots - 1, 1), dtype=torch.int32, device=self.device)
+        self.state_layers = ss
+        logger.info("hybrid model: %d state-space layers, %d state slots, %.2f GiB of recurrent state", len(ss),
+                    nslots, total / 2**30)
 
     def _init_eplb(self) -> None:
         from ..layers.moe import FusedMoE
@@ -367,6 +393,8 @@ class ModelRunner:
             self.block_table[:S, :W].copy_(btv, non_blocking=True)
         if nd < S:
             self._to_dev(self.prefill_qsl, (cu[nd:] - cu[nd]).astype(np.int32))
+        if self.state_table is not None and S:
+            self._to_dev(self.state_table.view(-1), (rows + 1).astype(np.int32))
         return nd, ndt
 
     def _prepare_inputs(self, so: SchedulerOutput):
@@ -491,7 +519,8 @@ class ModelRunner:
             seq_lens=self.seq_lens[:S], query_start_loc=self.query_start_loc[:S + 1],
             prefill_query_start_loc=self.prefill_qsl[:S - nd + 1] if nd < S else None,
             max_query_len=max_q, max_seq_len=max_seq, max_decode_query_len=self.max_decode_q,
-            decode_num_splits=nsplit, decode_workspace=self._workspace(max(ndt, 1), nsplit))
+            decode_num_splits=nsplit, decode_workspace=self._workspace(max(ndt, 1), nsplit),
+            state_table=self.state_table[:S] if self.state_table is not None else None)
 
     def _token_type_ids(self, req_ids, n_sched, T: int) -> Optional[torch.Tensor]:
         """Segment ids of the step's tokens (requests that carry none are all zero); None when no request has any."""
@@ -598,6 +627,8 @@ class ModelRunner:
                 # padded sequences: zero keys, slot -1 (no cache write), one query token each
                 self.seq_lens[S:graph_bs].zero_()
                 self.slot_mapping[S:graph_bs].fill_(-1)
+                if self.state_table is not None:
+                    self.state_table[S:graph_bs].zero_()
                 self.query_start_loc[S + 1: graph_bs + 1].copy_(
                     torch.arange(S + 1, graph_bs + 1, dtype=torch.int32, device=self.device))
             g, hidden_buf, md = self.graphs[graph_bs]
