@@ -62,3 +62,91 @@ def test_llava_matches_hf(tmp_path):
                               eos_token_id=None, **kw)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref, p
     assert list(again[0].outputs[0].token_ids) == list(outs[0].outputs[0].token_ids)
+
+
+def _tiny_qwen2_vl(tmp):
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.Qwen2VLConfig(
+        text_config=dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512,
+                         rope_parameters={"rope_type": "default", "mrope_section": [8, 12, 12], "rope_theta": 10000.0},
+                         bos_token_id=1, eos_token_id=2),
+        vision_config=dict(depth=2, embed_dim=64, hidden_size=128, num_heads=2, mlp_ratio=2, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, in_channels=3),
+        image_token_id=300, video_token_id=301, vision_start_token_id=302, vision_end_token_id=303)
+    m = tf.Qwen2VLForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+    m = m.float().eval()
+    path = os.path.join(tmp, "qwen2vl")
+    m.save_pretrained(path, safe_serialization=True)
+    return path, m
+
+
+def test_mrope_positions_layout():
+    from vllm_distributed_amd.models.qwen2_vl import mrope_positions
+    # 3 text tokens, an image of 1 x 4 x 6 patches (2 x 3 after merging), 2 text tokens
+    pos, delta = mrope_positions(3 + 6 + 2, [(3, 6)], [(1, 4, 6)], 2)
+    assert pos[:, :3].tolist() == [[0, 1, 2]] * 3
+    assert pos[0, 3:9].tolist() == [3] * 6
+    assert pos[1, 3:9].tolist() == [3, 3, 3, 4, 4, 4]
+    assert pos[2, 3:9].tolist() == [3, 4, 5, 3, 4, 5]
+    assert pos[:, 9:].tolist() == [[6, 7]] * 3           # continues after max(t, h, w) = 3
+    assert delta == 8 - 11
+
+
+def test_qwen2_vl_matches_hf(tmp_path):
+    """Vision tower over two different patch grids, merged embeddings, multimodal rotary positions in
+    prefill (chunked) and the position offset in decode: greedy tokens equal transformers'."""
+    path, hf = _tiny_qwen2_vl(str(tmp_path))
+    g = torch.Generator().manual_seed(3)
+    imgs = [{"pixel_values": torch.randn(4 * 6, 1176, generator=g), "image_grid_thw": torch.tensor([1, 4, 6])},
+            {"pixel_values": torch.randn(8 * 4, 1176, generator=g), "image_grid_thw": torch.tensor([1, 8, 4])}]
+    prompts = [([5, 17, 302, 300, 303, 9, 11, 250], [imgs[0]]),
+               ([7, 8, 9, 10] * 5, []),
+               ([3, 302, 300, 303, 44, 45, 302, 300, 303, 46], [imgs[1], imgs[0]])]
+    reqs = [{"prompt_token_ids": p, **({"multi_modal_data": {"image": m}} if m else {})} for p, m in prompts]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=16, enable_prefix_caching=False, block_size=16)
+    outs = llm.generate(reqs, SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    for (p, ims), o in zip(prompts, outs):
+        ids, k = [], 0
+        for t in p:
+            if t == 300:
+                n = int(ims[k]["image_grid_thw"].prod()) // 4
+                ids += [300] * n
+                k += 1
+            else:
+                ids.append(t)
+        assert list(o.prompt_token_ids) == ids
+        kw = {}
+        if ims:
+            kw = dict(pixel_values=torch.cat([i["pixel_values"] for i in ims]),
+                      image_grid_thw=torch.stack([i["image_grid_thw"] for i in ims]),
+                      mm_token_type_ids=torch.tensor([[1 if t == 300 else 0 for t in ids]], dtype=torch.int32))
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None, **kw)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, (p, list(o.outputs[0].token_ids), ref)
+    llm.shutdown()
+
+
+def test_patch_grid_preprocessing_matches_hf_layout():
+    """Same grid and patch order as transformers' Qwen2-VL image processor; pixel values differ only by
+    the resize filter (PIL on uint8 there, float bicubic here)."""
+    np = pytest.importorskip("numpy")
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+    from vllm_distributed_amd.multimodal import PatchGridProcessor, smart_resize
+    img = (np.random.default_rng(0).random((120, 200, 3)) * 255).astype(np.uint8)
+    px, grid = PatchGridProcessor(300, 14, 2, 2, 56 * 56, 14 * 14 * 4 * 1280).patches(img)
+    ref = Qwen2VLImageProcessorPil(min_pixels=56 * 56, max_pixels=14 * 14 * 4 * 1280)(
+        images=[Image.fromarray(img)], return_tensors="pt")
+    assert grid.tolist() == ref["image_grid_thw"][0].tolist() == [1, 8, 14]
+    assert px.shape == ref["pixel_values"].shape
+    assert (px - ref["pixel_values"]).abs().mean() < 0.02
+    assert smart_resize(120, 200, 28) == (112, 196)

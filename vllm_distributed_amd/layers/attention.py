@@ -79,7 +79,10 @@ class Attention(nn.Module):
         if conn is not None:
             conn.wait_for_layer_load(self.layer_name)
         if rotary is not None:
-            ops.rope_and_cache(positions[:n], qkv[:n], rotary.cos_sin_cache, self.k_cache, self.v_cache,
+            table, pos = rotary.cos_sin_cache, positions
+            if getattr(rotary, "step_table", None) is not None:
+                table, pos = rotary.step_table, rotary.step_index      # multimodal rotary: one row per token
+            ops.rope_and_cache(pos[:n], qkv[:n], table, self.k_cache, self.v_cache,
                                md.slot_mapping[:n], rotary.rotary_dim, D, Hq, Hkv, rotary.is_neox_style, ksc, vsc)
         else:
             ops.reshape_and_cache(qkv[:n, qs:qs + ks].view(n, Hkv, D), qkv[:n, qs + ks:].view(n, Hkv, D),

@@ -158,6 +158,47 @@ class LongRoPEScaledRotaryEmbedding(RotaryEmbedding):
 _CACHE: dict[Any, RotaryEmbedding] = {}
 
 
+class MRotaryEmbedding(RotaryEmbedding):
+    """Multimodal rotary embedding (Qwen2-VL): the frequency pairs are split into three sections that
+    take their angle from the temporal, the height and the width position of a token.  Text tokens
+    carry the same number on all three axes, which is the ordinary embedding, so steps without image
+    tokens (every decode step) run the plain path on 1-D positions.  For a step with 3-D positions the
+    model calls ``prepare`` once: it gathers one cos/sin row per token from the position table, and the
+    fused RoPE + cache-write kernel then indexes that per-step table by token number.
+    Reference: vllm/model_executor/layers/rotary_embedding.py (MRotaryEmbedding)."""
+
+    def __init__(self, head_size, rotary_dim, max_position, base, is_neox_style, mrope_section: list[int]):
+        super().__init__(head_size, rotary_dim, max_position, base, is_neox_style)
+        if sum(mrope_section) != rotary_dim // 2:
+            raise ValueError(f"mrope_section {mrope_section} does not add up to {rotary_dim // 2} frequency pairs")
+        axis = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(mrope_section)])
+        self.register_buffer("axis_of", axis.repeat(2), persistent=False)      # cos half, sin half
+        self.step_table: Optional[torch.Tensor] = None
+        self.step_index: Optional[torch.Tensor] = None
+
+    def prepare(self, positions: Optional[torch.Tensor]) -> None:
+        """positions [3, T] (or None / 1-D to return to the plain path)."""
+        if positions is None or positions.dim() == 1:
+            self.step_table = self.step_index = None
+            return
+        cs = self.cos_sin_cache[positions]                                # [3, T, rot]
+        T = cs.shape[1]
+        sel = self.axis_of.view(1, -1, 1).expand(T, -1, 1)
+        self.step_table = torch.gather(cs.permute(1, 2, 0), 2, sel).squeeze(-1).contiguous()
+        self.step_index = torch.arange(T, dtype=torch.long, device=cs.device)
+
+    def forward(self, positions: torch.Tensor, q: torch.Tensor, k: Optional[torch.Tensor] = None):
+        if positions.dim() == 2:
+            self.prepare(positions)
+            try:
+                ops.rotary_embedding(self.step_index, q, k, self.step_table, self.rotary_dim, self.head_size,
+                                     self.is_neox_style)
+            finally:
+                self.prepare(None)
+            return q, k
+        return super().forward(positions, q, k)
+
+
 def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is_neox_style: bool = True,
              rope_scaling: Optional[dict] = None, partial_rotary_factor: float = 1.0) -> RotaryEmbedding:
     if partial_rotary_factor < 1.0:
@@ -168,7 +209,10 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is
         return _CACHE[key]
     kind = None if rope_scaling is None else rope_scaling.get("rope_type", rope_scaling.get("type"))
     rs = rope_scaling or {}
-    if kind in (None, "default", "mrope"):
+    if rs.get("mrope_section"):
+        rope = MRotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style,
+                                [int(x) for x in rs["mrope_section"]])
+    elif kind in (None, "default", "mrope"):
         rope = RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style)
     elif kind == "llama3":
         rope = Llama3RotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, rs["factor"],

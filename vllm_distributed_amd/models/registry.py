@@ -50,6 +50,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "DeepseekV2ForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
     "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
     "DeepseekForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
+    "Qwen2VLForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "MambaForCausalLM": ("mamba", "MambaForCausalLM"),

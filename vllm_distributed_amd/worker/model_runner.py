@@ -75,6 +75,8 @@ class ModelRunner:
         self.kv_arena: Optional[torch.Tensor] = None
         self.attn_layers: dict[str, Attention] = {}
         self.state_table: Optional[torch.Tensor] = None      # hybrid models only, see _init_hybrid_state
+        self.uses_mrope = False
+        self._step_mrope: Optional[torch.Tensor] = None
         self.input_batch: Optional[InputBatch] = None
         self.graphs: dict[int, tuple] = {}
         self.sleep_allocator = None
@@ -151,6 +153,7 @@ class ModelRunner:
         for n, m in self.attn_layers.items():
             m.layer_name = n
         self._init_hybrid_state()
+        self.uses_mrope = bool(getattr(self.model, "uses_mrope", False))
         spec = self.vllm_config.speculative_config
         if spec is not None and get_pp_group().is_last_rank:
             from ..spec_decode import make_proposer
@@ -332,6 +335,10 @@ class ModelRunner:
         for nr in so.scheduled_new_reqs:
             ib.add_request(nr.req_id, nr.prompt_token_ids, nr.sampling_params, nr.block_ids, nr.num_computed_tokens,
                            nr.pooling_params, nr.lora_request, nr.mm_inputs, nr.mm_positions)
+            if self.uses_mrope and nr.mm_inputs:
+                st = ib.reqs[nr.req_id]
+                st.mrope_positions, st.mrope_delta = self.model.get_mrope_positions(
+                    len(nr.prompt_token_ids), nr.mm_positions, nr.mm_inputs)
         cr = so.scheduled_cached_reqs
         for i, rid in enumerate(cr.req_ids):
             st = ib.reqs.get(rid)
@@ -415,10 +422,42 @@ class ModelRunner:
             tmd, att = self._prepare_token_parallel(so, req_ids, rows, n_sched, req_idx, tok_rows, pos)
         else:
             self._to_dev(self.input_ids, ib.token_ids[tok_rows, pos])
+            if self.uses_mrope:
+                pos = self._mrope_positions(req_ids, rows, n_sched, cu, pos)
             nd, ndt = self._upload_attention_inputs(rows, n_sched, cu, pos, slot, seq_lens)
             att = (S, T, nd, ndt, int(seq_lens.max()) if S else 0, int(n_sched.max()) if S else 0)
         logits_idx = (cu[1:] - 1).astype(np.int64)
         return req_ids, rows, n_sched, cu, S, T, logits_idx, att, tmd
+
+    def _mrope_positions(self, req_ids, rows, n_sched, cu, pos: np.ndarray) -> np.ndarray:
+        """Multimodal rotary positions.  Requests with images carry three position rows for their prompt
+        and an offset for everything after it; text-only requests and generated tokens have one number
+        on all three axes.  Returns the 1-D positions (row 0) and leaves the [3, T] tensor of a step that
+        touches image prompts in ``self._step_mrope`` (None otherwise: the step runs the plain rotary path)."""
+        ib = self.input_batch
+        self._step_mrope = None
+        sts = [ib.reqs[r] for r in req_ids]
+        if not any(getattr(st, "mrope_positions", None) is not None for st in sts):
+            return pos
+        pos = pos.copy()
+        prompt_parts = []
+        for k, st in enumerate(sts):
+            mp = getattr(st, "mrope_positions", None)
+            if mp is None:
+                continue
+            a, b = int(cu[k]), int(cu[k + 1])
+            idx = int(ib.num_computed[rows[k]]) + np.arange(b - a)
+            inside = idx < mp.shape[1]
+            pos[a:b][~inside] = idx[~inside] + st.mrope_delta
+            if inside.any():
+                prompt_parts.append((a, inside, mp[:, idx[inside]]))
+        if prompt_parts:
+            p3 = np.broadcast_to(pos, (3, len(pos))).copy()
+            for a, inside, vals in prompt_parts:
+                p3[:, a:a + len(inside)][:, inside] = vals
+            self._step_mrope = torch.from_numpy(p3).to(self.device)
+            pos = p3[0].copy()
+        return pos
 
     def _prepare_token_parallel(self, so, req_ids, rows, n_sched, req_idx, tok_rows, pos):
         """Token parallelism: the root feeds all T rows through the dense layers, but every rank
@@ -463,8 +502,13 @@ class ModelRunner:
         if not so.scheduled_encoder_inputs:
             return
         todo = [(rid, i) for rid, idxs in so.scheduled_encoder_inputs.items() for i in idxs]
-        px = torch.stack([ib.reqs[rid].mm_inputs[i] for rid, i in todo]).to(self.device, self.dtype)
-        emb = self.model.encode_images(px)
+        if hasattr(self.model, "encode_mm_items"):
+            # items of different shapes (patch matrices with their grids)
+            emb = self.model.encode_mm_items([[torch.as_tensor(x).to(self.device) for x in ib.reqs[rid].mm_inputs[i]]
+                                              for rid, i in todo])
+        else:
+            px = torch.stack([ib.reqs[rid].mm_inputs[i] for rid, i in todo]).to(self.device, self.dtype)
+            emb = self.model.encode_images(px)
         for (rid, i), e in zip(todo, emb):
             self.encoder_cache.setdefault(rid, {})[i] = e
 
@@ -669,7 +713,10 @@ class ModelRunner:
                 extra = {}
                 if getattr(self.model, "uses_token_type_ids", False):
                     extra["token_type_ids"] = self._token_type_ids(req_ids, n_sched, T_in)
-                hidden = self.model(self.input_ids[:T_in], self.positions[:P_in], inter, inputs_embeds, **extra)
+                positions = self.positions[:P_in]
+                if self.uses_mrope and getattr(self, "_step_mrope", None) is not None and P_in == T:
+                    positions = self._step_mrope
+                hidden = self.model(self.input_ids[:T_in], positions, inter, inputs_embeds, **extra)
             if T_in > T and torch.is_tensor(hidden):
                 hidden = hidden[:T]
         if conn is not None:
