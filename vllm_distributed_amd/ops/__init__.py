@@ -535,6 +535,23 @@ def _moe_large(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale):
     return out2.view(T, k, -1).sum(dim=1)
 
 
+def moe_rows_form(num_pairs: int, num_experts: int, rows: int, weight_bytes: int = 2) -> bool:
+    """Grouped expert GEMM, which form: the row-split kernel (each wave 16 output rows over the whole K,
+    activations shared through LDS) pays once an expert sees enough tokens for the shared tile to matter
+    and the launch still fills the chip; below that the K-split kernel (four waves per 16 rows) has more
+    workgroups in flight.  Thresholds from benchmarks_dev/moe_probe.py on MI355X."""
+    forced = envs.VDA_MOE_ROWS_FORM
+    if forced >= 0:
+        return bool(forced)
+    avg = num_pairs / max(num_experts, 1)
+    fills = (rows // 64) * num_experts >= 512
+    if rows % 64:
+        return False
+    if weight_bytes == 1 and fills:
+        return True                      # 8-bit weights: ahead at every batch size once the launch fills the chip
+    return avg >= 8 and (fills or avg >= 64)
+
+
 def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,
               w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Routed SwiGLU expert MLPs.  x [T,H]; w13 [E,2I,H] (gate rows then up rows); w2 [E,H,I];
@@ -562,9 +579,11 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
     # one expert can receive at most one slot of every token
     max_pairs = T
     N.call("vda_moe_gate_up", inter.data_ptr(), x.data_ptr(), w13.data_ptr(), N.ptr(w13_scale), sorted_ids.data_ptr(),
-           offsets.data_ptr(), E, I, H, k, max_pairs, x.stride(0), N.dt(x.dtype), wd, st)
+           offsets.data_ptr(), E, I, H, k, max_pairs, x.stride(0), N.dt(x.dtype), wd,
+           int(moe_rows_form(T * k, E, I, w13.element_size())), st)
     N.call("vda_moe_down", out2.data_ptr(), inter.data_ptr(), w2.data_ptr(), N.ptr(w2_scale), tw.data_ptr(),
-           sorted_ids.data_ptr(), offsets.data_ptr(), E, H, I, max_pairs, N.dt(x.dtype), wd, st)
+           sorted_ids.data_ptr(), offsets.data_ptr(), E, H, I, max_pairs, N.dt(x.dtype), wd,
+           int(moe_rows_form(T * k, E, H, w2.element_size())), st)
     N.call("vda_moe_sum", out.data_ptr(), out2.data_ptr(), ids.data_ptr(), T, H, k, out.stride(0), N.dt(x.dtype), st)
     return out
 

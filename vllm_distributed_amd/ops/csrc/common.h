@@ -96,6 +96,7 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
 // Weight loaders: 8 consecutive K elements of one weight row as an MFMA operand.
 template <typename T> struct WLoad {
   using V8 = typename Vec<T>::v8;
+  static constexpr int kElemBytes = sizeof(T);
   static __device__ __forceinline__ V8 ld(const void* base, long elem_off) {
     return __builtin_nontemporal_load(reinterpret_cast<const V8*>(reinterpret_cast<const T*>(base) + elem_off));
   }
@@ -103,6 +104,7 @@ template <typename T> struct WLoad {
 // e4m3 weights, widened in registers (W8A16): half the HBM bytes of the 16-bit path
 template <typename T> struct WLoadFp8 {
   using V8 = typename Vec<T>::v8;
+  static constexpr int kElemBytes = 1;
   static __device__ __forceinline__ V8 ld(const void* base, long elem_off) {
     const u32x2 raw = __builtin_nontemporal_load(
         reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(base) + elem_off));

@@ -18,14 +18,19 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const long wp = (long)(n0 + r) * w_stride + g * 32;   // element offset into w
+  // K elements of MFMA k-step s for lane group g inside a 128-wide step.  The MFMA sums over K in any
+  // order, so the order is chosen for the memory system: one load instruction reads 64 contiguous bytes
+  // of each of its 16 weight rows (16-bit weights: 32 s + 8 g; 8-bit: 64 (s / 2) + 16 g + 8 (s % 2), the two
+  // halves of a lane's 16 bytes being one load) rather than four pieces 64 bytes apart.
+  auto koff = [&](int s_) { return WL::kElemBytes == 1 ? 64 * (s_ >> 1) + 16 * g + 8 * (s_ & 1) : 32 * s_ + 8 * g; };
+  const long wp = (long)(n0 + r) * w_stride;            // element offset into w
   const T* xp[MT];
   bool xv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mt * 16 + r;
     xv[mt] = m < M;
-    xp[mt] = x + (long)(xv[mt] ? m : 0) * x_stride + g * 32;
+    xp[mt] = x + (long)(xv[mt] ? m : 0) * x_stride;
   }
   f32x4 acc[MT];
 #pragma unroll
@@ -38,15 +43,15 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, con
     V8 wa[4], wb[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      wa[s] = WL::ld(w, wp + (long)c * 128 + 8 * s);
-      wb[s] = WL::ld(w, wp + (long)(c + 4) * 128 + 8 * s);
+      wa[s] = WL::ld(w, wp + (long)c * 128 + koff(s));
+      wb[s] = WL::ld(w, wp + (long)(c + 4) * 128 + koff(s));
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)c * 128 + 8 * s) : V8{};
-        const V8 xb = xv[mt] ? ld16<V8>(xp[mt] + (long)(c + 4) * 128 + 8 * s) : V8{};
+        const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)c * 128 + koff(s)) : V8{};
+        const V8 xb = xv[mt] ? ld16<V8>(xp[mt] + (long)(c + 4) * 128 + koff(s)) : V8{};
         acc[mt] = mfma16(wa[s], xa, acc[mt]);
         acc[mt] = mfma16(wb[s], xb, acc[mt]);
       }
@@ -56,12 +61,12 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(T* __restrict__ y, con
     V8 wa[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      wa[s] = WL::ld(w, wp + (long)c * 128 + 8 * s);
+      wa[s] = WL::ld(w, wp + (long)c * 128 + koff(s));
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)c * 128 + 8 * s) : V8{};
+        const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)c * 128 + koff(s)) : V8{};
         acc[mt] = mfma16(wa[s], xa, acc[mt]);
       }
     }

@@ -139,7 +139,11 @@ __global__ __launch_bounds__(256) void moe_grouped_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const long wrow0 = (long)e * w_expert_stride + (long)(n0 + r) * K + g * 32;
+  // K elements of MFMA k-step s for lane group g inside a 128-wide step: permuted so that one load
+  // instruction reads 64 contiguous bytes of each weight row (see moe_grouped_rows_kernel)
+  // (8-bit weights keep 32 contiguous elements per lane here: measured faster in this form)
+  auto koff = [&](int s_) { return WL::kElemBytes == 1 ? 32 * g + 8 * s_ : 32 * s_ + 8 * g; };
+  const long wrow0 = (long)e * w_expert_stride + (long)(n0 + r) * K;
   const long wrow1 = wrow0 + (long)N * K;           // the "up" half (GATE_UP only)
 
   const T* xp[4];
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void moe_grouped_kernel(
     const int i = mt * 16 + r;
     pid[mt] = i < cnt ? sorted[beg + i] : -1;
     const int row = pid[mt] < 0 ? 0 : (GATE_UP ? pid[mt] / top_k : pid[mt]);
-    xp[mt] = act + (long)row * act_stride + g * 32;
+    xp[mt] = act + (long)row * act_stride;
   }
   f32x4 acc0[4], acc1[4];
 #pragma unroll
@@ -160,15 +164,15 @@ __global__ __launch_bounds__(256) void moe_grouped_kernel(
     V8 wa[4], wb[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      wa[s] = WL::ld(w, wrow0 + (long)c * 128 + 8 * s);
-      if (GATE_UP) wb[s] = WL::ld(w, wrow1 + (long)c * 128 + 8 * s);
+      wa[s] = WL::ld(w, wrow0 + (long)c * 128 + koff(s));
+      if (GATE_UP) wb[s] = WL::ld(w, wrow1 + (long)c * 128 + koff(s));
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (mt < mt_n) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const V8 xa = pid[mt] >= 0 ? ld16<V8>(xp[mt] + (long)c * 128 + 8 * s) : V8{};
+          const V8 xa = pid[mt] >= 0 ? ld16<V8>(xp[mt] + (long)c * 128 + koff(s)) : V8{};
           acc0[mt] = mfma16(wa[s], xa, acc0[mt]);
           if (GATE_UP) acc1[mt] = mfma16(wb[s], xa, acc1[mt]);
         }
@@ -210,16 +214,140 @@ __global__ __launch_bounds__(256) void moe_grouped_kernel(
   }
 }
 
+// Row-split form of the grouped skinny GEMM (N % 64 == 0).  Each of the 4 waves owns 16 output rows
+// over the whole K, so nothing is reduced across waves; the 64-token x 128-K activation tile of a step is
+// copied into LDS once per workgroup (double-buffered) and read by all four waves.  In the K-split form
+// above every workgroup streamed the expert's activations from L2 by itself, which at 32 tokens per
+// expert was twice the weight traffic; here it is half of it, and the weight stream (the HBM-bound part)
+// is prefetched one step ahead.  The K elements a lane group takes for an MFMA k-step are permuted inside a
+// 128-wide step so that one load instruction reads 64 contiguous bytes of each of its 16 weight rows
+// (see koff below); with four 16-byte pieces 64 bytes apart per instruction the same kernel streamed
+// weights at 3 TB/s instead of 4.6-5.3 TB/s.
+template <typename T, typename WL, bool GATE_UP>
+__global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
+    T* __restrict__ out, const T* __restrict__ act, const void* __restrict__ w, const float* __restrict__ w_scale,
+    const float* __restrict__ topk_w, const int* __restrict__ sorted, const int* __restrict__ offsets,
+    int N, int K, int top_k, long act_stride, long out_stride, long w_expert_stride) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr int XS = 136;                      // LDS row stride in elements: 272 B keeps 16-byte reads conflict-free
+  __shared__ __attribute__((aligned(16))) T sx[2][64][XS];
+  const int e = blockIdx.y;
+  const int beg = offsets[e] + blockIdx.z * 64, end = offsets[e + 1];
+  if (beg >= end) return;                      // uniform over the workgroup
+  const int cnt = min(end - beg, 64);
+  const int mt_n = (cnt + 15) >> 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 16;
+  // K elements of MFMA k-step s for lane group g inside a 128-wide step, chosen so that one load
+  // instruction reads 64 contiguous bytes of each weight row: 16-bit weights 32 s + 8 g (16 bytes per
+  // lane), 8-bit weights 64 (s / 2) + 16 g + 8 (s % 2) (the two halves of a lane's 16 bytes are one load).
+  auto koff = [&](int s_) { return WL::kElemBytes == 1 ? 64 * (s_ >> 1) + 16 * g + 8 * (s_ & 1) : 32 * s_ + 8 * g; };
+  const long wrow0 = (long)e * w_expert_stride + (long)(n0 + r) * K;
+  const long wrow1 = wrow0 + (long)N * K;
+
+  // staging role: token (tid >> 4) + 16 i, 16-byte piece tid & 15
+  const int piece = tid & 15;
+  const T* xrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = (tid >> 4) + 16 * i;
+    const int id = t < cnt ? sorted[beg + t] : -1;
+    xrow[i] = id < 0 ? nullptr : act + (long)(GATE_UP ? id / top_k : id) * act_stride + piece * 8;
+  }
+  int pid[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int i = mt * 16 + r;
+    pid[mt] = i < cnt ? sorted[beg + i] : -1;
+  }
+  f32x4 acc0[4], acc1[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) { acc0[mt] = f32x4{0, 0, 0, 0}; acc1[mt] = f32x4{0, 0, 0, 0}; }
+
+  V8 wa[4], wb[4], wan[4], wbn[4], xr[4];
+  auto loadw = [&](int c, V8 (&a)[4], V8 (&b)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a[s] = WL::ld(w, wrow0 + (long)c * 128 + koff(s));
+      if (GATE_UP) b[s] = WL::ld(w, wrow1 + (long)c * 128 + koff(s));
+    }
+  };
+  auto loadx = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      xr[i] = (i < mt_n && xrow[i]) ? ld16<V8>(xrow[i] + (long)c * 128) : V8{};
+  };
+  auto storex = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < mt_n) *reinterpret_cast<V8*>(&sx[buf][(tid >> 4) + 16 * i][piece * 8]) = xr[i];
+  };
+
+  const int nchunk = K >> 7;
+  loadx(0);
+  loadw(0, wa, wb);
+  storex(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    if (more) { loadx(c + 1); loadw(c + 1, wan, wbn); }
+    const int buf = c & 1;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (mt < mt_n) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const V8 xa = *reinterpret_cast<const V8*>(&sx[buf][mt * 16 + r][koff(s)]);
+          acc0[mt] = mfma16(wa[s], xa, acc0[mt]);
+          if (GATE_UP) acc1[mt] = mfma16(wb[s], xa, acc1[mt]);
+        }
+      }
+    }
+    if (more) storex(buf ^ 1);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { wa[s] = wan[s]; if (GATE_UP) wb[s] = wbn[s]; }
+  }
+
+  const float ws = w_scale ? w_scale[e] : 1.f;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    if (mt < mt_n && pid[mt] >= 0) {
+      V4 o;
+      if (GATE_UP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float gte = acc0[mt][i] * ws, up = acc1[mt][i] * ws;
+          o[i] = (T)(gte / (1.f + __expf(-gte)) * up);
+        }
+      } else {
+        const float tw = topk_w[pid[mt]] * ws;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (T)(acc0[mt][i] * tw);
+      }
+      *reinterpret_cast<V4*>(out + (long)pid[mt] * out_stride + n0 + 4 * g) = o;
+    }
+  }
+}
+
 // w13: [E, 2*I, K] (gate rows then up rows), w2: [E, H, I]; wdtype VDA_FP8 selects e4m3 weights with
 // a per-expert fp32 scale.  max_pairs bounds the tokens of one expert (grid.z = ceil(max_pairs/64)).
+// rows_form selects the row-split kernel (when the row count is a multiple of 64); the caller decides
+// from the batch shape (see ops.fused_moe).
 VDA_EXPORT int vda_moe_gate_up(void* inter, const void* x, const void* w13, const float* w_scale, const int* sorted,
                                const int* offsets, int E, int I, int K, int top_k, int max_pairs, long x_stride,
-                               int dtype, int wdtype, hipStream_t st) {
+                               int dtype, int wdtype, int rows_form, hipStream_t st) {
   if (I % 16 || K % 128 || E < 1 || max_pairs < 1) return -1;
-  dim3 grid(I / 16, E, (max_pairs + 63) / 64), block(256);
+  const bool rows = rows_form && I % 64 == 0;
+  dim3 grid(rows ? I / 64 : I / 16, E, (max_pairs + 63) / 64), block(256);
   const long es = (long)2 * I * K;
-#define L(TT, WL) hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, true>), grid, block, 0, st, (TT*)inter, (const TT*)x, \
-                                     w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es)
+#define L(TT, WL) do { if (rows) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, true>), grid, block, 0, st, (TT*)inter, \
+        (const TT*)x, w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es); \
+    else hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, true>), grid, block, 0, st, (TT*)inter, (const TT*)x, \
+        w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es); } while (0)
   if (dtype == VDA_BF16) { if (wdtype == VDA_FP8) L(bf16_t, WLoadFp8<bf16_t>); else L(bf16_t, WLoad<bf16_t>); }
   else if (dtype == VDA_F16) { if (wdtype == VDA_FP8) L(f16_t, WLoadFp8<f16_t>); else L(f16_t, WLoad<f16_t>); }
   else return -3;
@@ -230,12 +358,15 @@ VDA_EXPORT int vda_moe_gate_up(void* inter, const void* x, const void* w13, cons
 
 VDA_EXPORT int vda_moe_down(void* out2, const void* inter, const void* w2, const float* w_scale, const float* topk_w,
                             const int* sorted, const int* offsets, int E, int H, int I, int max_pairs, int dtype,
-                            int wdtype, hipStream_t st) {
+                            int wdtype, int rows_form, hipStream_t st) {
   if (H % 16 || I % 128 || E < 1 || max_pairs < 1) return -1;
-  dim3 grid(H / 16, E, (max_pairs + 63) / 64), block(256);
+  const bool rows = rows_form && H % 64 == 0;
+  dim3 grid(rows ? H / 64 : H / 16, E, (max_pairs + 63) / 64), block(256);
   const long es = (long)H * I;
-#define L(TT, WL) hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, false>), grid, block, 0, st, (TT*)out2, (const TT*)inter, \
-                                     w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es)
+#define L(TT, WL) do { if (rows) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, false>), grid, block, 0, st, (TT*)out2, \
+        (const TT*)inter, w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es); \
+    else hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, false>), grid, block, 0, st, (TT*)out2, (const TT*)inter, \
+        w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es); } while (0)
   if (dtype == VDA_BF16) { if (wdtype == VDA_FP8) L(bf16_t, WLoadFp8<bf16_t>); else L(bf16_t, WLoad<bf16_t>); }
   else if (dtype == VDA_F16) { if (wdtype == VDA_FP8) L(f16_t, WLoadFp8<f16_t>); else L(f16_t, WLoad<f16_t>); }
   else return -3;

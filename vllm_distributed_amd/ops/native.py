@@ -53,8 +53,8 @@ _SIGS = {
     "vda_skinny_gemm": [P, P, P, P, P, I, I, I, L, L, L, I, I, P],
     "vda_moe_topk_softmax": [P, P, P, I, I, I, I, L, I, P],
     "vda_moe_align": [P, P, P, I, I, P],
-    "vda_moe_gate_up": [P, P, P, P, P, P, I, I, I, I, I, L, I, I, P],
-    "vda_moe_down": [P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "vda_moe_gate_up": [P, P, P, P, P, P, I, I, I, I, I, L, I, I, I, P],
+    "vda_moe_down": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "vda_moe_sum": [P, P, P, I, I, I, L, I, P],
     "vda_w4_skinny_gemm": [P, P, P, P, P, P, I, I, I, I, L, L, I, P],
     "vda_w4_dequant": [P, P, P, P, I, I, I, I, P],
