@@ -39,13 +39,13 @@ def main():
             w13 = (w13.float() / 0.01).to(torch.float8_e4m3fn)
             w2 = (w2.float() / 0.01).to(torch.float8_e4m3fn)
         wbytes = (w13.numel() * w13.element_size() + w2.numel() * w2.element_size())
-        for T in (8, 32, 128, 256):
+        for T in (8, 32, 128, 256, 512):
             x = torch.randn(T, H, device=dev, dtype=torch.bfloat16)
             logits = torch.randn(T, E, device=dev)
             tw, ids = torch.topk(torch.softmax(logits, -1), k)
             ids = ids.int()
             res = {}
-            for form in (0, 1):
+            for form in (0, 1, 2):
                 os.environ["VDA_MOE_ROWS_FORM"] = str(form)
                 out = ops.fused_moe(x, w13, w2, tw, ids, s13, s2)
                 res[form] = (bench(lambda: ops.fused_moe(x, w13, w2, tw, ids, s13, s2)), out)
@@ -53,7 +53,7 @@ def main():
             auto = bench(lambda: ops.fused_moe(x, w13, w2, tw, ids, s13, s2))
             diff = (res[0][1].float() - res[1][1].float()).abs().max().item()
             touched = min(E, T * k) / E
-            print(f"{name:24s} T={T:4d}: k-split {res[0][0]:8.1f} us | row-split {res[1][0]:8.1f} us "
+            print(f"{name:24s} T={T:4d}: k-split {res[0][0]:8.1f} us | row-split {res[1][0]:8.1f} / wide {res[2][0]:8.1f} us "
                   f"({wbytes * touched / res[1][0] / 1e6:5.2f} TB/s of touched weights) | by shape {auto:8.1f} us | max diff {diff:.4f}", flush=True)
 
 

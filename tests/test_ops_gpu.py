@@ -407,6 +407,30 @@ def test_fused_moe_grouped(dt, T, E, k, H, I):
     torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
 
 
+@pytest.mark.parametrize("form", [0, 1, 2])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("T,E,k,H,I", [(5, 8, 2, 512, 256), (130, 8, 2, 512, 384), (300, 4, 2, 256, 128),
+                                       (200, 2, 1, 384, 192)])
+def test_fused_moe_every_kernel_form(monkeypatch, form, fp8, T, E, k, H, I):
+    """K-split kernel, row-split kernel with 64 and with 128 tokens per pass (several passes per expert
+    in the larger cases), 16-bit and e4m3 weights, rows that are and are not a multiple of 64."""
+    monkeypatch.setenv("VDA_MOE_ROWS_FORM", str(form))
+    dt = torch.bfloat16
+    x = torch.randn(T, H, device=DEV, dtype=dt) * 0.5
+    w13 = torch.randn(E, 2 * I, H, device=DEV, dtype=dt) * (H ** -0.5)
+    w2 = torch.randn(E, H, I, device=DEV, dtype=dt) * (I ** -0.5)
+    s13 = s2 = None
+    if fp8:
+        s13 = w13.float().abs().amax(dim=(1, 2)) / 448.0
+        s2 = w2.float().abs().amax(dim=(1, 2)) / 448.0
+        w13 = (w13.float() / s13.view(E, 1, 1)).to(torch.float8_e4m3fn)
+        w2 = (w2.float() / s2.view(E, 1, 1)).to(torch.float8_e4m3fn)
+    tw, ids = R.moe_topk_softmax(torch.randn(T, E, device=DEV), k, True)
+    out = ops.fused_moe(x, w13, w2, tw, ids, s13, s2)
+    ref = R.fused_moe(x, w13, w2, tw, ids, s13, s2)
+    torch.testing.assert_close(out.float(), ref.float(), atol=3e-2, rtol=3e-2)
+
+
 def test_fused_moe_expert_parallel_mask_and_large_path(monkeypatch):
     dt = torch.bfloat16
     T, E, k, H, I = 96, 8, 2, 512, 256

@@ -89,7 +89,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_CUSTOM_AR_MAX_BYTES": (int, 16 * 1024 * 1024),
     "VDA_CUSTOM_AR_ONESHOT_BYTES": (int, 512 * 1024),
     "VDA_CUSTOM_AR_CHUNKED": (_bool, False),     # messages beyond one arena: chunk through it instead of RCCL
-    "VDA_MOE_ROWS_FORM": (int, -1),              # grouped expert GEMM: 1 row-split kernel, 0 K-split kernel, -1 by shape
+    "VDA_MOE_ROWS_FORM": (int, -1),              # grouped expert GEMM: 0 K-split kernel, 1 / 2 row-split kernel (64 / 128 tokens per pass), -1 by shape
     "VDA_CASCADE_MIN_PREFIX": (int, 256),        # cascade attention: shortest common prefix (tokens) worth a shared pass
     "VDA_CASCADE_MIN_SEQS": (int, 8),            # ... and fewest sequences in the step
     "VDA_ASYNC_TP_MIN_TOKENS": (int, 2048),      # async TP: batches of at least this many tokens run as 2 micro-batches

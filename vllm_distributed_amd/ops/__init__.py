@@ -535,21 +535,26 @@ def _moe_large(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale):
     return out2.view(T, k, -1).sum(dim=1)
 
 
-def moe_rows_form(num_pairs: int, num_experts: int, rows: int, weight_bytes: int = 2) -> bool:
-    """Grouped expert GEMM, which form: the row-split kernel (each wave 16 output rows over the whole K,
-    activations shared through LDS) pays once an expert sees enough tokens for the shared tile to matter
-    and the launch still fills the chip; below that the K-split kernel (four waves per 16 rows) has more
-    workgroups in flight.  Thresholds from benchmarks_dev/moe_probe.py on MI355X."""
+def moe_rows_form(num_pairs: int, num_experts: int, rows: int, weight_bytes: int = 2) -> int:
+    """Grouped expert GEMM, which form (0 K-split, 1 row-split with 64 tokens per pass, 2 with 128): the
+    row-split kernel (each wave 16 output rows over the whole K, activations shared through LDS) pays once
+    an expert sees enough tokens for the shared tile to matter and the launch still fills the chip; below
+    that the K-split kernel (four waves per 16 rows) has more workgroups in flight.  An expert with more
+    tokens than one pass holds streams its weights again, hence the wide pass once the average nears
+    half of the narrow one.  Thresholds from benchmarks_dev/moe_probe.py on MI355X."""
     forced = envs.VDA_MOE_ROWS_FORM
     if forced >= 0:
-        return bool(forced)
+        return int(forced)
+    if rows % 64:
+        return 0
     avg = num_pairs / max(num_experts, 1)
     fills = (rows // 64) * num_experts >= 512
-    if rows % 64:
-        return False
+    # the wide pass halves the resident workgroups (70 KiB of LDS): it wins only for 16-bit weights on a
+    # launch that fills the chip anyway
+    wide = 2 if (avg > 40 and weight_bytes == 2 and fills) else 1
     if weight_bytes == 1 and fills:
-        return True                      # 8-bit weights: ahead at every batch size once the launch fills the chip
-    return avg >= 8 and (fills or avg >= 64)
+        return wide                      # 8-bit weights: ahead at every batch size once the launch fills the chip
+    return wide if avg >= 8 and (fills or avg >= 64) else 0
 
 
 def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,

@@ -223,7 +223,9 @@ __global__ __launch_bounds__(256) void moe_grouped_kernel(
 // 128-wide step so that one load instruction reads 64 contiguous bytes of each of its 16 weight rows
 // (see koff below); with four 16-byte pieces 64 bytes apart per instruction the same kernel streamed
 // weights at 3 TB/s instead of 4.6-5.3 TB/s.
-template <typename T, typename WL, bool GATE_UP>
+// MT: 16-token tiles per workgroup pass (4 or 8); an expert with more tokens takes another pass over its
+// weights (grid.z), so the caller picks 8 once experts see more than ~32 tokens on average.
+template <typename T, typename WL, bool GATE_UP, int MT>
 __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
     T* __restrict__ out, const T* __restrict__ act, const void* __restrict__ w, const float* __restrict__ w_scale,
     const float* __restrict__ topk_w, const int* __restrict__ sorted, const int* __restrict__ offsets,
@@ -231,11 +233,11 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   constexpr int XS = 136;                      // LDS row stride in elements: 272 B keeps 16-byte reads conflict-free
-  __shared__ __attribute__((aligned(16))) T sx[2][64][XS];
+  __shared__ __attribute__((aligned(16))) T sx[2][16 * MT][XS];
   const int e = blockIdx.y;
-  const int beg = offsets[e] + blockIdx.z * 64, end = offsets[e + 1];
+  const int beg = offsets[e] + blockIdx.z * (16 * MT), end = offsets[e + 1];
   if (beg >= end) return;                      // uniform over the workgroup
-  const int cnt = min(end - beg, 64);
+  const int cnt = min(end - beg, 16 * MT);
   const int mt_n = (cnt + 15) >> 4;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -250,24 +252,24 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
 
   // staging role: token (tid >> 4) + 16 i, 16-byte piece tid & 15
   const int piece = tid & 15;
-  const T* xrow[4];
+  const T* xrow[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MT; ++i) {
     const int t = (tid >> 4) + 16 * i;
     const int id = t < cnt ? sorted[beg + t] : -1;
     xrow[i] = id < 0 ? nullptr : act + (long)(GATE_UP ? id / top_k : id) * act_stride + piece * 8;
   }
-  int pid[4];
+  int pid[MT];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int i = mt * 16 + r;
     pid[mt] = i < cnt ? sorted[beg + i] : -1;
   }
-  f32x4 acc0[4], acc1[4];
+  f32x4 acc0[MT], acc1[MT];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) { acc0[mt] = f32x4{0, 0, 0, 0}; acc1[mt] = f32x4{0, 0, 0, 0}; }
+  for (int mt = 0; mt < MT; ++mt) { acc0[mt] = f32x4{0, 0, 0, 0}; acc1[mt] = f32x4{0, 0, 0, 0}; }
 
-  V8 wa[4], wb[4], wan[4], wbn[4], xr[4];
+  V8 wa[4], wb[4], wan[4], wbn[4], xr[MT];
   auto loadw = [&](int c, V8 (&a)[4], V8 (&b)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -277,12 +279,12 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
   };
   auto loadx = [&](int c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
       xr[i] = (i < mt_n && xrow[i]) ? ld16<V8>(xrow[i] + (long)c * 128) : V8{};
   };
   auto storex = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
       if (i < mt_n) *reinterpret_cast<V8*>(&sx[buf][(tid >> 4) + 16 * i][piece * 8]) = xr[i];
   };
 
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
     if (more) { loadx(c + 1); loadw(c + 1, wan, wbn); }
     const int buf = c & 1;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       if (mt < mt_n) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
 
   const float ws = w_scale ? w_scale[e] : 1.f;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     if (mt < mt_n && pid[mt] >= 0) {
       V4 o;
       if (GATE_UP) {
@@ -335,16 +337,19 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
 
 // w13: [E, 2*I, K] (gate rows then up rows), w2: [E, H, I]; wdtype VDA_FP8 selects e4m3 weights with
 // a per-expert fp32 scale.  max_pairs bounds the tokens of one expert (grid.z = ceil(max_pairs/64)).
-// rows_form selects the row-split kernel (when the row count is a multiple of 64); the caller decides
-// from the batch shape (see ops.fused_moe).
+// rows_form: 0 K-split kernel; 1 / 2 row-split kernel with 64 / 128 tokens per pass (when the row count
+// is a multiple of 64); the caller decides from the batch shape (see ops.fused_moe).
 VDA_EXPORT int vda_moe_gate_up(void* inter, const void* x, const void* w13, const float* w_scale, const int* sorted,
                                const int* offsets, int E, int I, int K, int top_k, int max_pairs, long x_stride,
                                int dtype, int wdtype, int rows_form, hipStream_t st) {
   if (I % 16 || K % 128 || E < 1 || max_pairs < 1) return -1;
   const bool rows = rows_form && I % 64 == 0;
-  dim3 grid(rows ? I / 64 : I / 16, E, (max_pairs + 63) / 64), block(256);
+  const int per = rows && rows_form == 2 ? 128 : 64;
+  dim3 grid(rows ? I / 64 : I / 16, E, (max_pairs + per - 1) / per), block(256);
   const long es = (long)2 * I * K;
-#define L(TT, WL) do { if (rows) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, true>), grid, block, 0, st, (TT*)inter, \
+#define L(TT, WL) do { if (rows && per == 128) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, true, 8>), grid, block, 0, st, \
+        (TT*)inter, (const TT*)x, w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es); \
+    else if (rows) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, true, 4>), grid, block, 0, st, (TT*)inter, \
         (const TT*)x, w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es); \
     else hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, true>), grid, block, 0, st, (TT*)inter, (const TT*)x, \
         w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es); } while (0)
@@ -361,9 +366,12 @@ VDA_EXPORT int vda_moe_down(void* out2, const void* inter, const void* w2, const
                             int wdtype, int rows_form, hipStream_t st) {
   if (H % 16 || I % 128 || E < 1 || max_pairs < 1) return -1;
   const bool rows = rows_form && H % 64 == 0;
-  dim3 grid(rows ? H / 64 : H / 16, E, (max_pairs + 63) / 64), block(256);
+  const int per = rows && rows_form == 2 ? 128 : 64;
+  dim3 grid(rows ? H / 64 : H / 16, E, (max_pairs + per - 1) / per), block(256);
   const long es = (long)H * I;
-#define L(TT, WL) do { if (rows) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, false>), grid, block, 0, st, (TT*)out2, \
+#define L(TT, WL) do { if (rows && per == 128) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, false, 8>), grid, block, 0, st, \
+        (TT*)out2, (const TT*)inter, w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es); \
+    else if (rows) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, false, 4>), grid, block, 0, st, (TT*)out2, \
         (const TT*)inter, w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es); \
     else hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, false>), grid, block, 0, st, (TT*)out2, (const TT*)inter, \
         w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es); } while (0)
