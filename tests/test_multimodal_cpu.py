@@ -105,25 +105,31 @@ def test_qwen2_vl_matches_hf(tmp_path):
     g = torch.Generator().manual_seed(3)
     imgs = [{"pixel_values": torch.randn(4 * 6, 1176, generator=g), "image_grid_thw": torch.tensor([1, 4, 6])},
             {"pixel_values": torch.randn(8 * 4, 1176, generator=g), "image_grid_thw": torch.tensor([1, 8, 4])}]
+    vid = {"pixel_values_videos": torch.randn(3 * 4 * 4, 1176, generator=g), "video_grid_thw": torch.tensor([3, 4, 4])}
     prompts = [([5, 17, 302, 300, 303, 9, 11, 250], [imgs[0]]),
                ([7, 8, 9, 10] * 5, []),
-               ([3, 302, 300, 303, 44, 45, 302, 300, 303, 46], [imgs[1], imgs[0]])]
-    reqs = [{"prompt_token_ids": p, **({"multi_modal_data": {"image": m}} if m else {})} for p, m in prompts]
+               ([3, 302, 300, 303, 44, 45, 302, 300, 303, 46], [imgs[1], imgs[0]]),
+               ([9, 302, 301, 303, 12, 13], [vid])]
+    reqs = [{"prompt_token_ids": p, **({"multi_modal_data": {"video" if "video_grid_thw" in m[0] else "image": m}}
+                                        if m else {})} for p, m in prompts]
     llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
               max_num_batched_tokens=16, enable_prefix_caching=False, block_size=16)
     outs = llm.generate(reqs, SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
     for (p, ims), o in zip(prompts, outs):
         ids, k = [], 0
         for t in p:
-            if t == 300:
-                n = int(ims[k]["image_grid_thw"].prod()) // 4
-                ids += [300] * n
+            if t in (300, 301):
+                n = int(ims[k]["image_grid_thw" if t == 300 else "video_grid_thw"].prod()) // 4
+                ids += [t] * n
                 k += 1
             else:
                 ids.append(t)
         assert list(o.prompt_token_ids) == ids
         kw = {}
-        if ims:
+        if ims and "video_grid_thw" in ims[0]:
+            kw = dict(pixel_values_videos=ims[0]["pixel_values_videos"], video_grid_thw=ims[0]["video_grid_thw"][None],
+                      mm_token_type_ids=torch.tensor([[2 if t == 301 else 0 for t in ids]], dtype=torch.int32))
+        elif ims:
             kw = dict(pixel_values=torch.cat([i["pixel_values"] for i in ims]),
                       image_grid_thw=torch.stack([i["image_grid_thw"] for i in ims]),
                       mm_token_type_ids=torch.tensor([[1 if t == 300 else 0 for t in ids]], dtype=torch.int32))
@@ -150,3 +156,18 @@ def test_patch_grid_preprocessing_matches_hf_layout():
     assert px.shape == ref["pixel_values"].shape
     assert (px - ref["pixel_values"]).abs().mean() < 0.02
     assert smart_resize(120, 200, 28) == (112, 196)
+
+
+def test_video_frames_to_patch_grid():
+    from vllm_distributed_amd.multimodal import PatchGridProcessor
+    import numpy as np
+    proc = PatchGridProcessor(300, 14, 2, 2, 56 * 56, 14 * 14 * 4 * 1280, video_token_id=301)
+    frames = (np.random.default_rng(1).random((3, 56, 84, 3)) * 255).astype(np.uint8)
+    px, grid = proc.video_patches(frames)
+    assert grid.tolist() == [2, 4, 6] and px.shape == (2 * 4 * 6, 1176)      # odd frame count: last frame repeated
+    ids, inputs, hashes, pos = proc([1, 301, 2, 300, 3], {"video": frames, "image": frames[0]})
+    assert [p.length for p in pos] == [12, 6] and ids.count(301) == 12 and ids.count(300) == 6
+    # a still image is the video of its frame shown twice
+    one, g1 = proc.patches(frames[0])
+    two, g2 = proc.video_patches(np.stack([frames[0], frames[0]]))
+    assert g1.tolist() == g2.tolist() and torch.equal(one, two)

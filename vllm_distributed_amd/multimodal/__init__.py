@@ -167,11 +167,15 @@ def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56
 class PatchGridProcessor:
     """Qwen2-VL style inputs: an image becomes a [grid_t * grid_h * grid_w, C * tps * patch * patch] matrix of
     flattened patches (ordered so that each 2x2 merge block is contiguous) plus its grid; the prompt's image
-    token is expanded to grid_t * grid_h * grid_w / merge^2 placeholders.  Already pre-processed inputs are
-    accepted as ``{"pixel_values": [N, K], "image_grid_thw": [3]}``."""
+    token is expanded to grid_t * grid_h * grid_w / merge^2 placeholders.  Videos ([F, H, W, 3] frames under
+    ``multi_modal_data["video"]``, marked by the video token) take ``temporal_patch_size`` frames per temporal
+    step.  Already pre-processed inputs are accepted as ``{"pixel_values": [N, K], "image_grid_thw": [3]}`` /
+    ``{"pixel_values_videos": [N, K], "video_grid_thw": [3]}``."""
 
-    def __init__(self, image_token_id: int, patch: int, merge: int, tps: int, min_pixels: int, max_pixels: int):
+    def __init__(self, image_token_id: int, patch: int, merge: int, tps: int, min_pixels: int, max_pixels: int,
+                 video_token_id: int = -1):
         self.image_token_id, self.patch, self.merge, self.tps = image_token_id, patch, merge, tps
+        self.video_token_id = video_token_id
         self.min_pixels, self.max_pixels = min_pixels, max_pixels
 
     def patches(self, img: Any) -> tuple[torch.Tensor, torch.Tensor]:
@@ -195,33 +199,64 @@ class PatchGridProcessor:
         x = t.view(1, self.tps, 3, gh // m, m, p, gw // m, m, p).permute(0, 3, 6, 4, 7, 2, 1, 5, 8)
         return x.reshape(gh * gw, 3 * self.tps * p * p).contiguous(), torch.tensor([1, gh, gw])
 
+    def video_patches(self, video: Any) -> tuple[torch.Tensor, torch.Tensor]:
+        """Frames [F, H, W, 3] (uint8) -> patches of F / tps temporal steps; a trailing odd frame is repeated."""
+        if isinstance(video, dict):
+            key = "pixel_values_videos" if "pixel_values_videos" in video else "pixel_values"
+            return torch.as_tensor(video[key]).float(), torch.as_tensor(video["video_grid_thw"]).long().view(3)
+        t = torch.as_tensor(np.asarray(video) if not isinstance(video, torch.Tensor) else video)
+        if t.dim() != 4 or t.shape[-1] != 3:
+            raise ValueError(f"video must be [F, H, W, 3], got {tuple(t.shape)}")
+        t = t.permute(0, 3, 1, 2).float()
+        F_, _, H, W = t.shape
+        h, w = smart_resize(H, W, self.patch * self.merge, self.min_pixels, self.max_pixels)
+        if (h, w) != (H, W):
+            t = torch.nn.functional.interpolate(t, size=(h, w), mode="bicubic", align_corners=False, antialias=True)
+        t = t.clamp(0, 255) / 255.0
+        t = (t - torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+        if F_ % self.tps:
+            t = torch.cat([t, t[-1:].expand(self.tps - F_ % self.tps, -1, -1, -1)], dim=0)
+        gt, p, m = t.shape[0] // self.tps, self.patch, self.merge
+        gh, gw = h // p, w // p
+        x = t.view(gt, self.tps, 3, gh // m, m, p, gw // m, m, p).permute(0, 3, 6, 4, 7, 2, 1, 5, 8)
+        return x.reshape(gt * gh * gw, 3 * self.tps * p * p).contiguous(), torch.tensor([gt, gh, gw])
+
     def __call__(self, prompt_token_ids: list[int], mm_data: dict):
-        images = mm_data.get("image")
-        if images is None:
-            raise ValueError("multi_modal_data needs an 'image' entry")
-        if not isinstance(images, (list, tuple)):
-            images = [images]
+        def as_list(x):
+            return [] if x is None else (list(x) if isinstance(x, (list, tuple)) else [x])
+        images, videos = as_list(mm_data.get("image")), as_list(mm_data.get("video"))
+        if not images and not videos:
+            raise ValueError("multi_modal_data needs an 'image' or a 'video' entry")
+        marks = (self.image_token_id, self.video_token_id)
         runs, prev = [], -2
         for i, tok in enumerate(prompt_token_ids):
-            if tok != self.image_token_id:
+            if tok not in marks:
                 continue
-            if i != prev + 1:
-                runs.append([i, 1])
+            if i != prev + 1 or prompt_token_ids[i - 1] != tok:
+                runs.append([i, 1, tok])
             else:
                 runs[-1][1] += 1
             prev = i
-        if len(runs) != len(images):
-            raise ValueError(f"prompt has {len(runs)} image placeholders but {len(images)} images were given")
+        n_img = sum(1 for r in runs if r[2] == self.image_token_id)
+        if n_img != len(images) or len(runs) - n_img != len(videos):
+            raise ValueError(f"prompt has {n_img} image and {len(runs) - n_img} video placeholders but "
+                             f"{len(images)} images and {len(videos)} videos were given")
         out, positions, inputs, hashes, cur = [], [], [], [], 0
-        for (start, n), img in zip(runs, images):
-            px, grid = self.patches(img)
+        images, videos = iter(images), iter(videos)
+        for start, n, tok in runs:
+            if tok == self.image_token_id:
+                item = next(images)
+                px, grid = self.patches(item)
+            else:
+                item = next(videos)
+                px, grid = self.video_patches(item)
             length = int(grid.prod()) // self.merge ** 2
             out.extend(prompt_token_ids[cur:start])
             positions.append(PlaceholderRange(offset=len(out), length=length))
-            out.extend([self.image_token_id] * length)
+            out.extend([tok] * length)
             cur = start + n
             inputs.append([px, grid])
-            hashes.append(hash_item(px if isinstance(img, dict) else img))
+            hashes.append(hash_item(px if isinstance(item, dict) else item))
         out.extend(prompt_token_ids[cur:])
         return out, inputs, hashes, positions
 
@@ -231,7 +266,7 @@ def _qwen2_vl_processor(vllm_config):
     vc = hf.vision_config if isinstance(hf.vision_config, dict) else hf.vision_config.to_dict()
     return PatchGridProcessor(int(getattr(hf, "image_token_id", 151655)), int(vc.get("patch_size", 14)),
                               int(vc.get("spatial_merge_size", 2)), int(vc.get("temporal_patch_size", 2)),
-                              56 * 56, 14 * 14 * 4 * 1280)
+                              56 * 56, 14 * 14 * 4 * 1280, video_token_id=int(getattr(hf, "video_token_id", 151656)))
 
 
 MULTIMODAL_REGISTRY.register_processor("Qwen2VLForConditionalGeneration", _qwen2_vl_processor)
