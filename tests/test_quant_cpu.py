@@ -242,3 +242,89 @@ def test_int8_w8a8_checkpoint(tmp_path, strategy):
             ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
                               eos_token_id=None)[0, len(p):].tolist()
         assert list(o.outputs[0].token_ids) == ref, (strategy, p)
+
+
+_NF4 = [-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635,
+        -0.18477343022823334, -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725,
+        0.24611230194568634, 0.33791524171829224, 0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0]
+
+
+def _bnb4_quantise(w, blocksize=64, nested=True):
+    """bitsandbytes-style NF4 with (optionally) double-quantised scales; returns the checkpoint tensors and
+    the values they decode to."""
+    import json
+    qmap = torch.tensor(_NF4)
+    flat = w.reshape(-1, blocksize)
+    absmax = flat.abs().amax(1).clamp(min=1e-8)
+    codes = (flat / absmax[:, None]).unsqueeze(-1).sub(qmap).abs().argmin(-1).to(torch.uint8).view(-1)
+    packed = ((codes[0::2] << 4) | codes[1::2]).view(-1, 1)
+    state = {"quant_type": "nf4", "blocksize": blocksize, "dtype": "float32", "shape": list(w.shape)}
+    out = {"quant_map": qmap}
+    if nested:
+        nbs = 256
+        offset = float(absmax.mean())
+        a = absmax - offset
+        pad = (-a.numel()) % nbs
+        ap = torch.cat([a, a.new_zeros(pad)]).view(-1, nbs)
+        n_abs = ap.abs().amax(1).clamp(min=1e-8)
+        nmap = torch.linspace(-1, 1, 256)
+        ncodes = (ap / n_abs[:, None]).unsqueeze(-1).sub(nmap).abs().argmin(-1).to(torch.uint8).view(-1)[: a.numel()]
+        out.update(absmax=ncodes, nested_absmax=n_abs, nested_quant_map=nmap)
+        state.update(nested_blocksize=nbs, nested_dtype="float32", nested_offset=offset)
+        absmax = nmap[ncodes.long()] * n_abs.repeat_interleave(nbs)[: a.numel()] + offset
+    else:
+        out["absmax"] = absmax
+    out["quant_state.bitsandbytes__nf4"] = torch.tensor(list(json.dumps(state).encode()), dtype=torch.uint8)
+    deq = (qmap[codes.long()].view(-1, blocksize) * absmax[:, None]).view(w.shape)
+    return packed, out, deq
+
+
+@pytest.mark.parametrize("kind", ["nf4_nested", "nf4", "int8"])
+def test_bitsandbytes_checkpoint_is_dequantised_while_loading(tmp_path, kind):
+    """A pre-quantised bitsandbytes checkpoint (tensor names and packing as bitsandbytes writes them; the
+    package itself is not installed, so its own writer is unpinned) decodes to the tokens of the HF model
+    holding the dequantised weights."""
+    import json
+    import os
+
+    from safetensors.torch import load_file, save_file
+
+    from tests.test_e2e_cpu import _save_tiny
+    from vllm_distributed_amd import LLM, SamplingParams
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    out = {}
+    for name, t in sd.items():
+        if not (name.endswith("_proj.weight") and t.dim() == 2):
+            out[name] = t
+            continue
+        prefix = name[: -len(".weight")]
+        if kind == "int8":
+            scb = t.abs().amax(1).clamp(min=1e-8)
+            q = (t / scb[:, None] * 127).round().clamp(-127, 127).to(torch.int8)
+            out[name], out[prefix + ".SCB"] = q, scb
+            out[prefix + ".weight_format"] = torch.tensor(0, dtype=torch.uint8)
+            deq = q.float() * scb[:, None] / 127
+        else:
+            packed, extra, deq = _bnb4_quantise(t.float(), nested=kind == "nf4_nested")
+            out[name] = packed
+            for k, v in extra.items():
+                out[f"{name}.{k}"] = v
+        with torch.no_grad():
+            hf.get_submodule(prefix).weight.copy_(deq)
+    save_file(out, os.path.join(path, "model.safetensors"))
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    cfg["quantization_config"] = {"quant_method": "bitsandbytes", "load_in_4bit": kind != "int8",
+                                  "load_in_8bit": kind == "int8", "bnb_4bit_quant_type": "nf4"}
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, (kind, p)

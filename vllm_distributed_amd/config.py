@@ -216,9 +216,9 @@ class ModelConfig:
                 self.quantization = str(qc.get("quant_method", "")).lower() or None
         if self.quantization in ("awq_marlin", "gptq_marlin"):
             self.quantization = self.quantization.split("_")[0]
-        if self.quantization not in (None, "fp8", "compressed-tensors", "quark", "awq", "gptq"):
+        if self.quantization not in (None, "fp8", "compressed-tensors", "quark", "awq", "gptq", "bitsandbytes"):
             raise ValueError(f"unsupported quantization {self.quantization!r} "
-                             "(supported: fp8, compressed-tensors, quark, awq, gptq)")
+                             "(supported: fp8, compressed-tensors, quark, awq, gptq, bitsandbytes)")
         if self.served_model_name is None:
             self.served_model_name = self.model
         if self.task == "auto":

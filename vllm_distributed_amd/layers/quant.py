@@ -190,7 +190,10 @@ def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
         return None
     hf_q = mc.hf_config.get("quantization_config") if hasattr(mc.hf_config, "get") else \
         getattr(mc.hf_config, "quantization_config", None)
-    if q in ("awq", "gptq") or (q == "fp8" and hf_q and hf_q.get("weight_block_size")):
+    if q == "bitsandbytes" and not hf_q:
+        raise ValueError("bitsandbytes: only pre-quantised checkpoints are supported (their weights are expanded "
+                         "to 16 bit while loading); for on-the-fly quantisation use quantization='fp8'")
+    if q in ("awq", "gptq", "bitsandbytes") or (q == "fp8" and hf_q and hf_q.get("weight_block_size")):
         # weight-only formats without a kernel of their own: dequantised while the checkpoint loads
         from ..models.dequant import LoadTimeDequant
         return LoadTimeDequant(q, dict(hf_q or {}))

@@ -1,7 +1,8 @@
 """Load-time dequantisation of weight-only checkpoint formats.
 
-GPTQ and AWQ (4/8-bit integers with group scales and zero points) and block-wise fp8
-(``weight_scale_inv`` per 128x128 block, DeepSeek-V3 style) checkpoints are turned into 16-bit
+GPTQ and AWQ (4/8-bit integers with group scales and zero points), bitsandbytes (NF4 / FP4 with
+optional double quantisation, LLM.int8()) and block-wise fp8 (``weight_scale_inv`` per 128x128
+block, DeepSeek-V3 style) checkpoints are turned into 16-bit
 weights while the checkpoint streams in: the iterator below pairs every packed tensor with its
 scales / zero points and yields the ordinary ``<module>.weight``.  The model then runs with the
 exact values of the quantised model on the bf16 GEMM path; the memory saving of the format is
@@ -87,6 +88,37 @@ def dequantize_block_fp8(weight, scale_inv, block: tuple[int, int], dtype: torch
     return (weight.to(torch.float32) * s).to(dtype)
 
 
+def dequantize_bnb4(packed: torch.Tensor, absmax: torch.Tensor, quant_map: torch.Tensor, state: dict,
+                    nested_absmax: Optional[torch.Tensor], nested_quant_map: Optional[torch.Tensor],
+                    dtype: torch.dtype) -> torch.Tensor:
+    """bitsandbytes 4-bit (NF4 / FP4) -> [N, K].  ``packed`` holds two codes per byte (first element in the
+    high nibble), ``quant_map`` the 16 code values, ``absmax`` one scale per ``blocksize`` elements; with
+    double quantisation the scales themselves are 8-bit codes with their own map, block scales and offset."""
+    bs = int(state["blocksize"])
+    shape = tuple(int(x) for x in state["shape"])
+    n = 1
+    for d in shape:
+        n *= d
+    if nested_absmax is not None:
+        nbs = int(state.get("nested_blocksize", 256))
+        a = nested_quant_map.float()[absmax.long().view(-1)]
+        a = a * nested_absmax.float().repeat_interleave(nbs)[: a.numel()]
+        absmax = a + float(state.get("nested_offset", 0.0))
+    codes = packed.view(-1).to(torch.uint8)
+    vals = torch.stack([codes >> 4, codes & 15], dim=-1).view(-1)[:n].long()
+    w = quant_map.float()[vals]
+    pad = (-n) % bs
+    if pad:
+        w = torch.cat([w, w.new_zeros(pad)])
+    w = (w.view(-1, bs) * absmax.float().view(-1, 1)).view(-1)[:n]
+    return w.view(shape).to(dtype)
+
+
+def dequantize_bnb8(weight: torch.Tensor, scb: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """LLM.int8() weights: int8 rows with one fp scale per output row (value = q * SCB / 127)."""
+    return (weight.float() * (scb.float().view(-1, 1) / 127.0)).to(dtype)
+
+
 class Int4LinearMethod:
     """Linear layer over packed 4-bit weights with group scales and zero points (W4A16): decode-sized
     batches stream a quarter of the bytes through the MFMA skinny kernel (ops/csrc/w4.hip).
@@ -154,7 +186,57 @@ class LoadTimeDequant:
             return Int4LinearMethod(self.group_size)
         return None
 
+    def _wrap_bnb(self, weights, dtype: torch.dtype) -> Iterator[tuple[str, torch.Tensor]]:
+        """bitsandbytes checkpoints: ``X.weight`` (packed uint8 or int8) travels with ``X.weight.absmax``,
+        ``.quant_map``, ``.nested_absmax``, ``.nested_quant_map``, ``.quant_state.bitsandbytes__{nf4,fp4}``
+        (a JSON blob) or, for 8-bit, ``X.SCB``.  Tensors of one weight may arrive in any order."""
+        import json
+        pending: dict[str, dict] = {}
+
+        def try_finish(base: str):
+            d = pending[base]
+            if "weight" not in d:
+                return None
+            if d["weight"].dtype == torch.int8:
+                return dequantize_bnb8(d["weight"], d["SCB"], dtype) if "SCB" in d else None
+            st = d.get("state")
+            if st is None or "absmax" not in d or "quant_map" not in d:
+                return None
+            nested = "nested_blocksize" in st or "nested_offset" in st
+            if nested and not ("nested_absmax" in d and "nested_quant_map" in d):
+                return None
+            return dequantize_bnb4(d["weight"], d["absmax"], d["quant_map"], st, d.get("nested_absmax"),
+                                   d.get("nested_quant_map"), dtype)
+
+        for name, t in weights:
+            base = leaf = None
+            if ".weight." in name:
+                base, _, leaf = name.partition(".weight.")
+            elif name.endswith(".weight_format"):
+                continue                              # layout tag of LLM.int8() weights: row-major is the only one read
+            elif name.endswith(".SCB"):
+                base, _, leaf = name.rpartition(".")
+            elif name.endswith(".weight") and t.dtype in (torch.uint8, torch.int8):
+                base, leaf = name[: -len(".weight")], "weight"
+            if base is None:
+                yield name, t
+                continue
+            d = pending.setdefault(base, {})
+            if leaf.startswith("quant_state."):
+                d["state"] = json.loads(bytes(t.view(-1).to(torch.uint8).tolist()).decode("utf-8"))
+            else:
+                d[leaf] = t
+            w = try_finish(base)
+            if w is not None:
+                del pending[base]
+                yield f"{base}.weight", w
+        if pending:
+            raise ValueError(f"incomplete bitsandbytes tensors for {sorted(pending)[:4]}")
+
     def wrap(self, weights: Iterable[tuple[str, torch.Tensor]], dtype: torch.dtype) -> Iterator[tuple[str, torch.Tensor]]:
+        if self.method == "bitsandbytes":
+            yield from self._wrap_bnb(weights, dtype)
+            return
         pending: dict[str, dict[str, torch.Tensor]] = {}
         parts = ("qweight", "qzeros", "scales", "g_idx", "weight_scale_inv")
 
