@@ -155,6 +155,20 @@ def _save_tiny(tmp, kind):
                               num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
                               logit_scale=0.25)
         m = tf.CohereForCausalLM(cfg)
+    elif kind == "cohere2":
+        cfg = tf.Cohere2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=4,
+                               num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                               logit_scale=0.25, sliding_window=16,
+                               layer_types=["sliding_attention", "sliding_attention", "sliding_attention",
+                                            "full_attention"])
+        m = tf.Cohere2ForCausalLM(cfg)
+    elif kind == "granitemoeshared":
+        cfg = tf.GraniteMoeSharedConfig(vocab_size=320, hidden_size=128, intermediate_size=64, num_hidden_layers=2,
+                                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                                        num_local_experts=4, num_experts_per_tok=2, shared_intermediate_size=96,
+                                        embedding_multiplier=6.0, residual_multiplier=0.4, attention_multiplier=0.1,
+                                        logits_scaling=4.0)
+        m = tf.GraniteMoeSharedForCausalLM(cfg)
     elif kind == "nemotron":
         cfg = tf.NemotronConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
                                 num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -220,7 +234,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba"])
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

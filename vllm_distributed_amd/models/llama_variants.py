@@ -191,6 +191,29 @@ class CohereForCausalLM(LlamaForCausalLM):
     supports_pp = False
 
 
+class Cohere2DecoderLayer(CohereDecoderLayer):
+    """Command-R7B / Command-A: sliding-window layers carry the rotary embedding, the full-attention
+    layers between them use no positional encoding at all."""
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        kinds = getattr(config, "layer_types", None)
+        if kinds:
+            sliding = kinds[layer_idx] == "sliding_attention"
+        else:
+            sliding = (layer_idx + 1) % int(getattr(config, "sliding_window_pattern", 4)) != 0
+        return {"neox_style": False, "use_rope": sliding,
+                "sliding_window": getattr(config, "sliding_window", None) if sliding else None}
+
+
+class Cohere2Model(_NoResidualFinalNorm):
+    layer_cls = Cohere2DecoderLayer
+
+
+class Cohere2ForCausalLM(LlamaForCausalLM):
+    model_cls = Cohere2Model
+    supports_pp = False
+
+
 # ---- Nemotron ----------------------------------------------------------------------------------------
 def _plus_one_loader(param, tensor):
     param.data.copy_(tensor.to(param.dtype) + 1.0)

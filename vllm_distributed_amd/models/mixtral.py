@@ -222,3 +222,46 @@ class GraniteMoeForCausalLM(MixtralForCausalLM):
                 else:
                     yield name, t
         return super().load_weights(fix(weights))
+
+
+class GraniteMoeSharedDecoderLayer(GraniteMoeDecoderLayer):
+    """Granite-MoE with a dense gated MLP beside the routed experts (its checkpoint stores the gate and up
+    halves stacked in ``shared_mlp.input_linear``)."""
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = ""):
+        super().__init__(config, vllm_config, quant_config, prefix)
+        inter = int(getattr(config, "shared_intermediate_size", 0) or 0)
+        self.shared_mlp = LlamaMLP(config.hidden_size, inter, False, quant_config, f"{prefix}.shared_mlp") \
+            if inter > 0 else None
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states) * self.residual_multiplier
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        out = self.block_sparse_moe(hidden_states)
+        if self.shared_mlp is not None:
+            out = out + self.shared_mlp(hidden_states)
+        return out * self.residual_multiplier, residual
+
+
+class GraniteMoeSharedModel(GraniteMoeModel):
+    layer_cls = GraniteMoeSharedDecoderLayer
+
+
+class GraniteMoeSharedForCausalLM(GraniteMoeForCausalLM):
+    model_cls = GraniteMoeSharedModel
+
+    def load_weights(self, weights):
+        def fix(items):
+            for name, t in items:
+                if name.endswith(".shared_mlp.input_linear.weight"):
+                    yield name.replace(".input_linear.", ".gate_up_proj."), t      # already [gate rows | up rows]
+                elif name.endswith(".shared_mlp.output_linear.weight"):
+                    yield name.replace(".output_linear.", ".down_proj."), t
+                else:
+                    yield name, t
+        return super().load_weights(fix(weights))

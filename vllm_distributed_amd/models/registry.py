@@ -25,6 +25,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "OlmoForCausalLM": ("llama_variants", "OlmoForCausalLM"),
     "Olmo2ForCausalLM": ("llama_variants", "Olmo2ForCausalLM"),
     "CohereForCausalLM": ("llama_variants", "CohereForCausalLM"),
+    "Cohere2ForCausalLM": ("llama_variants", "Cohere2ForCausalLM"),
+    "GraniteMoeSharedForCausalLM": ("mixtral", "GraniteMoeSharedForCausalLM"),
     "NemotronForCausalLM": ("llama_variants", "NemotronForCausalLM"),
     "GlmForCausalLM": ("llama_variants", "GlmForCausalLM"),
     "Glm4ForCausalLM": ("llama_variants", "Glm4ForCausalLM"),
@@ -67,6 +69,11 @@ _MODELS: dict[str, tuple[str, str]] = {
     "RobertaForSequenceClassification": ("bert", "RobertaForSequenceClassification"),
     "XLMRobertaForSequenceClassification": ("bert", "RobertaForSequenceClassification"),
     "LlamaModel": ("pooling", "LlamaEmbeddingModel"),
+    "MistralModel": ("pooling", "LlamaEmbeddingModel"),
+    "Qwen2Model": ("pooling", "LlamaEmbeddingModel"),
+    "Qwen3Model": ("pooling", "LlamaEmbeddingModel"),
+    "MistralForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
+    "Qwen3ForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
     "LlamaForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
     "Qwen2ForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
     "EagleLlamaForCausalLM": ("eagle", "EagleLlamaForCausalLM"),
