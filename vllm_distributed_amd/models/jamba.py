@@ -1,4 +1,4 @@
-"""Jamba: a hybrid stack of Mamba-1 mixers and (rotary-free) attention layers, each followed by a dense
+"""Hybrid stacks.  Jamba: a hybrid stack of Mamba-1 mixers and (rotary-free) attention layers, each followed by a dense
 or a routed-expert MLP.  Attention layers use the paged KV cache; the Mamba layers keep one recurrent
 state per request in slots the model runner allocates beside the weights (worker/model_runner.py,
 ``_init_hybrid_state``), so both kinds of per-request memory live under one scheduler.
@@ -143,3 +143,71 @@ class JambaForCausalLM(nn.Module):
 
         return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie,
                                          expert_mapping=experts)
+
+
+# ---- Bamba -------------------------------------------------------------------------------------------
+class BambaLayer(nn.Module):
+    """Mamba-2 mixer or rotary (half of each head) attention, then a gated MLP.
+    Reference: vllm/model_executor/models/bamba.py."""
+
+    def __init__(self, config, vllm_config: VllmConfig, kind: str, prefix: str):
+        super().__init__()
+        from .mamba import Mamba2Mixer
+        quant_config = getattr(vllm_config, "quant_config", None)
+        d, eps = config.hidden_size, config.rms_norm_eps
+        self.kind = kind
+        if kind == "attention":
+            rp = getattr(config, "rope_parameters", None) or {}
+            theta = float(getattr(config, "rope_theta", None) or rp.get("rope_theta") or 10000.0)
+            self.self_attn = LlamaAttention(
+                config, d, config.num_attention_heads, config.num_key_value_heads, theta, None,
+                vllm_config.model_config.max_model_len, bias=bool(getattr(config, "attention_bias", False)),
+                o_bias=bool(getattr(config, "attention_bias", False)), quant_config=quant_config,
+                prefix=f"{prefix}.self_attn", cache_dtype=vllm_config.cache_config.cache_dtype)
+        else:
+            shim = SimpleNamespace(hidden_size=d, num_heads=config.mamba_n_heads, head_dim=config.mamba_d_head,
+                                   intermediate_size=config.mamba_n_heads * config.mamba_d_head,
+                                   state_size=config.mamba_d_state, conv_kernel=config.mamba_d_conv,
+                                   n_groups=config.mamba_n_groups, use_bias=bool(config.mamba_proj_bias),
+                                   use_conv_bias=bool(config.mamba_conv_bias), layer_norm_epsilon=eps,
+                                   gated_norm_groups=getattr(config, "gated_norm_groups", None))
+            self.mamba = Mamba2Mixer(shim, f"{prefix}.mamba")
+        self.feed_forward = LlamaMLP(d, config.intermediate_size, bool(getattr(config, "mlp_bias", False)),
+                                     quant_config, f"{prefix}.feed_forward")
+        self.input_layernorm = RMSNorm(d, eps)
+        self.pre_ff_layernorm = RMSNorm(d, eps)
+
+    forward = JambaLayer.forward
+
+
+class BambaForCausalLM(JambaForCausalLM):
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        nn.Module.__init__(self)
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        attn = set(getattr(config, "attn_layer_indices", None) or [])
+        kinds = getattr(config, "layers_block_type", None) or \
+            ["attention" if i in attn else "mamba" for i in range(config.num_hidden_layers)]
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([BambaLayer(config, vllm_config, kinds[i], f"model.layers.{i}")
+                                     for i in range(config.num_hidden_layers)])
+        self.final_layernorm = RMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.tie = bool(getattr(config, "tie_word_embeddings", False))
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
+        if self.tie:
+            self.lm_head.tie_weights(self.embed_tokens)
+        self.logits_processor = LogitsProcessor(config.vocab_size)
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        names = {".mamba.conv1d.weight": ".mamba.conv_weight", ".mamba.conv1d.bias": ".mamba.conv_bias",
+                 ".mamba.A_log": ".mamba.A", ".mamba.norm.weight": ".mamba.norm_weight"}
+
+        def fix(items):
+            for name, t in items:
+                name = name.removeprefix("model.")
+                for a, b in names.items():
+                    if name.endswith(a):
+                        name = name[: -len(a)] + b
+                yield name, t
+
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)

@@ -55,6 +55,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Qwen2VLForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
+    "BambaForCausalLM": ("jamba", "BambaForCausalLM"),
     "MambaForCausalLM": ("mamba", "MambaForCausalLM"),
     "FalconMambaForCausalLM": ("mamba", "FalconMambaForCausalLM"),
     "Mamba2ForCausalLM": ("mamba", "Mamba2ForCausalLM"),
