@@ -38,6 +38,8 @@ def main() -> None:
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--no-async-tp", action="store_true", help="keep TP all-reduces on the compute stream")
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
+    ap.add_argument("--quantization", default=None, help="e.g. fp8 (weights quantised while loading); default: none")
+    ap.add_argument("--expert-parallel", action="store_true", help="MoE models: shard experts, not expert matrices")
     a = ap.parse_args()
 
     import torch
@@ -53,6 +55,10 @@ def main() -> None:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
     kw = {}
+    if a.quantization:
+        kw["quantization"] = a.quantization
+    if a.expert_parallel:
+        kw["enable_expert_parallel"] = True
     if world > 1:
         kw["distributed_executor_backend"] = "external_launcher"
         if not a.no_async_tp:
@@ -121,7 +127,8 @@ def main() -> None:
             else f"output tokens/s per node ({a.model}, {a.input_len}-in/{a.output_len}-out)",
             "value": round(total_out / dt, 2), "unit": "tokens/s", "n_gpus": a.gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1000, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if not a.quantization else f"bf16 activations, {a.quantization} weights",
             "data": "synthetic random token prompts, random-init weights",
             "p50_ttft_ms": round(statistics.median(ttfts) * 1000, 2),
             "p50_itl_ms": round(statistics.median(itls) * 1000, 3) if itls else None,

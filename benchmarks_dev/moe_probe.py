@@ -13,7 +13,7 @@ from vllm_distributed_amd.ops import reference as R
 dev = "cuda"
 
 
-def bench(fn, iters=20):
+def bench(fn, iters=int(os.environ.get("REPS", "20"))):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -29,6 +29,9 @@ def main():
     # (name, experts on this GPU, hidden, intermediate, top_k, weight dtype)
     shapes = [("mixtral-8x7b tp1", 8, 4096, 14336, 2, torch.bfloat16), ("mixtral-8x7b fp8", 8, 4096, 14336, 2, "fp8"),
               ("qwen3-30b-a3b", 128, 2048, 768, 8, torch.bfloat16), ("mixtral ep8 (1 expert)", 1, 4096, 14336, 1, torch.bfloat16)]
+    if os.environ.get("SHAPE") is not None:          # counter passes: one shape, one batch size, few repetitions
+        shapes = [shapes[int(os.environ["SHAPE"])]]
+    batch_sizes = [int(x) for x in os.environ.get("TOKENS", "8,32,128,256,512").split(",")]
     for name, E, H, I, k, wdt in shapes:
         w13 = torch.randn(E, 2 * I, H, device=dev, dtype=torch.bfloat16) * 0.02
         w2 = torch.randn(E, H, I, device=dev, dtype=torch.bfloat16) * 0.02
@@ -39,7 +42,7 @@ def main():
             w13 = (w13.float() / 0.01).to(torch.float8_e4m3fn)
             w2 = (w2.float() / 0.01).to(torch.float8_e4m3fn)
         wbytes = (w13.numel() * w13.element_size() + w2.numel() * w2.element_size())
-        for T in (8, 32, 128, 256, 512):
+        for T in batch_sizes:
             x = torch.randn(T, H, device=dev, dtype=torch.bfloat16)
             logits = torch.randn(T, E, device=dev)
             tw, ids = torch.topk(torch.softmax(logits, -1), k)
