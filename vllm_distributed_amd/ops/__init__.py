@@ -549,11 +549,12 @@ def moe_rows_form(num_pairs: int, num_experts: int, rows: int, weight_bytes: int
         return 0
     avg = num_pairs / max(num_experts, 1)
     fills = (rows // 64) * num_experts >= 512
-    # the wide pass halves the resident workgroups (70 KiB of LDS): it wins only for 16-bit weights on a
-    # launch that fills the chip anyway
-    wide = 2 if (avg > 40 and weight_bytes == 2 and fills) else 1
+    # measured: with 8-bit weights the 128-token pass is ahead at every size once the launch fills the chip;
+    # with 16-bit weights from ~40 tokens per expert; a launch that does not fill the chip (one or two
+    # experts on the rank) wants it only when experts would otherwise need several passes
+    wide = 2 if ((fills and (weight_bytes == 1 or avg > 40)) or avg >= 192) else 1
     if weight_bytes == 1 and fills:
-        return wide                      # 8-bit weights: ahead at every batch size once the launch fills the chip
+        return wide
     return wide if avg >= 8 and (fills or avg >= 64) else 0
 
 

@@ -232,8 +232,11 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
     int N, int K, int top_k, long act_stride, long out_stride, long w_expert_stride) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
-  constexpr int XS = 136;                      // LDS row stride in elements: 272 B keeps 16-byte reads conflict-free
-  __shared__ __attribute__((aligned(16))) T sx[2][16 * MT][XS];
+  // 256-byte rows of sixteen 16-byte pieces, piece p of row t stored at p ^ (t & 15): the lane groups that
+  // ds_read_b128 serves together ({0-3,12-15} of one 16-lane quarter with {4-11} of the next) then hit
+  // sixteen different pieces, and the eight contiguous lanes of a ds_write_b128 group eight different ones
+  // (with plain padded rows the counters showed one extra LDS cycle per group on every operand read)
+  __shared__ __attribute__((aligned(16))) T sx[2][16 * MT][128];
   const int e = blockIdx.y;
   const int beg = offsets[e] + blockIdx.z * (16 * MT), end = offsets[e + 1];
   if (beg >= end) return;                      // uniform over the workgroup
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
   auto storex = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
-      if (i < mt_n) *reinterpret_cast<V8*>(&sx[buf][(tid >> 4) + 16 * i][piece * 8]) = xr[i];
+      if (i < mt_n) *reinterpret_cast<V8*>(&sx[buf][(tid >> 4) + 16 * i][(piece ^ ((tid >> 4) & 15)) * 8]) = xr[i];
   };
 
   const int nchunk = K >> 7;
@@ -293,25 +296,30 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
   loadw(0, wa, wb);
   storex(0);
   __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
+  // one K step: request the next step's activations and weights, multiply this step out of LDS buffer
+  // c & 1 with the weights in (ca, cb), then park the requested activations in the other buffer.  The two
+  // weight register sets swap roles from step to step (no copies).
+  auto step = [&](int c, V8 (&ca)[4], V8 (&cb)[4], V8 (&na)[4], V8 (&nb)[4]) {
     const bool more = c + 1 < nchunk;
-    if (more) { loadx(c + 1); loadw(c + 1, wan, wbn); }
+    if (more) { loadx(c + 1); loadw(c + 1, na, nb); }
     const int buf = c & 1;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (mt < mt_n) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const V8 xa = *reinterpret_cast<const V8*>(&sx[buf][mt * 16 + r][koff(s)]);
-          acc0[mt] = mfma16(wa[s], xa, acc0[mt]);
-          if (GATE_UP) acc1[mt] = mfma16(wb[s], xa, acc1[mt]);
+          const V8 xa = *reinterpret_cast<const V8*>(&sx[buf][mt * 16 + r][((koff(s) >> 3) ^ r) * 8]);
+          acc0[mt] = mfma16(ca[s], xa, acc0[mt]);
+          if (GATE_UP) acc1[mt] = mfma16(cb[s], xa, acc1[mt]);
         }
       }
     }
     if (more) storex(buf ^ 1);
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { wa[s] = wan[s]; if (GATE_UP) wb[s] = wbn[s]; }
+  };
+  for (int c = 0; c < nchunk; c += 2) {
+    step(c, wa, wb, wan, wbn);
+    if (c + 1 < nchunk) step(c + 1, wan, wbn, wa, wb);
   }
 
   const float ws = w_scale ? w_scale[e] : 1.f;
