@@ -440,13 +440,17 @@ __global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_ker
       rv[i] = KVLoad<T, F8>::ld(vc + (size_t)blk * blk_stride + off);
     }
   };
+  // XOR swizzle of the 16-byte pieces of a K row.  ds_read_b128 serves lanes {0-3,12-15,20-27},
+  // {4-11,16-19,28-31} (and the same in the upper half) together; with the key a lane reads (krow0 + 4u
+  // below) these masks put the sixteen lanes of every such group on sixteen different pieces, where the
+  // earlier three-bit mask left them two-way (one extra LDS cycle per group on every K operand read).
+  auto kswz = [](int key) { return KCH == 16 ? (key & 15) : (((key & 3) << 1) | ((key >> 3) & 1)); };
   auto sstore = [&](int buf, const V8 (&rk)[KPT], const V8 (&rv)[VPT]) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int pi = tid + 256 * i;
       const int key = pi / KCH, ch = pi % KCH;
-      const int swz = (key & 3) | (((key >> 3) & 1) << 2);
-      sK[buf][key * KCH + (ch ^ swz)] = rk[i];
+      sK[buf][key * KCH + (ch ^ kswz(key))] = rk[i];
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
@@ -479,9 +483,8 @@ __global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_ker
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int key = krow0 + 4 * u;
-      const int swz = (key & 3) | (((key >> 3) & 1) << 2);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) kf[u][s] = sK[buf][key * KCH + ((g * KS + s) ^ swz)];
+      for (int s = 0; s < KS; ++s) kf[u][s] = sK[buf][key * KCH + ((g * KS + s) ^ kswz(key))];
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
