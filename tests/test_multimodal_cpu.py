@@ -171,3 +171,43 @@ def test_video_frames_to_patch_grid():
     one, g1 = proc.patches(frames[0])
     two, g2 = proc.video_patches(np.stack([frames[0], frames[0]]))
     assert g1.tolist() == g2.tolist() and torch.equal(one, two)
+
+
+def test_qwen2_5_vl_matches_hf(tmp_path):
+    """Windowed vision attention (window of 2 x 2 merge groups, one full-attention block), RMSNorm / gated
+    MLP tower, window reordering undone after the merger."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.Qwen2_5_VLConfig(
+        text_config=dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512,
+                         rope_parameters={"rope_type": "default", "mrope_section": [8, 12, 12], "rope_theta": 10000.0},
+                         bos_token_id=1, eos_token_id=2),
+        vision_config=dict(depth=3, hidden_size=64, intermediate_size=96, num_heads=2, out_hidden_size=128,
+                           patch_size=14, spatial_merge_size=2, temporal_patch_size=2, window_size=56,
+                           fullatt_block_indexes=[1], in_channels=3),
+        image_token_id=300, video_token_id=301, vision_start_token_id=302, vision_end_token_id=303)
+    hf = tf.Qwen2_5_VLForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+    hf = hf.float().eval()
+    path = os.path.join(str(tmp_path), "qwen25vl")
+    hf.save_pretrained(path, safe_serialization=True)
+    g = torch.Generator().manual_seed(5)
+    img = {"pixel_values": torch.randn(6 * 10, 1176, generator=g), "image_grid_thw": torch.tensor([1, 6, 10])}
+    p = [5, 17, 302, 300, 303, 9, 11, 250]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16)
+    o = llm.generate([{"prompt_token_ids": p, "multi_modal_data": {"image": [img]}}],
+                     SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+    ids = [5, 17, 302] + [300] * 15 + [303, 9, 11, 250]
+    assert list(o.prompt_token_ids) == ids
+    with torch.no_grad():
+        ref = hf.generate(input_ids=torch.tensor([ids]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                          eos_token_id=None, pixel_values=img["pixel_values"], image_grid_thw=img["image_grid_thw"][None],
+                          mm_token_type_ids=torch.tensor([[1 if t == 300 else 0 for t in ids]], dtype=torch.int32)
+                          )[0, len(ids):].tolist()
+    assert list(o.outputs[0].token_ids) == ref
+    llm.shutdown()

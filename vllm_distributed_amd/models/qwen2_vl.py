@@ -199,3 +199,118 @@ class Qwen2VLForConditionalGeneration(nn.Module):
                                            tie_lm_head=self.language_model.tie)
         loaded |= load_weights_with_mapping(self, vis, [])
         return loaded
+
+
+# ---- Qwen2.5-VL --------------------------------------------------------------------------------------
+class _RMS(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim), requires_grad=False)
+        self.eps = eps
+
+    def forward(self, x):
+        f = x.float()
+        return (f * torch.rsqrt(f.pow(2).mean(-1, keepdim=True) + self.eps)).to(x.dtype) * self.weight
+
+
+class VisionBlock25(nn.Module):
+    """RMSNorm, gated SiLU MLP with biases; attention spans are handed in per call (windows or frames)."""
+
+    def __init__(self, dim: int, heads: int, mlp_dim: int):
+        super().__init__()
+        self.heads = heads
+        self.norm1, self.norm2 = _RMS(dim), _RMS(dim)
+        self.attn = nn.Module()
+        self.attn.qkv, self.attn.proj = nn.Linear(dim, 3 * dim), nn.Linear(dim, dim)
+        self.mlp = nn.Module()
+        self.mlp.gate_proj, self.mlp.up_proj = nn.Linear(dim, mlp_dim), nn.Linear(dim, mlp_dim)
+        self.mlp.down_proj = nn.Linear(mlp_dim, dim)
+
+    def forward(self, x, cos, sin, spans: list[int]):
+        N, dim = x.shape
+        q, k, v = self.attn.qkv(self.norm1(x)).view(N, 3, self.heads, dim // self.heads).unbind(1)
+        q = (q.float() * cos + _rotate_half(q.float()) * sin).to(x.dtype)
+        k = (k.float() * cos + _rotate_half(k.float()) * sin).to(x.dtype)
+        outs, o = [], 0
+        for n in spans:
+            qs, ks, vs = (t[o:o + n].transpose(0, 1) for t in (q, k, v))
+            outs.append(F.scaled_dot_product_attention(qs, ks, vs).transpose(0, 1))
+            o += n
+        x = x + self.attn.proj(torch.cat(outs, dim=0).reshape(N, dim))
+        h = self.norm2(x)
+        return x + self.mlp.down_proj(F.silu(self.mlp.gate_proj(h)) * self.mlp.up_proj(h))
+
+
+class Qwen25VisionTransformer(Qwen2VisionTransformer):
+    """Most blocks attend inside windows of ``window_size`` pixels; the blocks listed in
+    ``fullatt_block_indexes`` attend over the whole frame.  Tokens are reordered window by window (in units
+    of one merge group) for the whole tower and put back after the merger."""
+
+    def __init__(self, vc: dict, out_dim: int):
+        nn.Module.__init__(self)
+        g = vc.get
+        self.embed_dim = int(g("hidden_size", 1280))
+        self.heads = int(g("num_heads", 16))
+        self.patch, self.tps = int(g("patch_size", 14)), int(g("temporal_patch_size", 2))
+        self.merge = int(g("spatial_merge_size", 2))
+        self.window = int(g("window_size", 112)) // self.merge // self.patch      # window edge in merge groups
+        self.full_blocks = set(g("fullatt_block_indexes", None) or [])
+        cin = int(g("in_channels", None) or g("in_chans", 3))
+        self.patch_embed = nn.Module()
+        self.patch_embed.proj = nn.Conv3d(cin, self.embed_dim, kernel_size=(self.tps, self.patch, self.patch),
+                                          stride=(self.tps, self.patch, self.patch), bias=False)
+        self.blocks = nn.ModuleList([VisionBlock25(self.embed_dim, self.heads, int(g("intermediate_size", 3420)))
+                                     for _ in range(int(g("depth", 32)))])
+        m = self.merge ** 2
+        self.merger = nn.Module()
+        self.merger.ln_q = _RMS(self.embed_dim)
+        self.merger.mlp = nn.Sequential(nn.Linear(self.embed_dim * m, self.embed_dim * m), nn.GELU(),
+                                        nn.Linear(self.embed_dim * m, out_dim))
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def _windows(self, grids) -> tuple[torch.Tensor, list[int]]:
+        """Order of the merge groups window by window, and the length (in patches) of every window."""
+        order, spans, base, ws, unit = [], [], 0, self.window, self.merge ** 2
+        for t, h, w in grids:
+            gh, gw = h // self.merge, w // self.merge
+            idx = torch.arange(t * gh * gw).view(t, gh, gw)
+            ph, pw = ws - gh % ws, ws - gw % ws
+            idx = F.pad(idx, (0, pw, 0, ph), value=-1)
+            nh, nw = (gh + ph) // ws, (gw + pw) // ws
+            idx = idx.view(t, nh, ws, nw, ws).permute(0, 1, 3, 2, 4).reshape(t, nh * nw, ws * ws)
+            for row in idx.reshape(-1, ws * ws):
+                keep = row[row >= 0]
+                if keep.numel():
+                    order.append(keep + base)
+                    spans.append(int(keep.numel()) * unit)
+            base += t * gh * gw
+        return torch.cat(order), spans
+
+    def forward(self, patches: torch.Tensor, grids: list[tuple[int, int, int]]) -> torch.Tensor:
+        w = self.patch_embed.proj.weight
+        x = F.linear(patches.to(w.dtype), w.view(self.embed_dim, -1))
+        cos, sin = self._rotary(grids, x.device)
+        order, win_spans = self._windows(grids)
+        order = order.to(x.device)
+        unit = self.merge ** 2
+        regroup = lambda t: t.reshape(t.shape[0] // unit, unit, *t.shape[1:])[order].reshape(t.shape)   # noqa: E731
+        x, cos, sin = regroup(x), regroup(cos), regroup(sin)
+        frame_spans = [h * w_ for t, h, w_ in grids for _ in range(t)]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, cos, sin, frame_spans if i in self.full_blocks else win_spans)
+        out = self.merger.mlp(self.merger.ln_q(x).view(-1, self.embed_dim * unit))
+        return out[torch.argsort(order)]
+
+
+class Qwen2_5_VLForConditionalGeneration(Qwen2VLForConditionalGeneration):
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        nn.Module.__init__(self)
+        hf = vllm_config.model_config.hf_config
+        self.config = hf
+        vc = hf.vision_config if isinstance(hf.vision_config, dict) else hf.vision_config.to_dict()
+        self.merge = int(vc.get("spatial_merge_size", 2))
+        self.image_token_id = int(getattr(hf, "image_token_id", 151655))
+        self.visual = Qwen25VisionTransformer(vc, int(vc.get("out_hidden_size", None) or hf.hidden_size))
+        self.language_model = LlamaForCausalLM(vllm_config, prefix=maybe_prefix(prefix, "language_model"))
+        self.rotary = self.language_model.model.layers[self.language_model.model.start_layer].self_attn.rotary_emb

@@ -53,6 +53,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "DeepseekV3ForCausalLM": ("deepseek", "DeepseekV3ForCausalLM"),
     "DeepseekForCausalLM": ("deepseek", "DeepseekV2ForCausalLM"),
     "Qwen2VLForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
+    "Qwen2_5_VLForConditionalGeneration": ("qwen2_vl", "Qwen2_5_VLForConditionalGeneration"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "BambaForCausalLM": ("jamba", "BambaForCausalLM"),

@@ -270,3 +270,4 @@ def _qwen2_vl_processor(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("Qwen2VLForConditionalGeneration", _qwen2_vl_processor)
+MULTIMODAL_REGISTRY.register_processor("Qwen2_5_VLForConditionalGeneration", _qwen2_vl_processor)
