@@ -58,6 +58,10 @@ def _reference(model):
 
 @pytest.mark.parametrize("kind,kw", [("llama", {"tensor_parallel_size": 2}),
                                      ("opt", {"tensor_parallel_size": 2}),
+                                     ("bloom", {"tensor_parallel_size": 2}),          # ALiBi slopes per rank
+                                     ("falcon_new", {"tensor_parallel_size": 2}),     # one KV head, replicated
+                                     ("olmo2", {"tensor_parallel_size": 2}),          # q/k norm over all heads
+                                     ("jamba", {"tensor_parallel_size": 2}),          # Mamba channels + experts sharded
                                      ("llama", {"pipeline_parallel_size": 2}),
                                      ("llama", {"tensor_parallel_size": 2, "compilation_config":
                                                 {"enable_sequence_parallelism": True}}),

@@ -98,17 +98,22 @@ class LlamaAttention(nn.Module):
                                  self.q_size, dtype, positions.device)
 
     def _full_width_qk_norm(self, qkv: torch.Tensor) -> None:
-        """RMSNorm over all heads of q (and of k) at once; with TP the other ranks' heads are gathered first."""
+        """RMSNorm over all heads of q (and of k) at once; with TP the other ranks' heads are gathered first.
+        KV heads replicated over ranks (fewer KV heads than ranks) are counted once."""
         tp = get_tensor_model_parallel_world_size()
         r = get_tensor_model_parallel_rank()
-        for lo, size, norm in ((0, self.q_size, self.q_norm), (self.q_size, self.kv_size, self.k_norm)):
+        rep = max(1, tp // self.total_num_kv_heads)          # ranks holding the same KV head
+        for lo, size, norm, dup in ((0, self.q_size, self.q_norm, 1), (self.q_size, self.kv_size, self.k_norm, rep)):
             x = qkv[:, lo:lo + size].contiguous()
             if tp > 1:
                 x = tensor_model_parallel_all_gather(x, -1)
+                if dup > 1:
+                    x = x.view(x.shape[0], tp // dup, dup, size)[:, :, 0].reshape(x.shape[0], -1)
             if x.shape[-1] != norm.weight.shape[0]:
-                raise ValueError("full-width q/k norm needs num_key_value_heads to be a multiple of the TP size")
+                raise ValueError("full-width q/k norm: gathered width does not match the norm weight")
             y = norm(x)
-            qkv[:, lo:lo + size] = y[:, r * size:(r + 1) * size] if tp > 1 else y
+            own = r // dup
+            qkv[:, lo:lo + size] = y[:, own * size:(own + 1) * size] if tp > 1 else y
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
         qkv = self.qkv_proj(hidden_states)
