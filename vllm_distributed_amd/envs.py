@@ -70,7 +70,11 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_COMM_LIBRARY": (_path, None),           # override path of libvda_comm.so
     "VDA_FORCE_TORCH_OPS": (_bool, False),       # CPU/reference ops even on GPU (debug)
     "VDA_DECODE_SPLIT_TARGET_WGS": (int, 1024),  # split-KV until grid has this many WGs
-    "VDA_SKINNY_GEMM_MAX_M": (int, 8),
+    # 16-bit dense layers: rows served by the skinny MFMA kernel instead of the library GEMM.  0 = never:
+    # hipBLASLt streams 16-bit weights at 85-95 % of the HBM floor from M = 1 on gfx950 (Llama-3-8B, 32 in /
+    # 128 out: 0.699 s against 0.745 s at batch 8 and 0.698 s against 0.706 s at batch 1 with the skinny kernel).
+    # The kernel keeps its role for 8-bit weights (VDA_FP8_W8A16_MAX_M) and packed 4-bit weights.
+    "VDA_SKINNY_GEMM_MAX_M": (int, 0),
     "VDA_REHEARSE_ON_ONE_GPU": (_bool, False),   # all ranks share cuda:0: gloo groups + peer-memory all-reduce (tests)
     "VDA_GEMM_SELECTIONS": (str, None),          # CSV of library-GEMM algorithm choices; "off" disables
     "VDA_DISABLE_SKINNY_GEMM": (_bool, False),

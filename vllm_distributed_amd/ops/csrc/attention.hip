@@ -617,18 +617,26 @@ __global__ __launch_bounds__(64) void attn_reduce_kernel(T* out, const float* pa
                                                          int Hq, int nsplit, long out_stride) {
   const long th = blockIdx.x;          // token * Hq + head
   const int lane = threadIdx.x;
-  const float* lse = part_lse + th * nsplit;
-  float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, lse[s]);
+  // lane s holds partition s (nsplit <= 64): maximum and weight sum by wave reductions, weights handed out
+  // by shuffles; partitions without keys (short sequences under a split factor fixed at graph capture)
+  // carry -inf and are skipped without touching their rows
+  const float mine = lane < nsplit ? part_lse[th * nsplit + lane] : -INFINITY;
+  float M = mine;
+#pragma unroll
+  for (int o_ = 32; o_ > 0; o_ >>= 1) M = fmaxf(M, __shfl_xor(M, o_, 64));
   const float Mu = (M == -INFINITY) ? 0.f : M;
+  const float w_mine = (mine == -INFINITY) ? 0.f : fexp2(mine - Mu);
+  float W = w_mine;
+#pragma unroll
+  for (int o_ = 32; o_ > 0; o_ >>= 1) W += __shfl_xor(W, o_, 64);
   constexpr int PER = D / 64 > 0 ? D / 64 : 1;
   float o[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) o[i] = 0.f;
-  float W = 0.f;
+#pragma unroll 4
   for (int s = 0; s < nsplit; ++s) {
-    const float w = fexp2(lse[s] - Mu);
-    W += w;
+    const float w = __shfl(w_mine, s, 64);
+    if (w == 0.f) continue;                    // wave-uniform
     const float* po = part_out + (th * nsplit + s) * D;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
