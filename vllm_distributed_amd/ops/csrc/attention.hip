@@ -748,6 +748,7 @@ VDA_EXPORT int vda_paged_attention_decode(
     int max_q_len, long q_stride, long out_stride, float scale, float softcap, int window, int dtype,
     int kv_fp8, float k_scale, float v_scale, hipStream_t st) {
   if (Hq % Hkv) return -1;
+  if (nsplit < 1 || nsplit > 64) return -6;      // the reduce kernel keeps one partition per lane
   const int cols = max_q_len * (Hq / Hkv);
   if (cols > 32 || (cols > 16 && D > 128)) return -4;
   AttnParams p{q, k_cache, v_cache, out, part_out, part_lse, block_table, seq_lens, q_start_loc, alibi,

@@ -233,18 +233,25 @@ __global__ __launch_bounds__(64) void mla_reduce_kernel(T* out, const float* par
                                                         int nsplit, long out_stride) {
   const long th = blockIdx.x;
   const int lane = threadIdx.x;
-  const float* lse = part_lse + th * nsplit;
-  float M = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, lse[s]);
+  // lane s holds partition s (nsplit <= 64): wave reductions for the maximum and the weight sum, weights
+  // handed out by shuffles, partitions without keys skipped
+  const float mine = lane < nsplit ? part_lse[th * nsplit + lane] : -INFINITY;
+  float M = mine;
+#pragma unroll
+  for (int o_ = 32; o_ > 0; o_ >>= 1) M = fmaxf(M, __shfl_xor(M, o_, 64));
   const float Mu = (M == -INFINITY) ? 0.f : M;
+  const float w_mine = (mine == -INFINITY) ? 0.f : fexp2(mine - Mu);
+  float W = w_mine;
+#pragma unroll
+  for (int o_ = 32; o_ > 0; o_ >>= 1) W += __shfl_xor(W, o_, 64);
   constexpr int PER = (DV + 63) / 64;
   float o[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) o[i] = 0.f;
-  float W = 0.f;
+#pragma unroll 2
   for (int s = 0; s < nsplit; ++s) {
-    const float w = fexp2(lse[s] - Mu);
-    W += w;
+    const float w = __shfl(w_mine, s, 64);
+    if (w == 0.f) continue;
     const float* po = part_out + (th * nsplit + s) * DV;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -280,7 +287,8 @@ VDA_EXPORT int vda_mla_attention(void* out, const void* q, const void* kc, const
                                  int S, int T_tokens, int H, int DK, int DV, int BS, int max_blocks, int nsplit,
                                  int max_q, long q_stride, long out_stride, float scale, int dtype, hipStream_t st) {
   if (S <= 0 || T_tokens <= 0) return 0;
-  if (!vda_mla_supported(DK, DV) || BS % 8 || nsplit < 1 || (nsplit > 1 && (!part_out || !part_lse))) return -1;
+  if (!vda_mla_supported(DK, DV) || BS % 8 || nsplit < 1 || nsplit > 64 || (nsplit > 1 && (!part_out || !part_lse)))
+    return -1;      // (the reduce kernel keeps one partition per lane)
   MlaParams p;
   p.q = q; p.kc = kc; p.vt = vt; p.out = out; p.part_out = part_out; p.part_lse = part_lse;
   p.block_table = block_table; p.seq_lens = seq_lens; p.q_start_loc = q_start_loc;
