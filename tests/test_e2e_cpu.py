@@ -115,6 +115,16 @@ def _save_tiny(tmp, kind):
     elif kind == "gpt_bigcode":
         cfg = tf.GPTBigCodeConfig(vocab_size=320, n_embd=128, n_layer=2, n_head=2, n_positions=256, multi_query=True)
         m = tf.GPTBigCodeForCausalLM(cfg)
+    elif kind == "phimoe":
+        cfg = tf.PhimoeConfig(vocab_size=320, hidden_size=128, intermediate_size=128, num_hidden_layers=2,
+                              num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                              num_local_experts=4, num_experts_per_tok=2, sliding_window=None, attention_bias=True,
+                              lm_head_bias=True, router_jitter_noise=0.01, input_jitter_noise=0.0)
+        m = tf.PhimoeForCausalLM(cfg)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() >= 2:
+                    p.mul_(3.0)
     elif kind == "olmoe":
         cfg = tf.OlmoeConfig(vocab_size=320, hidden_size=128, intermediate_size=64, num_hidden_layers=2,
                              num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -244,7 +254,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba"])
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

@@ -32,14 +32,16 @@ def _num_experts(config) -> int:
 
 class SparseMoeBlock(nn.Module):
     def __init__(self, hidden_size: int, intermediate_size: int, num_experts: int, top_k: int, renormalize: bool,
-                 quant_config=None, prefix: str = "", shared_intermediate: int = 0, shared_gate: bool = False):
+                 quant_config=None, prefix: str = "", shared_intermediate: int = 0, shared_gate: bool = False,
+                 routing=None):
         super().__init__()
         self.gate = ReplicatedLinear(hidden_size, num_experts, bias=False, quant_config=None, prefix=f"{prefix}.gate")
         self.tp = get_tensor_model_parallel_world_size()
         self.has_shared = shared_intermediate > 0
         # with a shared expert both partial results are summed once, after adding them
         self.experts = FusedMoE(num_experts, top_k, hidden_size, intermediate_size, reduce_results=not self.has_shared,
-                                renormalize=renormalize, quant_config=quant_config, prefix=f"{prefix}.experts")
+                                renormalize=renormalize, quant_config=quant_config, prefix=f"{prefix}.experts",
+                                custom_routing_function=routing)
         if self.has_shared:
             self.shared_expert = LlamaMLP(hidden_size, shared_intermediate, quant_config=quant_config,
                                           prefix=f"{prefix}.shared_expert", reduce_results=False)
@@ -265,3 +267,60 @@ class GraniteMoeSharedForCausalLM(GraniteMoeForCausalLM):
                 else:
                     yield name, t
         return super().load_weights(fix(weights))
+
+
+# ---- Phi-3.5-MoE -------------------------------------------------------------------------------------
+def sparsemixer_routing(jitter_eps: float):
+    """Phi-MoE's top-2 router at inference: each pick is the arg-max of the (remaining) logits, weighted
+    by a softmax over the logits that lie within a relative band of 2 * jitter_eps below that maximum.
+    Reference: vllm/model_executor/models/phimoe.py (phimoe_routing_function)."""
+    def route(logits: torch.Tensor, top_k: int, renormalize: bool):
+        if top_k != 2:
+            raise ValueError("the sparsemixer router is defined for two experts per token")
+        scores = logits.float()
+        ws, ids = [], []
+        work = scores
+        for _ in range(2):
+            mx, ind = work.max(dim=-1, keepdim=True)
+            factor = scores.abs().clamp(min=mx)
+            outside = ((mx - scores) / factor) > (2 * jitter_eps)
+            gates = torch.softmax(work.masked_fill(outside, float("-inf")), dim=-1)
+            ws.append(gates.gather(-1, ind))
+            ids.append(ind)
+            work = scores.scatter(-1, ind, float("-inf"))
+        return torch.cat(ws, dim=-1), torch.cat(ids, dim=-1).to(torch.int32)
+    return route
+
+
+class PhiMoEDecoderLayer(MixtralDecoderLayer):
+    @classmethod
+    def make_norm(cls, config):
+        from .llama_variants import ResidualLayerNorm
+        return ResidualLayerNorm(config.hidden_size, getattr(config, "rms_norm_eps", 1e-5))
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        b = bool(getattr(config, "attention_bias", False))
+        return {"bias": b, "o_bias": b}
+
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        return SparseMoeBlock(config.hidden_size, config.intermediate_size, _num_experts(config),
+                              config.num_experts_per_tok, False, quant_config,
+                              prefix.replace(".mlp", ".block_sparse_moe"),
+                              routing=sparsemixer_routing(float(getattr(config, "router_jitter_noise", 0.01))))
+
+
+class PhiMoEModel(LlamaModel):
+    layer_cls = PhiMoEDecoderLayer
+
+
+class PhiMoEForCausalLM(MixtralForCausalLM):
+    model_cls = PhiMoEModel
+
+    def __init__(self, vllm_config, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        if getattr(self.config, "lm_head_bias", False) and hasattr(self.lm_head, "weight"):
+            from ..layers.basic import ParallelLMHead
+            self.lm_head = ParallelLMHead(self.config.vocab_size, self.config.hidden_size, bias=True)
+
+    def compute_logits(self, hidden_states):
+        return self.logits_processor(self.lm_head, hidden_states, getattr(self.lm_head, "bias", None))

@@ -14,6 +14,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     "Qwen2MoeForCausalLM": ("mixtral", "Qwen2MoeForCausalLM"),
     "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
+    "PhiMoEForCausalLM": ("mixtral", "PhiMoEForCausalLM"),
+    "PhimoeForCausalLM": ("mixtral", "PhiMoEForCausalLM"),
     "OlmoeForCausalLM": ("mixtral", "OlmoeForCausalLM"),
     "GraniteMoeForCausalLM": ("mixtral", "GraniteMoeForCausalLM"),
     "GemmaForCausalLM": ("llama_family", "GemmaForCausalLM"),
