@@ -125,6 +125,16 @@ def _save_tiny(tmp, kind):
             for n, p in m.named_parameters():
                 if p.dim() >= 2:
                     p.mul_(3.0)
+    elif kind == "dbrx":
+        cfg = tf.DbrxConfig(d_model=128, n_heads=2, n_layers=2, max_seq_len=256, vocab_size=320,
+                            attn_config=dict(kv_n_heads=1, clip_qkv=1.5, rope_theta=10000.0),
+                            ffn_config=dict(ffn_hidden_size=64, moe_num_experts=4, moe_top_k=2,
+                                            moe_normalize_expert_weights=1.0))
+        m = tf.DbrxForCausalLM(cfg)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() >= 2:
+                    p.mul_(3.0)
     elif kind == "olmoe":
         cfg = tf.OlmoeConfig(vocab_size=320, hidden_size=128, intermediate_size=64, num_hidden_layers=2,
                              num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -254,7 +264,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe"])
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

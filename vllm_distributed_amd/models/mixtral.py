@@ -324,3 +324,70 @@ class PhiMoEForCausalLM(MixtralForCausalLM):
 
     def compute_logits(self, hidden_states):
         return self.logits_processor(self.lm_head, hidden_states, getattr(self.lm_head, "bias", None))
+
+
+# ---- DBRX --------------------------------------------------------------------------------------------
+class DbrxDecoderLayer(MixtralDecoderLayer):
+    """Pre-norm block with scale-only LayerNorms, clipped fused QKV and a 16-expert top-4 router.
+    Reference: vllm/model_executor/models/dbrx.py."""
+
+    @classmethod
+    def make_norm(cls, config):
+        from .llama_variants import ResidualLayerNorm
+        return ResidualLayerNorm(config.hidden_size, 1e-5, bias=False)
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        return {"qkv_clip": getattr(config, "clip_qkv", None), "bias": False, "o_bias": False}
+
+
+class DbrxModel(LlamaModel):
+    layer_cls = DbrxDecoderLayer
+
+
+class DbrxForCausalLM(MixtralForCausalLM):
+    model_cls = DbrxModel
+
+    def __init__(self, vllm_config, prefix: str = ""):
+        c = vllm_config.model_config.hf_config
+        if not getattr(c, "hidden_size", None):
+            # the checkpoint's config nests its sizes; give them the names the shared layers read
+            ac, fc = c.attn_config, c.ffn_config
+            g = (lambda o, k, d=None: o.get(k, d)) if isinstance(ac, dict) else (lambda o, k, d=None: getattr(o, k, d))
+            c.hidden_size, c.num_attention_heads, c.num_hidden_layers = c.d_model, c.n_heads, c.n_layers
+            c.num_key_value_heads = g(ac, "kv_n_heads", c.n_heads)
+            c.clip_qkv, c.rope_theta = g(ac, "clip_qkv"), float(g(ac, "rope_theta", 10000.0))
+            c.intermediate_size = g(fc, "ffn_hidden_size")
+            c.num_local_experts, c.num_experts_per_tok = g(fc, "moe_num_experts"), g(fc, "moe_top_k")
+            c.max_position_embeddings = c.max_seq_len
+            c.tie_word_embeddings = bool(getattr(c, "tie_word_embeddings", False))
+        super().__init__(vllm_config, prefix)
+
+    def load_weights(self, weights):
+        E, F_ = self.num_experts(), int(self.config.intermediate_size)
+        top = {"transformer.wte.": "model.embed_tokens.", "transformer.norm_f.": "model.norm."}
+        inner = ((".norm_attn_norm.norm_1.", ".input_layernorm."), (".norm_attn_norm.norm_2.", ".post_attention_layernorm."),
+                 (".norm_attn_norm.attn.Wqkv.", ".self_attn.qkv_proj."), (".norm_attn_norm.attn.out_proj.", ".self_attn.o_proj."),
+                 (".ffn.router.layer.", ".block_sparse_moe.gate."))
+
+        def fix(items):
+            for name, t in items:
+                for a, b in top.items():
+                    if name.startswith(a):
+                        name = b + name[len(a):]
+                name = name.replace("transformer.blocks.", "model.layers.")
+                for a, b in inner:
+                    name = name.replace(a, b)
+                if ".ffn.experts.mlp." in name:
+                    base, leaf = name.split(".ffn.experts.mlp.")
+                    per = t.view(E, F_, -1)             # experts stacked along the rows
+                    for e in range(E):
+                        if leaf == "w2":                # stored [F, d]: the down projection's transpose
+                            yield f"{base}.block_sparse_moe.experts.{e}.w2.weight", per[e].t().contiguous()
+                        else:
+                            yield f"{base}.block_sparse_moe.experts.{e}.{'w1' if leaf == 'w1' else 'w3'}.weight", per[e]
+                    continue
+                yield name, t
+
+        g, d, u = self.expert_names
+        experts = FusedMoE.make_expert_params_mapping(g, d, u, E)
+        return load_weights_with_mapping(self, fix(weights), [], tie_lm_head=self.tie, expert_mapping=experts)

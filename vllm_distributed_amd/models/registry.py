@@ -16,6 +16,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
     "PhiMoEForCausalLM": ("mixtral", "PhiMoEForCausalLM"),
     "PhimoeForCausalLM": ("mixtral", "PhiMoEForCausalLM"),
+    "DbrxForCausalLM": ("mixtral", "DbrxForCausalLM"),
     "OlmoeForCausalLM": ("mixtral", "OlmoeForCausalLM"),
     "GraniteMoeForCausalLM": ("mixtral", "GraniteMoeForCausalLM"),
     "GemmaForCausalLM": ("llama_family", "GemmaForCausalLM"),
