@@ -159,3 +159,48 @@ def test_cascade_attention_on_gpu(tmp_path, monkeypatch):
         if ta[0] == tb[0]:
             assert abs(a.outputs[0].logprobs[0][ta[0]].logprob - b.outputs[0].logprobs[0][tb[0]].logprob) < 0.05
     assert same >= 4
+
+
+def test_qwen2_vl_on_gpu(tmp_path):
+    """Image prompt on the GPU: vision tower, embedding merge, multimodal rotary rows through the fused
+    RoPE + cache-write kernel in prefill, offset positions in graph-captured decode.  Teacher-forced
+    log-probabilities against transformers in fp32."""
+    from tests.test_multimodal_cpu import _tiny_qwen2_vl
+    from vllm_distributed_amd import SamplingParams
+    path, hf = _tiny_qwen2_vl(str(tmp_path))
+    g = torch.Generator().manual_seed(3)
+    img = {"pixel_values": torch.randn(4 * 6, 1176, generator=g), "image_grid_thw": torch.tensor([1, 4, 6])}
+    p = [5, 17, 302, 300, 303, 9, 11, 250]
+    ids = [5, 17, 302] + [300] * 6 + [303, 9, 11, 250]
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True, logprobs=0)
+    llm = _llm(path, enable_prefix_caching=False)
+    outs = llm.generate([{"prompt_token_ids": p, "multi_modal_data": {"image": [img]}},
+                         {"prompt_token_ids": [7, 8, 9, 10] * 4}], sp)
+    llm.shutdown()
+    for o, full, kw in ((outs[0], ids, dict(pixel_values=img["pixel_values"], image_grid_thw=img["image_grid_thw"][None],
+                                            mm_token_type_ids=None)),
+                        (outs[1], [7, 8, 9, 10] * 4, {})):
+        gen = list(o.outputs[0].token_ids)
+        seq = full + gen
+        if kw:
+            kw["mm_token_type_ids"] = torch.tensor([[1 if t == 300 else 0 for t in seq]], dtype=torch.int32)
+        with torch.no_grad():
+            lp = torch.log_softmax(hf(input_ids=torch.tensor([seq]), **kw).logits[0].float(), -1)
+        worst = max(abs(float(lp[len(full) + k - 1, t]) - o.outputs[0].logprobs[k][t].logprob)
+                    for k, t in enumerate(gen))
+        assert worst < 0.08, worst
+
+
+def test_encoder_only_embeddings_on_gpu(tmp_path):
+    """BERT on the GPU: bidirectional mode of the paged prefill kernel, [CLS] embeddings against transformers."""
+    from tests.test_pooling_cpu import _tiny_encoder
+    path, hf = _tiny_encoder(str(tmp_path), "bert")
+    prompts = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 30, [2, 3]]
+    llm = _llm(path, max_model_len=128)
+    outs = llm.embed(None, prompt_token_ids=prompts)
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = torch.nn.functional.normalize(hf(torch.tensor([p])).last_hidden_state[0, 0], dim=-1)
+        got = torch.as_tensor(o.outputs.embedding).float()
+        assert float(torch.dot(got, ref)) > 0.995, float(torch.dot(got, ref))
