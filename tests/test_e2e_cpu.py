@@ -167,6 +167,19 @@ def _save_tiny(tmp, kind):
             for n, p in m.named_parameters():
                 if p.dim() >= 2 and "A_log" not in n:
                     p.mul_(1.5)
+    elif kind == "granitemoehybrid":
+        cfg = tf.GraniteMoeHybridConfig(
+            vocab_size=320, hidden_size=128, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+            num_key_value_heads=1, max_position_embeddings=256, num_local_experts=4, num_experts_per_tok=2,
+            shared_intermediate_size=96, layer_types=["mamba", "attention", "mamba"], mamba_n_heads=8, mamba_d_head=32,
+            mamba_n_groups=2, mamba_d_state=16, mamba_d_conv=4, mamba_expand=2, mamba_chunk_size=8,
+            embedding_multiplier=6.0, residual_multiplier=0.4, attention_multiplier=0.1, logits_scaling=4.0,
+            position_embedding_type="rope")
+        m = tf.GraniteMoeHybridForCausalLM(cfg)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() >= 2 and "A_log" not in n:
+                    p.mul_(1.5)
     elif kind == "stablelm":
         cfg = tf.StableLmConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
                                 num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -264,12 +277,12 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx"])
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]
     # transformers' eager Mamba-2 normalises the gated output over the whole width, not per group
-    extra = {"hf_overrides": {"gated_norm_groups": 1}} if kind in ("mamba2", "bamba") else {}
+    extra = {"hf_overrides": {"gated_norm_groups": 1}} if kind in ("mamba2", "bamba", "granitemoehybrid") else {}
     llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
               max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16, **extra)
     outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=12,

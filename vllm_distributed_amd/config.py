@@ -281,7 +281,7 @@ class ModelConfig:
     def is_hybrid(self) -> bool:
         """Attention and state-space layers in one stack: paged KV for the former, one state slot per
         request for the latter; recurrent state rules out prefix reuse."""
-        return any(a in ("JambaForCausalLM", "BambaForCausalLM") for a in self.architectures)
+        return any(a in ("JambaForCausalLM", "BambaForCausalLM", "GraniteMoeHybridForCausalLM") for a in self.architectures)
 
     def get_total_num_attention_heads(self) -> int:
         if self.is_attention_free:

@@ -211,3 +211,122 @@ class BambaForCausalLM(JambaForCausalLM):
                 yield name, t
 
         return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)
+
+
+# ---- Granite-4 hybrid (GraniteMoeHybrid) -----------------------------------------------------------------
+class GraniteMoeHybridLayer(nn.Module):
+    """Mamba-2 mixer or attention (softmax scale and residual scale from the Granite multipliers), then
+    routed experts plus a shared gated MLP on the same normalised input.
+    Reference: vllm/model_executor/models/granitemoehybrid.py."""
+
+    def __init__(self, config, vllm_config: VllmConfig, kind: str, prefix: str):
+        super().__init__()
+        from .mamba import Mamba2Mixer
+        quant_config = getattr(vllm_config, "quant_config", None)
+        d, eps = config.hidden_size, config.rms_norm_eps
+        self.kind = kind
+        self.residual_multiplier = float(getattr(config, "residual_multiplier", 1.0) or 1.0)
+        if kind == "attention":
+            rp = getattr(config, "rope_parameters", None) or {}
+            theta = float(getattr(config, "rope_theta", None) or rp.get("rope_theta") or 10000.0)
+            bias = bool(getattr(config, "attention_bias", False))
+            self.self_attn = LlamaAttention(
+                config, d, config.num_attention_heads, config.num_key_value_heads, theta, None,
+                vllm_config.model_config.max_model_len, bias=bias, o_bias=bias, quant_config=quant_config,
+                prefix=f"{prefix}.self_attn", cache_dtype=vllm_config.cache_config.cache_dtype,
+                scale=float(getattr(config, "attention_multiplier", None) or (d // config.num_attention_heads) ** -0.5),
+                use_rope=getattr(config, "position_embedding_type", "rope") == "rope")
+        else:
+            shim = SimpleNamespace(hidden_size=d, num_heads=config.mamba_n_heads, head_dim=config.mamba_d_head,
+                                   intermediate_size=config.mamba_n_heads * config.mamba_d_head,
+                                   state_size=config.mamba_d_state, conv_kernel=config.mamba_d_conv,
+                                   n_groups=config.mamba_n_groups, use_bias=bool(config.mamba_proj_bias),
+                                   use_conv_bias=bool(config.mamba_conv_bias), layer_norm_epsilon=eps,
+                                   gated_norm_groups=getattr(config, "gated_norm_groups", None))
+            self.mamba = Mamba2Mixer(shim, f"{prefix}.mamba")
+        n_exp = int(getattr(config, "num_local_experts", 0) or 0)
+        self.block_sparse_moe = SparseMoeBlock(d, config.intermediate_size, n_exp, config.num_experts_per_tok, True,
+                                               quant_config, f"{prefix}.block_sparse_moe") if n_exp > 0 else None
+        shared = int(getattr(config, "shared_intermediate_size", 0) or 0)
+        self.shared_mlp = LlamaMLP(d, shared, False, quant_config, f"{prefix}.shared_mlp") if shared > 0 else None
+        self.input_layernorm = RMSNorm(d, eps)
+        self.post_attention_layernorm = RMSNorm(d, eps)
+
+    def forward(self, positions, hidden, residual):
+        if residual is None:
+            residual = hidden
+            hidden = self.input_layernorm(hidden)
+        else:
+            hidden, residual = self.input_layernorm(hidden, residual)
+        hidden = self.self_attn(positions, hidden) if self.kind == "attention" else self.mamba(hidden)
+        hidden, residual = self.post_attention_layernorm(hidden * self.residual_multiplier, residual)
+        out = self.block_sparse_moe(hidden) if self.block_sparse_moe is not None else 0
+        if self.shared_mlp is not None:
+            out = out + self.shared_mlp(hidden)
+        return out * self.residual_multiplier, residual
+
+
+class GraniteMoeHybridForCausalLM(JambaForCausalLM):
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        nn.Module.__init__(self)
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        kinds = ["attention" if k in ("attention", "full_attention") else "mamba"
+                 for k in (getattr(config, "layer_types", None) or getattr(config, "layers_block_type"))]
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
+        self.embed_scale = float(getattr(config, "embedding_multiplier", 1.0) or 1.0)
+        self.layers = nn.ModuleList([GraniteMoeHybridLayer(config, vllm_config, kinds[i], f"model.layers.{i}")
+                                     for i in range(config.num_hidden_layers)])
+        self.final_layernorm = RMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.tie = bool(getattr(config, "tie_word_embeddings", False))
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
+        if self.tie:
+            self.lm_head.tie_weights(self.embed_tokens)
+        self.logits_processor = LogitsProcessor(config.vocab_size, config.vocab_size,
+                                                1.0 / float(getattr(config, "logits_scaling", 1.0) or 1.0))
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None):
+        hidden = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
+        hidden = hidden * self.embed_scale
+        residual = None
+        for layer in self.layers:
+            hidden, residual = layer(positions, hidden, residual)
+        hidden, _ = self.final_layernorm(hidden, residual)
+        return hidden
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        from ..layers.moe import FusedMoE
+        n_exp = int(getattr(self.config, "num_local_experts", 0) or 0)
+        experts = FusedMoE.make_expert_params_mapping("gate_proj", "down_proj", "up_proj", n_exp) if n_exp else []
+        tails = {".mamba.conv1d.weight": ".mamba.conv_weight", ".mamba.conv1d.bias": ".mamba.conv_bias",
+                 ".mamba.A_log": ".mamba.A", ".mamba.norm.weight": ".mamba.norm_weight",
+                 ".shared_mlp.input_linear.weight": ".shared_mlp.gate_up_proj.weight",
+                 ".shared_mlp.output_linear.weight": ".shared_mlp.down_proj.weight",
+                 ".block_sparse_moe.router.weight": ".block_sparse_moe.gate.weight",
+                 ".block_sparse_moe.router.layer.weight": ".block_sparse_moe.gate.weight"}
+
+        def fix(items):
+            for name, t in items:
+                name = name.removeprefix("model.")
+                if name == "norm.weight":
+                    name = "final_layernorm.weight"
+                for a, b in tails.items():
+                    if name.endswith(a):
+                        name = name[: -len(a)] + b
+                # all experts stacked: [E, 2I, H] (gate rows, then up rows) and [E, H, I]
+                if name.endswith((".block_sparse_moe.experts.gate_up_proj", ".block_sparse_moe.input_linear.weight")):
+                    base = name[: name.index(".block_sparse_moe.")] + ".block_sparse_moe.experts."
+                    half = t.shape[1] // 2
+                    for e in range(t.shape[0]):
+                        yield f"{base}{e}.gate_proj.weight", t[e, :half]
+                        yield f"{base}{e}.up_proj.weight", t[e, half:]
+                    continue
+                if name.endswith((".block_sparse_moe.experts.down_proj", ".block_sparse_moe.output_linear.weight")):
+                    base = name[: name.index(".block_sparse_moe.")] + ".block_sparse_moe.experts."
+                    for e in range(t.shape[0]):
+                        yield f"{base}{e}.down_proj.weight", t[e]
+                    continue
+                yield name, t
+
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie,
+                                         expert_mapping=experts)

@@ -60,6 +60,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "BambaForCausalLM": ("jamba", "BambaForCausalLM"),
+    "GraniteMoeHybridForCausalLM": ("jamba", "GraniteMoeHybridForCausalLM"),
     "MambaForCausalLM": ("mamba", "MambaForCausalLM"),
     "FalconMambaForCausalLM": ("mamba", "FalconMambaForCausalLM"),
     "Mamba2ForCausalLM": ("mamba", "Mamba2ForCausalLM"),
