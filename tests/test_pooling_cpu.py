@@ -153,3 +153,41 @@ def test_encoder_only_classifiers_match_hf(tmp_path, kind):
         ref = torch.sigmoid(logits) if logits.numel() == 1 else torch.softmax(logits, -1)
         torch.testing.assert_close(out.outputs.data.float().flatten(), ref, atol=2e-4, rtol=1e-3)
     llm.shutdown()
+
+
+@pytest.mark.parametrize("arch", ["Qwen2ForRewardModel", "Qwen2ForProcessRewardModel"])
+def test_qwen2_reward_heads(tmp_path, arch):
+    """Reward heads over every prompt token.  These classes are not in transformers (parity with the original
+    remote code unpinned): a tiny HF Qwen2 backbone plus random head weights, checked against the head applied
+    in plain PyTorch to transformers' own hidden states."""
+    import json
+
+    import transformers as tf
+    from safetensors.torch import save_file
+    torch.manual_seed(0)
+    cfg = tf.Qwen2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=256)
+    hf = tf.Qwen2Model(cfg).float().eval()
+    n = 1 if arch == "Qwen2ForRewardModel" else 2
+    head = {"score.0.weight": torch.randn(128, 128) * 0.1, "score.0.bias": torch.randn(128) * 0.1,
+            "score.2.weight": torch.randn(n, 128) * 0.1, "score.2.bias": torch.randn(n) * 0.1}
+    path = str(tmp_path / "rm")
+    os.makedirs(path)
+    save_file({**{"model." + k: v.contiguous() for k, v in hf.state_dict().items()}, **head},
+              os.path.join(path, "model.safetensors"))
+    c = cfg.to_dict()
+    c["architectures"] = [arch]
+    json.dump(c, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 6]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4,
+              task="reward")
+    outs = llm.encode(None, prompt_token_ids=prompts)
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            h = hf(torch.tensor([p])).last_hidden_state[0]
+            ref = torch.relu(h @ head["score.0.weight"].T + head["score.0.bias"]) @ head["score.2.weight"].T \
+                + head["score.2.bias"]
+            if n == 2:
+                ref = torch.softmax(ref, -1)
+        torch.testing.assert_close(o.outputs.data.float().view(len(p), n), ref, atol=2e-4, rtol=1e-3)

@@ -63,3 +63,41 @@ class LlamaForSequenceClassification(LlamaEmbeddingModel):
                 return None
             return n if n.startswith(("model.", "score.")) else "model." + n
         return load_weights_with_mapping(self, weights, _STACKED, rename=rename)
+
+
+class Qwen2ForRewardModel(LlamaEmbeddingModel):
+    """Per-token rewards: Qwen2 backbone, then Linear -> ReLU -> Linear to ``num_labels`` values for every
+    prompt token (pooling type ALL).  The process-reward variant has two labels and a softmax.
+    Reference: vllm/model_executor/models/qwen2_rm.py.  transformers does not carry these classes, so the
+    test checks the head against a plain PyTorch forward on the backbone's own hidden states."""
+    num_labels = 1
+    softmax = False
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        d = self.config.hidden_size
+        self.score_in = ReplicatedLinear(d, d, bias=True, prefix=maybe_prefix(prefix, "score.0"))
+        self.score_out = ReplicatedLinear(d, self.num_labels, bias=True, prefix=maybe_prefix(prefix, "score.2"))
+        self.pooler = Pooler.from_config(getattr(vllm_config.model_config, "pooler_config", None), PoolingType.ALL,
+                                         normalize=False, softmax=self.softmax)
+
+    def pool(self, hidden: torch.Tensor, params=None) -> torch.Tensor:
+        x = self.pooler.extract(hidden)
+        x = x.unsqueeze(0) if x.dim() == 1 else x
+        return self.pooler.head(self.score_out(torch.relu(self.score_in(x))), params)
+
+    def load_weights(self, weights):
+        def rename(n: str):
+            if n.startswith("lm_head."):
+                return None
+            if n.startswith("score.0."):
+                return "score_in." + n[len("score.0."):]
+            if n.startswith("score.2."):
+                return "score_out." + n[len("score.2."):]
+            return n if n.startswith("model.") else "model." + n
+        return load_weights_with_mapping(self, weights, _STACKED, rename=rename)
+
+
+class Qwen2ForProcessRewardModel(Qwen2ForRewardModel):
+    num_labels = 2
+    softmax = True

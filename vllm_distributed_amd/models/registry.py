@@ -75,6 +75,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "RobertaForSequenceClassification": ("bert", "RobertaForSequenceClassification"),
     "XLMRobertaForSequenceClassification": ("bert", "RobertaForSequenceClassification"),
     "LlamaModel": ("pooling", "LlamaEmbeddingModel"),
+    "Qwen2ForRewardModel": ("pooling", "Qwen2ForRewardModel"),
+    "Qwen2ForProcessRewardModel": ("pooling", "Qwen2ForProcessRewardModel"),
     "MistralModel": ("pooling", "LlamaEmbeddingModel"),
     "Qwen2Model": ("pooling", "LlamaEmbeddingModel"),
     "Qwen3Model": ("pooling", "LlamaEmbeddingModel"),
