@@ -128,7 +128,7 @@ def _save_tiny(tmp, kind):
     elif kind == "dbrx":
         cfg = tf.DbrxConfig(d_model=128, n_heads=2, n_layers=2, max_seq_len=256, vocab_size=320,
                             attn_config=dict(kv_n_heads=1, clip_qkv=1.5, rope_theta=10000.0),
-                            ffn_config=dict(ffn_hidden_size=64, moe_num_experts=4, moe_top_k=2,
+                            ffn_config=dict(ffn_hidden_size=128, moe_num_experts=4, moe_top_k=2,
                                             moe_normalize_expert_weights=1.0))
         m = tf.DbrxForCausalLM(cfg)
         with torch.no_grad():
