@@ -1,4 +1,4 @@
-"""Online serving benchmark against an OpenAI-compatible endpoint: Poisson/gamma arrivals,
+"""Online serving benchmark against an OpenAI-compatible endpoint: Poisson/gamma arrivals, ramp-up,
 max-concurrency cap, streaming TTFT / TPOT / ITL / E2EL percentiles, goodput SLOs.
 Reference: benchmarks/benchmark_serving.py, backend_request_func.py, vllm/benchmarks/serve.py."""
 from __future__ import annotations
@@ -39,6 +39,10 @@ def add_cli_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--tokenizer", default=None)
     p.add_argument("--request-rate", type=float, default=float("inf"))
     p.add_argument("--burstiness", type=float, default=1.0)
+    p.add_argument("--ramp-up-strategy", default=None, choices=["linear", "exponential"],
+                   help="sweep the request rate from --ramp-up-start-rps to --ramp-up-end-rps over the run")
+    p.add_argument("--ramp-up-start-rps", type=float, default=1.0)
+    p.add_argument("--ramp-up-end-rps", type=float, default=1.0)
     p.add_argument("--max-concurrency", type=int, default=None)
     p.add_argument("--ignore-eos", action="store_true")
     p.add_argument("--percentile-metrics", default="ttft,tpot,itl")
@@ -93,12 +97,28 @@ async def _one(client, url: str, model: str, r: SampleRequest, chat: bool, ignor
     return res
 
 
-async def _arrivals(reqs, rate: float, burstiness: float, seed: int):
+def _rate_at(i: int, n: int, rate: float, ramp: Optional[str], start: float, end: float) -> float:
+    """Request rate in force when request i of n is sent: constant, or ramping from ``start`` to ``end``
+    (linear in the request index, or exponential) as in the reference's --ramp-up-strategy."""
+    if not ramp:
+        return rate
+    f = i / max(n - 1, 1)
+    if ramp == "linear":
+        return start + (end - start) * f
+    if ramp == "exponential":
+        return start * (end / start) ** f
+    raise ValueError(f"unknown ramp-up strategy {ramp!r} (linear, exponential)")
+
+
+async def _arrivals(reqs, rate: float, burstiness: float, seed: int, ramp: Optional[str] = None,
+                    ramp_start: float = 1.0, ramp_end: float = 1.0):
     g = np.random.default_rng(seed)
-    for r in reqs:
+    n = len(reqs)
+    for i, r in enumerate(reqs):
         yield r
-        if rate != float("inf"):
-            await asyncio.sleep(float(g.gamma(shape=burstiness, scale=1.0 / (rate * burstiness))))
+        cur = _rate_at(i, n, rate, ramp, ramp_start, ramp_end)
+        if cur != float("inf"):
+            await asyncio.sleep(float(g.gamma(shape=burstiness, scale=1.0 / (cur * burstiness))))
 
 
 def summarize(results: list[RequestResult], duration: float, pcts: list[float], goodput: Optional[dict]) -> dict:
@@ -151,7 +171,9 @@ async def benchmark(args, reqs: list[SampleRequest], transport=None) -> dict:
                 return await _one(client, args.endpoint, model, r, chat, args.ignore_eos)
         t0 = time.perf_counter()
         tasks = []
-        async for r in _arrivals(reqs, args.request_rate, args.burstiness, args.seed):
+        async for r in _arrivals(reqs, args.request_rate, args.burstiness, args.seed,
+                                 getattr(args, "ramp_up_strategy", None), getattr(args, "ramp_up_start_rps", 1.0),
+                                 getattr(args, "ramp_up_end_rps", 1.0)):
             tasks.append(asyncio.create_task(limited(r)))
         results = await asyncio.gather(*tasks)
         dur = time.perf_counter() - t0

@@ -1,5 +1,5 @@
 """``vda`` / ``python -m vllm_distributed_amd`` command line:
-serve | chat | complete | bench {latency,throughput,serve} | run-batch | collect-env.
+serve | chat | complete | bench {latency,throughput,serve,prefix-caching,structured-output} | run-batch | collect-env.
 Reference: vllm/entrypoints/cli/main.py, serve.py:35-249, openai.py, benchmark/*, run_batch.py."""
 from __future__ import annotations
 
@@ -128,8 +128,9 @@ def build_parser() -> argparse.ArgumentParser:
 
     bp = sub.add_parser("bench", help="benchmarks")
     bsub = bp.add_subparsers(dest="bench_cmd", required=True)
-    from ...benchmarks import latency, serve, throughput
-    for name, mod in (("latency", latency), ("throughput", throughput), ("serve", serve)):
+    from ...benchmarks import latency, prefix_caching, serve, structured_output, throughput
+    for name, mod in (("latency", latency), ("throughput", throughput), ("serve", serve),
+                      ("prefix-caching", prefix_caching), ("structured-output", structured_output)):
         x = bsub.add_parser(name)
         mod.add_cli_args(x)
         x.set_defaults(fn=mod.main)
