@@ -25,6 +25,11 @@ def main():
     with open(f"{out_path}.{os.environ['RANK']}", "w") as f:
         json.dump(toks, f)
     llm.shutdown()
+    # results are on disk: skip interpreter-exit destructors (a gloo helper thread that outlives its peers
+    # aborts the process at exit under heavy load, which says nothing about the run)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -12,6 +12,7 @@ import numpy as np
 
 def add_cli_args(p: argparse.ArgumentParser) -> None:
     from ..engine.arg_utils import EngineArgs
+    p.add_argument("--model", type=str, required=True)
     p.add_argument("--num-prompts", type=int, default=64)
     p.add_argument("--prefix-len", type=int, default=1024, help="tokens shared by every prompt")
     p.add_argument("--suffix-len", type=int, default=64, help="distinct tokens behind the shared prefix")

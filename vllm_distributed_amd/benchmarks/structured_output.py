@@ -17,6 +17,7 @@ _SCHEMA = {"type": "object", "properties": {"name": {"type": "string", "maxLengt
 
 def add_cli_args(p: argparse.ArgumentParser) -> None:
     from ..engine.arg_utils import EngineArgs
+    p.add_argument("--model", type=str, required=True)
     p.add_argument("--num-prompts", type=int, default=32)
     p.add_argument("--input-len", type=int, default=64)
     p.add_argument("--output-len", type=int, default=64)

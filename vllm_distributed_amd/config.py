@@ -555,7 +555,7 @@ class SchedulerConfig:
     max_num_partial_prefills: int = 1
     #: How many of those may be "long" prompts.
     max_long_partial_prefills: int = 1
-    #: Prompts longer than this are "long" (0 = 4% of max_model_len when partial prefills > 1).
+    #: Prompts longer than this are "long" (0 = 4 percent of max_model_len when partial prefills > 1).
     long_prefill_token_threshold: int = 0
     #: fcfs or priority.
     policy: str = "fcfs"

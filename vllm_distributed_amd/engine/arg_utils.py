@@ -165,7 +165,7 @@ class EngineArgs:
             tp, optional = _optional_type(hints[f.name])
             flag = "--" + f.name.replace("_", "-")
             names = [flag] + cls._ALIASES.get(f.name, [])
-            help_ = docs.get(cls._RENAMED_DOC.get(f.name, f.name), "")
+            help_ = docs.get(cls._RENAMED_DOC.get(f.name, f.name), "").replace("%", "%%")   # argparse expands %
             default = f.default if f.default is not dataclasses.MISSING else None
             if f.name == "model":
                 continue    # positional / --model handled by the caller
