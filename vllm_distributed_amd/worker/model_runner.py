@@ -697,7 +697,8 @@ class ModelRunner:
                 inter = intermediate_tensors
             T_in, P_in = T, T_a
             tp = self.sp_multiple
-            if tp > 1 and tmd is None and inputs_embeds is None and T % tp and T + tp <= self.input_ids.shape[0]:
+            if tp > 1 and tmd is None and inputs_embeds is None and T % tp and T + tp <= self.input_ids.shape[0] \
+                    and not self.uses_mrope:
                 # sequence parallelism splits the rows over the TP ranks: pad to a multiple of tp with
                 # rows that attention ignores (they lie beyond num_actual_tokens)
                 T_in = P_in = (T + tp - 1) // tp * tp
