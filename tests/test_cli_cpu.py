@@ -50,3 +50,19 @@ def test_bench_latency_and_throughput(tmp_path):
           "--output-json", str(oj2), "--skip-tokenizer-init"] + COMMON)
     r = json.loads(oj2.read_text())
     assert r["num_requests"] == 5 and r["output_tokens_per_second"] > 0
+
+
+def test_bench_subcommands_parse_and_ramp_up_rates():
+    """The benchmark subcommands build their parsers (help strings expand cleanly) and the ramp-up schedule
+    hits its end points."""
+    import argparse
+
+    from vllm_distributed_amd.benchmarks import latency, prefix_caching, serve, structured_output, throughput
+    from vllm_distributed_amd.benchmarks.serve import _rate_at
+    for mod in (latency, prefix_caching, structured_output, throughput, serve):
+        p = argparse.ArgumentParser()
+        mod.add_cli_args(p)
+        assert "--model" in p.format_help()
+    assert _rate_at(0, 11, 5.0, "linear", 1.0, 11.0) == 1.0 and _rate_at(10, 11, 5.0, "linear", 1.0, 11.0) == 11.0
+    assert abs(_rate_at(5, 11, 5.0, "exponential", 1.0, 16.0) - 4.0) < 1e-9
+    assert _rate_at(3, 11, 5.0, None, 1.0, 16.0) == 5.0
