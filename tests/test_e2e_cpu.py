@@ -465,3 +465,31 @@ def test_cascade_attention_same_tokens(tmp_path, monkeypatch):
     assert res["cascade_calls"] > 0 and res["plain_calls"] == 0
     assert all(p == 64 for p in calls)              # four whole blocks of the 70-token prefix
     assert res["cascade"] == res["plain"]
+
+
+def test_gemma3_multimodal_checkpoint_served_as_text(tmp_path):
+    """A Gemma3ForConditionalGeneration checkpoint: the decoder is loaded from under ``language_model``, the
+    vision tower is ignored, and text generation equals transformers' on the same checkpoint."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.Gemma3Config(
+        text_config=dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                         num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=256,
+                         query_pre_attn_scalar=32, sliding_window=16,
+                         layer_types=["sliding_attention", "sliding_attention", "full_attention"]),
+        vision_config=dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                           image_size=28, patch_size=14), mm_tokens_per_image=4, image_token_index=300)
+    hf = tf.Gemma3ForConditionalGeneration(cfg).float().eval()
+    path = os.path.join(str(tmp_path), "gemma3mm")
+    hf.save_pretrained(path, safe_serialization=True)
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 40]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+              max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=10,
+                                                                                   ignore_eos=True))
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([p]), max_new_tokens=10, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref
+    llm.shutdown()

@@ -425,3 +425,21 @@ class BaichuanForCausalLM(LlamaForCausalLM):
 
 
 BaiChuanForCausalLM = BaichuanForCausalLM
+
+
+class Gemma3TextOnlyFromMultimodal(Gemma3ForCausalLM):
+    """Gemma-3 multimodal checkpoints (architecture ``Gemma3ForConditionalGeneration``) served as text
+    models: the decoder's weights are read from the checkpoint, the vision tower and projector are not
+    loaded, and image inputs are not accepted."""
+
+    def load_weights(self, weights):
+        def fix(items):
+            for name, t in items:
+                if name.startswith("model.language_model."):
+                    yield "model." + name[len("model.language_model."):], t
+                elif name.startswith("language_model."):
+                    yield name[len("language_model."):], t
+                elif name.startswith("lm_head."):
+                    yield name, t
+                # vision_tower.*, multi_modal_projector.*: not part of the text path
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)

@@ -34,6 +34,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "GlmForCausalLM": ("llama_variants", "GlmForCausalLM"),
     "Glm4ForCausalLM": ("llama_variants", "Glm4ForCausalLM"),
     "Gemma3ForCausalLM": ("llama_variants", "Gemma3ForCausalLM"),
+    "Gemma3ForConditionalGeneration": ("llama_variants", "Gemma3TextOnlyFromMultimodal"),
     "InternLM2ForCausalLM": ("llama_variants", "InternLM2ForCausalLM"),
     "InternLM3ForCausalLM": ("llama", "LlamaForCausalLM"),
     "BaichuanForCausalLM": ("llama_variants", "BaichuanForCausalLM"),
