@@ -180,6 +180,16 @@ def _save_tiny(tmp, kind):
             for n, p in m.named_parameters():
                 if p.dim() >= 2 and "A_log" not in n:
                     p.mul_(1.5)
+    elif kind == "nemotron_h":
+        cfg = tf.NemotronHConfig(vocab_size=320, hidden_size=128, layers_block_type=["mamba", "mlp", "attention", "mlp"],
+                                 num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=256,
+                                 intermediate_size=256, ssm_state_size=16, mamba_num_heads=8, mamba_head_dim=32,
+                                 n_groups=2, conv_kernel=4, chunk_size=8, use_mamba_kernels=False)
+        m = tf.NemotronHForCausalLM(cfg)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() >= 2 and "A_log" not in n:
+                    p.mul_(1.5)
     elif kind == "stablelm":
         cfg = tf.StableLmConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
                                 num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -277,7 +287,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid"])
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

@@ -281,7 +281,7 @@ class ModelConfig:
     def is_hybrid(self) -> bool:
         """Attention and state-space layers in one stack: paged KV for the former, one state slot per
         request for the latter; recurrent state rules out prefix reuse."""
-        return any(a in ("JambaForCausalLM", "BambaForCausalLM", "GraniteMoeHybridForCausalLM") for a in self.architectures)
+        return any(a in ("JambaForCausalLM", "BambaForCausalLM", "GraniteMoeHybridForCausalLM", "NemotronHForCausalLM") for a in self.architectures)
 
     def get_total_num_attention_heads(self) -> int:
         if self.is_attention_free:
@@ -314,8 +314,10 @@ class ModelConfig:
         return max(1, self.get_total_num_kv_heads() // pc.tensor_parallel_size)
 
     def get_total_num_hidden_layers(self) -> int:
-        return self.hf_config.get("num_hidden_layers") or self.hf_config.get("n_layer") or \
-            self.hf_config.get("n_layers")
+        n = self.hf_config.get("num_hidden_layers") or self.hf_config.get("n_layer") or self.hf_config.get("n_layers")
+        if not n:      # configs that list their blocks instead (Nemotron-H)
+            n = len(self.hf_config.get("layers_block_type") or self.hf_config.get("hybrid_override_pattern") or [])
+        return n
 
     def get_num_layers(self, pc: "ParallelConfig", pp_rank: Optional[int] = None) -> int:
         from .parallel.utils import get_pp_indices

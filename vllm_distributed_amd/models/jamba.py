@@ -330,3 +330,88 @@ class GraniteMoeHybridForCausalLM(JambaForCausalLM):
 
         return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie,
                                          expert_mapping=experts)
+
+
+# ---- Nemotron-H ----------------------------------------------------------------------------------------
+class NemotronHBlock(nn.Module):
+    """One pre-norm residual block around a single mixer: a Mamba-2 layer, an attention layer without
+    positional encoding, or a squared-ReLU MLP.  Reference: vllm/model_executor/models/nemotron_h.py."""
+
+    def __init__(self, config, vllm_config: VllmConfig, kind: str, prefix: str):
+        super().__init__()
+        from .llama_variants import NemotronMLP
+        from .mamba import Mamba2Mixer
+        quant_config = getattr(vllm_config, "quant_config", None)
+        d, eps = config.hidden_size, float(getattr(config, "layer_norm_epsilon", 1e-5))
+        self.kind = kind
+        self.norm = RMSNorm(d, eps)
+        if kind == "attention":
+            bias = bool(getattr(config, "attention_bias", False))
+            self.mixer = LlamaAttention(
+                config, d, config.num_attention_heads, config.num_key_value_heads, 10000.0, None,
+                vllm_config.model_config.max_model_len, bias=bias, o_bias=bias, quant_config=quant_config,
+                prefix=f"{prefix}.mixer", cache_dtype=vllm_config.cache_config.cache_dtype, use_rope=False)
+        elif kind == "mamba":
+            shim = SimpleNamespace(hidden_size=d, num_heads=config.mamba_num_heads, head_dim=config.mamba_head_dim,
+                                   intermediate_size=config.mamba_num_heads * config.mamba_head_dim,
+                                   state_size=config.ssm_state_size, conv_kernel=config.conv_kernel,
+                                   n_groups=config.n_groups, use_bias=bool(getattr(config, "use_bias", False)),
+                                   use_conv_bias=bool(getattr(config, "use_conv_bias", True)), layer_norm_epsilon=eps,
+                                   gated_norm_groups=getattr(config, "gated_norm_groups", None),
+                                   time_step_limit=getattr(config, "time_step_limit", None))
+            self.mixer = Mamba2Mixer(shim, f"{prefix}.mixer")
+        elif kind == "mlp":
+            self.mixer = NemotronMLP(d, config.intermediate_size, bool(getattr(config, "mlp_bias", False)),
+                                     getattr(config, "mlp_hidden_act", "relu2"), quant_config, f"{prefix}.mixer")
+        else:
+            raise ValueError(f"Nemotron-H block type {kind!r} is not supported (mamba, attention, mlp)")
+
+    def forward(self, positions, hidden, residual):
+        if residual is None:
+            residual = hidden
+            hidden = self.norm(hidden)
+        else:
+            hidden, residual = self.norm(hidden, residual)
+        hidden = self.mixer(positions, hidden) if self.kind == "attention" else self.mixer(hidden)
+        return hidden, residual
+
+
+class NemotronHForCausalLM(JambaForCausalLM):
+    stacked_params_mapping = [(".qkv_proj", ".q_proj", "q"), (".qkv_proj", ".k_proj", "k"), (".qkv_proj", ".v_proj", "v")]
+    packed_modules_mapping = {"qkv_proj": ["q_proj", "k_proj", "v_proj"]}
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        nn.Module.__init__(self)
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        names = {"linear_attention": "mamba", "full_attention": "attention", "M": "mamba", "*": "attention", "-": "mlp"}
+        kinds = getattr(config, "layers_block_type", None) or list(getattr(config, "hybrid_override_pattern", ""))
+        kinds = [names.get(k, k) for k in kinds]
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([NemotronHBlock(config, vllm_config, k, f"model.layers.{i}")
+                                     for i, k in enumerate(kinds)])
+        self.final_layernorm = RMSNorm(config.hidden_size, float(getattr(config, "layer_norm_epsilon", 1e-5)))
+        self.tie = bool(getattr(config, "tie_word_embeddings", False))
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
+        if self.tie:
+            self.lm_head.tie_weights(self.embed_tokens)
+        self.logits_processor = LogitsProcessor(config.vocab_size)
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        tails = {".mixer.conv1d.weight": ".mixer.conv_weight", ".mixer.conv1d.bias": ".mixer.conv_bias",
+                 ".mixer.A_log": ".mixer.A", ".mixer.norm.weight": ".mixer.norm_weight"}
+
+        def fix(items):
+            for name, t in items:
+                name = name.removeprefix("backbone.").removeprefix("model.")
+                for old in ("embeddings.", "embedding."):
+                    if name.startswith(old):
+                        name = "embed_tokens." + name[len(old):]
+                if name == "norm_f.weight":
+                    name = "final_layernorm.weight"
+                for a, b in tails.items():
+                    if name.endswith(a):
+                        name = name[: -len(a)] + b
+                yield name, t
+
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)

@@ -61,6 +61,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "BambaForCausalLM": ("jamba", "BambaForCausalLM"),
+    "NemotronHForCausalLM": ("jamba", "NemotronHForCausalLM"),
     "GraniteMoeHybridForCausalLM": ("jamba", "GraniteMoeHybridForCausalLM"),
     "MambaForCausalLM": ("mamba", "MambaForCausalLM"),
     "FalconMambaForCausalLM": ("mamba", "FalconMambaForCausalLM"),
