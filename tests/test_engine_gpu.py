@@ -21,14 +21,15 @@ def _llm(path, **kw):
 
 
 @pytest.mark.parametrize("kind", ["llama", "qwen2", "mixtral", "mamba", "mamba2", "deepseek_v2_mla", "bloom", "cohere",
-                                  "gemma3", "olmo2", "falcon_new", "jamba", "bamba", "dbrx"])
+                                  "gemma3", "olmo2", "falcon_new", "jamba", "bamba", "dbrx", "nemotron_h",
+                                  "granitemoehybrid"])
 def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     import transformers as tf
     from vllm_distributed_amd import SamplingParams
     path, _ = _save_tiny(str(tmp_path), kind)
     sp = SamplingParams(temperature=0, max_tokens=12, ignore_eos=True, logprobs=0)
     # transformers' eager Mamba-2 normalises the gated output over the whole width, not per group
-    extra = {"hf_overrides": {"gated_norm_groups": 1}} if kind in ("mamba2", "bamba") else {}
+    extra = {"hf_overrides": {"gated_norm_groups": 1}} if kind in ("mamba2", "bamba", "granitemoehybrid") else {}
     a = _llm(path, **extra)                          # hipGraph decode
     outs_g = a.generate(prompt_token_ids=PROMPTS, sampling_params=sp)
     if kind == "deepseek_v2_mla":      # the latent-cache kernel, not the expanded-head fallback, must be what ran
