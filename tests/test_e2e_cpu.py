@@ -169,7 +169,7 @@ def _save_tiny(tmp, kind):
                     p.mul_(1.5)
     elif kind == "granitemoehybrid":
         cfg = tf.GraniteMoeHybridConfig(
-            vocab_size=320, hidden_size=128, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+            vocab_size=320, hidden_size=128, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
             num_key_value_heads=1, max_position_embeddings=256, num_local_experts=4, num_experts_per_tok=2,
             shared_intermediate_size=96, layer_types=["mamba", "attention", "mamba"], mamba_n_heads=8, mamba_d_head=32,
             mamba_n_groups=2, mamba_d_state=16, mamba_d_conv=4, mamba_expand=2, mamba_chunk_size=8,

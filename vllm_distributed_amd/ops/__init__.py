@@ -563,6 +563,11 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
     """Routed SwiGLU expert MLPs.  x [T,H]; w13 [E,2I,H] (gate rows then up rows); w2 [E,H,I];
     topk_w f32 [T,k]; topk_ids i32 [T,k] with local expert ids, negative = not on this rank."""
     if not _dev(x) or not moe_grouped_ok(x, w13, w2):
+        if _dev(x) and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(
+                f"expert shapes {tuple(w13.shape)} / {tuple(w2.shape)} are outside the grouped MoE kernel (hidden and "
+                "expert width must be multiples of 128); the PyTorch fallback synchronises and cannot be captured "
+                "into a hipGraph: run with enforce_eager=True")
         return R.fused_moe(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale)
     T, H = x.shape
     k = topk_ids.shape[1]
