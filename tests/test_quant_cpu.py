@@ -328,3 +328,65 @@ def test_bitsandbytes_checkpoint_is_dequantised_while_loading(tmp_path, kind):
             ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
                               eos_token_id=None)[0, len(p):].tolist()
         assert list(o.outputs[0].token_ids) == ref, (kind, p)
+
+
+def _mxfp4_quantise(w: torch.Tensor):
+    """-> (packed uint8 [N, K/2], e8m0 scales uint8 [N, K/32], dequantised fp32)."""
+    grid = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+    N, K = w.shape
+    b = w.float().reshape(N, K // 32, 32)
+    e = torch.floor(torch.log2(b.abs().amax(-1, keepdim=True).clamp(min=2.0 ** -100))) - 2
+    s = torch.exp2(e)
+    v = (b / s).clamp(-6, 6)
+    idx = (v.abs().unsqueeze(-1) - grid).abs().argmin(-1)
+    codes = (idx + 8 * (v < 0)).to(torch.uint8).reshape(N, K)
+    packed = codes[:, 0::2] | (codes[:, 1::2] << 4)
+    deq = (grid[idx] * torch.where(v < 0, -1.0, 1.0) * s).reshape(N, K)
+    return packed.contiguous(), (e.reshape(N, K // 32) + 127).to(torch.uint8), deq
+
+
+def test_mxfp4_rounding_of_activations_lands_on_the_grid():
+    from vllm_distributed_amd.models.dequant import dequantize_mxfp4, quant_dequant_mxfp4
+    torch.manual_seed(0)
+    x = torch.randn(6, 64) * 3
+    y = quant_dequant_mxfp4(x)
+    packed, sc, deq = _mxfp4_quantise(y)                 # already representable: quantising again changes nothing
+    assert torch.equal(deq, y)
+    assert torch.equal(dequantize_mxfp4(packed, sc, torch.float32), y)
+    assert float((y - x).abs().max()) <= float(x.abs().max()) / 4
+    assert torch.equal(quant_dequant_mxfp4(torch.zeros(2, 32)), torch.zeros(2, 32))
+
+
+def test_quark_mxfp4_checkpoint_is_dequantised_while_loading(tmp_path):
+    """A quark microscaling-fp4 checkpoint (uint8 `weight` with two codes per byte, uint8 `weight_scale`
+    exponents; lm_head excluded) decodes to the tokens of the HF model holding the dequantised weights.
+    quark is not installed: its own exporter is unpinned, the layout follows the reference's
+    quark_w4a4_mxfp4.py / mxfp4_utils.py."""
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    out = {}
+    for name, t in sd.items():
+        if not (name.endswith("_proj.weight") and t.dim() == 2):
+            out[name] = t
+            continue
+        prefix = name[: -len(".weight")]
+        out[name], out[prefix + ".weight_scale"], deq = _mxfp4_quantise(t.float())
+        with torch.no_grad():
+            hf.get_submodule(prefix).weight.copy_(deq)
+    save_file(out, os.path.join(path, "model.safetensors"))
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    spec = {"dtype": "fp4", "group_size": 32, "scale_format": "e8m0", "qscheme": "per_group", "is_dynamic": False}
+    cfg["quantization_config"] = {"quant_method": "quark", "exclude": ["lm_head"],
+                                  "global_quant_config": {"weight": spec, "input_tensors": dict(spec, is_dynamic=True)}}
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, p

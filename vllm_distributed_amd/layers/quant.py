@@ -199,6 +199,13 @@ def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
         return LoadTimeDequant(q, dict(hf_q or {}))
     if q == "fp8":
         return Fp8Config.from_config(hf_q) if hf_q else Fp8Config(False, "dynamic")
+    if q == "quark":
+        wq = ((hf_q or {}).get("global_quant_config") or {}).get("weight") or {}
+        if isinstance(wq, dict) and wq.get("dtype") == "fp4":
+            if int(wq.get("group_size", 32)) != 32 or wq.get("scale_format", "e8m0") != "e8m0":
+                raise ValueError("quark fp4: only the microscaling layout (groups of 32, e8m0 scales) is supported")
+            from ..models.dequant import LoadTimeDequant
+            return LoadTimeDequant("mxfp4", dict(hf_q or {}))
     if q in ("compressed-tensors", "quark"):
         # accept only the plain per-tensor fp8 flavour of these container formats
         groups = (hf_q or {}).get("config_groups") or {}

@@ -88,6 +88,42 @@ def dequantize_block_fp8(weight, scale_inv, block: tuple[int, int], dtype: torch
     return (weight.to(torch.float32) * s).to(dtype)
 
 
+_E2M1 = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0)
+MX_BLOCK = 32
+
+
+def dequantize_mxfp4(packed: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """OCP microscaling fp4: ``packed`` uint8 [N, K/2] holds two E2M1 codes per byte (element 2i in the low
+    nibble), ``scale`` uint8 [N, K/32] one E8M0 exponent (2^(s-127)) per 32 elements.
+    Reference: vllm/model_executor/layers/quantization/utils/mxfp4_utils.py (dequant_mxfp4)."""
+    if packed.dtype != torch.uint8 or scale.dtype != torch.uint8:
+        raise ValueError("mxfp4: packed weights and scales are uint8")
+    N, K2 = packed.shape
+    if scale.shape != (N, 2 * K2 // MX_BLOCK):
+        raise ValueError(f"mxfp4: scale shape {tuple(scale.shape)} does not match weights {tuple(packed.shape)}")
+    lut = torch.tensor(_E2M1, dtype=torch.float32, device=packed.device)
+    codes = torch.stack((packed & 15, packed >> 4), dim=-1).reshape(N, 2 * K2).long()
+    s = torch.exp2(scale.to(torch.float32) - 127.0)
+    return (lut[codes].view(N, -1, MX_BLOCK) * s.unsqueeze(-1)).view(N, 2 * K2).to(dtype)
+
+
+def quant_dequant_mxfp4(x: torch.Tensor) -> torch.Tensor:
+    """Round ``x`` to what microscaling fp4 can hold (shared power-of-two scale per 32 elements of the last
+    dimension, E2M1 elements, round to nearest even) and return it in x's dtype: what a W4A4 checkpoint's
+    activations see.  Reference: mxfp4_utils.py (quant_dequant_mxfp4)."""
+    shape = x.shape
+    b = x.float().reshape(-1, MX_BLOCK)
+    amax = b.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp(min=2.0 ** -126))) - 2.0        # 6 = 1.5 * 2^2 is the largest element
+    s = torch.exp2(e.clamp(-127.0, 127.0))
+    v = (b / s).clamp(-6.0, 6.0)
+    a = v.abs()
+    # E2M1 grid: steps of 0.5 below 2, of 1 below 4, of 2 up to 6
+    step = torch.where(a < 2.0, 0.5, torch.where(a < 4.0, 1.0, 2.0))
+    q = torch.round(a / step) * step
+    return (torch.sign(v) * q * s).reshape(shape).to(x.dtype)
+
+
 def dequantize_bnb4(packed: torch.Tensor, absmax: torch.Tensor, quant_map: torch.Tensor, state: dict,
                     nested_absmax: Optional[torch.Tensor], nested_quant_map: Optional[torch.Tensor],
                     dtype: torch.dtype) -> torch.Tensor:
@@ -159,8 +195,9 @@ class Int4LinearMethod:
 class LoadTimeDequant:
     """What the loader needs to know about a weight-only format.  4-bit GPTQ / AWQ linear layers without
     activation reordering keep their 4-bit weights (repacked for the W4A16 kernel, ``Int4LinearMethod``);
-    everything else (2/8-bit, act-order, expert weights, block fp8) is expanded to 16 bit while loading,
-    so those layers are ordinary ones."""
+    everything else (2/8-bit, act-order, expert weights, block fp8, microscaling fp4) is expanded to 16 bit
+    while loading, so those layers are ordinary ones.  Microscaling fp4 checkpoints calibrated for 4-bit
+    activations run with 16-bit activations here (``quant_dequant_mxfp4`` is the rounding they assume)."""
 
     def __init__(self, method: str, cfg: dict):
         self.method = method
@@ -239,8 +276,13 @@ class LoadTimeDequant:
             return
         pending: dict[str, dict[str, torch.Tensor]] = {}
         parts = ("qweight", "qzeros", "scales", "g_idx", "weight_scale_inv")
+        mx = self.method == "mxfp4"
 
         def finish(prefix: str, d: dict):
+            if mx:
+                if "weight" in d and "weight_scale" in d:
+                    return dequantize_mxfp4(d["weight"], d["weight_scale"], dtype)
+                return None
             if self.method == "fp8":
                 if "weight" in d and "weight_scale_inv" in d:
                     return dequantize_block_fp8(d["weight"], d["weight_scale_inv"], self.block, dtype)
@@ -266,13 +308,15 @@ class LoadTimeDequant:
         for name, t in weights:
             prefix, _, leaf = name.rpartition(".")
             held = leaf in parts or (self.method == "fp8" and leaf == "weight" and t.dtype == torch.float8_e4m3fn)
+            if mx:      # excluded layers keep 16-bit weights and pass through
+                held = leaf in ("weight", "weight_scale") and t.dtype == torch.uint8
             if not held:
                 yield name, t
                 continue
             d = pending.setdefault(prefix, {})
             d[leaf] = t
             # GPTQ: g_idx may come last, so integer formats are completed at the end unless it is here
-            ready = self.method in ("fp8", "awq") or "g_idx" in d
+            ready = self.method in ("fp8", "awq", "mxfp4") or "g_idx" in d
             if ready:
                 w = finish(prefix, d)
                 if w is not None:
