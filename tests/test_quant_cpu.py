@@ -390,3 +390,48 @@ def test_quark_mxfp4_checkpoint_is_dequantised_while_loading(tmp_path):
             ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
                               eos_token_id=None)[0, len(p):].tolist()
         assert list(o.outputs[0].token_ids) == ref, p
+
+
+def test_modelopt_nvfp4_checkpoint_is_dequantised_while_loading(tmp_path):
+    """ModelOpt NVFP4 layout (uint8 `weight`, fp8 `weight_scale` per 16, fp32 `weight_scale_2` and
+    `input_scale`; names as the reference's modelopt.py registers them, the exporter itself is not
+    installed) decodes to the tokens of the HF model holding the dequantised weights."""
+    grid = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    out = {}
+    for name, t in sd.items():
+        if not (name.endswith("_proj.weight") and t.dim() == 2):
+            out[name] = t
+            continue
+        prefix = name[: -len(".weight")]
+        N, K = t.shape
+        g2 = t.abs().max().float() / (6.0 * 448.0)
+        b = t.float().reshape(N, K // 16, 16)
+        sc = (b.abs().amax(-1) / 6.0 / g2).clamp(min=2.0 ** -9).to(torch.float8_e4m3fn)
+        s = sc.float().unsqueeze(-1) * g2
+        v = (b / s).clamp(-6, 6)
+        idx = (v.abs().unsqueeze(-1) - grid).abs().argmin(-1)
+        codes = (idx + 8 * (v < 0)).to(torch.uint8).reshape(N, K)
+        out[name] = (codes[:, 0::2] | (codes[:, 1::2] << 4)).contiguous()
+        out[prefix + ".weight_scale"] = sc
+        out[prefix + ".weight_scale_2"] = g2.reshape(())
+        out[prefix + ".input_scale"] = torch.tensor(0.01)
+        with torch.no_grad():
+            hf.get_submodule(prefix).weight.copy_((grid[idx] * torch.where(v < 0, -1.0, 1.0) * s).reshape(N, K))
+    save_file(out, os.path.join(path, "model.safetensors"))
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    cfg["quantization_config"] = {"quant_method": "modelopt", "quant_algo": "NVFP4", "group_size": 16,
+                                  "kv_cache_quant_algo": None, "exclude_modules": ["lm_head"]}
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, p

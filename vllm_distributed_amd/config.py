@@ -216,9 +216,14 @@ class ModelConfig:
                 self.quantization = str(qc.get("quant_method", "")).lower() or None
         if self.quantization in ("awq_marlin", "gptq_marlin"):
             self.quantization = self.quantization.split("_")[0]
-        if self.quantization not in (None, "fp8", "compressed-tensors", "quark", "awq", "gptq", "bitsandbytes"):
-            raise ValueError(f"unsupported quantization {self.quantization!r} "
-                             "(supported: fp8, compressed-tensors, quark, awq, gptq, bitsandbytes)")
+        if self.quantization == "modelopt":
+            # ModelOpt exports name the scheme in quant_algo: FP8 is the plain per-tensor fp8 layout
+            algo = str((hf.get("quantization_config") or {}).get("quant_algo", "FP8")).upper()
+            self.quantization = "modelopt_fp4" if "FP4" in algo else "fp8"
+        if self.quantization not in (None, "fp8", "compressed-tensors", "quark", "awq", "gptq", "bitsandbytes",
+                                     "modelopt_fp4"):
+            raise ValueError(f"unsupported quantization {self.quantization!r} (supported: fp8, compressed-tensors, "
+                             "quark, awq, gptq, bitsandbytes, modelopt, modelopt_fp4)")
         if self.served_model_name is None:
             self.served_model_name = self.model
         if self.task == "auto":

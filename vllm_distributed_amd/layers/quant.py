@@ -193,10 +193,18 @@ def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
     if q == "bitsandbytes" and not hf_q:
         raise ValueError("bitsandbytes: only pre-quantised checkpoints are supported (their weights are expanded "
                          "to 16 bit while loading); for on-the-fly quantisation use quantization='fp8'")
+    if q == "modelopt_fp4":
+        if int((hf_q or {}).get("group_size", 16) or 16) != 16:
+            raise ValueError("modelopt fp4: only groups of 16 (NVFP4) are supported")
+        from ..models.dequant import LoadTimeDequant
+        return LoadTimeDequant("nvfp4", dict(hf_q or {}))
     if q in ("awq", "gptq", "bitsandbytes") or (q == "fp8" and hf_q and hf_q.get("weight_block_size")):
         # weight-only formats without a kernel of their own: dequantised while the checkpoint loads
         from ..models.dequant import LoadTimeDequant
         return LoadTimeDequant(q, dict(hf_q or {}))
+    if q == "fp8" and hf_q and str(hf_q.get("quant_method", "")).lower() == "modelopt":
+        # ModelOpt FP8 export: fp8 weights with per-tensor weight_scale and a calibrated input_scale
+        return Fp8Config(True, "static", list(hf_q.get("exclude_modules") or []))
     if q == "fp8":
         return Fp8Config.from_config(hf_q) if hf_q else Fp8Config(False, "dynamic")
     if q == "quark":

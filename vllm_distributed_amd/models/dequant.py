@@ -107,6 +107,20 @@ def dequantize_mxfp4(packed: torch.Tensor, scale: torch.Tensor, dtype: torch.dty
     return (lut[codes].view(N, -1, MX_BLOCK) * s.unsqueeze(-1)).view(N, 2 * K2).to(dtype)
 
 
+def dequantize_nvfp4(packed: torch.Tensor, scale: torch.Tensor, global_scale: torch.Tensor,
+                     dtype: torch.dtype) -> torch.Tensor:
+    """NVFP4: E2M1 codes two per byte (element 2i in the low nibble) [N, K/2], one fp8-e4m3 scale per 16
+    elements [N, K/16], and a per-tensor fp32 scale multiplying them.
+    Reference: vllm/model_executor/layers/quantization/modelopt.py (ModelOptNvFp4LinearMethod)."""
+    N, K2 = packed.shape
+    if packed.dtype != torch.uint8 or scale.shape != (N, 2 * K2 // 16):
+        raise ValueError(f"nvfp4: weights {tuple(packed.shape)} {packed.dtype} / scales {tuple(scale.shape)} mismatch")
+    lut = torch.tensor(_E2M1, dtype=torch.float32, device=packed.device)
+    codes = torch.stack((packed & 15, packed >> 4), dim=-1).reshape(N, 2 * K2).long()
+    s = scale.to(torch.float32) * global_scale.to(torch.float32).max()
+    return (lut[codes].view(N, -1, 16) * s.unsqueeze(-1)).view(N, 2 * K2).to(dtype)
+
+
 def quant_dequant_mxfp4(x: torch.Tensor) -> torch.Tensor:
     """Round ``x`` to what microscaling fp4 can hold (shared power-of-two scale per 32 elements of the last
     dimension, E2M1 elements, round to nearest even) and return it in x's dtype: what a W4A4 checkpoint's
@@ -277,8 +291,13 @@ class LoadTimeDequant:
         pending: dict[str, dict[str, torch.Tensor]] = {}
         parts = ("qweight", "qzeros", "scales", "g_idx", "weight_scale_inv")
         mx = self.method == "mxfp4"
+        nv = self.method == "nvfp4"
 
         def finish(prefix: str, d: dict):
+            if nv:
+                if all(k in d for k in ("weight", "weight_scale", "weight_scale_2")):
+                    return dequantize_nvfp4(d["weight"], d["weight_scale"], d["weight_scale_2"], dtype)
+                return None
             if mx:
                 if "weight" in d and "weight_scale" in d:
                     return dequantize_mxfp4(d["weight"], d["weight_scale"], dtype)
@@ -310,13 +329,18 @@ class LoadTimeDequant:
             held = leaf in parts or (self.method == "fp8" and leaf == "weight" and t.dtype == torch.float8_e4m3fn)
             if mx:      # excluded layers keep 16-bit weights and pass through
                 held = leaf in ("weight", "weight_scale") and t.dtype == torch.uint8
+            if nv:
+                if leaf == "input_scale":       # calibrated for 4-bit activations; activations stay 16-bit here
+                    continue
+                held = (leaf == "weight" and t.dtype == torch.uint8) or leaf == "weight_scale_2" \
+                    or (leaf == "weight_scale" and t.dtype == torch.float8_e4m3fn)
             if not held:
                 yield name, t
                 continue
             d = pending.setdefault(prefix, {})
             d[leaf] = t
             # GPTQ: g_idx may come last, so integer formats are completed at the end unless it is here
-            ready = self.method in ("fp8", "awq", "mxfp4") or "g_idx" in d
+            ready = self.method in ("fp8", "awq", "mxfp4", "nvfp4") or "g_idx" in d
             if ready:
                 w = finish(prefix, d)
                 if w is not None:
