@@ -6,6 +6,13 @@ of requests is admitted at once and run to completion through the whole engine
 reported value is generated tokens per second over the timed rounds, aggregate
 over all GPUs; p50 TTFT / ITL of the timed rounds are reported alongside.
 
+A round of the 70B model takes tens of seconds, so the process works against a
+wall-clock budget (--time-budget, start-up included): warm-up and timed rounds
+that would not fit are dropped, at least one warm-up and three timed rounds
+always run, and a complete JSON line is printed (flushed) after every timed
+round with the number of rounds really timed in "steps", so the last line of
+stdout is the result whenever the process ends.
+
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29511 bench.py --gpus 8 --steps 3 --warmup 1
@@ -23,6 +30,13 @@ if ROOT not in sys.path:
 os.environ.setdefault("VLLM_ENABLE_V1_MULTIPROCESSING", "0")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("VLLM_LOGGING_LEVEL", "WARNING")
+T_PROCESS_START = time.time()
+
+
+def note(msg: str) -> None:
+    """Progress lines go to stderr: stdout carries only the JSON result lines."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - T_PROCESS_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main() -> None:
@@ -40,6 +54,11 @@ def main() -> None:
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
     ap.add_argument("--quantization", default=None, help="e.g. fp8 (weights quantised while loading); default: none")
     ap.add_argument("--expert-parallel", action="store_true", help="MoE models: shard experts, not expert matrices")
+    ap.add_argument("--time-budget", type=float, default=float(os.environ.get("VDA_BENCH_BUDGET_S", "420")),
+                    help="wall-clock seconds for the whole process (start-up included); warm-up and timed rounds "
+                         "that would not fit are dropped (never below one warm-up and --min-steps timed rounds) "
+                         "and the JSON line reports the rounds really run; 0 = run exactly --steps/--warmup")
+    ap.add_argument("--min-steps", type=int, default=3, help="timed rounds that run whatever the budget says")
     a = ap.parse_args()
 
     import torch
@@ -73,6 +92,7 @@ def main() -> None:
     eng = llm.llm_engine
     sp = SamplingParams(temperature=0.0, max_tokens=a.output_len, ignore_eos=True,
                         output_kind=RequestOutputKind.CUMULATIVE)
+    note(f"engine ready after {time.time() - T_PROCESS_START:.1f} s")
 
     def prompts(round_idx: int):
         # distinct synthetic prompts every round (no reuse between rounds)
@@ -84,6 +104,15 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def elapsed() -> float:
+        """Seconds since process start, the same number on every rank (the slowest rank's clock)."""
+        e = time.time() - T_PROCESS_START
+        if world > 1:
+            t = torch.tensor([e], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
 
     def one_round(idx: int):
         ps = prompts(idx)
@@ -105,49 +134,73 @@ def main() -> None:
         assert len(ntok) == a.batch and all(v == a.output_len for v in ntok.values()), "round did not complete"
         return list(first.values()), gaps
 
-    for w in range(a.warmup):
+    budget = a.time_budget
+    # ---- warm-up: at least one full round; more only while min_steps timed rounds still fit behind them ----
+    warm_done, round_s = 0, 0.0
+    for w in range(max(a.warmup, 1)):
+        if w > 0 and budget > 0 and elapsed() + round_s * (1 + max(a.min_steps, 1)) * 1.1 > budget:
+            break
+        sync()
+        t_w = time.perf_counter()
         one_round(-1 - w)
-    sync()
-    t0 = time.perf_counter()
-    ttfts, itls = [], []
-    for k in range(a.steps):
-        f, g = one_round(k)
-        ttfts += f
-        itls += g
-    sync()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    total_out = a.batch * a.output_len * a.steps
-    if rank == 0:
+        sync()
+        round_s = time.perf_counter() - t_w
+        warm_done += 1
+        note(f"warm-up round {warm_done}: {round_s:.1f} s")
+    if a.warmup == 0:
+        warm_done = 1      # one round always runs untimed: the first round pays one-time allocations
+
+    # ---- timed rounds: each bracketed by barrier + device sync; a full JSON line after every round ----
+    dt, steps_done, ttfts, itls = 0.0, 0, [], []
+
+    def report():
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d = float(t.item())
+        if rank != 0:
+            return
+        total_out = a.batch * a.output_len * steps_done
         print(json.dumps({
             "metric": "output tokens/s per node (Llama-3-70B TP=N, 1024-in/128-out)" if "70b" in a.model
             else f"output tokens/s per node ({a.model}, {a.input_len}-in/{a.output_len}-out)",
-            "value": round(total_out / dt, 2), "unit": "tokens/s", "n_gpus": a.gpus, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1000, 2), "higher_is_better": True,
+            "value": round(total_out / d, 2), "unit": "tokens/s", "n_gpus": a.gpus, "steps": steps_done,
+            "warmup": warm_done, "ms_per_step": round(d / steps_done * 1000, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16" if not a.quantization else f"bf16 activations, {a.quantization} weights",
             "data": "synthetic random token prompts, random-init weights",
             "p50_ttft_ms": round(statistics.median(ttfts) * 1000, 2),
             "p50_itl_ms": round(statistics.median(itls) * 1000, 3) if itls else None,
-            "total_tokens_per_s": round(a.batch * (a.input_len + a.output_len) * a.steps / dt, 1),
+            "total_tokens_per_s": round(a.batch * (a.input_len + a.output_len) * steps_done / d, 1),
+            "requested_steps": a.steps, "requested_warmup": a.warmup, "time_budget_s": budget,
+            "step_definition": f"one serving round: {a.batch} requests admitted at once and run to completion",
             "config": {"model": a.model, "global_batch": a.batch, "seq_len": a.input_len + a.output_len,
                        "input_len": a.input_len, "output_len": a.output_len, "parallelism": f"tp{a.gpus}"}}),
             flush=True)
+
+    for k in range(a.steps):
+        if budget > 0 and k >= a.min_steps and elapsed() + round_s * 1.1 > budget:
+            note(f"time budget: stopping after {k} of {a.steps} timed rounds")
+            break
+        sync()
+        t0 = time.perf_counter()
+        f, g = one_round(k)
+        sync()
+        r = time.perf_counter() - t0
+        dt += r
+        round_s = max(round_s * 0.5, r)
+        steps_done += 1
+        ttfts += f
+        itls += g
+        report()
     llm.shutdown()
     if world > 1 and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-    # the measurement is out; leave without running interpreter-exit destructors of the communication
-    # libraries (a helper thread still alive there aborts the process and would turn a finished run into a
-    # failed one for the launcher)
     sys.stdout.flush()
     sys.stderr.flush()
-    if os.environ.get("VDA_BENCH_SOFT_EXIT") == "1":
-        return          # under a profiler: its at-exit handlers write the trace files
-    os._exit(0)
+    if os.environ.get("VDA_BENCH_HARD_EXIT") == "1":
+        os._exit(0)
 
 
 if __name__ == "__main__":
