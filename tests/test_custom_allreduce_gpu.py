@@ -37,7 +37,7 @@ def _run_ranks(world, script):
     print(outs[0])
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_custom_allreduce_shared_gpu(world):
     _run_ranks(world, "car_worker.py")
 
@@ -46,3 +46,10 @@ def test_custom_allreduce_shared_gpu(world):
 def test_quantised_allreduce_shared_gpu(world):
     """int8 / int4 two-shot all-reduce: error within the two-rounding-step bound, graph replay."""
     _run_ranks(world, "qr_worker.py")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_peer_all_to_all_shared_gpu(world):
+    """all-to-all-v of rows through peer memory: bit-exact against the same exchange over gloo, the
+    return trip, hipGraph replay with changing counts, expert-parallel dispatch / combine round trip."""
+    _run_ranks(world, "a2a_worker.py")

@@ -84,6 +84,8 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_MLA": (_bool, True),                    # DeepSeek: latent KV cache + absorbed projections; 0 = expanded heads
     "VDA_INT4_WEIGHTS": (_bool, True),           # keep 4-bit GPTQ/AWQ linear weights packed (W4A16 kernel); 0 = expand at load
     "VDA_FP8_W8A16_MAX_M": (int, 64),            # fp8 linear: up to this M stream weights, beyond use fp8 MFMA GEMM
+    "VDA_DISABLE_PEER_ALL2ALL": (_bool, False),  # expert / token parallel row exchange through torch.distributed instead of peer memory
+    "VDA_EP_DISPATCH": (_bool, True),            # expert parallel without DP attention: route tokens to expert owners (False: replicate + mask + all-reduce)
     "VDA_MOE_GROUPED_MAX_PAIRS": (int, 2048),    # (token, slot) pairs served by the grouped skinny MoE kernel
     "VLLM_FUSED_MOE_CHUNK_SIZE": (int, 32768),
     "VLLM_MOE_DP_CHUNK_SIZE": (int, 256),

@@ -116,6 +116,10 @@ class FusedMoE(nn.Module):
         if intermediate_size % self.shard_size:
             raise ValueError(f"{prefix}: intermediate size {intermediate_size} not divisible by TP {self.shard_size}")
         self.intermediate_size_per_partition = intermediate_size // self.shard_size
+        from .. import envs
+        self._ep_route = bool(envs.VDA_EP_DISPATCH)
+        self._ep_disp = None
+        self._max_tokens = int(get_current_vllm_config().scheduler_config.max_num_batched_tokens)
         qm = quant_config.get_quant_method(self, prefix) if quant_config is not None else None
         self.quant_method = qm or UnquantizedMoEMethod()
         self.quant_method.create_weights(self, self.local_num_experts, hidden_size,
@@ -191,9 +195,49 @@ class FusedMoE(nn.Module):
             return w, ids.to(torch.int32)
         return ops.moe_topk_softmax(router_logits, k, self.renormalize)
 
+    def _forward_ep_dispatch(self, x: torch.Tensor, lg: torch.Tensor) -> torch.Tensor:
+        """Expert parallel over ranks that all hold the same tokens (TP attention in front): rank r routes
+        its 1/ep slice of the tokens to the expert owners through the all-to-all-v, the owners compute,
+        the results return and are weighted at the source, and an all-gather replicates the rows again.
+        Per xGMI link: T k H / ep^2 bytes each way plus the all-gather, against the T H of an all-reduce."""
+        from ..parallel.all2all import get_expert_dispatcher
+        ep = get_ep_group()
+        T, H = x.shape
+        Tp = -(-T // self.ep_size)
+        if self._ep_disp is None:
+            self._ep_disp = get_expert_dispatcher(ep, self.local_num_experts, self.top_k, H * x.element_size(),
+                                                  -(-self._max_tokens // self.ep_size))
+        lo = self.ep_rank * Tp
+        pad = self.ep_size * Tp - T
+        if pad:
+            x = torch.nn.functional.pad(x, (0, 0, 0, pad))
+            lg = torch.nn.functional.pad(lg, (0, 0, 0, pad))
+        xs, lgs = x[lo:lo + Tp], lg[lo:lo + Tp]
+        topk_w, topk_ids = self.select_experts(lgs)
+        if self.eplb_state is not None:
+            topk_ids = self.eplb_state.map_topk(self.eplb_layer, topk_ids)
+        if pad:     # rows past T are padding: they go nowhere
+            live = (torch.arange(lo, lo + Tp, device=x.device) < T).unsqueeze(1)
+            topk_ids = torch.where(live, topk_ids, torch.full((), -1, dtype=topk_ids.dtype, device=x.device))
+        if self.eplb_state is not None:
+            self.eplb_state.record(self.eplb_layer, topk_ids)
+        if self.routed_scaling_factor != 1.0:
+            topk_w = topk_w * self.routed_scaling_factor
+        recv, local_ids, st = self._ep_disp.dispatch(xs.contiguous(), topk_ids.to(torch.int32))
+        ones = torch.ones((recv.shape[0], 1), dtype=torch.float32, device=x.device)
+        y = self.quant_method.apply(self, recv, ones, local_ids)
+        out = ep.all_gather(self._ep_disp.combine(y, topk_w, st), dim=0)[:T]
+        if not self.reduce_results:
+            # the caller adds a tensor-parallel partial sum (shared experts) and all-reduces the total:
+            # hand it the complete routed output in 1 / tp parts
+            out = out / self.tp_size
+        return out
+
     def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
         x, lg = hidden_states, router_logits
         dispatch = self.dp_size > 1
+        if self.use_ep and not dispatch and self._ep_route:
+            return self._forward_ep_dispatch(x, lg)
         if dispatch:
             from ..parallel.all2all import dp_combine, dp_dispatch
             x, lg, meta = dp_dispatch(x, lg)

@@ -507,32 +507,150 @@ def moe_grouped_ok(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor) -> bool
             and w13.shape[0] <= 1024)
 
 
-def _moe_large(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale):
-    """Prefill-sized batches: sort the (token, slot) pairs by expert and run one hipBLASLt GEMM
-    pair per expert on the contiguous slices (compute bound: the library GEMM is the right tool)."""
-    T, k = topk_ids.shape
+EPI_PLAIN, EPI_GATE_UP, EPI_DOWN = 0, 1, 2
+SC_NONE, SC_TOKEN, SC_BLOCK = 0, 1, 2
+
+
+def per_group_fp8_quant(x: torch.Tensor, group: int = 128):
+    """e4m3 quantisation with one dynamic scale per ``group`` consecutive elements of a row
+    (absmax / 448).  Returns (fp8 [.., K], fp32 scales [.., K / group])."""
+    K = x.shape[-1]
+    if not _dev(x) or K % group or group % 8:
+        return R.per_group_fp8_quant(x, group)
+    x2 = _contig_last(x).view(-1, K)
+    out = torch.empty(x2.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    scales = torch.empty((x2.shape[0], K // group), dtype=torch.float32, device=x.device)
+    N.call("vda_per_group_fp8_quant", out.data_ptr(), scales.data_ptr(), x2.data_ptr(), x2.shape[0], K, group,
+           x2.stride(0), out.stride(0), N.dt(x.dtype), N.stream())
+    return out.view(x.shape), scales.view(*x.shape[:-1], K // group)
+
+
+def _tile_rows(avg_rows: float) -> int:
+    """Activation rows per tile of the tiled GEMM: 128, or 64 when the matrices see few rows each."""
+    return 64 if avg_rows <= 64 else 128
+
+
+def tile_gemm_ok(K: int, in_dtype: torch.dtype) -> bool:
+    eb = 1 if in_dtype == torch.float8_e4m3fn else 2
+    return (K * eb) % 128 == 0 and in_dtype in (torch.float8_e4m3fn, torch.bfloat16, torch.float16)
+
+
+def fp8_gemm(xq: torch.Tensor, w: torch.Tensor, x_scale: torch.Tensor, w_scale: torch.Tensor,
+             out_dtype: torch.dtype, bias: Optional[torch.Tensor] = None, block: bool = False) -> torch.Tensor:
+    """y = (xq * x_scale) @ (w * w_scale).T on the fp8 matrix cores.  xq [M, K] e4m3, w [N, K] e4m3.
+    ``block=False``: x_scale per row [M] (or one element, broadcast), w_scale one element.
+    ``block=True``: x_scale [M, K/128] (groups of 128 along K), w_scale [ceil(N/128), K/128]."""
+    M, K = xq.shape
+    N_ = w.shape[0]
+    if not _dev(xq) or not tile_gemm_ok(K, xq.dtype) or xq.stride(1) != 1 or (xq.stride(0) % 16) or N_ % 4:
+        return R.fp8_gemm(xq, w, x_scale, w_scale, out_dtype, bias, block)
+    xs = x_scale.reshape(M, -1) if block else (x_scale.reshape(-1) if x_scale.numel() == M
+                                               else x_scale.reshape(1).expand(M))
+    xs = xs.contiguous().float()
+    ws = w_scale.contiguous().float() if block else w_scale.reshape(1).float()
+    out = torch.empty((M, N_), dtype=out_dtype, device=xq.device)
+    N.call("vda_tile_gemm", out.data_ptr(), xq.data_ptr(), w.data_ptr(), xs.data_ptr(), ws.data_ptr(), None,
+           N.ptr(bias), None, None, None, None, None, M, N_, K, 1, 0, xq.stride(0), out.stride(0), 0, EPI_PLAIN,
+           SC_BLOCK if block else SC_TOKEN, _tile_rows(M), N.dt(xq.dtype), N.dt(out_dtype), N.stream())
+    return out
+
+
+def sort_by_key(keys: torch.Tensor, num_keys: int):
+    """Counting sort of positions by key: returns (sorted positions int32 [n], offsets int32
+    [num_keys + 1]); positions with a negative key are left out (they sit past offsets[num_keys])."""
+    keys = keys.contiguous().view(-1)
+    n = keys.numel()
+    if not _dev(keys):
+        k64 = keys.long()
+        order = torch.argsort(torch.where(k64 < 0, num_keys, k64), stable=True).to(torch.int32)
+        cnt = torch.bincount(k64[k64 >= 0], minlength=num_keys)
+        off = torch.zeros(num_keys + 1, dtype=torch.int32, device=keys.device)
+        off[1:] = cnt.cumsum(0).to(torch.int32)
+        return order, off
+    keys = keys.to(torch.int32)
+    sorted_ids = torch.zeros(n, dtype=torch.int32, device=keys.device)
+    meta = torch.empty(3 * num_keys + 2, dtype=torch.int32, device=keys.device)
+    offsets = meta[:num_keys + 1]
+    if n > 4096:
+        N.call("vda_moe_align_large", sorted_ids.data_ptr(), offsets.data_ptr(), meta[num_keys + 1:].data_ptr(),
+               meta[2 * num_keys + 1:].data_ptr(), keys.data_ptr(), n, num_keys, N.stream())
+    else:
+        N.call("vda_moe_align", sorted_ids.data_ptr(), offsets.data_ptr(), keys.data_ptr(), n, num_keys, N.stream())
+    return sorted_ids, offsets
+
+
+def moe_align_tiles(topk_ids: torch.Tensor, E: int, rows_per_tile: int):
+    """Sort the (token, slot) pairs by expert and cut every expert's range into m-tiles of
+    ``rows_per_tile`` pairs.  Returns (sorted ids, offsets [E + 1], tile table, bound on tiles);
+    everything stays on the device, nothing synchronises."""
+    ids = topk_ids.contiguous().view(-1)
+    n = ids.numel()
+    dev = ids.device
+    sorted_ids = torch.empty(n, dtype=torch.int32, device=dev)
+    meta = torch.empty(3 * E + 2, dtype=torch.int32, device=dev)
+    offsets, counts, cursor = meta[:E + 1], meta[E + 1:2 * E + 1], meta[2 * E + 1:3 * E + 1]
+    st = N.stream()
+    if n > 4096:
+        N.call("vda_moe_align_large", sorted_ids.data_ptr(), offsets.data_ptr(), counts.data_ptr(), cursor.data_ptr(),
+               ids.data_ptr(), n, E, st)
+    else:
+        N.call("vda_moe_align", sorted_ids.data_ptr(), offsets.data_ptr(), ids.data_ptr(), n, E, st)
+    max_tiles = min(n, n // rows_per_tile + E)
+    tiles = torch.empty(3 * max_tiles + 1, dtype=torch.int32, device=dev)
+    N.call("vda_moe_tile_map", tiles[:max_tiles].data_ptr(), tiles[max_tiles:2 * max_tiles].data_ptr(),
+           tiles[2 * max_tiles:3 * max_tiles].data_ptr(), tiles[3 * max_tiles:].data_ptr(), offsets.data_ptr(), E,
+           rows_per_tile, max_tiles, st)
+    return sorted_ids, offsets, tiles, max_tiles
+
+
+def _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales: bool = False):
+    """Compute-bound batches: both expert GEMMs run as LDS-tiled MFMA GEMMs over the expert-sorted pairs
+    (ops/csrc/gemm_tile.hip).  e4m3 weights: activations are quantised per token (or per group of 128
+    with block-scaled weights) and the fp8 matrix cores do the products; 16-bit weights: 16-bit MFMA."""
+    T, H = x.shape
+    k = topk_ids.shape[1]
     E, I2, _ = w13.shape
     I = I2 // 2
-    flat = topk_ids.reshape(-1)
-    keys = torch.where(flat < 0, E, flat)
-    order = torch.argsort(keys, stable=True)
-    counts = torch.bincount(keys, minlength=E + 1)[:E].tolist()
-    xg = x[order // k]
-    out2 = torch.zeros((T * k, w2.shape[1]), dtype=x.dtype, device=x.device)
-    s = 0
-    for e, c in enumerate(counts):
-        if c == 0:
-            continue
-        a, b = w13[e], w2[e]
-        if a.dtype == torch.float8_e4m3fn:
-            a = fp8_dequant(a, w13_scale[e:e + 1], x.dtype)
-            b = fp8_dequant(b, w2_scale[e:e + 1], x.dtype)
-        h = act_and_mul(torch.mm(xg[s:s + c], a.t()))
-        o = torch.mm(h, b.t())
-        idx = order[s:s + c]
-        out2[idx] = o * topk_w.reshape(-1)[idx].to(x.dtype).unsqueeze(1)
-        s += c
-    return out2.view(T, k, -1).sum(dim=1)
+    P_ = T * k
+    dev = x.device
+    rows = _tile_rows(P_ / E)
+    sorted_ids, _, tiles, max_tiles = moe_align_tiles(topk_ids, E, rows)
+    te, tb, tend, ntl = (tiles[:max_tiles], tiles[max_tiles:2 * max_tiles], tiles[2 * max_tiles:3 * max_tiles],
+                         tiles[3 * max_tiles:])
+    fp8 = w13.dtype == torch.float8_e4m3fn
+    st = N.stream()
+    inter = torch.empty((P_, I), dtype=x.dtype, device=dev)
+    out2 = torch.empty((P_, H), dtype=x.dtype, device=dev)
+    out = torch.empty((T, H), dtype=x.dtype, device=dev)
+    tw = topk_w.contiguous()
+    if fp8:
+        mode = SC_BLOCK if block_scales else SC_TOKEN
+        xq, xs = per_group_fp8_quant(x) if block_scales else per_token_fp8_quant(x)
+        xs = xs.contiguous()
+    else:
+        mode, xq, xs = SC_NONE, _contig_last(x), None
+    N.call("vda_tile_gemm", inter.data_ptr(), xq.data_ptr(), w13.data_ptr(), N.ptr(xs), N.ptr(w13_scale), None, None,
+           sorted_ids.data_ptr(), te.data_ptr(), tb.data_ptr(), tend.data_ptr(), ntl.data_ptr(), 0, I, H, k,
+           max_tiles, xq.stride(0), I, I2 * H, EPI_GATE_UP, mode, rows, N.dt(xq.dtype), N.dt(x.dtype), st)
+    if fp8:
+        hq, hs = per_group_fp8_quant(inter) if block_scales else per_token_fp8_quant(inter)
+        hs = hs.contiguous()
+    else:
+        hq, hs = inter, None
+    N.call("vda_tile_gemm", out2.data_ptr(), hq.data_ptr(), w2.data_ptr(), N.ptr(hs), N.ptr(w2_scale),
+           tw.data_ptr(), None, sorted_ids.data_ptr(), te.data_ptr(), tb.data_ptr(), tend.data_ptr(),
+           ntl.data_ptr(), 0, H, I, 1, max_tiles, hq.stride(0), H, H * I, EPI_DOWN, mode, rows, N.dt(hq.dtype),
+           N.dt(x.dtype), st)
+    N.call("vda_moe_sum", out.data_ptr(), out2.data_ptr(), topk_ids.contiguous().data_ptr(), T, H, k,
+           out.stride(0), N.dt(x.dtype), st)
+    return out
+
+
+def moe_tiled_ok(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor) -> bool:
+    I = w13.shape[1] // 2
+    return (x.dtype in (torch.bfloat16, torch.float16) and w13.dtype in (x.dtype, torch.float8_e4m3fn)
+            and w13.dtype == w2.dtype and tile_gemm_ok(w13.shape[2], w13.dtype) and tile_gemm_ok(I, w13.dtype)
+            and I % 64 == 0 and w2.shape[1] % 4 == 0 and w13.shape[0] <= 1024)
 
 
 def moe_rows_form(num_pairs: int, num_experts: int, rows: int, weight_bytes: int = 2) -> int:
@@ -559,22 +677,30 @@ def moe_rows_form(num_pairs: int, num_experts: int, rows: int, weight_bytes: int
 
 
 def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,
-              w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+              w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None,
+              block_scales: bool = False) -> torch.Tensor:
     """Routed SwiGLU expert MLPs.  x [T,H]; w13 [E,2I,H] (gate rows then up rows); w2 [E,H,I];
-    topk_w f32 [T,k]; topk_ids i32 [T,k] with local expert ids, negative = not on this rank."""
-    if not _dev(x) or not moe_grouped_ok(x, w13, w2):
+    topk_w f32 [T,k]; topk_ids i32 [T,k] with local expert ids, negative = not on this rank.
+    e4m3 weights carry one scale per expert, or with ``block_scales`` one per 128 x 128 block
+    (w13_scale [E, 2I/128, H/128], w2_scale [E, H/128, I/128])."""
+    if _dev(x) and block_scales and not moe_tiled_ok(x, w13, w2):
+        raise RuntimeError(f"block-scaled expert shapes {tuple(w13.shape)} / {tuple(w2.shape)} are outside the tiled "
+                           "fp8 GEMM (hidden and expert width must be multiples of 128)")
+    if not _dev(x) or (not moe_grouped_ok(x, w13, w2) and not moe_tiled_ok(x, w13, w2)):
         if _dev(x) and torch.cuda.is_current_stream_capturing():
             raise RuntimeError(
                 f"expert shapes {tuple(w13.shape)} / {tuple(w2.shape)} are outside the grouped MoE kernel (hidden and "
                 "expert width must be multiples of 128); the PyTorch fallback synchronises and cannot be captured "
                 "into a hipGraph: run with enforce_eager=True")
-        return R.fused_moe(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale)
+        return R.fused_moe(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales)
+    if not moe_grouped_ok(x, w13, w2):
+        return _moe_tiled(_contig_last(x), w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales)
     T, H = x.shape
     k = topk_ids.shape[1]
     E, I2, _ = w13.shape
     I = I2 // 2
-    if T * k > envs.VDA_MOE_GROUPED_MAX_PAIRS:
-        return _moe_large(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale)
+    if T * k > envs.VDA_MOE_GROUPED_MAX_PAIRS or block_scales:
+        return _moe_tiled(_contig_last(x), w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales)
     x = _contig_last(x)
     dev = x.device
     ids = topk_ids.contiguous()

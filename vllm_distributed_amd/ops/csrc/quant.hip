@@ -136,6 +136,57 @@ VDA_EXPORT int vda_per_token_fp8_quant(void* out, float* scales, const void* in,
   return 0;
 }
 
+// e4m3 with one dynamic scale per `group` consecutive elements of a row (group % 8 == 0, a power of two
+// times 8 up to 512): group / 8 lanes share a group, each lane 8 elements, scale = absmax / 448.  The
+// activation side of block-scaled fp8 GEMMs (1 x 128 groups).  Role of the reference's Triton
+// per_token_group_quant_fp8 (vllm/model_executor/layers/quantization/utils/fp8_utils.py:357).
+template <typename T>
+__global__ __launch_bounds__(256) void quant_per_group_kernel(uint8_t* __restrict__ out, float* __restrict__ scales,
+                                                              const T* __restrict__ in, int rows, int H, int group,
+                                                              long in_stride, long out_stride) {
+  using V8 = typename Vec<T>::v8;
+  const int lpg = group >> 3;                      // lanes per group (a power of two <= 64)
+  const int gpr = H / group;                       // groups per row
+  const long vec = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)rows * gpr * lpg;
+  const bool live = vec < total;
+  const long gidx = vec / lpg;
+  const int l = (int)(vec % lpg);
+  const long row = gidx / gpr;
+  const int gi = (int)(gidx % gpr);
+  V8 x = V8{};
+  if (live) x = ld16<V8>(in + row * in_stride + (long)gi * group + 8 * l);
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)x[j]));
+  for (int o = lpg >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const float scale = fmaxf(m / 448.f, 1.f / (448.f * 512.f));
+  const float inv = 1.f / scale;
+  if (!live) return;
+  u32x2 o;
+  o[0] = pack_fp8x4((float)x[0] * inv, (float)x[1] * inv, (float)x[2] * inv, (float)x[3] * inv);
+  o[1] = pack_fp8x4((float)x[4] * inv, (float)x[5] * inv, (float)x[6] * inv, (float)x[7] * inv);
+  *reinterpret_cast<u32x2*>(out + row * out_stride + (long)gi * group + 8 * l) = o;
+  if (l == 0) scales[row * gpr + gi] = scale;
+}
+
+VDA_EXPORT int vda_per_group_fp8_quant(void* out, float* scales, const void* in, int rows, int H, int group,
+                                       long in_stride, long out_stride, int dtype, hipStream_t st) {
+  if (group < 8 || group > 512 || (group & (group - 1)) || H % group) return -1;
+  if (rows == 0) return 0;
+  const long total = (long)rows * (H / 8);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype == VDA_BF16)
+    hipLaunchKernelGGL(quant_per_group_kernel<bf16_t>, grid, block, 0, st, (uint8_t*)out, scales, (const bf16_t*)in,
+                       rows, H, group, in_stride, out_stride);
+  else if (dtype == VDA_F16)
+    hipLaunchKernelGGL(quant_per_group_kernel<f16_t>, grid, block, 0, st, (uint8_t*)out, scales, (const f16_t*)in,
+                       rows, H, group, in_stride, out_stride);
+  else return -3;
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
 // int8: one workgroup per token row.  Dynamic: scale[row] = max(|row|)/127 and the scale is written
 // out; static: the given scale is used for every row.  Values are rounded to nearest and saturated.
 // Role of the reference's csrc/quantization/compressed_tensors/int8_quant_kernels.cu:109-338

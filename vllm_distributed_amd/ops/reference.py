@@ -262,6 +262,40 @@ def fp8_dequant(q, scale, dtype):
     return (q.float() * scale).to(dtype)
 
 
+def per_group_fp8_quant(x, group: int = 128):
+    """One dynamic scale per ``group`` consecutive elements of a row (the last group may be short)."""
+    K = x.shape[-1]
+    ng = -(-K // group)
+    xf = x.float()
+    pad = ng * group - K
+    if pad:
+        xf = F.pad(xf, (0, pad))
+    g = xf.reshape(*x.shape[:-1], ng, group)
+    scale = (g.abs().amax(dim=-1, keepdim=True) / FP8_MAX).clamp(min=1.0 / (FP8_MAX * 512.0))
+    q = (g / scale).clamp(-FP8_MAX, FP8_MAX).reshape(*x.shape[:-1], ng * group)[..., :K].to(torch.float8_e4m3fn)
+    return q, scale.squeeze(-1)
+
+
+def expand_block_scales(scale: torch.Tensor, rows: int, cols: int, block: int = 128) -> torch.Tensor:
+    """[.., ceil(rows/block), ceil(cols/block)] block scales -> one scale per element [.., rows, cols]."""
+    s = scale.repeat_interleave(block, dim=-2).repeat_interleave(block, dim=-1)
+    return s[..., :rows, :cols]
+
+
+def fp8_gemm(xq, w, x_scale, w_scale, out_dtype, bias=None, block: bool = False):
+    M, K = xq.shape
+    if block:
+        xf = xq.float() * x_scale.reshape(M, -1).float().repeat_interleave(128, dim=1)[:, :K]
+        wf = w.float() * expand_block_scales(w_scale.float(), w.shape[0], K)
+    else:
+        xf = xq.float() * (x_scale.reshape(-1, 1).float() if x_scale.numel() == M else x_scale.reshape(()).float())
+        wf = w.float() * w_scale.reshape(()).float()
+    y = xf @ wf.t()
+    if bias is not None:
+        y = y + bias.float()
+    return y.to(out_dtype)
+
+
 def skinny_gemm(x, w, bias=None, w_scale=None):
     if w.dtype == torch.float8_e4m3fn:
         w = (w.float() * (w_scale.float() if w_scale is not None else 1.0)).to(x.dtype)
@@ -278,9 +312,11 @@ def moe_topk_softmax(logits: torch.Tensor, k: int, renormalize: bool):
 
 
 def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,
-              w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+              w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None,
+              block_scales: bool = False) -> torch.Tensor:
     """out[t] = sum_j topk_w[t, j] * W2_e( silu(Wg_e x_t) * (Wu_e x_t) ), e = topk_ids[t, j];
-    negative ids (expert on another rank) contribute nothing.  fp32 accumulation."""
+    negative ids (expert on another rank) contribute nothing.  fp32 accumulation.  ``block_scales``:
+    the weight scales are per 128 x 128 block instead of per expert."""
     T, H = x.shape
     E, I2, _ = w13.shape
     I = I2 // 2
@@ -290,8 +326,12 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
         tok, slot = torch.where(topk_ids == e)
         if tok.numel() == 0:
             continue
-        a = w13[e].float() * (w13_scale[e].float() if w13_scale is not None else 1.0)
-        b = w2[e].float() * (w2_scale[e].float() if w2_scale is not None else 1.0)
+        if block_scales:
+            a = w13[e].float() * expand_block_scales(w13_scale[e].float(), I2, H)
+            b = w2[e].float() * expand_block_scales(w2_scale[e].float(), w2.shape[1], I)
+        else:
+            a = w13[e].float() * (w13_scale[e].float() if w13_scale is not None else 1.0)
+            b = w2[e].float() * (w2_scale[e].float() if w2_scale is not None else 1.0)
         h = xf[tok] @ a.t()
         act = (torch.nn.functional.silu(h[:, :I]) * h[:, I:]).to(x.dtype).float()
         out.index_add_(0, tok, (act @ b.t()) * topk_w[tok, slot].float().unsqueeze(1))

@@ -6,8 +6,9 @@ reduce-scatter of the partial expert outputs -- two large collectives per layer 
 per-peer sends.  Replicas pad to the largest token count of the step (known from the forward
 context; all replicas enter every step together in lock-step mode).
 
-``AllToAllManager`` additionally offers a true variable-split all-to-all (``all_to_all_single``)
-for callers that route tokens to expert owners explicitly.
+``RowExchange`` is the all-to-all-v of rows (peer memory over xGMI on one node, torch.distributed
+otherwise) and ``ExpertDispatcher`` the expert-parallel dispatch / combine built on it: tokens go
+to the ranks that own their experts instead of every rank seeing every token.
 Reference: vllm/distributed/device_communicators/all2all.py (NaiveAll2AllManager :14-79,
 pplx / DeepEP managers :82-), vllm/model_executor/layers/fused_moe/layer.py:1470-1494.
 """
@@ -18,8 +19,12 @@ from typing import Optional
 
 import torch
 
+from .. import envs
 from ..forward_context import get_forward_context
+from ..logger import init_logger
 from .state import GroupCoordinator, get_dp_group
+
+logger = init_logger(__name__)
 
 
 @dataclass
@@ -67,29 +72,157 @@ def dp_combine(out: torch.Tensor, meta: DispatchMeta) -> torch.Tensor:
     return mine[: meta.sizes[meta.rank]]
 
 
-class AllToAllManager:
-    """Variable-split all-to-all over a group (expert-owner routing)."""
+class RowExchange:
+    """All-to-all-v of rows over a group with fixed result slots: ``recv[src * cap + j]`` is the j-th row
+    rank ``src`` sent here.  On GPUs of one node the rows move through peer memory over xGMI
+    (``PeerAllToAll``: no host sync, hipGraph-capturable); otherwise (CPU tensors, several nodes, the
+    one-device rehearsal when the kernel is unavailable) the same contract is served by padded
+    ``all_to_all_single`` calls of torch.distributed."""
 
-    def __init__(self, group: GroupCoordinator):
+    def __init__(self, group: GroupCoordinator, cap: int, row_bytes: int):
         self.group = group
+        self.world, self.rank = group.world_size, group.rank_in_group
+        self.cap, self.row_bytes = int(cap), int(row_bytes)
+        self.peer = None
+        if group.device.type == "cuda" and self.world > 1 and not envs.VDA_DISABLE_PEER_ALL2ALL:
+            from .custom_allreduce import PeerAllToAll
+            try:
+                self.peer = PeerAllToAll.maybe_create(group.cpu_group, group.device, self.cap, self.row_bytes)
+            except Exception as e:   # noqa: BLE001
+                logger.warning("peer-memory all-to-all unavailable for group %s: %s", group.name, e)
 
-    def exchange_counts(self, send_counts: torch.Tensor) -> torch.Tensor:
-        recv = torch.empty_like(send_counts)
-        self.group.all_to_all_single(recv, send_counts)
-        return recv
+    # ---- host / torch.distributed form of the same contract -------------------------------------------
+    def _host_exchange(self, send: torch.Tensor, counts: torch.Tensor, meta: Optional[torch.Tensor]):
+        """send [world, cap, W] padded regions by destination, counts [world]."""
+        g = self.group
+        recv = torch.empty_like(send)
+        g.all_to_all_single(recv.view(-1, send.shape[-1]), send.view(-1, send.shape[-1]))
+        rc = torch.empty_like(counts)
+        g.all_to_all_single(rc, counts)
+        rmeta = None
+        if meta is not None:
+            rmeta = torch.empty_like(meta)
+            g.all_to_all_single(rmeta.view(-1), meta.view(-1))
+        return recv, rmeta, rc
 
-    def dispatch(self, rows: torch.Tensor, send_counts: list[int], recv_counts: Optional[list[int]] = None
-                 ) -> tuple[torch.Tensor, list[int]]:
-        """``rows`` sorted by destination rank; returns the rows received and their per-source counts."""
-        if recv_counts is None:
-            sc = torch.tensor(send_counts, dtype=torch.int64, device=rows.device)
-            recv_counts = self.exchange_counts(sc).tolist()
-        out = torch.empty((sum(recv_counts), *rows.shape[1:]), dtype=rows.dtype, device=rows.device)
-        self.group.all_to_all_single(out, rows, recv_counts, send_counts)
-        return out, recv_counts
+    def exchange(self, x: torch.Tensor, sorted_ids: torch.Tensor, offsets: torch.Tensor, k_div: int = 1,
+                 meta: Optional[torch.Tensor] = None, cap: int = 0):
+        """Row ``sorted_ids[i] // k_div`` of ``x`` goes to rank d for offsets[d] <= i < offsets[d + 1];
+        ``meta[sorted_ids[i]]`` (int32) travels with it.  Returns (recv [world * cap, W], recv_meta
+        [world * cap] or None, recv_counts int32 [world])."""
+        cap = int(cap) or self.cap
+        if self.peer is not None and x.is_cuda:
+            return self.peer.exchange(x, sorted_ids, offsets, k_div, meta, cap)
+        W = x.shape[1]
+        send = torch.zeros((self.world, cap, W), dtype=x.dtype, device=x.device)
+        smeta = torch.zeros((self.world, cap), dtype=torch.int32, device=x.device) if meta is not None else None
+        off = offsets.tolist()
+        for d in range(self.world):
+            n = min(off[d + 1] - off[d], cap)
+            if n > 0:
+                idx = sorted_ids[off[d]:off[d] + n].long()
+                send[d, :n] = x[idx // k_div]
+                if smeta is not None:
+                    smeta[d, :n] = meta.view(-1)[idx]
+        counts = (offsets[1:] - offsets[:-1]).clamp(max=cap).to(torch.int32)
+        recv, rmeta, rc = self._host_exchange(send, counts, smeta)
+        return recv.view(-1, W), (rmeta.view(-1) if rmeta is not None else None), rc
 
-    def combine(self, rows: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
-        """Inverse of dispatch: what was received goes back to where it came from."""
-        out = torch.empty((sum(send_counts), *rows.shape[1:]), dtype=rows.dtype, device=rows.device)
-        self.group.all_to_all_single(out, rows, send_counts, recv_counts)
-        return out
+    def exchange_regions(self, y: torch.Tensor, counts: torch.Tensor, cap: int = 0):
+        """``y`` [world * cap, W] already grouped by destination with counts[d] valid rows each."""
+        cap = int(cap) or self.cap
+        if self.peer is not None and y.is_cuda:
+            return self.peer.exchange_regions(y, counts, cap)
+        W = y.shape[1]
+        recv, _, rc = self._host_exchange(y[: self.world * cap].reshape(self.world, cap, W).contiguous(),
+                                          counts.to(torch.int32), None)
+        return recv.view(-1, W), rc
+
+    def check_error(self) -> int:
+        return self.peer.check_error() if self.peer is not None else 0
+
+    def close(self) -> None:
+        if self.peer is not None:
+            self.peer.close()
+            self.peer = None
+
+
+@dataclass
+class EpState:
+    dest: torch.Tensor          # [P] destination rank of every (token, slot) pair, -1 = padding
+    inv: torch.Tensor           # [P] position of pair p in the destination-sorted order
+    offsets: torch.Tensor       # [world + 1]
+    recv_counts: torch.Tensor   # [world]
+    cap: int
+
+
+class ExpertDispatcher:
+    """Expert-parallel token routing: every (token, slot) pair travels to the rank that owns its expert,
+    the owner runs its experts on what it received, and the results travel back to be weighted and
+    summed at the source.  Per link this moves T * k * H / world bytes each way instead of the
+    all-gather + all-reduce of replicate-and-mask.
+    Reference: vllm/model_executor/layers/fused_moe/layer.py:1439-1484 (dispatch / combine around the
+    expert computation), vllm/distributed/device_communicators/all2all.py."""
+
+    def __init__(self, group: GroupCoordinator, experts_per_rank: int, top_k: int, row_bytes: int, max_tokens: int):
+        self.group = group
+        self.world, self.rank = group.world_size, group.rank_in_group
+        self.epr, self.top_k = experts_per_rank, top_k
+        cap = -(-max(max_tokens, 1) * top_k // 16) * 16
+        self.rx = RowExchange(group, cap, row_bytes)
+
+    def dispatch(self, x: torch.Tensor, topk_ids: torch.Tensor):
+        """x [T, H]; topk_ids int32 [T, k] global (physical) expert ids, negative = padding.  Returns
+        (rows received [world * cap, H], their local expert ids int32 [world * cap, 1] with -1 on empty
+        slots, state for ``combine``)."""
+        from .. import ops
+        T, k = topk_ids.shape
+        cap = min(self.rx.cap, -(-max(T, 1) * k // 16) * 16)
+        ids = topk_ids.reshape(-1)
+        dest = torch.where(ids >= 0, ids // self.epr, ids)
+        sorted_ids, offsets = ops.sort_by_key(dest, self.world)
+        recv, rmeta, rc = self.rx.exchange(x, sorted_ids, offsets, k, ids.contiguous(), cap)
+        slot = torch.arange(cap, device=x.device, dtype=torch.int32).unsqueeze(0)
+        local = torch.where(slot < rc.unsqueeze(1), rmeta.view(self.world, cap) - self.rank * self.epr,
+                            torch.full((), -1, dtype=torch.int32, device=x.device))
+        # inverse permutation of the live part of the sort (entries past offsets[world] are not pairs)
+        P_ = sorted_ids.numel()
+        seq = torch.arange(P_, device=x.device, dtype=torch.int64)
+        inv = torch.zeros(P_ + 1, dtype=torch.int64, device=x.device)
+        inv[torch.where(seq < offsets[self.world].long(), sorted_ids.long(), torch.full_like(seq, P_))] = seq
+        inv = inv[:P_]
+        return recv, local.reshape(-1, 1).contiguous(), EpState(dest, inv, offsets, rc, cap)
+
+    def combine(self, y: torch.Tensor, topk_w: torch.Tensor, st: EpState) -> torch.Tensor:
+        """y [world * cap, H]: outputs of the rows received by ``dispatch`` (same slots).  Returns
+        out [T, H] = sum_j topk_w[t, j] * y(pair t, j)."""
+        T, k = topk_w.shape
+        ret, _ = self.rx.exchange_regions(y, st.recv_counts, st.cap)
+        d = st.dest.long()
+        valid = d >= 0
+        dc = d.clamp(min=0)
+        pos = (dc * st.cap + (st.inv.long() - st.offsets.long()[dc])).clamp(min=0, max=ret.shape[0] - 1)
+        w = torch.where(valid.view(T, k), topk_w.float(), torch.zeros((), device=y.device))
+        rows = ret[pos].view(T, k, -1).float()
+        rows = torch.where(valid.view(T, k, 1), rows, torch.zeros((), device=y.device))   # unwritten slots may hold NaN
+        return (rows * w.unsqueeze(-1)).sum(dim=1).to(y.dtype)
+
+
+_DISPATCHERS: dict = {}
+
+
+def get_expert_dispatcher(group: GroupCoordinator, experts_per_rank: int, top_k: int, row_bytes: int,
+                          max_tokens: int) -> ExpertDispatcher:
+    """One dispatcher (one arena) per (group, shape): every MoE layer of a model shares it, calls are
+    ordered by the stream."""
+    key = (group.name, tuple(group.ranks), experts_per_rank, top_k, row_bytes, max_tokens)
+    d = _DISPATCHERS.get(key)
+    if d is None:
+        d = _DISPATCHERS[key] = ExpertDispatcher(group, experts_per_rank, top_k, row_bytes, max_tokens)
+    return d
+
+
+def close_dispatchers() -> None:
+    for d in _DISPATCHERS.values():
+        d.rx.close()
+    _DISPATCHERS.clear()

@@ -20,25 +20,10 @@
 // error word is set and the kernel leaves, so a lost peer can never hang the GPU.
 // Role of the reference's csrc/custom_all_reduce.cuh (1-stage :296-312, 2-stage
 // :319-364, ROCm scoped atomics :243-282) and csrc/quickreduce.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <string.h>
-
-#define VDA_EXPORT extern "C" __attribute__((visibility("default")))
-#define MAX_RANKS 8
-#define MAX_BLOCKS 64
+#include "peer_sync.h"
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-struct Signal {
-  // arrival[block][src_rank]: written by src_rank's block `block`, read by the owner
-  alignas(128) uint32_t arrival[MAX_BLOCKS][MAX_RANKS];
-  alignas(128) uint32_t counter[MAX_BLOCKS];   // owner only: barriers passed by this block
-  alignas(128) uint32_t calls[MAX_BLOCKS];     // owner only: calls made (parity selects the staging half)
-  alignas(128) uint32_t error;                 // non-zero after a time-out
-};
 
 struct CarCtx {
   int rank, world;
@@ -74,31 +59,8 @@ template <typename T> __device__ __forceinline__ u32x4 acc_pack(const float* a) 
   return raw;
 }
 
-// All ranks' block `blockIdx.x` meet.  Returns false on time-out.
 __device__ __forceinline__ bool cross_barrier(const CarArgs& a, uint32_t target) {
-  __threadfence_system();
-  __syncthreads();
-  __shared__ int ok;
-  if (threadIdx.x == 0) ok = 1;
-  __syncthreads();
-  if (threadIdx.x < a.world) {
-    const int peer = threadIdx.x;
-    __scoped_atomic_store_n(&a.sig[peer]->arrival[blockIdx.x][a.rank], target, __ATOMIC_RELEASE,
-                            __MEMORY_SCOPE_SYSTEM);
-    unsigned long long spins = 0;
-    while ((int32_t)(__scoped_atomic_load_n(&a.sig[a.rank]->arrival[blockIdx.x][peer], __ATOMIC_ACQUIRE,
-                                            __MEMORY_SCOPE_SYSTEM) - target) < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > a.spin_limit) {
-        __scoped_atomic_store_n(&a.sig[a.rank]->error, 1u + (uint32_t)peer, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
-        ok = 0;
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  __threadfence_system();
-  return ok != 0;
+  return peer_barrier(a.sig, a.rank, a.world, a.spin_limit, target);
 }
 
 // Element ownership is FIXED: 16-byte element i belongs to thread (i mod GRID_THREADS) of the
@@ -179,8 +141,6 @@ __global__ __launch_bounds__(512) void car_kernel(CarArgs a, const u32x4* __rest
 // ---------------------------------------------------------------------------
 // host API
 // ---------------------------------------------------------------------------
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
-
 // Allocate the arena (2 staging halves) and the uncached signal block; return IPC handles.
 VDA_EXPORT int vda_car_alloc(size_t arena_bytes, void** data, void** sig, char* data_handle /*64*/,
                              char* sig_handle /*64*/) {

@@ -52,6 +52,13 @@ def comm_library() -> ctypes.CDLL:
         lib.vda_qr_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), sz, i32, u64]
         lib.vda_qr_create.restype = vp
         lib.vda_qr_allreduce.argtypes = [vp, vp, vp, sz, i32, i32, vp]
+        lib.vda_a2a_half_bytes.argtypes = [i32, i32, i32]
+        lib.vda_a2a_half_bytes.restype = sz
+        lib.vda_a2a_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, i32, u64]
+        lib.vda_a2a_create.restype = vp
+        lib.vda_a2a_destroy.argtypes = [vp]
+        lib.vda_a2a_error.argtypes = [vp]
+        lib.vda_a2a_exchange.argtypes = [vp, vp, ctypes.c_long, vp, vp, i32, vp, vp, ctypes.c_long, i32, vp, vp, i32, i32, vp]
         _LIB = lib
     return _LIB
 
@@ -289,3 +296,129 @@ class QuickAllReduce(CustomAllReduce):
                 raise RuntimeError(f"quantised all-reduce launch failed with {rc}")
             off += n
         return out
+
+
+class PeerAllToAll(CustomAllReduce):
+    """All-to-all-v of rows through peer memory (parallel/csrc/all2all.hip): every rank packs the rows it
+    sends, grouped by destination, into its own IPC-exported arena and pulls its region of every peer's
+    arena over all xGMI links at once.  ``cap`` rows per (source, destination) pair and ``row_bytes`` per
+    row are fixed at construction; counts live on the device, so a call never syncs with the host and is
+    hipGraph-capturable.  Results sit at fixed positions: ``recv[src * cap + j]`` is the j-th row rank
+    ``src`` sent here.
+    Reference role: vllm/distributed/device_communicators/all2all.py:77-264 (pplx / DeepEP managers)."""
+    SUPPORTED_WORLD = (2, 3, 4, 5, 6, 7, 8)
+
+    def __init__(self, cpu_group, device: torch.device, cap: int, row_bytes: int):
+        self.lib = comm_library()
+        self.group = cpu_group
+        self.device = device
+        self.rank = dist.get_rank(cpu_group)
+        self.world = dist.get_world_size(cpu_group)
+        self.cap, self.row_bytes = int(cap), int(row_bytes)
+        self.disabled = True
+        half = int(self.lib.vda_a2a_half_bytes(self.world, self.cap, self.row_bytes))
+        pd, ps = self._exchange_arena(2 * half)
+        spins = int(envs.VDA_COMM_SPIN_TIMEOUT_MS * 1e4)
+        self.ctx = self.lib.vda_a2a_create(self.rank, self.world, pd, ps, self.cap, self.row_bytes, spins)
+        if not self.ctx:
+            raise RuntimeError("could not create the all-to-all context")
+        dist.barrier(group=cpu_group)
+        self.disabled = False
+
+    @classmethod
+    def maybe_create(cls, cpu_group, device: torch.device, cap: int, row_bytes: int) -> Optional["PeerAllToAll"]:
+        world = dist.get_world_size(cpu_group)
+        if world not in cls.SUPPORTED_WORLD:
+            return None
+        ok, obj, err = 1, None, ""
+        try:
+            obj = cls(cpu_group, device, cap, row_bytes)
+            ok = int(obj._self_test())
+        except Exception as e:  # noqa: BLE001 - any failure just disables the fast path
+            ok, err = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
+        if int(flag.item()) == 0:
+            if dist.get_rank(cpu_group) == 0:
+                logger.warning("peer-memory all-to-all disabled (%s); using torch.distributed", err or "self-test failed on a peer")
+            if obj is not None:
+                obj.disabled = True
+            return None
+        if dist.get_rank(cpu_group) == 0:
+            logger.info("peer-memory all-to-all enabled: %d ranks, %d rows of %d bytes per pair", world, cap, row_bytes)
+        return obj
+
+    def _self_test(self) -> bool:
+        n = min(self.cap, 37)
+        w = self.row_bytes // 2
+        for it in range(3):                 # consecutive calls exercise both arena halves
+            # rank r sends (d + 1 + it) % (n + 1) rows to rank d, row j filled with r * 1000 + d * 10 + j
+            counts = [(d + 1 + it + self.rank) % (n + 1) for d in range(self.world)]
+            rows, dest = [], []
+            for d, c in enumerate(counts):
+                for j in range(c):
+                    rows.append(torch.full((w,), float((self.rank * 100 + d * 10 + j) % 251), dtype=torch.bfloat16))
+                    dest.append(d)
+            x = torch.stack(rows).to(self.device) if rows else torch.zeros((1, w), dtype=torch.bfloat16, device=self.device)
+            order = torch.arange(len(dest), dtype=torch.int32, device=self.device)
+            off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=self.device)
+            recv, _, rc = self.exchange(x, order, off)
+            torch.cuda.synchronize(self.device)
+            if self.lib.vda_a2a_error(self.ctx) != 0:
+                return False
+            rc = rc.cpu().tolist()
+            for s in range(self.world):
+                want = (self.rank + 1 + it + s) % (n + 1)
+                if rc[s] != want:
+                    return False
+                for j in range(want):
+                    if float(recv[s * self.cap + j, 0]) != float((s * 100 + self.rank * 10 + j) % 251):
+                        return False
+        return True
+
+    def exchange(self, x: torch.Tensor, sorted_ids: torch.Tensor, offsets: torch.Tensor, k_div: int = 1,
+                 meta: Optional[torch.Tensor] = None, cap: int = 0):
+        """Send row ``sorted_ids[i] // k_div`` of ``x`` to rank d for offsets[d] <= i < offsets[d + 1].
+        ``cap``: rows per (source, destination) pair of this call (default: the arena's capacity; the same
+        on every rank).  Returns (recv [world * cap, W], recv_meta int32 [world * cap] or None,
+        recv_counts int32 [world])."""
+        return self._run(x, sorted_ids, offsets, k_div, meta, 1, cap)
+
+    def exchange_regions(self, y: torch.Tensor, counts: torch.Tensor, cap: int = 0):
+        """``y`` [world * cap, W]: rows [d * cap, d * cap + counts[d]) go to rank d (the way back of an
+        earlier ``exchange``: pass its recv_counts).  Returns recv [world * cap, W] and its counts."""
+        recv, _, rc = self._run(y, None, counts, 1, None, 0, cap)
+        return recv, rc
+
+    def _run(self, x, sorted_ids, offs, k_div, meta, gather, cap=0):
+        assert x.dim() == 2 and x.stride(1) == 1
+        cap = int(cap) or self.cap
+        wb = x.shape[1] * x.element_size()
+        if wb % 16 or wb > self.row_bytes or (x.stride(0) * x.element_size()) % 16 or cap > self.cap:
+            raise ValueError(f"{cap} rows of {wb} bytes do not fit the all-to-all arena ({self.cap} rows of "
+                             f"{self.row_bytes} bytes per pair)")
+        if not gather and x.shape[0] < self.world * cap:
+            raise ValueError("region form needs world * cap rows")
+        recv = torch.empty((self.world * cap, x.shape[1]), dtype=x.dtype, device=x.device)
+        rmeta = torch.empty(self.world * cap, dtype=torch.int32, device=x.device) if meta is not None else None
+        rc = torch.empty(self.world, dtype=torch.int32, device=x.device)
+        rcode = self.lib.vda_a2a_exchange(
+            self.ctx, x.data_ptr(), x.stride(0) * x.element_size(), sorted_ids.data_ptr() if sorted_ids is not None else None,
+            offs.data_ptr(), int(k_div), meta.data_ptr() if meta is not None else None, recv.data_ptr(),
+            recv.stride(0) * recv.element_size(), wb, rmeta.data_ptr() if rmeta is not None else None, rc.data_ptr(),
+            gather, cap, torch.cuda.current_stream().cuda_stream)
+        if rcode:
+            raise RuntimeError(f"peer-memory all-to-all launch failed with {rcode}")
+        return recv, rmeta, rc
+
+    def check_error(self) -> int:
+        return int(self.lib.vda_a2a_error(self.ctx))
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None):
+            self.lib.vda_a2a_destroy(self.ctx)
+            self.ctx = None
+            for p in self._opened:
+                self.lib.vda_car_close(p)
+            self.lib.vda_car_free(*self._own)
+        self.disabled = True

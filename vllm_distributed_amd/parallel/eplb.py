@@ -201,6 +201,7 @@ class EplbState:
         self._index_maps()
         self.load_window = np.zeros((self.window, self.num_layers, self.num_physical), dtype=np.int64)
         self.pass_load = torch.zeros((self.num_layers, self.num_physical), dtype=torch.int64)
+        self._dev, self._maps_stale = None, True
         self.step = 0
         self.rearrangements = 0
 
@@ -217,24 +218,42 @@ class EplbState:
                 seen[layer, e] += 1
         self.logcnt = cnt
 
+    def _device_maps(self, device: torch.device) -> None:
+        """Routing tables and the load counters as persistent tensors on the model's device: updated in
+        place after a rearrangement, so captured hipGraphs keep reading the current placement and the
+        per-step bookkeeping needs no host round trip."""
+        width = self.num_physical - self.num_logical + 1          # most replicas one expert can have
+        if self._dev is None or self._dev != device:
+            self._dev = device
+            self._l2p_dev = torch.zeros((self.num_layers, self.num_logical, width), dtype=torch.int64, device=device)
+            self._cnt_dev = torch.ones((self.num_layers, self.num_logical), dtype=torch.int64, device=device)
+            self.pass_load = self.pass_load.to(device)
+            self._maps_stale = True
+        if self._maps_stale:
+            l2p = np.zeros((self.num_layers, self.num_logical, width), dtype=np.int64)
+            l2p[:, :, :self.log2phy.shape[2]] = np.maximum(self.log2phy, 0)
+            self._l2p_dev.copy_(torch.from_numpy(l2p))
+            self._cnt_dev.copy_(torch.from_numpy(self.logcnt))
+            self._maps_stale = False
+
     def map_topk(self, layer: int, topk_ids: torch.Tensor) -> torch.Tensor:
         """Logical expert ids -> physical slot ids; replicas are chosen round-robin by token index."""
-        l2p = torch.as_tensor(self.log2phy[layer], device=topk_ids.device)
-        cnt = torch.as_tensor(self.logcnt[layer], device=topk_ids.device)
+        self._device_maps(topk_ids.device)
         ids = topk_ids.long()
         tok = torch.arange(ids.shape[0], device=ids.device).unsqueeze(1)
-        rep = tok % cnt[ids]
-        return l2p[ids, rep].to(topk_ids.dtype)
+        rep = tok % self._cnt_dev[layer][ids]
+        return self._l2p_dev[layer][ids, rep].to(topk_ids.dtype)
 
     def record(self, layer: int, phys_ids: torch.Tensor) -> None:
-        flat = phys_ids.reshape(-1).long().cpu()
-        flat = flat[flat >= 0]
-        self.pass_load[layer] += torch.bincount(flat, minlength=self.num_physical)
+        """Count the routed pairs per physical slot (negative ids = padding / not routed) on the device."""
+        self._device_maps(phys_ids.device)
+        flat = phys_ids.reshape(-1).long()
+        self.pass_load[layer].index_add_(0, flat.clamp(min=0), (flat >= 0).to(torch.int64))
 
     def step_done(self, group=None, weights=None, p2p_group=None) -> bool:
         """Call once per engine step; returns True when a rearrangement happened.  ``group`` carries the
         (host) load all-reduce, ``p2p_group`` the weight exchange (defaults to ``group``)."""
-        load = self.pass_load.clone()
+        load = self.pass_load.cpu().clone()
         if group is not None and dist.get_world_size(group) > 1:
             dist.all_reduce(load, group=group)
         self.load_window[self.step % self.window] = load.numpy()
@@ -255,6 +274,7 @@ class EplbState:
             rearrange_expert_weights(self.phy2log, new_p2l, weights, group)
         self.phy2log = new_p2l
         self._index_maps()
+        self._maps_stale = True
         self.rearrangements += 1
         logger.info("EPLB: experts rearranged (#%d)", self.rearrangements)
 

@@ -84,7 +84,7 @@ class GroupCoordinator:
         if self.world_size > 1 and self._use_device_comm:
             self._init_device_comms()
         if self.world_size > 1 and self._use_mq:
-            from .shm_ring import MessageQueue
+            from ..runtime.shm_ring import MessageQueue
             self.mq_broadcaster = MessageQueue.create_from_process_group(self.cpu_group, 1 << 22, 6)
 
     def _init_device_comms(self) -> None:

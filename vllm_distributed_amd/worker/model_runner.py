@@ -213,8 +213,8 @@ class ModelRunner:
         for i, m in enumerate(layers):
             m.eplb_state, m.eplb_layer = self.eplb_state, i
         self._eplb_layers = layers
-        # placement changes are applied eagerly between steps: captured graphs would bake the old maps in
-        self.use_graphs = False
+        # routing tables and load counters are persistent device tensors updated in place and expert weights
+        # move inside their own storage, so captured decode graphs stay valid across rearrangements
         logger.info("EPLB on: %d MoE layers, %d logical -> %d physical experts", len(layers),
                     first.global_num_experts, first.num_physical_experts)
 
