@@ -66,6 +66,25 @@ def test_tp2_on_one_gpu(tmp_path, eager, async_tp):
     assert same >= 0.5 * sum(len(a) for a in single[0])
 
 
+@pytest.mark.parametrize("world,eager", [(2, False), (2, True)])
+def test_expert_parallel_on_one_gpu(tmp_path, world, eager):
+    """Expert parallelism with token routing: every rank sends its slice of the tokens to the expert
+    owners through the peer-memory all-to-all-v, inside captured decode graphs when eager is off."""
+    from tests.test_e2e_cpu import _save_tiny
+    model, _ = _save_tiny(str(tmp_path), "mixtral")
+    kw = dict(device="cuda", dtype="bfloat16", gpu_memory_utilization=0.03, enforce_eager=eager, max_num_seqs=8)
+    single, _ = _launch(1, model, str(tmp_path / "one"), kw, {})
+    env = {"VDA_REHEARSE_ON_ONE_GPU": "1", "VLLM_LOGGING_LEVEL": "INFO"}
+    got, logs = _launch(world, model, str(tmp_path / "ep"),
+                        dict(kw, tensor_parallel_size=world, enable_expert_parallel=True), env)
+    assert all(g == got[0] for g in got), "expert-parallel ranks disagree"
+    assert any("peer-memory all-to-all enabled" in l for l in logs), logs[0][-2000:]
+    first = [a[0] == b[0] for a, b in zip(got[0], single[0])]
+    assert sum(first) >= len(first) - 1
+    same = sum(x == y for a, b in zip(got[0], single[0]) for x, y in zip(a, b))
+    assert same >= 0.5 * sum(len(a) for a in single[0])
+
+
 def test_rccl_wrapper_single_rank_and_graph_capture():
     import torch.distributed as dist
     from vllm_distributed_amd.parallel.rccl import RcclCommunicator

@@ -226,7 +226,7 @@ class FusedMoE(nn.Module):
         recv, local_ids, st = self._ep_disp.dispatch(xs.contiguous(), topk_ids.to(torch.int32))
         ones = torch.ones((recv.shape[0], 1), dtype=torch.float32, device=x.device)
         y = self.quant_method.apply(self, recv, ones, local_ids)
-        out = ep.all_gather(self._ep_disp.combine(y, topk_w, st), dim=0)[:T]
+        out = self._ep_disp.rx.all_gather_rows(self._ep_disp.combine(y, topk_w, st))[:T]
         if not self.reduce_results:
             # the caller adds a tensor-parallel partial sum (shared experts) and all-reduces the total:
             # hand it the complete routed output in 1 / tp parts

@@ -58,12 +58,15 @@ __global__ __launch_bounds__(256) void moe_topk_softmax_kernel(float* __restrict
       const int oi = __shfl_xor(bi, o, 64);
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
+    // no candidate left (NaN logits, e.g. attention over an empty context in a warm-up run): still hand
+    // out a valid, distinct expert id with weight 0, never an out-of-range one
+    if (bi == 0x7fffffff) { bi = j; best = 0.f; }
     if ((bi & 63) == lane) v[bi >> 6] = -1.f;
     picked += best;
     if (lane == j) { my_w = best; my_id = bi; }
   }
   if (lane < k) {
-    const float scale = renorm ? 1.f / picked : inv;
+    const float scale = renorm ? (picked > 0.f ? 1.f / picked : 0.f) : inv;
     topk_w[(long)t * k + lane] = my_w * scale;
     topk_id[(long)t * k + lane] = my_id;
   }

@@ -138,6 +138,18 @@ class RowExchange:
                                           counts.to(torch.int32), None)
         return recv.view(-1, W), rc
 
+    def all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """[n, W] on every rank (same n) -> [world * n, W]: every rank pulls every peer's rows at once, the
+        direct all-gather of a fully connected xGMI node, through the same kernel (and as capturable)."""
+        n, W = x.shape
+        cap = -(-max(n, 1) // 16) * 16
+        if self.peer is None or not x.is_cuda or cap > self.cap:
+            return self.group.all_gather(x, dim=0)
+        ids = torch.arange(n, dtype=torch.int32, device=x.device).repeat(self.world)
+        off = torch.arange(self.world + 1, dtype=torch.int32, device=x.device) * n
+        recv, _, _ = self.peer.exchange(x, ids, off, 1, None, cap)
+        return recv.view(self.world, cap, W)[:, :n].reshape(self.world * n, W)
+
     def check_error(self) -> int:
         return self.peer.check_error() if self.peer is not None else 0
 
@@ -179,6 +191,8 @@ class ExpertDispatcher:
         T, k = topk_ids.shape
         cap = min(self.rx.cap, -(-max(T, 1) * k // 16) * 16)
         ids = topk_ids.reshape(-1)
+        # ids outside [0, world * experts_per_rank) (padding; a router fed NaNs) go nowhere
+        ids = torch.where((ids >= 0) & (ids < self.world * self.epr), ids, torch.full_like(ids, -1))
         dest = torch.where(ids >= 0, ids // self.epr, ids)
         sorted_ids, offsets = ops.sort_by_key(dest, self.world)
         recv, rmeta, rc = self.rx.exchange(x, sorted_ids, offsets, k, ids.contiguous(), cap)
