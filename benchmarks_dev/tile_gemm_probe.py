@@ -86,9 +86,30 @@ def moe():
               f"{t3 * 1e3:>15.2f} {fl / t3 / 1e12:>6.0f}", flush=True)
 
 
+def decode():
+    """Llama-3-70B projections at decode batch sizes: library GEMM against the tiled 16-bit kernel."""
+    print("\nLlama-3-70B projections, bf16, us per call (lib / tile128 / tile64) and weight TB/s of the best")
+    shapes = [("qkv", 10240, 8192), ("o", 8192, 8192), ("gate_up", 57344, 8192), ("down", 8192, 28672)]
+    for M in (64, 128, 256):
+        tot = [0.0, 0.0, 0.0]
+        for name, N_, K in shapes:
+            x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+            w = torch.randn(N_, K, device=DEV, dtype=torch.bfloat16) * 0.02
+            t0 = timeit(lambda: torch.nn.functional.linear(x, w), reps=20)
+            t1 = timeit(lambda: ops.tile_linear(x, w, None, 128), reps=20)
+            t2 = timeit(lambda: ops.tile_linear(x, w, None, 64), reps=20)
+            best = min(t0, t1, t2)
+            print(f"M={M:>4} {name:>8}: {t0 * 1e6:>7.1f} {t1 * 1e6:>7.1f} {t2 * 1e6:>7.1f}   {N_ * K * 2 / best / 1e12:.2f} TB/s", flush=True)
+            for i, t in enumerate((t0, t1, t2)):
+                tot[i] += t
+        print(f"M={M:>4}    layer: {tot[0] * 1e6:>7.1f} {tot[1] * 1e6:>7.1f} {tot[2] * 1e6:>7.1f}", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "dense"):
         dense()
     if which in ("all", "moe"):
         moe()
+    if which in ("all", "decode"):
+        decode()

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run_ranks(world, script):
+def _run_ranks(world, script, extra_env=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -21,6 +21,7 @@ def _run_ranks(world, script):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", VDA_COMM_SPIN_TIMEOUT_MS="5000")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "scripts", script)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -53,3 +54,8 @@ def test_peer_all_to_all_shared_gpu(world):
     """all-to-all-v of rows through peer memory: bit-exact against the same exchange over gloo, the
     return trip, hipGraph replay with changing counts, expert-parallel dispatch / combine round trip."""
     _run_ranks(world, "a2a_worker.py")
+
+
+def test_withheld_call_is_reported_not_served():
+    """A rank that never makes its call: the peers' kernels time out, return, and the per-step check raises."""
+    _run_ranks(2, "car_timeout_worker.py", {"VDA_COMM_SPIN_TIMEOUT_MS": "100"})

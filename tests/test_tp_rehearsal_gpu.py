@@ -85,6 +85,26 @@ def test_expert_parallel_on_one_gpu(tmp_path, world, eager):
     assert same >= 0.5 * sum(len(a) for a in single[0])
 
 
+@pytest.mark.parametrize("world,eager", [(2, False), (3, False), (2, True)])
+def test_token_parallel_on_one_gpu(tmp_path, world, eager):
+    """Token parallelism through the peer-memory row exchange: scatter / gather of attention rows and the
+    sampled-id row, inside captured decode graphs when eager is off; tokens must equal the single-rank run
+    (every row is computed by the same kernels, only on another rank)."""
+    from tests.test_e2e_cpu import _save_tiny
+    model, _ = _save_tiny(str(tmp_path), "llama")
+    kw = dict(device="cuda", dtype="bfloat16", gpu_memory_utilization=0.08, enforce_eager=eager, max_num_seqs=8,
+              enable_prefix_caching=False)
+    single, _ = _launch(1, model, str(tmp_path / "one"), kw, {})
+    env = {"VDA_REHEARSE_ON_ONE_GPU": "1", "VLLM_LOGGING_LEVEL": "INFO"}
+    got, logs = _launch(world, model, str(tmp_path / "tk"),
+                        dict(kw, enable_token_parallel=True, token_parallel_size=world), env)
+    assert any("peer-memory all-to-all enabled" in l for l in logs), logs[0][-2000:]
+    if not eager:
+        assert any("captured" in l and "decode graphs" in l for l in logs), logs[0][-2000:]
+    for r in range(world):
+        assert got[r] == single[0], f"rank {r} diverged"
+
+
 def test_rccl_wrapper_single_rank_and_graph_capture():
     import torch.distributed as dist
     from vllm_distributed_amd.parallel.rccl import RcclCommunicator

@@ -877,8 +877,8 @@ class VllmConfig:
         if self.device_config.device == "cpu" or mc.enforce_eager:
             self.compilation_config.level = 0
         if pc.token_parallel_size > 1:
-            # variable per-rank row counts each step: graphs are not captured
-            self.compilation_config.level = 0
+            # per-rank row counts vary from step to step; decode graphs are captured all the same when the
+            # ranks exchange rows through peer memory (the runner turns graphs off when they cannot)
             if pc.distributed_executor_backend == "mp":
                 pc.distributed_executor_backend = "external_launcher"
         if pc.distributed_executor_backend == "external_launcher":

@@ -66,6 +66,16 @@ class TokenParallelMetadata:
     num_local_tokens: int = 0
     num_total_tokens: int = 0
     is_root: bool = True
+    # peer-memory form (parallel/all2all.py::RowExchange): every index lives in persistent device buffers
+    # the runner refills each step, so the same launches serve eager steps and captured graphs
+    exchange: object = None                    # RowExchange of the token-parallel group, None = torch.distributed
+    sorted_ids: Optional[torch.Tensor] = None  # int32, root: batch rows grouped by owning rank
+    offsets: Optional[torch.Tensor] = None     # int32 [world + 1], root: row range per rank (zeros elsewhere)
+    gather_offsets: Optional[torch.Tensor] = None   # int32 [world + 1]: this rank's local rows all go to the root
+    iota: Optional[torch.Tensor] = None        # int32 0, 1, 2, ...
+    back: Optional[torch.Tensor] = None        # int64 [T], root: slot (owner * cap + local index) of batch row i
+    cap: int = 0                               # rows per (source, destination) pair of this step's exchanges
+    dummy: Optional[torch.Tensor] = None       # one row of zeros (what a rank with nothing to send passes)
 
 
 @dataclass

@@ -5,8 +5,9 @@ Per attention layer on the root:
     qkv = W_qkv h                                  (all T rows of the step)
     rows are permuted so that every rank's rows are contiguous (explicit permutation: under
     continuous batching one rank's requests are not contiguous in the batch), then ONE
-    variable-split all-to-all sends rank r its rows -- on MI355X the root has a private xGMI link
-    to each of up to 7 peers, so the per-peer sends proceed in parallel at link rate;
+    all-to-all-v sends rank r its rows -- on MI355X the root has a private xGMI link to each of up
+    to 7 peers, and the peer-memory exchange (parallel/all2all.py::RowExchange) lets every peer pull
+    its rows at link rate with device-side counts, so the step is hipGraph-capturable;
     every rank runs RoPE + KV write + paged attention for its own requests against its own pool;
     a second all-to-all returns the attention rows to the root, which undoes the permutation and
     applies W_o (+ the TP all-reduce inside the root's TP group).
@@ -35,6 +36,12 @@ def tknp_metadata() -> Optional[TokenParallelMetadata]:
 def scatter_rows(x: Optional[torch.Tensor], md: TokenParallelMetadata, width: int, dtype: torch.dtype,
                  device: torch.device) -> torch.Tensor:
     """Root passes its [T, width] rows in batch order; every rank gets its own [T_local, width] rows."""
+    if md.exchange is not None:
+        # root: rows grouped by owner through the index list; the others contribute nothing.  Region 0 of
+        # what arrives (the root's rows for this rank, in batch order) is the local batch.
+        src = x if md.is_root else md.dummy[:, :width]
+        recv, _, _ = md.exchange.exchange(src, md.sorted_ids, md.offsets, 1, None, md.cap)
+        return recv[: md.num_local_tokens]
     g = get_tknp_group()
     n = g.world_size
     out = torch.empty((md.num_local_tokens, width), dtype=dtype, device=device)
@@ -51,6 +58,10 @@ def scatter_rows(x: Optional[torch.Tensor], md: TokenParallelMetadata, width: in
 
 def gather_rows(x_local: torch.Tensor, md: TokenParallelMetadata) -> Optional[torch.Tensor]:
     """Inverse of scatter_rows: the root gets all rows back in batch order, the others None."""
+    if md.exchange is not None:
+        src = x_local if x_local.shape[0] else md.dummy[:, : x_local.shape[1]]
+        recv, _, _ = md.exchange.exchange(src, md.iota, md.gather_offsets, 1, None, md.cap)
+        return recv.index_select(0, md.back) if md.is_root else None
     g = get_tknp_group()
     n = g.world_size
     width = x_local.shape[1]

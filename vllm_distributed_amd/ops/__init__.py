@@ -579,6 +579,18 @@ def sort_by_key(keys: torch.Tensor, num_keys: int):
     return sorted_ids, offsets
 
 
+def tile_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, rows_per_tile: int = 0
+                ) -> torch.Tensor:
+    """y = x @ w.T (+ bias) through the LDS-tiled 16-bit MFMA GEMM (x [M, K], w [N, K], same 16-bit dtype)."""
+    M, K = x.shape
+    N_ = w.shape[0]
+    out = torch.empty((M, N_), dtype=x.dtype, device=x.device)
+    N.call("vda_tile_gemm", out.data_ptr(), x.data_ptr(), w.data_ptr(), None, None, None, N.ptr(bias), None, None,
+           None, None, None, M, N_, K, 1, 0, x.stride(0), out.stride(0), 0, EPI_PLAIN, SC_NONE,
+           rows_per_tile or _tile_rows(M), N.dt(x.dtype), N.dt(x.dtype), N.stream())
+    return out
+
+
 def moe_align_tiles(topk_ids: torch.Tensor, E: int, rows_per_tile: int):
     """Sort the (token, slot) pairs by expert and cut every expert's range into m-tiles of
     ``rows_per_tile`` pairs.  Returns (sorted ids, offsets [E + 1], tile table, bound on tiles);

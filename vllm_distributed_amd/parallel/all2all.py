@@ -236,6 +236,14 @@ def get_expert_dispatcher(group: GroupCoordinator, experts_per_rank: int, top_k:
     return d
 
 
+def check_dispatcher_errors() -> None:
+    for d in _DISPATCHERS.values():
+        e = d.rx.check_error()
+        if e:
+            raise RuntimeError(f"peer-memory all-to-all of group {d.group.name} timed out waiting for rank {e - 1}; "
+                               "the step's results are invalid")
+
+
 def close_dispatchers() -> None:
     for d in _DISPATCHERS.values():
         d.rx.close()

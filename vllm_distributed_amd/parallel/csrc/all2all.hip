@@ -32,6 +32,7 @@ struct A2aCtx {
   char* data[MAX_RANKS];
   Signal* sig[MAX_RANKS];
   unsigned long long spin_limit;
+  uint32_t* host_err;
 };
 
 struct A2aArgs {
@@ -40,6 +41,7 @@ struct A2aArgs {
   int rank, world, cap, row_bytes;
   size_t half_bytes, meta_off, rows_off;
   unsigned long long spin_limit;
+  uint32_t* host_err;
 };
 
 constexpr int A2A_THREADS = 512;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(A2A_THREADS) void a2a_kernel(A2aArgs a, const char*
         reinterpret_cast<int*>(mine + a.meta_off)[(size_t)d * a.cap + j] = meta_in[src_idx];
     }
   }
-  const bool ok = peer_barrier(a.sig, a.rank, a.world, a.spin_limit, cnt + 1);
+  const bool ok = peer_barrier(a.sig, a.rank, a.world, a.spin_limit, cnt + 1, a.host_err);
 
   // ---- pull: region [me] of every peer -> recv[src] -------------------------------------------------
   if (ok) {
@@ -138,13 +140,19 @@ VDA_EXPORT void* vda_a2a_create(int rank, int world, void** peer_data, void** pe
   c->rows_off = a2a_rows_off(world, cap);
   for (int i = 0; i < world; ++i) { c->data[i] = (char*)peer_data[i]; c->sig[i] = (Signal*)peer_sig[i]; }
   c->spin_limit = spin_limit;
+  c->host_err = alloc_host_err();
   return c;
 }
 
-VDA_EXPORT void vda_a2a_destroy(void* ctx) { delete (A2aCtx*)ctx; }
+VDA_EXPORT void vda_a2a_destroy(void* ctx) {
+  A2aCtx* c = (A2aCtx*)ctx;
+  if (c->host_err) hipHostFree(c->host_err);
+  delete c;
+}
 
 VDA_EXPORT int vda_a2a_error(void* ctx) {
   A2aCtx* c = (A2aCtx*)ctx;
+  if (c->host_err) return (int)*(volatile uint32_t*)c->host_err;
   uint32_t e = 0;
   if (hipMemcpy(&e, &c->sig[c->rank]->error, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int)e;
@@ -172,6 +180,7 @@ VDA_EXPORT int vda_a2a_exchange(void* ctx, const void* x, long x_row_stride, con
   for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
   a.rank = c->rank; a.world = c->world; a.cap = cap; a.row_bytes = c->row_bytes;
   a.half_bytes = c->half_bytes; a.meta_off = c->meta_off; a.rows_off = c->rows_off; a.spin_limit = c->spin_limit;
+  a.host_err = c->host_err;
   if (gather)
     hipLaunchKernelGGL(a2a_kernel<true>, dim3(MAX_BLOCKS), dim3(A2A_THREADS), 0, st, a, (const char*)x, x_row_stride,
                        sorted, offsets_or_counts, k_div, meta_in, (char*)recv, recv_row_stride, copy_bytes, recv_meta,

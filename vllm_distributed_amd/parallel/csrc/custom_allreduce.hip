@@ -32,6 +32,7 @@ struct CarCtx {
   char* data[MAX_RANKS];         // peer arenas (own entry is the local pointer)
   Signal* sig[MAX_RANKS];
   unsigned long long spin_limit;
+  uint32_t* host_err;            // pinned host word: non-zero after a time-out
 };
 
 struct CarArgs {
@@ -40,6 +41,7 @@ struct CarArgs {
   int rank, world;
   size_t half_bytes, in_bytes;
   unsigned long long spin_limit;
+  uint32_t* host_err;
 };
 
 template <typename T> struct Pack { T v[16 / sizeof(T)]; };
@@ -60,7 +62,7 @@ template <typename T> __device__ __forceinline__ u32x4 acc_pack(const float* a) 
 }
 
 __device__ __forceinline__ bool cross_barrier(const CarArgs& a, uint32_t target) {
-  return peer_barrier(a.sig, a.rank, a.world, a.spin_limit, target);
+  return peer_barrier(a.sig, a.rank, a.world, a.spin_limit, target, a.host_err);
 }
 
 // Element ownership is FIXED: 16-byte element i belongs to thread (i mod GRID_THREADS) of the
@@ -183,14 +185,22 @@ VDA_EXPORT void* vda_car_create(int rank, int world, void** peer_data, void** pe
   c->in_bytes = in_b;
   for (int i = 0; i < world; ++i) { c->data[i] = (char*)peer_data[i]; c->sig[i] = (Signal*)peer_sig[i]; }
   c->spin_limit = spin_limit;
+  c->host_err = alloc_host_err();
   return c;
 }
 
-VDA_EXPORT void vda_car_destroy(void* ctx) { delete (CarCtx*)ctx; }
+VDA_EXPORT void vda_car_destroy(void* ctx) {
+  CarCtx* c = (CarCtx*)ctx;
+  if (c->host_err) hipHostFree(c->host_err);
+  delete c;
+}
 VDA_EXPORT size_t vda_car_max_bytes(void* ctx) { return ((CarCtx*)ctx)->in_bytes; }
 
+// Non-zero (1 + the peer that did not arrive) after a barrier time-out.  Reads the pinned host word the
+// kernels write, so polling it costs nothing; valid once the stream that ran the call has been synchronised.
 VDA_EXPORT int vda_car_error(void* ctx) {
   CarCtx* c = (CarCtx*)ctx;
+  if (c->host_err) return (int)*(volatile uint32_t*)c->host_err;
   uint32_t e = 0;
   if (hipMemcpy(&e, &c->sig[c->rank]->error, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int)e;
@@ -209,7 +219,7 @@ VDA_EXPORT int vda_car_allreduce(void* ctx, const void* in, void* out, size_t nb
   CarArgs a;
   for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
   a.rank = c->rank; a.world = c->world; a.half_bytes = c->half_bytes; a.in_bytes = c->in_bytes;
-  a.spin_limit = c->spin_limit;
+  a.spin_limit = c->spin_limit; a.host_err = c->host_err;
   const int threads = 512;
   const int blocks = MAX_BLOCKS;   // fixed grid: see the ownership rule above the kernel
 #define L(T, TS) hipLaunchKernelGGL((car_kernel<T, TS>), dim3(blocks), dim3(threads), 0, st, a, (const u32x4*)in, \
@@ -440,6 +450,7 @@ VDA_EXPORT void* vda_qr_create(int rank, int world, void** peer_data, void** pee
   c->half_bytes = vda_qr_half_bytes(max_bytes, bits);
   for (int i = 0; i < world; ++i) { c->data[i] = (char*)peer_data[i]; c->sig[i] = (Signal*)peer_sig[i]; }
   c->spin_limit = spin_limit;
+  c->host_err = alloc_host_err();
   return c;
 }
 
@@ -452,7 +463,7 @@ VDA_EXPORT int vda_qr_allreduce(void* ctx, const void* in, void* out, size_t nby
   CarArgs a;
   for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
   a.rank = c->rank; a.world = c->world; a.half_bytes = c->half_bytes; a.in_bytes = c->in_bytes;
-  a.spin_limit = c->spin_limit;
+  a.spin_limit = c->spin_limit; a.host_err = c->host_err;
 #define L(T, B) hipLaunchKernelGGL((qr_kernel<T, B>), dim3(MAX_BLOCKS), dim3(512), 0, st, a, (const u32x4*)in, \
                                    (u32x4*)out, nunits)
   if (bits == 8) { if (dtype == 0) L(bf16_t, 8); else L(f16_t, 8); }

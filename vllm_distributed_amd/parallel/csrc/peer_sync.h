@@ -23,7 +23,7 @@ struct Signal {
 // after it.  Every spin is bounded; on time-out the error word of this rank is set to 1 + the peer
 // that did not arrive and false is returned (the caller skips its reads and leaves).
 __device__ __forceinline__ bool peer_barrier(Signal* const* sig, int rank, int world, unsigned long long spin_limit,
-                                             uint32_t target) {
+                                             uint32_t target, uint32_t* host_err) {
   __threadfence_system();
   __syncthreads();
   __shared__ int ok;
@@ -38,6 +38,8 @@ __device__ __forceinline__ bool peer_barrier(Signal* const* sig, int rank, int w
       __builtin_amdgcn_s_sleep(1);
       if (++spins > spin_limit) {
         __scoped_atomic_store_n(&sig[rank]->error, 1u + (uint32_t)peer, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
+        // the same word in host-mapped memory: the worker polls it after every step without a device copy
+        if (host_err) __scoped_atomic_store_n(host_err, 1u + (uint32_t)peer, __ATOMIC_RELAXED, __MEMORY_SCOPE_SYSTEM);
         ok = 0;
         break;
       }
@@ -46,6 +48,14 @@ __device__ __forceinline__ bool peer_barrier(Signal* const* sig, int rank, int w
   __syncthreads();
   __threadfence_system();
   return ok != 0;
+}
+
+// One pinned, device-visible word per context for the time-out report.
+static inline uint32_t* alloc_host_err() {
+  uint32_t* p = nullptr;
+  if (hipHostMalloc((void**)&p, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return nullptr;
+  *p = 0;
+  return p;
 }
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)

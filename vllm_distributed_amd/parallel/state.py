@@ -71,6 +71,7 @@ class GroupCoordinator:
         self.device = torch.device(f"cuda:{local_rank}") if backend == "nccl" else \
             (torch.device("cuda:0") if self.staged else torch.device("cpu"))
         self.ca_comm = None       # peer-memory all-reduce
+        self.ca_comm_async = None # second context (own arena, own call counters) for the communication stream
         self.qr_comm = None       # quantised peer-memory all-reduce (opt-in)
         self.rccl_comm = None     # stream-explicit RCCL (graph capturable)
         self.mq_broadcaster = None
@@ -145,20 +146,24 @@ class GroupCoordinator:
         """Host copy of a device tensor in staged mode, the tensor itself otherwise."""
         return x.cpu() if (self.staged and x.is_cuda) else x
 
-    def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+    def all_reduce(self, x: torch.Tensor, _side_stream: bool = False) -> torch.Tensor:
         """Out of place for the peer-memory path, in place otherwise; always use the return value."""
         if self.world_size == 1:
             return x
         if x.is_cuda:
-            if self.qr_comm is not None:          # opt-in, lossy, large messages only
+            # A peer-memory context keeps per-workgroup call counters and parity-selected staging halves:
+            # two kernels of ONE context in flight on two streams would corrupt each other's parity, so
+            # calls issued on the communication stream use a context of their own.
+            ca = self.ca_comm_async if _side_stream else self.ca_comm
+            if self.qr_comm is not None and not _side_stream:          # opt-in, lossy, large messages only
                 out = self.qr_comm.all_reduce(x)
                 if out is not None:
                     return out
-            if self.ca_comm is not None and (self.rccl_comm is None or envs.VDA_CUSTOM_AR_CHUNKED
-                                             or x.numel() * x.element_size() <= self.ca_comm.max_bytes):
+            if ca is not None and (self.rccl_comm is None or envs.VDA_CUSTOM_AR_CHUNKED
+                                   or x.numel() * x.element_size() <= ca.max_bytes):
                 # latency-bound sizes (decode) take the peer-memory kernel; messages beyond one arena
                 # (prefill chunks, 100+ MiB) are bandwidth bound and go to RCCL
-                out = self.ca_comm.all_reduce(x)
+                out = ca.all_reduce(x)
                 if out is not None:
                     return out
             if self.rccl_comm is not None:
@@ -179,16 +184,34 @@ class GroupCoordinator:
         cur = torch.cuda.current_stream(x.device)
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=x.device)
+            if self.ca_comm is not None:
+                # first asynchronous call (every rank makes it at the same point): second context
+                from .custom_allreduce import CustomAllReduce
+                torch.cuda.synchronize(x.device)
+                self.ca_comm_async = CustomAllReduce.maybe_create(self.cpu_group, self.device)
         comm = self._comm_stream
         ready = torch.cuda.Event()
         ready.record(cur)
         comm.wait_event(ready)
         x.record_stream(comm)              # produced on the caller's stream, consumed on the comm stream
         with torch.cuda.stream(comm):
-            out = self.all_reduce(x)
+            out = self.all_reduce(x, _side_stream=True)
             done = torch.cuda.Event()
             done.record(comm)
         return AsyncWork(out, done)
+
+    def check_comm_errors(self) -> None:
+        """Raise if a peer-memory collective of this group timed out since the last check.  A kernel
+        whose barrier timed out skipped its reads, so the step that contained it produced garbage: the
+        worker must die (the engine then reports ENGINE_CORE_DEAD) rather than serve it.  Reads pinned
+        host words only; call after the stream has been synchronised (the sampled-token read-back)."""
+        for name in ("ca_comm", "ca_comm_async", "qr_comm"):
+            c = getattr(self, name, None)
+            if c is not None and not c.disabled:
+                e = c.check_error()
+                if e:
+                    raise RuntimeError(f"peer-memory collective of group {self.name} timed out waiting for rank "
+                                       f"{e - 1} of the group ({name}); the step's results are invalid")
 
     def all_gather(self, x: torch.Tensor, dim: int = -1) -> torch.Tensor:
         if self.world_size == 1:

@@ -65,9 +65,10 @@ class ModelRunner:
         self.max_decode_q = max(1, min(1 + self.num_spec_tokens, 32 // group if self.head_size <= 128 else 16 // group))
         self.tknp_size = pc.token_parallel_size
         self.tknp_rank = get_tknp_group().rank_in_group if self.tknp_size > 1 else 0
-        # token parallelism exchanges a different number of rows every step: eager only
-        self.use_graphs = self.is_gpu and vllm_config.compilation_config.level > 0 and not mc.enforce_eager \
-            and self.tknp_size == 1
+        # token parallelism: the rows every rank attends for change from step to step, but the peer-memory
+        # row exchange reads its counts and index lists from device buffers, so decode steps are captured
+        # at the padded batch size like any other (without that exchange: eager only)
+        self.use_graphs = self.is_gpu and vllm_config.compilation_config.level > 0 and not mc.enforce_eager
         self.capture_sizes = list(vllm_config.compilation_config.cudagraph_capture_sizes or []) if self.use_graphs else []
         self.model: Optional[nn.Module] = None
         self.sampler = Sampler()
@@ -95,6 +96,8 @@ class ModelRunner:
         self.kv_connector = None
         self.lora_manager = None
         self.eplb_state = None
+        self.tk_rx = None              # peer-memory row exchange of the token-parallel group (set by load_model)
+        self._tknp_step_bs = None
         self.encoder_cache: dict[str, dict[int, torch.Tensor]] = {}     # request -> item index -> embeddings
         self._init_buffers()
 
@@ -118,12 +121,36 @@ class ModelRunner:
         self.cascade_qsl = torch.zeros(2, dtype=torch.int32, device=dev)
         self.cascade_suffix_lens = torch.zeros(Spad, dtype=torch.int32, device=dev)
         self.pin = self.is_gpu
+        self._stage_bufs, self._stage_idx, self._stage_off = None, 0, 0
+        # one step uploads ~24 bytes per token plus one block-table row per sequence
+        self._stage_bytes = int(Tpad * 40 + Spad * (self.max_blocks * 4 + 64) + (1 << 20))
         self.intermediate: Optional[IntermediateTensors] = None
 
+    def _stage(self, src: np.ndarray) -> torch.Tensor:
+        """Host array -> a slice of a persistent pinned arena (what an asynchronous upload reads from).
+        Three arenas rotate by step: a slice is reused two steps later, after the step that read it has
+        passed its end-of-step synchronisation.  Pinning a fresh tensor per upload, as before, cost a
+        page-locking system call each time."""
+        src = np.ascontiguousarray(src)
+        if not self.pin:
+            return torch.from_numpy(src)
+        nb = src.nbytes
+        if self._stage_bufs is None:
+            self._stage_bufs = [torch.empty(self._stage_bytes, dtype=torch.uint8).pin_memory() for _ in range(3)]
+        off = (self._stage_off + 15) // 16 * 16
+        if off + nb > self._stage_bytes:
+            return torch.from_numpy(src).pin_memory()          # oversize upload: rare, pay the pin
+        self._stage_off = off + nb
+        view = self._stage_bufs[self._stage_idx][off:off + nb].view(torch.from_numpy(src[:0]).dtype).view(src.shape)
+        view.numpy()[...] = src
+        return view
+
+    def _next_stage(self) -> None:
+        self._stage_idx = (self._stage_idx + 1) % 3
+        self._stage_off = 0
+
     def _to_dev(self, dst: torch.Tensor, src: np.ndarray) -> None:
-        t = torch.from_numpy(src)
-        if self.pin:
-            t = t.pin_memory()
+        t = self._stage(src)
         dst[: t.shape[0]].copy_(t, non_blocking=True)
 
     # ------------------------------------------------------------------
@@ -168,9 +195,55 @@ class ModelRunner:
         pc = self.parallel_config
         if pc.enable_eplb and pc.enable_expert_parallel:
             self._init_eplb()
+        self._init_tknp_exchange()
         if self.vllm_config.lora_config is not None:
             from ..lora.manager import LoRAManager
             self.lora_manager = LoRAManager(self.model, self.vllm_config, self.device)
+
+    def _init_tknp_exchange(self) -> None:
+        """Token parallelism on GPUs of one node: rows travel through the peer-memory all-to-all-v
+        (device-side counts and index lists in persistent buffers), which is what lets decode steps run
+        as captured graphs; without it (CPU, several nodes, kernel unavailable) the layers fall back to
+        torch.distributed all-to-all with host-side split lists, eager only."""
+        self.tk_rx = None
+        if self.tknp_size == 1:
+            return
+        if self.is_gpu and not envs.VDA_DISABLE_PEER_ALL2ALL:
+            from ..parallel.all2all import RowExchange
+            it = torch.empty((), dtype=self.dtype).element_size()
+            width = (self.num_heads + 2 * self.num_kv_heads) * self.head_size
+            cap = max(self.max_num_tokens, max(self.capture_sizes, default=0))
+            # a row also carries the sampled token ids of a step (4 bytes per sequence) from the root
+            row_bytes = -(-max(width * it, 4 * max(self.max_num_reqs, max(self.capture_sizes, default=0))) // 16) * 16
+            rx = RowExchange(get_tknp_group(), cap, row_bytes)
+            if rx.peer is not None:
+                self.tk_rx = rx
+                n, dev = self.tknp_size, self.device
+                self.tk_sorted = torch.zeros(cap, dtype=torch.int32, device=dev)
+                self.tk_offsets = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+                self.tk_goff = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+                self.tk_iota = torch.arange(cap, dtype=torch.int32, device=dev)
+                self.tk_back = torch.zeros(cap, dtype=torch.int64, device=dev)
+                self.tk_dummy = torch.zeros((1, row_bytes // it), dtype=self.dtype, device=dev)
+                self.tk_ids_row = torch.zeros((1, row_bytes // 4), dtype=torch.int32, device=dev)
+                self.tk_bcast_off = torch.arange(n + 1, dtype=torch.int32, device=dev)      # the root: one row to everyone
+                self.tk_row0 = torch.zeros(n, dtype=torch.int32, device=dev)                # ... always its row 0
+                self.tk_zero_off = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+                return
+            rx.close()
+        if self.use_graphs:
+            logger.info("token parallelism without the peer-memory row exchange: decode graphs off")
+        self.use_graphs = False
+        self.capture_sizes = []
+
+    def _tknp_graph_bs(self, S: int, n_sched: np.ndarray) -> Optional[int]:
+        """Padded batch size of the captured graph this step replays, None for an eager step.  Decided
+        from the GLOBAL batch, which every token-parallel rank sees alike."""
+        if not self.use_graphs or not self.graphs or self.lora_manager is not None or not len(n_sched):
+            return None
+        if int(n_sched.max()) != 1 or S > self.capture_sizes[0]:
+            return None
+        return self.vllm_config.pad_for_cudagraph(S)
 
     def _init_hybrid_state(self) -> None:
         """Hybrid models (attention and state-space layers in one stack, e.g. Jamba): the paged KV cache
@@ -394,10 +467,7 @@ class ModelRunner:
         self._to_dev(self.seq_lens, seq_lens)
         self._to_dev(self.query_start_loc, cu)
         if S:
-            btv = torch.from_numpy(np.ascontiguousarray(ib.block_tables[0][rows, :W]))
-            if self.pin:
-                btv = btv.pin_memory()
-            self.block_table[:S, :W].copy_(btv, non_blocking=True)
+            self.block_table[:S, :W].copy_(self._stage(ib.block_tables[0][rows, :W]), non_blocking=True)
         if nd < S:
             self._to_dev(self.prefill_qsl, (cu[nd:] - cu[nd]).astype(np.int32))
         if self.state_table is not None and S:
@@ -480,6 +550,35 @@ class ModelRunner:
         perm_t = inv_t = None
         if is_root:
             self._to_dev(self.input_ids, ib.token_ids[tok_rows, pos])
+        att = (S_l, T_l, nd, ndt, int(seq_l.max()) if S_l else 0, int(n_l.max()) if S_l else 0)
+        if self.tk_rx is not None:
+            # peer-memory form: index lists and counts go into the persistent device buffers
+            gbs = self._tknp_graph_bs(len(req_ids), n_sched)
+            self._tknp_step_bs = gbs
+            cap = gbs if gbs is not None else max(T, 1)
+            goff = np.full(self.tknp_size + 1, T_l, dtype=np.int32)
+            goff[0] = 0
+            self._to_dev(self.tk_goff, goff)
+            if is_root:
+                perm = np.argsort(tok_owner, kind="stable")
+                self._to_dev(self.tk_sorted, perm.astype(np.int32))
+                off = np.zeros(self.tknp_size + 1, dtype=np.int32)
+                off[1:] = np.cumsum(per_rank)
+                self._to_dev(self.tk_offsets, off)
+                local_idx = np.empty(T, dtype=np.int64)
+                local_idx[perm] = np.arange(T) - off[:-1][tok_owner[perm]]
+                back = tok_owner * cap + local_idx
+                if gbs is not None and gbs > T:
+                    back = np.concatenate([back, np.zeros(gbs - T, dtype=np.int64)])
+                self._to_dev(self.tk_back, back)
+            n_tot = gbs if gbs is not None else T
+            tmd = TokenParallelMetadata(
+                tokens_per_rank=per_rank.tolist(), num_local_tokens=gbs if gbs is not None else T_l,
+                num_total_tokens=n_tot, is_root=is_root, exchange=self.tk_rx, sorted_ids=self.tk_sorted,
+                offsets=self.tk_offsets, gather_offsets=self.tk_goff, iota=self.tk_iota, back=self.tk_back[:n_tot],
+                cap=cap, dummy=self.tk_dummy)
+            return tmd, att
+        if is_root:
             perm = np.argsort(tok_owner, kind="stable")
             if not np.array_equal(perm, np.arange(T)):
                 inv = np.empty_like(perm)
@@ -488,7 +587,6 @@ class ModelRunner:
                 inv_t = torch.from_numpy(inv).to(self.device, non_blocking=True)
         tmd = TokenParallelMetadata(tokens_per_rank=per_rank.tolist(), perm=perm_t, inv_perm=inv_t,
                                     num_local_tokens=T_l, num_total_tokens=T, is_root=is_root)
-        att = (S_l, T_l, nd, ndt, int(seq_l.max()) if S_l else 0, int(n_l.max()) if S_l else 0)
         return tmd, att
 
     # ---- multimodal -----------------------------------------------------------------------------------
@@ -645,6 +743,7 @@ class ModelRunner:
         self._update_states(so)
         if not so.total_num_scheduled_tokens:
             return self._finish_kv_only(so)
+        self._next_stage()
         req_ids, rows, n_sched, cu, S, T, logits_idx, att, tmd = self._prepare_inputs(so)
         inputs_embeds = None
         if getattr(self.model, "is_multimodal", False):
@@ -657,7 +756,9 @@ class ModelRunner:
         pure_decode = nd == S and max_q == 1
         pp = get_pp_group()
         graph_bs = None
-        if self.use_graphs and pure_decode and S <= (self.capture_sizes[0] if self.capture_sizes else 0) \
+        if tmd is not None:
+            graph_bs = self._tknp_step_bs if self.tk_rx is not None else None     # decided on the global batch
+        elif self.use_graphs and pure_decode and S <= (self.capture_sizes[0] if self.capture_sizes else 0) \
                 and self.graphs and self.lora_manager is None and inputs_embeds is None:
             graph_bs = self.vllm_config.pad_for_cudagraph(S)
         if self.lora_manager is not None:
@@ -667,14 +768,15 @@ class ModelRunner:
             conn.bind_connector_metadata(so.kv_connector_metadata)
 
         if graph_bs is not None:
-            if graph_bs > S:
+            Sg = S_a                 # sequences THIS rank attends for (== S without token parallelism)
+            if graph_bs > Sg:
                 # padded sequences: zero keys, slot -1 (no cache write), one query token each
-                self.seq_lens[S:graph_bs].zero_()
-                self.slot_mapping[S:graph_bs].fill_(-1)
+                self.seq_lens[Sg:graph_bs].zero_()
+                self.slot_mapping[Sg:graph_bs].fill_(-1)
                 if self.state_table is not None:
-                    self.state_table[S:graph_bs].zero_()
-                self.query_start_loc[S + 1: graph_bs + 1].copy_(
-                    torch.arange(S + 1, graph_bs + 1, dtype=torch.int32, device=self.device))
+                    self.state_table[Sg:graph_bs].zero_()
+                self.query_start_loc[Sg + 1: graph_bs + 1].copy_(
+                    torch.arange(Sg + 1, graph_bs + 1, dtype=torch.int32, device=self.device))
             g, hidden_buf, md = self.graphs[graph_bs]
             with set_forward_context(md, kv_connector=conn, num_tokens=T):
                 if conn is not None:
@@ -727,10 +829,22 @@ class ModelRunner:
             self.lora_manager.clear_active()       # the output head and warm-up runs are not adapted
         if self.eplb_state is not None:
             self._eplb_step()
+        tk_plain = tmd is not None and self._tknp_plain_step(so, rows, conn)
         if tmd is not None and not tmd.is_root:
             # the root samples; everybody applies the same tokens to the persistent batch
             if not pp.is_last_rank:
                 return EMPTY_MODEL_RUNNER_OUTPUT
+            if tk_plain:
+                ids = self._tknp_share_sampled(None, S)
+                self._check_comm_errors()
+                done = (ib.num_computed[rows] + n_sched) >= ib.num_tokens[rows]
+                sampled_lists = [[t] if done[i] else [] for i, t in enumerate(ids)]
+                self._apply_sampled(req_ids, sampled_lists)
+                self._step += 1
+                return ModelRunnerOutput(
+                    req_ids=req_ids, req_id_to_index={r: i for i, r in enumerate(req_ids)},
+                    sampled_token_ids=sampled_lists, spec_token_ids=None, logprobs=None, prompt_logprobs_dict={},
+                    finished_sending=None, finished_recving=None, num_nans_in_logits=None)
             out = get_tknp_group().broadcast_object(None, src=0)
             self._apply_sampled(out.req_ids, out.sampled_token_ids)
             return out
@@ -761,11 +875,14 @@ class ModelRunner:
         sampled_t, logprobs_t, multi = out
         prompt_lp = self._prompt_logprobs(so, hidden, req_ids, rows, n_sched, cu)
 
+        if tk_plain:
+            self._tknp_share_sampled(sampled_t, S)          # device to device, queued before the host sync below
         # the one host sync of the step
         if multi is not None:
             sampled_lists = multi
         else:
             sampled_lists = [[t] for t in sampled_t.tolist()]
+        self._check_comm_errors()            # the stream is drained: a timed-out collective has reported by now
         # requests still in the middle of their prompt discard the sample
         done = (ib.num_computed[rows] + n_sched) >= ib.num_tokens[rows]
         for i in range(len(req_ids)):
@@ -782,9 +899,39 @@ class ModelRunner:
             sampled_token_ids=sampled_lists, spec_token_ids=spec_tokens, logprobs=lp_lists,
             prompt_logprobs_dict=prompt_lp, finished_sending=finished_sending, finished_recving=finished_recving,
             num_nans_in_logits=getattr(self, "_last_nans", None))
-        if tmd is not None:
+        if tmd is not None and not tk_plain:
             get_tknp_group().broadcast_object(result, src=0)
         return result
+
+    def _check_comm_errors(self) -> None:
+        if not self.is_gpu:
+            return
+        get_tp_group().check_comm_errors()
+        if self.tk_rx is not None and self.tk_rx.check_error():
+            raise RuntimeError("token-parallel row exchange timed out waiting for a peer; the step's results are invalid")
+        from ..parallel.all2all import check_dispatcher_errors
+        check_dispatcher_errors()
+
+    def _tknp_plain_step(self, so, rows, conn) -> bool:
+        """True when the step's result is just one sampled id per request (no log-probabilities, drafts,
+        transfer bookkeeping): then the root's ids reach the other token-parallel ranks as one int32 row
+        through the peer-memory exchange instead of a pickled object over gloo.  Every rank evaluates this
+        on the same scheduler output and the same mirrored batch, so all take the same branch."""
+        ib = self.input_batch
+        return (self.tk_rx is not None and not so.scheduled_spec_decode_tokens and self.drafter is None
+                and conn is None and not envs.VLLM_COMPUTE_NANS_IN_LOGITS
+                and not getattr(self.model, "is_pooling_model", False)
+                and not bool((ib.num_logprobs[rows] >= 0).any()) and not bool((ib.num_prompt_logprobs[rows] >= 0).any()))
+
+    def _tknp_share_sampled(self, sampled: Optional[torch.Tensor], S: int) -> Optional[list[int]]:
+        """Root: send the S sampled ids to every rank.  Others: receive them (one host sync)."""
+        rx = self.tk_rx
+        if sampled is not None:
+            self.tk_ids_row[0, :S] = sampled.to(torch.int32)
+            rx.exchange(self.tk_ids_row, self.tk_row0, self.tk_bcast_off, 1, None, 1)
+            return None
+        recv, _, _ = rx.exchange(self.tk_ids_row, self.tk_row0, self.tk_zero_off, 1, None, 1)
+        return recv[0, :S].tolist()
 
     def _pool(self, so, hidden, req_ids, rows, n_sched, cu, fs, fr) -> ModelRunnerOutput:
         """Pooling models: one vector (or score) per request once its whole prompt has been run."""
@@ -1006,6 +1153,10 @@ class ModelRunner:
                     probe.add_(1)
                 _CAPTURE_STATE_ANCHOR = (anchor, probe)
         self.graph_pool = torch.cuda.graph_pool_handle()
+        if self.tk_rx is not None:
+            # nothing moves during warm-up and capture: every rank sends zero rows
+            for t in (self.tk_offsets, self.tk_goff, self.tk_back):
+                t.zero_()
         with graph_capture(self.device) as cap:
             for bs in sorted(self.capture_sizes, reverse=True):
                 nsplit = self._decode_splits(bs, 0, True)
@@ -1013,11 +1164,20 @@ class ModelRunner:
                 self.slot_mapping[:bs].fill_(-1)
                 self.query_start_loc[:bs + 1].copy_(torch.arange(bs + 1, dtype=torch.int32, device=self.device))
                 md = self._build_attn_metadata(bs, bs, bs, bs, 0, 1, nsplit)
+                tmd = None
+                if self.tk_rx is not None:
+                    # token parallelism: bs rows on the root, up to bs local rows on every rank; counts and
+                    # index lists are read from the persistent buffers at replay
+                    tmd = TokenParallelMetadata(
+                        tokens_per_rank=[], num_local_tokens=bs, num_total_tokens=bs, is_root=self.tknp_rank == 0,
+                        exchange=self.tk_rx, sorted_ids=self.tk_sorted, offsets=self.tk_offsets,
+                        gather_offsets=self.tk_goff, iota=self.tk_iota, back=self.tk_back[:bs], cap=bs,
+                        dummy=self.tk_dummy)
                 for _ in range(self.vllm_config.compilation_config.cudagraph_num_of_warmups):
-                    with set_forward_context(md):
+                    with set_forward_context(md, tknp=tmd):
                         self.model(self.input_ids[:bs], self.positions[:bs], self._capture_inter(bs), None)
                 g = torch.cuda.CUDAGraph()
-                with set_forward_context(md):
+                with set_forward_context(md, tknp=tmd):
                     with torch.cuda.graph(g, pool=self.graph_pool, stream=cap.stream):
                         out = self.model(self.input_ids[:bs], self.positions[:bs], self._capture_inter(bs), None)
                 self.graphs[bs] = (g, out, md)

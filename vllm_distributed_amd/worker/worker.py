@@ -154,6 +154,10 @@ class Worker:
                     "non-torch %.1f, graph reserve %.1f -> KV cache %.1f GiB",
                     total / 2**30, budget / 2**30, now_torch / 2**30, activation_peak / 2**30,
                     max(non_torch, 0) / 2**30, graph_reserve / 2**30, avail / 2**30)
+        if envs.VDA_REHEARSE_ON_ONE_GPU and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            # ranks sharing one device: nobody allocates its KV cache while another rank still measures
+            torch.distributed.barrier()
         return int(max(avail, 0))
 
     def initialize_from_config(self, kv_cache_config) -> None:
