@@ -75,3 +75,166 @@ def test_shared_storage_connector(tmp_path):
     assert [list(o.outputs[0].token_ids) for o in out_b] == ref
     # second instance found the prompts on disk: block-aligned prefixes were not recomputed
     assert all(o.num_cached_tokens == (len(p) - 1) // 16 * 16 for o, p in zip(out_b, PROMPTS))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# heterogeneous tensor parallelism, parameter validation, lifecycle while WAITING_FOR_REMOTE_KVS
+# (modelled on the reference's tests/v1/kv_connector/unit/test_remote_prefill_lifecycle.py and
+# test_nixl_connector.py, with fake runners in place of GPUs)
+# ---------------------------------------------------------------------------------------------------------
+import time
+from types import SimpleNamespace
+
+import torch
+
+from vllm_distributed_amd.parallel.kv_transfer.xgmi import RecvSpec, XgmiConnector, XgmiMetadata, head_range, \
+    head_segments
+from vllm_distributed_amd.parallel.kv_transfer.base import KVConnectorRole
+
+
+@pytest.mark.parametrize("heads,ptp,dtp", [(8, 1, 2), (8, 2, 8), (8, 4, 2), (8, 8, 1), (2, 2, 8), (2, 8, 2), (4, 4, 4),
+                                           (1, 4, 2), (8, 2, 2)])
+def test_head_segments_cover_every_consumer_head_exactly(heads, ptp, dtp):
+    for r in range(dtp):
+        lo, hi = head_range(r, dtp, heads)
+        got = []
+        for p, src_h, dst_h, n in head_segments(r, dtp, ptp, heads):
+            plo, phi = head_range(p, ptp, heads)
+            assert 0 <= src_h and src_h + n <= phi - plo and 0 <= p < ptp
+            got += [(plo + src_h + i, dst_h + i) for i in range(n)]
+        assert got == [(lo + i, i) for i in range(hi - lo)]
+
+
+def _fake_side(tp, rank, role, port, heads_total=4, nb=12, bs=4, d=8, layers=("l0", "l1"), engine_id="E", key="k"):
+    """A connector with a fake runner: per layer K [nb, h, bs, d] and V [nb, h, d, bs] as uint8 rows, plus a
+    head-less (replicated) tensor per block."""
+    h = max(1, heads_total // tp)
+    per = h * bs * d * 2
+    extra = 32
+    chunk = torch.zeros(len(layers) * nb * (2 * per + extra), dtype=torch.uint8)
+    parts, off = {}, 0
+    for n in layers:
+        parts[n] = [(0, off, nb * per, h), (0, off + nb * per, nb * per, h), (0, off + 2 * nb * per, nb * extra, 0)]
+        off += nb * (2 * per + extra)
+    runner = SimpleNamespace(is_gpu=False, device=torch.device("cpu"), kv_chunks=[chunk], kv_regions=[],
+                             kv_layer_parts=parts, kv_cache_config=SimpleNamespace(num_blocks=nb))
+    cfg = SimpleNamespace(
+        kv_transfer_config=SimpleNamespace(engine_id=engine_id, kv_port=port, is_kv_producer=role == "p",
+                                           kv_connector_extra_config={"auth_key": key, "side_channel_host": "127.0.0.1"}),
+        cache_config=SimpleNamespace(block_size=bs), parallel_config=SimpleNamespace(tensor_parallel_size=tp),
+        model_config=SimpleNamespace(get_total_num_kv_heads=lambda: heads_total))
+    c = XgmiConnector.__new__(XgmiConnector)
+    XgmiConnector.__init__(c, cfg, KVConnectorRole.WORKER)
+    c.runner, c.tp_rank, c.total_kv_heads = runner, rank, heads_total
+    if role == "p":
+        from vllm_distributed_amd.engine.transport import Listener
+        import threading
+        c.listener = Listener(f"tcp://127.0.0.1:{port + rank}")
+        threading.Thread(target=c._serve, daemon=True).start()
+    return c, runner, (h, bs, d, per, extra)
+
+
+def _wait_done(conn, rid, timeout=10.0):
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        with conn._lock:
+            if rid in conn._done_recving:
+                return True
+        time.sleep(0.01)
+    return False
+
+
+@pytest.mark.parametrize("ptp,dtp", [(1, 2), (2, 1), (2, 4), (2, 2)])
+def test_pull_with_another_tensor_parallel_degree(ptp, dtp):
+    """Every consumer rank must end up with exactly its heads of the exported blocks, whatever the
+    producer's sharding; head-less tensors arrive whole."""
+    port = _free_port()
+    H, nb, bs, d = 4, 12, 4, 8
+    full = {n: (torch.randint(0, 255, (nb, H, bs * d * 2), dtype=torch.uint8),
+                torch.randint(0, 255, (nb, H, bs * d * 2), dtype=torch.uint8),
+                torch.randint(0, 255, (nb, 32), dtype=torch.uint8)) for n in ("l0", "l1")}
+    prods = []
+    for r in range(ptp):
+        c, run, (h, _, _, per, extra) = _fake_side(ptp, r, "p", port)
+        lo, hi = head_range(r, ptp, H)
+        for n, views in c._my_views().items():
+            views[0][0].copy_(full[n][0][:, lo:hi].reshape(nb, -1))
+            views[1][0].copy_(full[n][1][:, lo:hi].reshape(nb, -1))
+            views[2][0].copy_(full[n][2])
+        prods.append(c)
+    remote = [7, 2, 9]
+    local = [1, 5, 3]
+    token = prods[0]._sign("", remote)
+    try:
+        for r in range(dtp):
+            c, run, _ = _fake_side(dtp, r, "d", port)
+            spec = RecvSpec(local, remote, "127.0.0.1", port, "E", token, remote, 0)
+            c._start_pull("req", spec)
+            assert _wait_done(c, "req") and not c._failed_recving
+            lo, hi = head_range(r, dtp, H)
+            for n, views in c._my_views().items():
+                for part in range(2):
+                    want = full[n][part][remote][:, lo:hi].reshape(len(remote), -1)
+                    assert torch.equal(views[part][0][local], want), (n, part, r)
+                assert torch.equal(views[2][0][local], full[n][2][remote])
+                untouched = [b for b in range(nb) if b not in local]
+                assert int(views[0][0][untouched].sum()) == 0
+            c.shutdown()
+        # every producer rank saw as many DONE notices as consumers read from it: the export is released
+        time.sleep(0.2)
+        for p in prods:
+            with p._lock:
+                assert "req" in p._done_sending and not p._done_votes
+    finally:
+        for p in prods:
+            p.shutdown()
+
+
+def test_forged_transfer_parameters_are_refused():
+    """Block ids the producer did not export (or out of range, or lists of unequal length) never reach a
+    copy: the pull fails, the request is reported as failed and nothing is written."""
+    port = _free_port()
+    p, _, _ = _fake_side(1, 0, "p", port)
+    for n, views in p._my_views().items():
+        views[0][0].fill_(7)
+    d, _, _ = _fake_side(1, 0, "d", port)
+    good = [3, 4]
+    token = p._sign("", good)
+    try:
+        cases = [
+            RecvSpec([1, 2], [5, 6], "127.0.0.1", port, "E", token, [5, 6], 0),        # other blocks, stolen token
+            RecvSpec([1, 2], good, "127.0.0.1", port, "E", "0" * 64, good, 0),         # no valid token
+            RecvSpec([1, 2], [3, 99], "127.0.0.1", port, "E", token, [3, 99], 0),      # remote id out of range
+            RecvSpec([1, 99], good, "127.0.0.1", port, "E", token, good, 0),           # local id out of range
+            RecvSpec([1], good, "127.0.0.1", port, "E", token, good, 0),               # lengths differ
+        ]
+        for i, spec in enumerate(cases):
+            d._meta = XgmiMetadata({f"bad{i}": spec}, {})
+            d.start_load_kv()
+            assert _wait_done(d, f"bad{i}"), i
+        fin = d.get_finished(set())
+        assert fin[1] == {f"bad{i}" for i in range(len(cases))}
+        assert d.failed_recving() == fin[1]
+        for n, views in d._my_views().items():
+            assert int(views[0][0].sum()) == 0
+        # and the genuine request still works
+        d._meta = XgmiMetadata({"ok": RecvSpec([1, 2], good, "127.0.0.1", port, "E", token, good, 0)}, {})
+        d.start_load_kv()
+        assert _wait_done(d, "ok")
+        assert d.get_finished(set())[1] == {"ok"} and not d.failed_recving()
+        assert int(d._my_views()["l0"][0][0][[1, 2]].min()) == 7
+    finally:
+        p.shutdown()
+        d.shutdown()
+
+
+def test_layout_mismatch_is_refused_at_handshake():
+    port = _free_port()
+    p, _, _ = _fake_side(1, 0, "p", port, d=8)
+    d, _, _ = _fake_side(1, 0, "d", port, d=16)          # another head size
+    try:
+        with pytest.raises(ValueError, match="differs in dtype, head size"):
+            d._peer("127.0.0.1", port, 0)
+    finally:
+        p.shutdown()
+        d.shutdown()

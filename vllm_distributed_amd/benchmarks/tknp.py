@@ -30,13 +30,16 @@ def main(argv=None) -> list[dict]:
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.85)
     ap.add_argument("--output-json", default=None)
+    ap.add_argument("--enforce-eager", action="store_true",
+                    help="no captured decode graphs (what the reference's benchmark runs: its token-parallel "
+                         "path cannot be captured)")
     a = ap.parse_args(argv)
     from .. import LLM, SamplingParams
     batches = [int(x) for x in a.batch_sizes.split(",")]
     lens = [int(x) for x in a.seq_lens.split(",")]
     tknp = a.token_parallel_size
     llm = LLM(model=a.model, load_format=a.load_format, dtype=a.dtype, device=a.device, skip_tokenizer_init=True,
-              enforce_eager=True, enable_prefix_caching=False, max_model_len=max(lens) + a.decode_tokens + 8,
+              enforce_eager=a.enforce_eager, enable_prefix_caching=False, max_model_len=max(lens) + a.decode_tokens + 8,
               max_num_seqs=max(batches), max_num_batched_tokens=max(8192, max(lens)),
               gpu_memory_utilization=a.gpu_memory_utilization,
               distributed_executor_backend="external_launcher" if "RANK" in os.environ else None,

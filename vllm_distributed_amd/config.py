@@ -751,6 +751,10 @@ class KVTransferConfig:
     def __post_init__(self):
         if self.engine_id is None:
             self.engine_id = str(uuid.uuid4())
+        # secret the exporting scheduler signs block lists with and its workers check them against (it
+        # travels to the workers inside this config); ranks started separately (external launcher) must
+        # be given the same "auth_key"
+        self.kv_connector_extra_config.setdefault("auth_key", uuid.uuid4().hex)
         if self.kv_role not in (None, "kv_producer", "kv_consumer", "kv_both"):
             raise ValueError("kv_role must be kv_producer, kv_consumer or kv_both")
         if self.kv_connector is not None and self.kv_role is None:

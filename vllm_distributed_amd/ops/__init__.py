@@ -173,6 +173,19 @@ def transfer_blocks(dst: torch.Tensor, src: torch.Tensor, dst_ids: torch.Tensor,
            dst_ids.numel(), dst.stride(0) * dst.element_size(), N.stream())
 
 
+def transfer_block_slices(dst: torch.Tensor, src: torch.Tensor, dst_ids: torch.Tensor, src_ids: torch.Tensor,
+                          copy_bytes: int, dst_off: int = 0, src_off: int = 0):
+    """Bytes [dst_off, dst_off + copy_bytes) of block dst_ids[i] of ``dst`` [blocks, bytes] (uint8 rows) come
+    from bytes [src_off, ...) of block src_ids[i] of ``src``; the two sides may have different row lengths."""
+    if not (dst.is_cuda or src.is_cuda) or envs.VDA_FORCE_TORCH_OPS:
+        d, s_ = dst_ids.long().to(dst.device), src_ids.long().to(src.device)
+        dst[d, dst_off:dst_off + copy_bytes] = src[s_, src_off:src_off + copy_bytes].to(dst.device)
+        return
+    assert dst.dtype == torch.uint8 and src.dtype == torch.uint8 and dst.stride(1) == 1 and src.stride(1) == 1
+    N.call("vda_transfer_blocks_ex", dst.data_ptr(), src.data_ptr(), dst_ids.data_ptr(), src_ids.data_ptr(),
+           dst_ids.numel(), copy_bytes, dst.stride(0), src.stride(0), dst_off, src_off, N.stream())
+
+
 def gather_cache(k_cache, v_cache, slots):
     """Token-major copies [T, Hkv, D] of the K and V rows at the given slots."""
     if not _dev(k_cache):

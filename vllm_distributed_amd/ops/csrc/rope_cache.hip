@@ -209,27 +209,40 @@ VDA_EXPORT int vda_copy_blocks(void* cache, const long* pairs, int num_pairs, lo
 }
 
 // Copy blocks between two cache tensors (possibly on different devices mapped
-// through peer access, or pinned host memory): dst[dst_ids[i]] = src[src_ids[i]].
+// through peer access, or pinned host memory): `copy` 16-byte units starting at unit `dst_off` of block
+// dst_ids[i] of dst come from unit `src_off` on of block src_ids[i] of src.  The two sides may have
+// different block pitches: a decode instance with another tensor-parallel degree than the prefill
+// instance copies only its slice of the KV heads of every block (heads are the outer dimension of a block).
 __global__ __launch_bounds__(256) void transfer_blocks_kernel(u32x4* __restrict__ dst, const u32x4* __restrict__ src,
                                                               const long* __restrict__ dst_ids,
-                                                              const long* __restrict__ src_ids, long block_vec16) {
-  const u32x4* s = src + src_ids[blockIdx.x] * block_vec16;
-  u32x4* d = dst + dst_ids[blockIdx.x] * block_vec16;
-  for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < block_vec16; i += (long)gridDim.y * blockDim.x)
+                                                              const long* __restrict__ src_ids, long copy,
+                                                              long dst_pitch, long src_pitch, long dst_off,
+                                                              long src_off) {
+  const u32x4* s = src + src_ids[blockIdx.x] * src_pitch + src_off;
+  u32x4* d = dst + dst_ids[blockIdx.x] * dst_pitch + dst_off;
+  for (long i = (long)blockIdx.y * blockDim.x + threadIdx.x; i < copy; i += (long)gridDim.y * blockDim.x)
     d[i] = s[i];
+}
+
+VDA_EXPORT int vda_transfer_blocks_ex(void* dst, const void* src, const long* dst_ids, const long* src_ids, int n,
+                                      long copy_bytes, long dst_pitch_bytes, long src_pitch_bytes, long dst_off_bytes,
+                                      long src_off_bytes, hipStream_t st) {
+  if (copy_bytes % 16 || dst_pitch_bytes % 16 || src_pitch_bytes % 16 || dst_off_bytes % 16 || src_off_bytes % 16)
+    return -1;
+  if (copy_bytes + dst_off_bytes > dst_pitch_bytes || copy_bytes + src_off_bytes > src_pitch_bytes) return -1;
+  if (n == 0 || copy_bytes == 0) return 0;
+  const long v = copy_bytes / 16;
+  int gy = (int)((v + 255) / 256);
+  if (gy > 16) gy = 16;
+  hipLaunchKernelGGL(transfer_blocks_kernel, dim3(n, gy), dim3(256), 0, st, (u32x4*)dst, (const u32x4*)src, dst_ids,
+                     src_ids, v, dst_pitch_bytes / 16, src_pitch_bytes / 16, dst_off_bytes / 16, src_off_bytes / 16);
+  VDA_CHECK_LAUNCH();
+  return 0;
 }
 
 VDA_EXPORT int vda_transfer_blocks(void* dst, const void* src, const long* dst_ids, const long* src_ids, int n,
                                    long block_bytes, hipStream_t st) {
-  if (block_bytes % 16) return -1;
-  if (n == 0) return 0;
-  const long v = block_bytes / 16;
-  int gy = (int)((v + 255) / 256);
-  if (gy > 16) gy = 16;
-  hipLaunchKernelGGL(transfer_blocks_kernel, dim3(n, gy), dim3(256), 0, st, (u32x4*)dst, (const u32x4*)src, dst_ids,
-                     src_ids, v);
-  VDA_CHECK_LAUNCH();
-  return 0;
+  return vda_transfer_blocks_ex(dst, src, dst_ids, src_ids, n, block_bytes, block_bytes, block_bytes, 0, 0, st);
 }
 
 // Gather the K (or V) rows of one sequence back into token-major [T, Hkv, D]

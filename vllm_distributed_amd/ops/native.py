@@ -36,6 +36,7 @@ _SIGS = {
     "vda_rope_and_cache": [P, P, P, P, P, P, I, I, I, I, I, I, L, I, I, I, F, F, P],
     "vda_copy_blocks": [P, P, I, L, P],
     "vda_transfer_blocks": [P, P, P, P, I, L, P],
+    "vda_transfer_blocks_ex": [P, P, P, P, I, L, L, L, L, L, P],
     "vda_gather_cache": [P, P, P, P, P, I, I, I, I, I, P],
     "vda_paged_attention_decode": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, P],
     "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, I, P,

@@ -49,6 +49,11 @@ class KVConnectorBase:
         """(request ids whose export finished, request ids whose import finished) since last call."""
         return None, None
 
+    def failed_recving(self) -> set[str]:
+        """Of the imports reported by the last ``get_finished``: those that failed (nothing usable arrived;
+        the scheduler has the prompt computed locally).  Cleared by the call."""
+        return set()
+
     def shutdown(self) -> None:
         pass
 

@@ -58,6 +58,12 @@ class MultiConnector(KVConnectorBase):
         for c in self.children:
             c.wait_for_save()
 
+    def failed_recving(self):
+        out = set()
+        for c in self.children:
+            out |= c.failed_recving()
+        return out
+
     def get_finished(self, finished_req_ids):
         sending, recving = set(), set()
         for c in self.children:

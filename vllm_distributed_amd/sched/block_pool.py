@@ -246,7 +246,9 @@ class BlockPool:
         return self.free_queue.num_free_blocks
 
     def get_usage(self) -> float:
-        return 1.0 - self.get_num_free_blocks() / self.num_gpu_blocks
+        """Fraction of the allocatable blocks in use (the null block is never handed out and not counted)."""
+        usable = max(self.num_gpu_blocks - 1, 1)
+        return max(0.0, 1.0 - self.get_num_free_blocks() / usable)
 
     def take_events(self) -> list[KVCacheEvent]:
         ev, self._events = self._events, []

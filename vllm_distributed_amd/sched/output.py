@@ -86,6 +86,8 @@ class ModelRunnerOutput:
     pooler_output: list = field(default_factory=list)
     finished_sending: Optional[set[str]] = None
     finished_recving: Optional[set[str]] = None
+    # subset of finished_recving whose transfer failed: nothing usable arrived, the prompt is computed locally
+    failed_recving: Optional[set[str]] = None
     num_nans_in_logits: Optional[dict[str, int]] = None
 
 

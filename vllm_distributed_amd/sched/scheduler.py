@@ -126,6 +126,10 @@ class Scheduler(SchedulerInterface):
         self.finished_req_ids: set[str] = set()
         # P/D: requests whose remote KV arrived
         self.finished_recving_kv_req_ids: set[str] = set()
+        self.failed_recving_kv_req_ids: set[str] = set()
+        # requests finished (aborted) while their remote KV was still arriving: the blocks stay allocated
+        # until the worker reports the transfer over, or the copy would land in somebody else's blocks
+        self.abandoned_recving: dict[str, Request] = {}
 
         self.encoder_cache_manager = EncoderCacheManager(sc.encoder_cache_size)
         self.max_num_encoder_input_tokens = sc.max_num_encoder_input_tokens
@@ -562,12 +566,17 @@ class Scheduler(SchedulerInterface):
         if wait_drop:
             self.waiting.remove_requests(wait_drop)
         for req in run_drop + wait_drop:
+            recving = req.status == RequestStatus.WAITING_FOR_REMOTE_KVS \
+                and req.request_id not in self.finished_recving_kv_req_ids
             req.status = finished_status
-            self._free_request(req)
+            self._free_request(req, keep_blocks=recving)
+            if recving:
+                self.abandoned_recving[req.request_id] = req
 
-    def _free_request(self, req: Request) -> Optional[dict]:
+    def _free_request(self, req: Request, keep_blocks: bool = False) -> Optional[dict]:
         assert req.is_finished()
         delay, kv_params = self._connector_finished(req)
+        delay = delay or keep_blocks
         self.encoder_cache_manager.free(req)
         rid = req.request_id
         self.finished_req_ids.add(rid)
@@ -624,6 +633,12 @@ class Scheduler(SchedulerInterface):
         rid = req.request_id
         if rid not in self.finished_recving_kv_req_ids:
             return False
+        if rid in self.failed_recving_kv_req_ids:
+            # the transfer failed: the blocks are there but hold nothing; compute the prompt here
+            self.failed_recving_kv_req_ids.discard(rid)
+            self.finished_recving_kv_req_ids.discard(rid)
+            req.num_computed_tokens = 0
+            return True
         block_ids = self.kv_cache_manager.get_block_ids(rid)[0]
         n_computed = len(block_ids) * self.block_size
         # always leave the last token to be computed locally
@@ -636,7 +651,14 @@ class Scheduler(SchedulerInterface):
         return True
 
     def _update_from_kv_xfer_finished(self, mro: ModelRunnerOutput) -> None:
+        for rid in mro.failed_recving or ():
+            self.failed_recving_kv_req_ids.add(rid)
         for rid in mro.finished_recving or ():
+            gone = self.abandoned_recving.pop(rid, None)
+            if gone is not None:
+                self.failed_recving_kv_req_ids.discard(rid)
+                self._free_blocks(gone)              # aborted while receiving: now nobody writes there any more
+                continue
             self.finished_recving_kv_req_ids.add(rid)
         for rid in mro.finished_sending or ():
             req = self.requests.get(rid)

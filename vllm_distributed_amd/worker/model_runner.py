@@ -350,6 +350,9 @@ class ModelRunner:
         self.kv_caches = []
         # layer name -> (chunk index, byte offset of K inside the chunk, bytes of K == bytes of V)
         self.kv_layer_loc: dict[str, tuple[int, int, int]] = {}
+        # layer name -> [(chunk index, byte offset, bytes, KV heads)] for every per-block tensor of the layer
+        # (K and V; latent + transposed latent; state tensors).  Heads = 0: not sharded by head (copied whole).
+        self.kv_layer_parts: dict[str, list[tuple[int, int, int, int]]] = {}
         nb = cfg.num_blocks
         for ci, g in enumerate(groups):
             off = 0
@@ -369,9 +372,14 @@ class ModelRunner:
                                              "a multiple of 16 bytes")
                         parts.append(raw[o2: o2 + nb * pb].view(dt_i).view(nb, *shape))
                         o2 += nb * pb
+                    locs, o3 = [], 0
+                    for pb in sp.part_bytes():
+                        locs.append((ci, off + o3, nb * pb, 0))
+                        o3 += nb * pb
                     for n in t.shared_by:
                         self.attn_layers[n].bind_kv_cache(*parts)
                         self.kv_layer_loc[n] = (ci, off, t.size)
+                        self.kv_layer_parts[n] = locs
                     self.kv_caches.append(tuple(parts))
                     off += t.size
                     continue
@@ -382,6 +390,7 @@ class ModelRunner:
                     for n in t.shared_by:
                         self.attn_layers[n].bind_kv_cache(k, v)
                         self.kv_layer_loc[n] = (ci, off, t.size)
+                        self.kv_layer_parts[n] = [(ci, off, kb, 0), (ci, off + kb, t.size - kb, 0)]
                     self.kv_caches.append((k, v))
                     off += t.size
                     continue
@@ -391,6 +400,7 @@ class ModelRunner:
                 for n in t.shared_by:
                     self.attn_layers[n].bind_kv_cache(k, v)
                     self.kv_layer_loc[n] = (ci, off, half)
+                    self.kv_layer_parts[n] = [(ci, off, half, sp.num_kv_heads), (ci, off + half, half, sp.num_kv_heads)]
                 self.kv_caches.append((k, v))
                 off += t.size
         self.input_batch = InputBatch(self.max_num_reqs, self.max_model_len, self.block_size, self.vocab_size,
@@ -852,6 +862,7 @@ class ModelRunner:
             return hidden
         finished_sending, finished_recving = (conn.get_finished(so.finished_req_ids) if conn is not None
                                               else (None, None))
+        failed_recving = (conn.failed_recving() or None) if conn is not None else None
 
         if getattr(self.model, "is_pooling_model", False):
             return self._pool(so, hidden, req_ids, rows, n_sched, cu, finished_sending, finished_recving)
@@ -898,6 +909,7 @@ class ModelRunner:
             req_ids=req_ids, req_id_to_index={r: i for i, r in enumerate(req_ids)},
             sampled_token_ids=sampled_lists, spec_token_ids=spec_tokens, logprobs=lp_lists,
             prompt_logprobs_dict=prompt_lp, finished_sending=finished_sending, finished_recving=finished_recving,
+            failed_recving=failed_recving,
             num_nans_in_logits=getattr(self, "_last_nans", None))
         if tmd is not None and not tk_plain:
             get_tknp_group().broadcast_object(result, src=0)
@@ -970,10 +982,11 @@ class ModelRunner:
         conn.bind_connector_metadata(so.kv_connector_metadata)
         conn.start_load_kv()
         fs, fr = conn.get_finished(so.finished_req_ids)
+        failed = conn.failed_recving() or None
         conn.clear_connector_metadata()
         if not fs and not fr:
             return EMPTY_MODEL_RUNNER_OUTPUT
-        return ModelRunnerOutput(finished_sending=fs, finished_recving=fr)
+        return ModelRunnerOutput(finished_sending=fs, finished_recving=fr, failed_recving=failed)
 
     # ------------------------------------------------------------------
     def _sampling_metadata(self, req_ids: list[str], rows: np.ndarray) -> SamplingMetadata:
