@@ -435,3 +435,112 @@ def test_modelopt_nvfp4_checkpoint_is_dequantised_while_loading(tmp_path):
             ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
                               eos_token_id=None)[0, len(p):].tolist()
         assert list(o.outputs[0].token_ids) == ref, p
+
+
+@pytest.mark.parametrize("kind", ["llama", "mixtral"])
+def test_block_scaled_fp8_checkpoint_runs_natively(tmp_path, kind, monkeypatch):
+    """128 x 128 block-scaled fp8 (DeepSeek-V3 style ``weight_scale_inv``): the weights stay e4m3 in the
+    model (half the bytes of the expanded form), activations are quantised per group of 128 on the fly, and
+    the tokens equal those of the HF model holding the dequantised weights with the same activation rounding
+    emulated in front of every quantised projection."""
+    import json
+    import os
+
+    import transformers as tf
+    from safetensors.torch import load_file, save_file
+
+    from vllm_distributed_amd import LLM, SamplingParams
+    torch.manual_seed(0)
+    if kind == "llama":
+        cfg = tf.LlamaConfig(vocab_size=320, hidden_size=256, intermediate_size=256, num_hidden_layers=2,
+                             num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256, head_dim=64)
+        hf = tf.LlamaForCausalLM(cfg)
+    else:
+        cfg = tf.MixtralConfig(vocab_size=320, hidden_size=128, intermediate_size=128, num_hidden_layers=2,
+                               num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=256,
+                               num_local_experts=4, num_experts_per_tok=2, sliding_window=None, head_dim=64)
+        hf = tf.MixtralForCausalLM(cfg)
+    hf = hf.float().eval()
+    path = str(tmp_path / kind)
+    hf.save_pretrained(path, safe_serialization=True)
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    out, n_q, emulated_all, deq_sd = {}, 0, True, {}
+
+    def _round128(x):
+        from vllm_distributed_amd.ops import reference as R
+        xq, xs = R.per_group_fp8_quant(x.reshape(-1, x.shape[-1]), 128)
+        return (xq.float().view(*xs.shape, -1) * xs.unsqueeze(-1)).view(x.shape)
+    for name, t in sd.items():
+        leaf = name.rsplit(".", 2)[-2]
+        if not (t.dim() == 2 and name.endswith(".weight") and (leaf.endswith("_proj") or leaf in ("w1", "w2", "w3"))):
+            out[name] = t
+            continue
+        N, K = t.shape
+        bn = bk = 128
+        blocks = t.view(N // bn, bn, K // bk, bk)
+        s = (blocks.abs().amax(dim=(1, 3)) / 448.0).clamp(min=1e-8)
+        q = (blocks / s[:, None, :, None]).view(N, K).to(torch.float8_e4m3fn)
+        out[name], out[name[: -len(".weight")] + ".weight_scale_inv"] = q, s.float()
+        deq = (q.float().view(N // bn, bn, K // bk, bk) * s[:, None, :, None]).view(N, K)
+        n_q += 1
+        try:
+            mod = hf.get_submodule(name[: -len(".weight")])
+        except AttributeError:
+            # experts held as stacked tensors by this transformers version: write the dequantised weights
+            # back through a reload below, without the activation rounding (loose comparison for them)
+            emulated_all = False
+            deq_sd[name] = deq
+            continue
+        with torch.no_grad():
+            mod.weight.copy_(deq)
+
+        def rounded(x, _m=mod):
+            from vllm_distributed_amd.ops import reference as R
+            xq, xs = R.per_group_fp8_quant(x.reshape(-1, x.shape[-1]), 128)
+            xd = (xq.float().view(*xs.shape, -1) * xs.unsqueeze(-1)).view(x.shape)
+            return torch.nn.functional.linear(xd, _m.weight, _m.bias)
+        mod.forward = rounded
+    assert n_q > 0
+    if deq_sd:
+        full = dict(sd)
+        full.update(deq_sd)
+        save_file(full, os.path.join(path, "model.safetensors"))
+        fresh = type(hf).from_pretrained(path).float().eval()
+        for n_, m_ in hf.named_modules():            # keep the patched forwards of the attention projections
+            if "forward" in m_.__dict__:
+                tgt = fresh.get_submodule(n_)
+                with torch.no_grad():
+                    tgt.weight.copy_(m_.weight)
+                fwd = m_.__dict__["forward"]
+                tgt.forward = (lambda x, _f=fwd.__defaults__, _m=tgt: __import__("torch").nn.functional.linear(
+                    _round128(x), _m.weight, _m.bias))
+        hf = fresh
+    save_file(out, os.path.join(path, "model.safetensors"))
+    c = json.load(open(os.path.join(path, "config.json")))
+    c["quantization_config"] = {"quant_method": "fp8", "weight_block_size": [128, 128], "activation_scheme": "dynamic"}
+    json.dump(c, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30, list(range(40, 75))]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=8,
+                                                                                 ignore_eos=True))
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    params = dict(model.named_parameters())
+    fp8 = [n for n, p in params.items() if p.dtype == torch.float8_e4m3fn]
+    assert fp8 and any(n.endswith("weight_scale_inv") for n in params), "weights must stay in fp8 with block scales"
+    llm.shutdown()
+    same = total = 0
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        got = list(o.outputs[0].token_ids)
+        same += sum(a == b for a, b in zip(got, ref))
+        total += len(ref)
+        if emulated_all:
+            assert got[:4] == ref[:4], (kind, p, got, ref)
+        else:
+            assert got[0] == ref[0], (kind, p, got, ref)
+    # fp32 accumulation order differs: allow a late near-tie (more of them where the reference does not
+    # round the experts' activations)
+    assert same >= (0.9 if emulated_all else 0.6) * total, (same, total)

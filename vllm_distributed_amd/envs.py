@@ -83,6 +83,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_W4_SKINNY_MAX_M": (int, 32),            # W4A16: rows served by the packed-weight skinny kernel
     "VDA_MLA": (_bool, True),                    # DeepSeek: latent KV cache + absorbed projections; 0 = expanded heads
     "VDA_INT4_WEIGHTS": (_bool, True),           # keep 4-bit GPTQ/AWQ linear weights packed (W4A16 kernel); 0 = expand at load
+    "VDA_FP8_BLOCK_NATIVE": (_bool, True),       # 128x128 block-scaled fp8 checkpoints: keep weights in fp8 (0: expand to 16 bit at load)
     "VDA_FP8_W8A16_MAX_M": (int, 64),            # fp8 linear: up to this M stream weights, beyond use fp8 MFMA GEMM
     "VDA_DISABLE_PEER_ALL2ALL": (_bool, False),  # expert / token parallel row exchange through torch.distributed instead of peer memory
     "VDA_EP_DISPATCH": (_bool, True),            # expert parallel without DP attention: route tokens to expert owners (False: replicate + mask + all-reduce)

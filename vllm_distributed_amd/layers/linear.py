@@ -122,6 +122,17 @@ class ColumnParallelLinear(LinearBase):
         return y
 
 
+def _in_blocks(prefix: str, param, off: int, size: int, tp: int) -> tuple[int, int]:
+    """Offsets of a logical shard along the output dimension, in units of the parameter's scale blocks
+    (``block_n`` attribute: one scale row per that many weight rows; 1 for ordinary parameters)."""
+    blk = int(getattr(param, "block_n", 1) or 1)
+    if blk == 1:
+        return off, size
+    if off % blk or (size % blk and tp > 1):
+        raise ValueError(f"{prefix}: a shard of {size} rows at row {off} does not line up with {blk}-row scale blocks")
+    return off // blk, -(-size // blk)
+
+
 class MergedColumnParallelLinear(ColumnParallelLinear):
     """Several column-parallel projections of the same input fused into one GEMM
     (gate_proj + up_proj).  ``shard_id`` selects the logical projection."""
@@ -154,6 +165,7 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
             return default_weight_loader(param, loaded)
         off = sum(self.output_sizes[:shard_id]) // self.tp_size
         size = self.output_sizes[shard_id] // self.tp_size
+        off, size = _in_blocks(self.prefix, param, off, size, self.tp_size)
         dst = param.data.narrow(out_dim, off, size)
         src = loaded.narrow(out_dim, self.tp_rank * size, size)
         if dst.shape != src.shape:
@@ -202,6 +214,7 @@ class QKVParallelLinear(ColumnParallelLinear):
         if out_dim is None:
             return default_weight_loader(param, loaded)
         off, size = self._offsets()[shard_id]
+        off, size = _in_blocks(self.prefix, param, off, size, self.tp_size)
         src_rank = self.tp_rank if shard_id == "q" else self.tp_rank // self.num_kv_head_replicas
         dst = param.data.narrow(out_dim, off, size)
         src = loaded.narrow(out_dim, src_rank * size, size)

@@ -152,6 +152,17 @@ class FusedMoE(nn.Module):
             else:
                 param.data[local] = loaded.reshape(()).to(param.dtype)
             return True
+        if kind == "block_scale":
+            # one scale per 128 x 128 block: same sharding as the weights, in units of blocks
+            Ib = I // 128
+            if shard_id == "w2":
+                src = loaded.narrow(1, self.shard_rank * Ib, Ib) if self.shard_size > 1 else loaded
+                param.data[local].copy_(src)
+            else:
+                src = loaded.narrow(0, self.shard_rank * Ib, Ib) if self.shard_size > 1 else loaded
+                off = 0 if shard_id == "w1" else Ib
+                param.data[local, off:off + Ib].copy_(src)
+            return True
         if shard_id == "w2":
             src = loaded.narrow(1, self.shard_rank * I, I) if self.shard_size > 1 else loaded
             param.data[local].copy_(src)

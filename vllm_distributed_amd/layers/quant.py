@@ -73,6 +73,21 @@ class Fp8Config(QuantizationConfig):
         self.is_checkpoint_fp8_serialized = is_checkpoint_fp8_serialized
         self.activation_scheme = activation_scheme
         self.ignored_layers = ignored_layers or []
+        # [rows, columns] of one weight-scale block (DeepSeek-V3 style ``weight_scale_inv``); None: per tensor
+        self.weight_block_size = [int(b) for b in weight_block_size] if weight_block_size else None
+        if self.weight_block_size is not None:
+            if not is_checkpoint_fp8_serialized:
+                raise ValueError("block-wise fp8 needs an fp8 checkpoint")
+            if self.weight_block_size != [128, 128]:
+                raise ValueError(f"fp8 weight blocks of {self.weight_block_size} are not supported (128 x 128)")
+            if activation_scheme != "dynamic":
+                raise ValueError("block-wise fp8 weights go with dynamic (per 128-group) activation scales")
+
+    @property
+    def mla_compatible(self) -> bool:
+        """Block-scaled checkpoints: kv_b_proj is expanded to 16 bit while loading (its halves are the
+        absorbed W_UK / W_UV of the latent-attention path), so that path stays available."""
+        return self.weight_block_size is not None
 
     @classmethod
     def from_config(cls, cfg: dict) -> "Fp8Config":
@@ -198,6 +213,10 @@ def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
             raise ValueError("modelopt fp4: only groups of 16 (NVFP4) are supported")
         from ..models.dequant import LoadTimeDequant
         return LoadTimeDequant("nvfp4", dict(hf_q or {}))
+    if q == "fp8" and hf_q and hf_q.get("weight_block_size") and envs.VDA_FP8_BLOCK_NATIVE \
+            and list(hf_q.get("weight_block_size")) == [128, 128]:
+        # 128 x 128 block scales run natively: weights stay e4m3, activations are quantised per 128-group
+        return Fp8Config.from_config(hf_q)
     if q in ("awq", "gptq", "bitsandbytes") or (q == "fp8" and hf_q and hf_q.get("weight_block_size")):
         # weight-only formats without a kernel of their own: dequantised while the checkpoint loads
         from ..models.dequant import LoadTimeDequant
@@ -291,6 +310,18 @@ class Fp8LinearMethod:
         set_weight_attrs(w, {"input_dim": 1, "output_dim": 0})
         layer.register_parameter("weight", w)
         layer.orig_dtype = dtype
+        if self.cfg.weight_block_size is not None:
+            bn, bk = self.cfg.weight_block_size
+            tp = getattr(layer, "tp_size", 1)
+            if tp > 1 and ((hasattr(layer, "input_size_per_partition") and in_per_rank % bk)
+                           or (hasattr(layer, "output_size_per_partition") and out_per_rank % bn)):
+                raise ValueError(f"{layer.prefix}: a tensor-parallel shard of {out_per_rank} x {in_per_rank} does not "
+                                 f"line up with {bn} x {bk} scale blocks")
+            s = nn.Parameter(torch.ones(-(-out_per_rank // bn), -(-in_per_rank // bk), dtype=torch.float32),
+                             requires_grad=False)
+            set_weight_attrs(s, {"input_dim": 1, "output_dim": 0, "block_n": bn, "block_k": bk})
+            layer.register_parameter("weight_scale_inv", s)
+            return
         n_shards = len(getattr(layer, "output_sizes", [0]))
         layer.logical_widths = [s // getattr(layer, "tp_size", 1) for s in getattr(layer, "output_sizes", [out_per_rank])] \
             if hasattr(layer, "output_sizes") else [out_per_rank]
@@ -304,6 +335,17 @@ class Fp8LinearMethod:
                 layer.register_parameter("input_scale", ins)
 
     def process_weights_after_loading(self, layer: nn.Module) -> None:
+        if self.cfg.weight_block_size is not None:
+            if str(getattr(layer, "prefix", "")).endswith("kv_b_proj") or layer.weight.shape[1] % 128:
+                # the latent-attention path slices this weight into its absorbed halves (and a K that is no
+                # multiple of 128 has no tiled kernel): expand to 16 bit once, here
+                from ..ops import reference as R
+                w = layer.weight.data.float() * R.expand_block_scales(layer.weight_scale_inv.data.float(),
+                                                                      *layer.weight.shape)
+                layer.weight = nn.Parameter(w.to(layer.orig_dtype), requires_grad=False)
+                layer.weight_scale_inv = None
+                layer.fp8_expanded = True
+            return
         if not self.cfg.is_checkpoint_fp8_serialized:
             q, s = per_tensor_quantize(layer.weight.data)
             layer.weight = nn.Parameter(q, requires_grad=False)
@@ -319,7 +361,13 @@ class Fp8LinearMethod:
     def apply(self, layer: nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]) if x.dim() != 2 else x
-        y = apply_fp8_linear(x2, layer.weight, layer.weight_scale, getattr(layer, "input_scale", None), bias)
+        if getattr(layer, "fp8_expanded", False):
+            y = torch.nn.functional.linear(x2, layer.weight, bias)
+        elif self.cfg.weight_block_size is not None:
+            xq, xs = ops.per_group_fp8_quant(x2.contiguous(), 128)
+            y = ops.fp8_gemm(xq, layer.weight, xs, layer.weight_scale_inv, x.dtype, bias, block=True)
+        else:
+            y = apply_fp8_linear(x2, layer.weight, layer.weight_scale, getattr(layer, "input_scale", None), bias)
         return y if x.dim() == 2 else y.view(*shape[:-1], -1)
 
 
@@ -338,6 +386,17 @@ class Fp8MoEMethod:
         layer.register_parameter("w2_weight", w2)
         for p in (w13, w2):
             set_weight_attrs(p, {"weight_loader": layer.weight_loader})
+        if self.cfg.weight_block_size is not None:
+            if I % 128 or H % 128:
+                raise ValueError(f"block-scaled experts need hidden ({H}) and expert width per rank ({I}) to be "
+                                 "multiples of 128")
+            s13 = nn.Parameter(torch.ones(E, 2 * I // 128, H // 128, dtype=torch.float32), requires_grad=False)
+            s2 = nn.Parameter(torch.ones(E, H // 128, I // 128, dtype=torch.float32), requires_grad=False)
+            layer.register_parameter("w13_weight_scale_inv", s13)
+            layer.register_parameter("w2_weight_scale_inv", s2)
+            for p in (s13, s2):
+                set_weight_attrs(p, {"weight_loader": layer.weight_loader, "moe_kind": "block_scale"})
+            return
         if serialized:
             s13 = nn.Parameter(torch.ones(E, 2, dtype=torch.float32), requires_grad=False)
             s2 = nn.Parameter(torch.ones(E, dtype=torch.float32), requires_grad=False)
@@ -357,6 +416,8 @@ class Fp8MoEMethod:
     def process_weights_after_loading(self, layer) -> None:
         E = layer.w13_weight.shape[0]
         I = layer.w13_weight.shape[1] // 2
+        if self.cfg.weight_block_size is not None:
+            return
         if not self.cfg.is_checkpoint_fp8_serialized:
             q13 = torch.empty_like(layer.w13_weight.data, dtype=FP8)
             q2 = torch.empty_like(layer.w2_weight.data, dtype=FP8)
@@ -381,6 +442,9 @@ class Fp8MoEMethod:
         layer.w13_weight_scale = nn.Parameter(mx.contiguous(), requires_grad=False)
 
     def apply(self, layer, x: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+        if self.cfg.weight_block_size is not None:
+            return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids, layer.w13_weight_scale_inv,
+                                 layer.w2_weight_scale_inv, block_scales=True)
         return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids, layer.w13_weight_scale,
                              layer.w2_weight_scale)
 

@@ -332,8 +332,15 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
         else:
             a = w13[e].float() * (w13_scale[e].float() if w13_scale is not None else 1.0)
             b = w2[e].float() * (w2_scale[e].float() if w2_scale is not None else 1.0)
-        h = xf[tok] @ a.t()
+        xe = xf[tok]
+        if block_scales:      # what the device kernels do: activations rounded to e4m3 per group of 128
+            q, s_ = per_group_fp8_quant(xe.to(x.dtype))
+            xe = (q.float().view(*s_.shape, -1) * s_.unsqueeze(-1)).view(xe.shape)
+        h = xe @ a.t()
         act = (torch.nn.functional.silu(h[:, :I]) * h[:, I:]).to(x.dtype).float()
+        if block_scales:
+            q, s_ = per_group_fp8_quant(act.to(x.dtype))
+            act = (q.float().view(*s_.shape, -1) * s_.unsqueeze(-1)).view(act.shape)
         out.index_add_(0, tok, (act @ b.t()) * topk_w[tok, slot].float().unsqueeze(1))
     return out.to(x.dtype)
 
