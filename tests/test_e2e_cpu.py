@@ -29,6 +29,19 @@ def _save_tiny(tmp, kind):
     elif kind == "gpt2":
         cfg = tf.GPT2Config(vocab_size=320, n_embd=128, n_layer=2, n_head=2, n_positions=256)
         m = tf.GPT2LMHeadModel(cfg)
+    elif kind in ("llama4", "llama4_top2"):
+        # rotary + chunked layers (chunks of 32 positions) and a global layer without positions; layers 1 and 3 are MoE
+        cfg = tf.Llama4TextConfig(vocab_size=320, hidden_size=128, intermediate_size=128, intermediate_size_mlp=256,
+                                  num_hidden_layers=4, num_attention_heads=2, num_key_value_heads=1, head_dim=64,
+                                  max_position_embeddings=256, num_local_experts=4, interleave_moe_layer_step=2,
+                                  num_experts_per_tok=2 if kind == "llama4_top2" else 1,
+                                  attention_chunk_size=32, floor_scale=16, attn_scale=0.1, pad_token_id=0,
+                                  bos_token_id=1, eos_token_id=2, tie_word_embeddings=False)
+        m = tf.Llama4ForCausalLM(cfg)
+        with torch.no_grad():       # the default initialisation leaves the router indifferent
+            for n, p_ in m.named_parameters():
+                if "router" in n or "experts" in n:
+                    p_.normal_(0, 0.08)
     elif kind == "mixtral":
         cfg = tf.MixtralConfig(vocab_size=320, hidden_size=128, intermediate_size=128, num_hidden_layers=2,
                                num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -287,7 +300,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h"])
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]
@@ -318,6 +331,24 @@ def test_chunked_prefill_prefix_cache_and_preemption_same_tokens(tmp_path):
               max_num_seqs=16, max_num_batched_tokens=48, enable_prefix_caching=True, num_gpu_blocks_override=24)
     got = [list(o.outputs[0].token_ids) for o in llm.generate(prompt_token_ids=prompts, sampling_params=sp)]
     assert got == ref
+    llm.shutdown()
+
+
+def test_llama4_chunked_attention_with_chunked_prefill(tmp_path):
+    """Prefill pieces that start and end in the middle of attention chunks, decode steps that cross chunk
+    boundaries, prefix-cache hits that skip whole chunks: same tokens as transformers."""
+    path, hf = _save_tiny(str(tmp_path), "llama4")
+    prompts = [[(i * 13 + j * 7) % 300 + 3 for j in range(n)] for i, n in enumerate((70, 33, 31, 100, 64))]
+    prompts.append(prompts[0][:48] + [9, 8, 7])
+    sp = SamplingParams(temperature=0, max_tokens=40, ignore_eos=True)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+              max_num_seqs=8, max_num_batched_tokens=24, enable_prefix_caching=True, block_size=16)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=sp)
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=40, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, len(p)
     llm.shutdown()
 
 

@@ -50,6 +50,14 @@ class AttentionMetadata:
     cascade_seq_len: Optional[torch.Tensor] = None        # int32 [1] = cascade_prefix_len
     cascade_query_start_loc: Optional[torch.Tensor] = None   # int32 [2] = (0, T)
     cascade_suffix_seq_lens: Optional[torch.Tensor] = None   # int32 [S] = seq_lens - cascade_prefix_len
+    # chunked local attention (layers whose tokens only see their own chunk of ``local_chunk`` positions):
+    # every (sequence, chunk) pair touched by the step is a virtual sequence whose block table starts at the
+    # chunk's first block.  Decode-form sequences map to one virtual sequence each, in the same order.
+    local_block_table: Optional[torch.Tensor] = None        # int32 [S_virtual, chunk / block_size]
+    local_seq_lens: Optional[torch.Tensor] = None           # int32 [S_virtual]: keys inside the chunk
+    local_query_start_loc: Optional[torch.Tensor] = None    # int32 [S_virtual + 1]
+    local_prefill_query_start_loc: Optional[torch.Tensor] = None
+    local_num_prefill_seqs: int = 0
     # host copies for connectors / debugging
     seq_lens_cpu: Any = None
     query_start_loc_cpu: Any = None

@@ -22,8 +22,12 @@ class Attention(nn.Module):
     def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
                  alibi_slopes: Optional[list[float]] = None, sliding_window: Optional[int] = None,
                  logits_soft_cap: Optional[float] = None, prefix: str = "", cache_dtype: str = "auto",
-                 causal: bool = True):
+                 causal: bool = True, local_chunk: int = 0):
         super().__init__()
+        # > 0: chunked local attention (Llama-4 rotary layers): position p sees positions
+        # [p - p % local_chunk, p] only; the runner supplies the per-chunk virtual batch
+        # (reference: vllm/v1/attention/backends/utils.py:242 make_local_attention_virtual_batches)
+        self.local_chunk = int(local_chunk or 0)
         self.num_heads, self.head_size, self.scale = num_heads, head_size, float(scale)
         self.causal = causal          # False: encoder models, every token sees its whole sequence
         self.num_kv_heads = num_kv_heads or num_heads
@@ -89,19 +93,28 @@ class Attention(nn.Module):
                                   self.k_cache, self.v_cache, md.slot_mapping[:n], ksc, vsc)
         q = qkv[:, :qs].view(T, Hq, D)
         nd, ndt = md.num_decode_seqs, md.num_decode_tokens
-        if md.cascade_prefix_len and not self.sliding_window and self.causal:
+        if self.local_chunk and md.local_block_table is not None:
+            # same tokens, other sequences: one virtual sequence per (sequence, chunk)
+            bt, sl, qsl = md.local_block_table, md.local_seq_lens, md.local_query_start_loc
+            pqsl, n_pre = md.local_prefill_query_start_loc, md.local_num_prefill_seqs
+        else:
+            if self.local_chunk and md.max_seq_len > self.local_chunk:
+                raise RuntimeError("chunked local attention needs the runner's per-chunk batch layout")
+            bt, sl, qsl = md.block_table, md.seq_lens, md.query_start_loc
+            pqsl, n_pre = md.prefill_query_start_loc, md.num_prefill_seqs
+        if md.cascade_prefix_len and not self.sliding_window and self.causal and not self.local_chunk:
             self._cascade(out, q, md, n, ksc, vsc)
         else:
             if nd > 0:
-                ops.paged_attention_decode(out[:ndt], q[:ndt], self.k_cache, self.v_cache, md.block_table[:nd],
-                                           md.seq_lens[:nd], md.query_start_loc[:nd + 1], self.scale,
+                ops.paged_attention_decode(out[:ndt], q[:ndt], self.k_cache, self.v_cache, bt[:nd],
+                                           sl[:nd], qsl[:nd + 1], self.scale,
                                            num_splits=md.decode_num_splits, max_q_len=md.max_decode_query_len,
                                            window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
                                            workspace=md.decode_workspace, k_scale=ksc, v_scale=vsc)
-            if md.num_prefill_seqs > 0:
+            if n_pre > 0:
                 e = ndt + md.num_prefill_tokens
-                ops.paged_attention_prefill(out[ndt:e], q[ndt:e], self.k_cache, self.v_cache, md.block_table[nd:],
-                                            md.seq_lens[nd:], md.prefill_query_start_loc, self.scale,
+                ops.paged_attention_prefill(out[ndt:e], q[ndt:e], self.k_cache, self.v_cache, bt[nd:nd + n_pre],
+                                            sl[nd:nd + n_pre], pqsl, self.scale,
                                             window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
                                             k_scale=ksc, v_scale=vsc, causal=self.causal)
         if conn is not None:

@@ -206,7 +206,7 @@ class FusedMoE(nn.Module):
             return w, ids.to(torch.int32)
         return ops.moe_topk_softmax(router_logits, k, self.renormalize)
 
-    def _forward_ep_dispatch(self, x: torch.Tensor, lg: torch.Tensor) -> torch.Tensor:
+    def _forward_ep_dispatch(self, x: torch.Tensor, lg: torch.Tensor, routed=None) -> torch.Tensor:
         """Expert parallel over ranks that all hold the same tokens (TP attention in front): rank r routes
         its 1/ep slice of the tokens to the expert owners through the all-to-all-v, the owners compute,
         the results return and are weighted at the source, and an all-gather replicates the rows again.
@@ -222,9 +222,15 @@ class FusedMoE(nn.Module):
         pad = self.ep_size * Tp - T
         if pad:
             x = torch.nn.functional.pad(x, (0, 0, 0, pad))
-            lg = torch.nn.functional.pad(lg, (0, 0, 0, pad))
-        xs, lgs = x[lo:lo + Tp], lg[lo:lo + Tp]
-        topk_w, topk_ids = self.select_experts(lgs)
+            if routed is None:
+                lg = torch.nn.functional.pad(lg, (0, 0, 0, pad))
+            else:
+                routed = tuple(torch.nn.functional.pad(t, (0, 0, 0, pad)) for t in routed)
+        xs = x[lo:lo + Tp]
+        if routed is None:
+            topk_w, topk_ids = self.select_experts(lg[lo:lo + Tp])
+        else:
+            topk_w, topk_ids = routed[0][lo:lo + Tp], routed[1][lo:lo + Tp]
         if self.eplb_state is not None:
             topk_ids = self.eplb_state.map_topk(self.eplb_layer, topk_ids)
         if pad:     # rows past T are padding: they go nowhere
@@ -244,15 +250,19 @@ class FusedMoE(nn.Module):
             out = out / self.tp_size
         return out
 
-    def forward(self, hidden_states: torch.Tensor, router_logits: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, router_logits: Optional[torch.Tensor], routed=None) -> torch.Tensor:
+        """``routed`` = (weights f32 [T, k], logical expert ids i32 [T, k]) when the caller did the routing
+        itself (models that scale the experts' INPUT by the router score pass weights of one)."""
         x, lg = hidden_states, router_logits
         dispatch = self.dp_size > 1
         if self.use_ep and not dispatch and self._ep_route:
-            return self._forward_ep_dispatch(x, lg)
+            return self._forward_ep_dispatch(x, lg, routed)
         if dispatch:
+            if routed is not None:
+                raise NotImplementedError("caller-side routing together with data-parallel dispatch")
             from ..parallel.all2all import dp_combine, dp_dispatch
             x, lg, meta = dp_dispatch(x, lg)
-        topk_w, topk_ids = self.select_experts(lg)
+        topk_w, topk_ids = self.select_experts(lg) if routed is None else routed
         if self.eplb_state is not None:
             topk_ids = self.eplb_state.map_topk(self.eplb_layer, topk_ids)      # logical -> physical slot
             self.eplb_state.record(self.eplb_layer, topk_ids)

@@ -12,6 +12,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Qwen2ForCausalLM": ("llama", "Qwen2ForCausalLM"),
     "Qwen3ForCausalLM": ("llama", "Qwen3ForCausalLM"),
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
+    "Llama4ForCausalLM": ("llama4", "Llama4ForCausalLM"),
+    "Llama4ForConditionalGeneration": ("llama4", "Llama4ForConditionalGeneration"),
     "Qwen2MoeForCausalLM": ("mixtral", "Qwen2MoeForCausalLM"),
     "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
     "PhiMoEForCausalLM": ("mixtral", "PhiMoEForCausalLM"),

@@ -99,6 +99,8 @@ class ModelRunner:
         self.tk_rx = None              # peer-memory row exchange of the token-parallel group (set by load_model)
         self._tknp_step_bs = None
         self.encoder_cache: dict[str, dict[int, torch.Tensor]] = {}     # request -> item index -> embeddings
+        self.local_chunk = 0           # chunk length of chunked-local attention layers (set by load_model)
+        self._l_counts = (0, 0)        # (virtual sequences, virtual prefill-form sequences) of the step
         self._init_buffers()
 
     # ------------------------------------------------------------------
@@ -180,6 +182,7 @@ class ModelRunner:
         for n, m in self.attn_layers.items():
             m.layer_name = n
         self._init_hybrid_state()
+        self._init_local_attention()
         self.uses_mrope = bool(getattr(self.model, "uses_mrope", False))
         spec = self.vllm_config.speculative_config
         if spec is not None and get_pp_group().is_last_rank:
@@ -199,6 +202,69 @@ class ModelRunner:
         if self.vllm_config.lora_config is not None:
             from ..lora.manager import LoRAManager
             self.lora_manager = LoRAManager(self.model, self.vllm_config, self.device)
+
+    def _init_local_attention(self) -> None:
+        """Chunked local attention (Llama-4's rotary layers): tokens attend inside their own chunk of
+        ``local_chunk`` positions.  The step's sequences are re-cut into one virtual sequence per
+        (sequence, chunk) with a block table that starts at the chunk's first block, so the ordinary
+        paged kernels serve these layers unchanged.  Reference: vllm/v1/attention/backends/utils.py:242-420
+        (make_local_attention_virtual_batches)."""
+        chunks = {m.local_chunk for m in self.attn_layers.values() if getattr(m, "local_chunk", 0)}
+        if not chunks:
+            return
+        if len(chunks) > 1:
+            raise ValueError(f"layers disagree on the local attention chunk: {sorted(chunks)}")
+        C = chunks.pop()
+        if C % self.block_size:
+            raise ValueError(f"attention chunk {C} must be a multiple of the KV block size {self.block_size}")
+        self.local_chunk = C
+        # a decode-form sequence must lie inside one chunk: one query token each
+        self.max_decode_q = 1
+        dev = self.device
+        Spad = self.block_table.shape[0]
+        # a prefill of n tokens touches at most n / C + 2 chunks
+        self.l_max = Spad * 2 + self.max_num_tokens // C + 1
+        self.l_width = C // self.block_size
+        self.l_block_table = torch.zeros((self.l_max, self.l_width), dtype=torch.int32, device=dev)
+        self.l_seq_lens = torch.zeros(self.l_max, dtype=torch.int32, device=dev)
+        self.l_qsl = torch.zeros(self.l_max + 1, dtype=torch.int32, device=dev)
+        self.l_prefill_qsl = torch.zeros(self.l_max + 1, dtype=torch.int32, device=dev)
+        self._stage_bytes += self.l_max * (self.l_width * 4 + 64)
+
+    def _upload_local_attention(self, rows, n_sched, cu, seq_lens, nd: int) -> None:
+        """Per-chunk view of the step's sequences (see _init_local_attention)."""
+        C, bs, W = self.local_chunk, self.block_size, self.l_width
+        S = len(rows)
+        n = n_sched.astype(np.int64)
+        end = seq_lens.astype(np.int64)                 # one past the last position of this step
+        start = end - n
+        c_lo, c_hi = start // C, (end - 1) // C
+        per_seq = np.maximum(c_hi - c_lo + 1, 0)
+        if nd and (per_seq[:nd] != 1).any():
+            raise RuntimeError("a decode-form sequence spans two attention chunks")
+        Sv = int(per_seq.sum())
+        if Sv > self.l_max:
+            raise RuntimeError(f"{Sv} (sequence, chunk) pairs exceed the local-attention tables ({self.l_max})")
+        owner = np.repeat(np.arange(S, dtype=np.int64), per_seq)
+        first = np.zeros(S + 1, dtype=np.int64)
+        np.cumsum(per_seq, out=first[1:])
+        chunk = c_lo[owner] + (np.arange(Sv, dtype=np.int64) - first[:-1][owner])
+        q_lo = np.maximum(start[owner], chunk * C)
+        q_hi = np.minimum(end[owner], (chunk + 1) * C)
+        l_len = (q_hi - chunk * C).astype(np.int32)
+        l_cu = np.zeros(Sv + 1, dtype=np.int32)
+        np.cumsum(q_hi - q_lo, out=l_cu[1:])
+        bt = self.input_batch.block_tables[0]
+        cols = chunk[:, None] * (C // bs) + np.arange(W, dtype=np.int64)[None, :]
+        valid = cols < bt.shape[1]
+        l_bt = np.where(valid, bt[rows[owner][:, None], np.minimum(cols, bt.shape[1] - 1)], 0).astype(np.int32)
+        self._to_dev(self.l_seq_lens, l_len)
+        self._to_dev(self.l_qsl, l_cu)
+        if Sv:
+            self.l_block_table[:Sv].copy_(self._stage(l_bt), non_blocking=True)
+        if nd < Sv:
+            self._to_dev(self.l_prefill_qsl, (l_cu[nd:] - l_cu[nd]).astype(np.int32))
+        self._l_counts = (Sv, Sv - nd)
 
     def _init_tknp_exchange(self) -> None:
         """Token parallelism on GPUs of one node: rows travel through the peer-memory all-to-all-v
@@ -482,6 +548,8 @@ class ModelRunner:
             self._to_dev(self.prefill_qsl, (cu[nd:] - cu[nd]).astype(np.int32))
         if self.state_table is not None and S:
             self._to_dev(self.state_table.view(-1), (rows + 1).astype(np.int32))
+        if self.local_chunk:
+            self._upload_local_attention(rows, n_sched, cu, seq_lens, nd)
         return nd, ndt
 
     def _prepare_inputs(self, so: SchedulerOutput):
@@ -664,8 +732,15 @@ class ModelRunner:
             self._ws = ws = (po, pl, need)
         return ws[0], ws[1]
 
-    def _build_attn_metadata(self, S, T, nd, ndt, max_seq, max_q, nsplit) -> AttentionMetadata:
-        return AttentionMetadata(
+    def _build_attn_metadata(self, S, T, nd, ndt, max_seq, max_q, nsplit, decode_only=False) -> AttentionMetadata:
+        local = {}
+        if self.local_chunk:
+            # decode_only (captured graphs, warm-up): the virtual sequences are the S sequences themselves
+            Sv, n_pre = (S, 0) if decode_only else self._l_counts
+            local = dict(local_block_table=self.l_block_table[:Sv], local_seq_lens=self.l_seq_lens[:Sv],
+                         local_query_start_loc=self.l_qsl[:Sv + 1], local_num_prefill_seqs=n_pre,
+                         local_prefill_query_start_loc=self.l_prefill_qsl[:n_pre + 1] if n_pre else None)
+        return AttentionMetadata(**local,
             num_actual_tokens=T, num_decode_seqs=nd, num_decode_tokens=ndt, num_prefill_seqs=S - nd,
             num_prefill_tokens=T - ndt, slot_mapping=self.slot_mapping, block_table=self.block_table[:S],
             seq_lens=self.seq_lens[:S], query_start_loc=self.query_start_loc[:S + 1],
@@ -787,6 +862,9 @@ class ModelRunner:
                     self.state_table[Sg:graph_bs].zero_()
                 self.query_start_loc[Sg + 1: graph_bs + 1].copy_(
                     torch.arange(Sg + 1, graph_bs + 1, dtype=torch.int32, device=self.device))
+                if self.local_chunk:
+                    self.l_seq_lens[Sg:graph_bs].zero_()
+                    self.l_qsl[Sg + 1: graph_bs + 1].copy_(self.query_start_loc[Sg + 1: graph_bs + 1])
             g, hidden_buf, md = self.graphs[graph_bs]
             with set_forward_context(md, kv_connector=conn, num_tokens=T):
                 if conn is not None:
@@ -818,7 +896,7 @@ class ModelRunner:
                 self.positions[T:T_in].zero_()
             mbs = None
             if self.async_tp and T >= envs.VDA_ASYNC_TP_MIN_TOKENS and conn is None and self.lora_manager is None \
-                    and inputs_embeds is None and T_in == T and not P:
+                    and inputs_embeds is None and T_in == T and not P and not self.local_chunk:
                 mbs = self._make_micro_batches(rows, n_sched, cu, S, T, nd)
             with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T, micro_batches=mbs):
                 if conn is not None:
@@ -1128,7 +1206,10 @@ class ModelRunner:
             self.slot_mapping[:num_tokens].fill_(-1)
             self.query_start_loc[:S + 1].copy_(torch.arange(S + 1, dtype=torch.int32, device=self.device))
             nsplit = self._decode_splits(S, 0, True)
-            md = self._build_attn_metadata(S, num_tokens, S, num_tokens, 0, 1, nsplit)
+            if self.local_chunk:
+                self.l_seq_lens[:S].zero_()
+                self.l_qsl[:S + 1].copy_(self.query_start_loc[:S + 1])
+            md = self._build_attn_metadata(S, num_tokens, S, num_tokens, 0, 1, nsplit, decode_only=True)
         with set_forward_context(md, num_tokens=0):
             out = self.model(self.input_ids[:num_tokens], self.positions[:num_tokens], inter, None)
         return out
@@ -1176,7 +1257,10 @@ class ModelRunner:
                 self.seq_lens[:bs].zero_()
                 self.slot_mapping[:bs].fill_(-1)
                 self.query_start_loc[:bs + 1].copy_(torch.arange(bs + 1, dtype=torch.int32, device=self.device))
-                md = self._build_attn_metadata(bs, bs, bs, bs, 0, 1, nsplit)
+                if self.local_chunk:
+                    self.l_seq_lens[:bs].zero_()
+                    self.l_qsl[:bs + 1].copy_(self.query_start_loc[:bs + 1])
+                md = self._build_attn_metadata(bs, bs, bs, bs, 0, 1, nsplit, decode_only=True)
                 tmd = None
                 if self.tk_rx is not None:
                     # token parallelism: bs rows on the root, up to bs local rows on every rank; counts and
