@@ -75,6 +75,10 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     # 128 out: 0.699 s against 0.745 s at batch 8 and 0.698 s against 0.706 s at batch 1 with the skinny kernel).
     # The kernel keeps its role for 8-bit weights (VDA_FP8_W8A16_MAX_M) and packed 4-bit weights.
     "VDA_SKINNY_GEMM_MAX_M": (int, 0),
+    # 16-bit dense layers with this many rows run the weight-streaming split-K MFMA kernel (ops/csrc/gemm_decode.hip)
+    "VDA_DECODE_GEMM_MIN_M": (int, 33),
+    "VDA_DECODE_GEMM_MAX_M": (int, 0),           # 0 = never (default: the tuned library GEMMs are faster, see docs/kernels.md)
+    "VDA_DECODE_GEMM_WS_MB": (int, 128),         # fp32 split-K workspace per device
     "VDA_REHEARSE_ON_ONE_GPU": (_bool, False),   # all ranks share cuda:0: gloo groups + peer-memory all-reduce (tests)
     "VDA_GEMM_SELECTIONS": (str, None),          # CSV of library-GEMM algorithm choices; "off" disables
     "VDA_DISABLE_SKINNY_GEMM": (_bool, False),
@@ -138,6 +142,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
 # Knobs that change numerics or graph shape: part of the config fingerprint.
 _HASHED = (
     "VDA_FORCE_TORCH_OPS", "VDA_SKINNY_GEMM_MAX_M", "VDA_DISABLE_SKINNY_GEMM", "VDA_INT4_WEIGHTS", "VDA_MLA",
+    "VDA_DECODE_GEMM_MIN_M", "VDA_DECODE_GEMM_MAX_M",
     "VLLM_ROCM_QUICK_REDUCE_QUANTIZATION", "VLLM_DISABLE_CUSTOM_ALL_REDUCE",
     "VLLM_FUSED_MOE_CHUNK_SIZE",
 )

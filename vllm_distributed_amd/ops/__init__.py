@@ -428,11 +428,49 @@ def skinny_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return y
 
 
+_DECODE_WS: dict = {}
+
+
+def decode_gemm_ok(M: int, N_: int, K: int, dtype: torch.dtype) -> bool:
+    """Shapes the weight-streaming decode GEMM takes (and is meant for: the rows of a decode batch)."""
+    return (envs.VDA_DECODE_GEMM_MIN_M <= M <= min(envs.VDA_DECODE_GEMM_MAX_M, 256) and K % 256 == 0 and N_ % 4 == 0
+            and N_ >= 512 and dtype in (torch.bfloat16, torch.float16))
+
+
+def decode_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ w.T (+ bias) for x [M <= 256, K], w [N, K] contiguous: the weights stream once from HBM
+    through registers into the MFMAs, K split over workgroups (ops/csrc/gemm_decode.hip)."""
+    if not _dev(x):
+        y = torch.nn.functional.linear(x, w, bias)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    M, K = x.shape
+    N_ = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous() or x.stride(1) != 1:
+        raise ValueError("decode_gemm: x must be [M, K] with unit column stride and w [N, K] contiguous")
+    if out is None:
+        out = torch.empty((M, N_), dtype=x.dtype, device=x.device)
+    ws = _DECODE_WS.get(x.device)
+    if ws is None:          # split-K partial sums; one arena per device, reused by every call (stream order)
+        ws = _DECODE_WS[x.device] = torch.empty(envs.VDA_DECODE_GEMM_WS_MB << 18, dtype=torch.float32, device=x.device)
+    N.call("vda_decode_gemm", out.data_ptr(), x.data_ptr(), w.data_ptr(), N.ptr(bias), ws.data_ptr(),
+           ws.numel() * 4, M, N_, K, x.stride(0), out.stride(0), N.dt(x.dtype), N.stream())
+    return out
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Unquantised linear: skinny MFMA kernel for decode-sized M, hipBLASLt otherwise."""
-    if x.is_cuda and x.dim() == 2 and x.stride(-1) == 1 and w.stride(-1) == 1 \
-            and skinny_gemm_ok(x.shape[0], w.shape[0], x.shape[1], x.dtype):
-        return skinny_gemm(x, w, bias)
+    """Unquantised linear: skinny MFMA kernel for the smallest M, the weight-streaming split-K kernel for
+    decode batches, hipBLASLt otherwise."""
+    if x.is_cuda and x.dim() == 2 and x.stride(-1) == 1 and w.stride(-1) == 1:
+        M, K = x.shape
+        if skinny_gemm_ok(M, w.shape[0], K, x.dtype):
+            return skinny_gemm(x, w, bias)
+        if decode_gemm_ok(M, w.shape[0], K, x.dtype) and w.dtype == x.dtype and w.is_contiguous() \
+                and x.stride(0) % 8 == 0 and (bias is None or bias.dtype == x.dtype):
+            return decode_gemm(x, w, bias)
     return torch.nn.functional.linear(x, w, bias)
 
 
