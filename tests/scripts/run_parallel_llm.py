@@ -24,12 +24,7 @@ def main():
     toks = [list(o.outputs[0].token_ids) for o in outs]
     with open(f"{out_path}.{os.environ['RANK']}", "w") as f:
         json.dump(toks, f)
-    llm.shutdown()
-    # results are on disk: skip interpreter-exit destructors (a gloo helper thread that outlives its peers
-    # aborts the process at exit under heavy load, which says nothing about the run)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+    llm.shutdown()          # closes communicators and process groups in order (Worker.shutdown)
 
 
 if __name__ == "__main__":

@@ -103,6 +103,38 @@ def test_engine_sleep_wake_with_graphs(tmp_path):
     llm.shutdown()
 
 
+def test_sleep_forgets_cached_prefixes_and_clears_the_cache(tmp_path):
+    """Sleeping through the engine core (the path the server's /sleep takes) with prefix caching on: the
+    dropped KV cache must not serve prefix hits after wake-up, the re-backed cache memory must be clear
+    (stale NaN patterns there would leak through zero-weighted slots), and the engine refuses to sleep
+    while requests run."""
+    from vllm_distributed_amd import SamplingParams
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    llm = _llm(path, enable_sleep_mode=True, enable_prefix_caching=True)
+    core = llm.llm_engine.engine_core.engine_core
+    mr = core.model_executor.worker.model_runner
+    prompts = [p * 3 for p in PROMPTS]                   # several full blocks each
+    first = [list(o.outputs[0].token_ids) for o in llm.generate(prompt_token_ids=prompts, sampling_params=sp)]
+    # poison what the allocator will hand back: fill free device memory with NaN patterns, then release it
+    core.sleep(1)
+    junk = torch.full((256 << 20,), float("nan"), dtype=torch.float32, device="cuda")
+    del junk
+    torch.cuda.empty_cache()
+    core.wake_up()
+    assert all(float(k.float().abs().max()) == 0.0 and float(v.float().abs().max()) == 0.0
+               for k, v in mr.kv_caches[:2]), "the KV cache came back with stale contents"
+    again = [list(o.outputs[0].token_ids) for o in llm.generate(prompt_token_ids=prompts, sampling_params=sp)]
+    assert again == first
+    # a running request blocks sleep
+    llm.llm_engine.add_request("busy", {"prompt_token_ids": prompts[0]}, sp)
+    llm.llm_engine.step()
+    with pytest.raises(RuntimeError, match="while requests are running"):
+        core.sleep(1)
+    llm.llm_engine.abort_request(["busy"])
+    llm.shutdown()
+
+
 def test_lora_fused_kernels_match_grouped_gemms(tmp_path, monkeypatch):
     """Multi-LoRA on the GPU: the fused shrink / expand kernels (decode-sized batches) and the grouped
     library-GEMM path must generate the same tokens, adapters must change the output, and a batch may mix

@@ -328,6 +328,26 @@ def test_topk_topp_mask_matches_sort_reference():
     assert torch.equal(a[keep_a & keep_b], logits[keep_a & keep_b])
 
 
+def test_top_p_threshold_is_repeatable():
+    """Flat distributions with many near-boundary tokens: the kept set and the seeded draw must be the same
+    on every run (the histogram is summed in fixed point, independent of atomic arrival order)."""
+    S, V = 16, 128256
+    logits = torch.randn(S, V, device=DEV) * 0.3
+    p = torch.linspace(0.05, 0.95, S, device=DEV)
+    k = torch.zeros(S, dtype=torch.int32, device=DEV)
+    first = ops.topk_topp_mask(logits.clone(), k, p, None)
+    seeds = torch.arange(S, device=DEV) * 31 + 5
+    temp = torch.ones(S, device=DEV)
+    tok = ops.sample(logits, temp, k, p, None, seeds)
+    for _ in range(20):
+        assert torch.equal(torch.isinf(ops.topk_topp_mask(logits.clone(), k, p, None)), torch.isinf(first))
+        assert torch.equal(ops.sample(logits, temp, k, p, None, seeds), tok)
+    # and the kept mass is the requested fraction (within one boundary token)
+    probs = torch.softmax(logits, -1)
+    kept = (probs * (~torch.isinf(first))).sum(-1)
+    assert bool(((kept >= p - 1e-4) & (kept <= p + probs.max(-1).values + 1e-4)).all()), (kept, p)
+
+
 def test_penalties():
     S, V = 4, 1000
     logits = torch.randn(S, V, device=DEV)

@@ -157,6 +157,12 @@ class EngineCore:
         pass
 
     def sleep(self, level: int = 1) -> None:
+        """Release device memory.  The KV cache is dropped, not saved, so nothing may be running (its
+        blocks would be gone at wake-up) and cached prefixes are forgotten first."""
+        if self.scheduler.has_unfinished_requests():
+            raise RuntimeError("cannot sleep while requests are running: their KV cache would be dropped")
+        if not self.scheduler.reset_prefix_cache():
+            raise RuntimeError("cannot sleep: the prefix cache still holds referenced blocks")
         self.model_executor.sleep(level)
 
     def wake_up(self, tags: Optional[list[str]] = None) -> None:

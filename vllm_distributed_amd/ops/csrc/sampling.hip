@@ -56,36 +56,47 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const T* __restrict__ logi
   if (threadIdx.x == 0) out[blockIdx.x] = a.i;
 }
 
-// One radix descent.  weight(i) = 1 (COUNT) or exp(z_i - zmax) for keys >= floor_key.
-// Returns the key u* with  W{key >= u*} >= target  and  W{key > u*} < target.
+// One radix descent.  weight(i) = 1 (COUNT) or exp(z_i - zmax) for keys >= floor_key; target = a number of
+// entries (COUNT) or a fraction of the total weight.  Returns the key u* with  W{key >= u*} >= target  and
+// W{key > u*} < target.  Weights are accumulated as 32.32 fixed-point integers: integer addition does not
+// depend on the order in which the lanes' atomics land, so the same logits always give the same
+// threshold (a float histogram could flip the boundary key between runs and between ranks that must
+// sample identically).
 template <bool COUNT>
 __device__ uint32_t radix_threshold(const float* __restrict__ row, int V, float inv_t, float zmax, float target,
-                                    uint32_t floor_key, float* hist /*[256]*/, uint32_t* s_sel, float* s_rem) {
+                                    uint32_t floor_key, unsigned long long* hist /*[256]*/, uint32_t* s_sel,
+                                    unsigned long long* s_rem) {
   uint32_t prefix = 0;
-  float remaining = target;
+  unsigned long long remaining = COUNT ? (unsigned long long)target : 0ull;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
-    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0.f;
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0ull;
     __syncthreads();
     for (int i = threadIdx.x; i < V; i += blockDim.x) {
       const float z = row[i] * inv_t;
       const uint32_t k = fkey(z);
       if (k < floor_key) continue;
       if (pass > 0 && (k >> (shift + 8)) != prefix) continue;
-      const float w = COUNT ? 1.f : __expf(z - zmax);
-      atomicAdd(&hist[(k >> shift) & 255u], w);
+      const unsigned long long w = COUNT ? 1ull : (unsigned long long)(__expf(z - zmax) * 4294967296.f);
+      if (w) atomicAdd(&hist[(k >> shift) & 255u], w);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      float cum = 0.f;
+      if (!COUNT && pass == 0) {
+        unsigned long long total = 0ull;
+        for (int b = 0; b < 256; ++b) total += hist[b];
+        remaining = (unsigned long long)((double)target * (double)total);
+        if (remaining < 1ull) remaining = 1ull;
+      }
+      unsigned long long cum = 0ull;
       int chosen = -1, lowest = 0;
       for (int b = 255; b >= 0; --b) {
-        const float w = hist[b];
-        if (w > 0.f) lowest = b;
-        if (chosen < 0 && cum + w >= remaining && w > 0.f) { chosen = b; *s_rem = remaining - cum; }
+        const unsigned long long w = hist[b];
+        if (w > 0ull) lowest = b;
+        if (chosen < 0 && cum + w >= remaining && w > 0ull) { chosen = b; *s_rem = remaining - cum; }
         cum += w;
       }
-      if (chosen < 0) { chosen = lowest; *s_rem = 0.f; }   // rounding: keep everything
+      if (chosen < 0) { chosen = lowest; *s_rem = 0ull; }   // rounding: keep everything
       *s_sel = (uint32_t)chosen;
     }
     __syncthreads();
@@ -106,9 +117,9 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
   __shared__ float red[16];
   __shared__ float rv[16];
   __shared__ int ri[16];
-  __shared__ float hist[256];
+  __shared__ unsigned long long hist[256];
   __shared__ uint32_t s_sel;
-  __shared__ float s_rem;
+  __shared__ unsigned long long s_rem;
   const int rowi = blockIdx.x;
   const float* row = logits + (long)rowi * stride;
   const float temp = temperature ? temperature[rowi] : 1.f;
@@ -129,14 +140,8 @@ __global__ __launch_bounds__(1024) void sample_kernel(const float* __restrict__ 
   const float p = top_p ? top_p[rowi] : 1.f;
   const float mp = min_p ? min_p[rowi] : 0.f;
   if (k > 0 && k < V) thr = radix_threshold<true>(row, V, inv_t, zmax, (float)k, 0u, hist, &s_sel, &s_rem);
-  if (p < 1.f) {
-    float zsum = 0.f;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-      const float z = row[i] * inv_t;
-      if (fkey(z) >= thr) zsum += __expf(z - zmax);
-    }
-    zsum = block_sum(zsum, red);
-    const uint32_t tp = radix_threshold<false>(row, V, inv_t, zmax, p * zsum, thr, hist, &s_sel, &s_rem);
+  if (p < 1.f) {     // the fraction p of the weight that survived top-k (the descent sums it in its first pass)
+    const uint32_t tp = radix_threshold<false>(row, V, inv_t, zmax, p, thr, hist, &s_sel, &s_rem);
     thr = max(thr, tp);
   }
   if (mp > 0.f) thr = max(thr, fkey(zmax + __logf(mp)));
@@ -163,9 +168,9 @@ __global__ __launch_bounds__(1024) void topk_topp_mask_kernel(float* __restrict_
                                                               const float* __restrict__ top_p,
                                                               const float* __restrict__ min_p, int V, long stride) {
   __shared__ float red[16];
-  __shared__ float hist[256];
+  __shared__ unsigned long long hist[256];
   __shared__ uint32_t s_sel;
-  __shared__ float s_rem;
+  __shared__ unsigned long long s_rem;
   const int rowi = blockIdx.x;
   float* row = logits + (long)rowi * stride;
   float mx = -INFINITY;
@@ -177,11 +182,7 @@ __global__ __launch_bounds__(1024) void topk_topp_mask_kernel(float* __restrict_
   const float mp = min_p ? min_p[rowi] : 0.f;
   if (k > 0 && k < V) thr = radix_threshold<true>(row, V, 1.f, zmax, (float)k, 0u, hist, &s_sel, &s_rem);
   if (p < 1.f) {
-    float zsum = 0.f;
-    for (int i = threadIdx.x; i < V; i += blockDim.x)
-      if (fkey(row[i]) >= thr) zsum += __expf(row[i] - zmax);
-    zsum = block_sum(zsum, red);
-    thr = max(thr, radix_threshold<false>(row, V, 1.f, zmax, p * zsum, thr, hist, &s_sel, &s_rem));
+    thr = max(thr, radix_threshold<false>(row, V, 1.f, zmax, p, thr, hist, &s_sel, &s_rem));
   }
   if (mp > 0.f) thr = max(thr, fkey(zmax + __logf(mp)));
   if (thr == 0) return;

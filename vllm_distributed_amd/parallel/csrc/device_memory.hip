@@ -194,6 +194,12 @@ VDA_EXPORT long long vda_vmm_wake(int tag) {
       e = hipMemcpy(b.va, b.host_copy, b.size, hipMemcpyHostToDevice);
       hipHostFree(b.host_copy);
       b.host_copy = nullptr;
+    } else if (e == hipSuccess) {
+      // dropped, not saved: the fresh pages hold whatever their last owner left.  Cleared like the
+      // first allocation was, because kernels multiply masked-out cache slots by zero weights and a
+      // NaN bit pattern there would survive the product.
+      e = hipMemset(b.va, 0, b.size);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
     }
     hipSetDevice(prev);
     if (e != hipSuccess) { g_vmm_last_error = (int)e; return -1; }

@@ -285,4 +285,42 @@ class Worker:
         return self.model_runner.lora_manager.pin_adapter(lora_id)
 
     def shutdown(self) -> None:
-        pass
+        """Orderly end of a multi-rank run: the ranks meet (bounded wait), then every communicator, IPC
+        mapping and process group is closed here, in a known order, rather than by interpreter teardown,
+        where a peer that has already gone makes a communication helper thread abort the process."""
+        if getattr(self, "_shut", False):
+            return
+        self._shut = True
+        mr = getattr(self, "model_runner", None)
+        if mr is not None:
+            conn = getattr(mr, "kv_connector", None)
+            if conn is not None:
+                try:
+                    conn.shutdown()
+                except Exception as e:   # noqa: BLE001
+                    logger.warning("KV connector shutdown: %s", e)
+            if getattr(mr, "tk_rx", None) is not None:
+                try:
+                    mr.tk_rx.close()
+                except Exception:        # noqa: BLE001
+                    pass
+                mr.tk_rx = None
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        from ..parallel.all2all import close_dispatchers
+        try:
+            if torch.cuda.is_available() and self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            world = pstate.get_world_group()
+            if world.cpu_group is not None:
+                import datetime
+                dist.monitored_barrier(world.cpu_group, timeout=datetime.timedelta(seconds=10),
+                                       wait_all_ranks=False)
+        except Exception as e:           # noqa: BLE001 - a peer is gone: close what is ours anyway
+            logger.warning("peers did not meet at shutdown: %s", e)
+        try:
+            close_dispatchers()
+            pstate.cleanup_dist_env_and_memory()
+        except Exception as e:           # noqa: BLE001
+            logger.warning("distributed teardown: %s", e)
