@@ -39,6 +39,37 @@ def note(msg: str) -> None:
         print(f"[bench {time.time() - T_PROCESS_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def run_disagg(a) -> None:
+    """xPyD deployment on one node through the peer-memory KV connector; one JSON line in this file's format."""
+    import re
+    m = re.fullmatch(r"(\d+)p(\d+)d", a.disagg.lower())
+    if not m:
+        raise SystemExit("--disagg takes xPyD, e.g. 1p1d or 4p4d")
+    x, y = int(m.group(1)), int(m.group(2))
+    from vllm_distributed_amd.benchmarks import disagg
+    model = "llama-3-8b" if a.model == "llama-3-70b" else a.model
+    out_len = 200 if a.output_len == 128 else a.output_len
+    argv = ["--model", model, "--prefill", str(x), "--decode", str(y), "--input-len", str(a.input_len),
+            "--output-len", str(out_len), "--num-prompts", str(a.num_prompts),
+            "--request-rate", str(a.request_rate), "--gpu-memory-utilization", str(min(a.gpu_memory_utilization, 0.9)),
+            "--max-num-batched-tokens", str(a.max_num_batched_tokens)]
+    if a.enforce_eager:
+        argv.append("--enforce-eager")
+    if a.rehearse_on_one_gpu:
+        argv.append("--rehearse-on-one-gpu")
+    res = disagg.main(argv)["disagg"]
+    print(json.dumps({
+        "metric": "disagg_output_tokens_per_s_per_gpu", "value": res["output_tok_s_per_gpu"], "unit": "tokens/s/GPU",
+        "n_gpus": res["n_gpus"], "steps": res["completed"], "warmup": x * y, "ms_per_step": None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": res["output_tok_s_per_gpu"] / 738.0,
+        "dtype": "bf16", "data": "synthetic", "rehearsal_on_one_gpu": bool(a.rehearse_on_one_gpu),
+        "ttft_ms": res["ttft_ms"], "itl_ms": res["itl_ms"], "output_tok_s": res["output_tok_s"],
+        "num_errors": res["num_errors"],
+        "config": {"model": model, "deployment": a.disagg.lower(), "input_len": a.input_len, "output_len": out_len,
+                   "num_prompts": a.num_prompts, "request_rate": res["request_rate"], "connector": "XgmiConnector"},
+    }), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,7 +90,16 @@ def main() -> None:
                          "that would not fit are dropped (never below one warm-up and --min-steps timed rounds) "
                          "and the JSON line reports the rounds really run; 0 = run exactly --steps/--warmup")
     ap.add_argument("--min-steps", type=int, default=3, help="timed rounds that run whatever the budget says")
+    ap.add_argument("--disagg", default=None, metavar="xPyD",
+                    help="disaggregated prefill/decode instead of the flagship run: e.g. 1p1d or 4p4d, Llama-3-8B, "
+                         "1024-token prompts, 200 generated tokens (benchmarks/disagg.py); needs x + y GPUs unless "
+                         "--rehearse-on-one-gpu")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="--disagg: every engine on GPU 0")
+    ap.add_argument("--num-prompts", type=int, default=200, help="--disagg: requests")
+    ap.add_argument("--request-rate", type=float, default=float("inf"), help="--disagg: Poisson arrivals per second")
     a = ap.parse_args()
+    if a.disagg:
+        return run_disagg(a)
 
     import torch
     import torch.distributed as dist

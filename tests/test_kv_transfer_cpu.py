@@ -1,6 +1,7 @@
 """KV connectors end to end on CPU: a prefill instance exports the KV of a prompt, a decode
 instance imports it and must continue with exactly the tokens of a single-instance run
 (modelled on tests/v1/kv_connector/{unit,nixl_integration})."""
+import os
 import socket
 
 import pytest
@@ -238,3 +239,26 @@ def test_layout_mismatch_is_refused_at_handshake():
     finally:
         p.shutdown()
         d.shutdown()
+
+
+def test_disagg_benchmark_harness_on_cpu(tmp_path):
+    """benchmarks/disagg.py end to end (1 prefill + 1 decode engine process, socket data plane): every
+    request completes through the router path and the report carries the metrics of the study."""
+    import json
+    import subprocess
+    import sys
+    from tests.test_e2e_cpu import _save_tiny
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    out = tmp_path / "res.json"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "vllm_distributed_amd.benchmarks.disagg", "--model", path,
+                        "--load-format", "auto", "--dtype", "float32", "--device", "cpu", "--prefill", "1",
+                        "--decode", "1", "--input-len", "64", "--output-len", "6", "--num-prompts", "5",
+                        "--vocab-size", "300", "--max-num-seqs", "8", "--max-num-batched-tokens", "256",
+                        "--request-rate", "50", "--output-json", str(out)],
+                       cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.load(open(out))["disagg"]
+    assert res["completed"] == 5 and res["num_errors"] == 0
+    assert res["n_gpus"] == 2 and res["output_tok_s"] > 0
+    assert res["ttft_ms"]["p99"] >= res["ttft_ms"]["p50"] > 0 and res["itl_ms"]["p50"] > 0
