@@ -86,6 +86,32 @@ def moe():
               f"{t3 * 1e3:>15.2f} {fl / t3 / 1e12:>6.0f}", flush=True)
 
 
+def moe_decode():
+    """Mixtral-8x7B expert layer with fp8 weights at decode batch sizes: the row-split streaming kernel
+    (weights widened in registers, 16-bit MFMA) against the tiled kernel (activations quantised, fp8 MFMA)."""
+    print("\nMixtral-8x7B expert layer, fp8 weights, decode batches: us per layer (grouped rows W8A16 / tiled fp8)")
+    E, k, H, I = 8, 2, 4096, 14336
+    copies = 3                                   # 1.4 GB of weights each: never resident in the Infinity Cache
+    q13 = [(torch.randn(E, 2 * I, H, device=DEV, dtype=torch.bfloat16) * 0.03).to(FP8) for _ in range(copies)]
+    q2 = [(torch.randn(E, H, I, device=DEV, dtype=torch.bfloat16) * 0.03).to(FP8) for _ in range(copies)]
+    s13 = torch.full((E,), 0.01, device=DEV)
+    s2 = torch.full((E,), 0.01, device=DEV)
+    for T in (16, 32, 64, 128, 256, 512, 1024):
+        x = torch.randn(T, H, device=DEV, dtype=torch.bfloat16)
+        tw, ids = R.moe_topk_softmax(torch.randn(T, E, device=DEV), k, True)
+        it = [0]
+
+        def run():
+            i = it[0] = (it[0] + 1) % copies
+            ops.fused_moe(x, q13[i], q2[i], tw, ids, s13, s2)
+        os.environ["VDA_MOE_GROUPED_MAX_PAIRS"] = os.environ["VDA_MOE_GROUPED_MAX_PAIRS_FP8"] = "1000000"
+        t1 = timeit(run, reps=12, warm=3)
+        os.environ["VDA_MOE_GROUPED_MAX_PAIRS"] = "0"
+        t2 = timeit(run, reps=12, warm=3)
+        nbytes = 3.0 * E * H * I
+        print(f"T={T:>5}: {t1 * 1e6:>8.1f} {t2 * 1e6:>8.1f}   best {nbytes / min(t1, t2) / 1e12:.2f} TB/s", flush=True)
+
+
 def decode():
     """Llama-3-70B projections at decode batch sizes: library GEMM against the tiled 16-bit kernel."""
     print("\nLlama-3-70B projections, bf16, us per call (lib / tile128 / tile64) and weight TB/s of the best")
@@ -111,5 +137,7 @@ if __name__ == "__main__":
         dense()
     if which in ("all", "moe"):
         moe()
+    if which in ("all", "moe_decode"):
+        moe_decode()
     if which in ("all", "decode"):
         decode()

@@ -762,7 +762,12 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
     k = topk_ids.shape[1]
     E, I2, _ = w13.shape
     I = I2 // 2
-    if T * k > envs.VDA_MOE_GROUPED_MAX_PAIRS or block_scales:
+    # e4m3 experts: from a few hundred pairs on, quantised activations through the fp8 MFMA tiles beat
+    # widening the weights for 16-bit MFMAs (Mixtral-8x7B layer, 256 pairs: 396 us against 420; 2048: 684 / 1367)
+    limit = envs.VDA_MOE_GROUPED_MAX_PAIRS
+    if w13.dtype == torch.float8_e4m3fn:
+        limit = min(limit, envs.VDA_MOE_GROUPED_MAX_PAIRS_FP8)
+    if T * k > limit or block_scales:
         return _moe_tiled(_contig_last(x), w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales)
     x = _contig_last(x)
     dev = x.device

@@ -9,14 +9,15 @@
 // fp8 form issues v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, the instruction that runs at
 // twice the 16-bit MFMA rate on CDNA4 (the plain 16x16x32 fp8 form runs at the 16-bit rate).
 //
-// Tile: 128 weight rows x (32 * TN) activation rows x 128 bytes of K per step (128 e4m3 or 64 16-bit
-// elements), 4 waves as 2 (weight rows) x 2 (activation rows), each wave 4 x TN accumulator tiles of
+// Tile: 256 weight rows x (32 * TN) activation rows x 128 bytes of K per step (128 e4m3 or 64 16-bit
+// elements), 8 waves as 4 (weight rows) x 2 (activation rows), each wave 4 x TN accumulator tiles of
 // 16 x 16.  The weights are the MFMA A operand and the activations the B operand, so a lane ends up with
 // four consecutive output columns of one activation row (an 8-byte store) and the SiLU(gate) * up pair of
-// a gated MLP sits in the same lane: a gate/up tile is 64 gate rows plus the 64 up rows of the same
-// columns.  Both operands go global -> LDS with 16-byte global_load_lds (no staging registers), two LDS
-// buffers, the next step's loads in flight during this step's MFMAs; two workgroups per CU (64 KiB of
-// LDS each) cover each other's barrier waits.
+// a gated MLP sits in the same lane: a gate/up tile is 128 gate rows plus the 128 up rows of the same
+// columns.  Both operands go global -> LDS with 16-byte global_load_lds (no staging registers) into a ring
+// of three LDS stages: the fill of step kt + 2 is issued at the start of step kt and is still in flight
+// when the step ends (counted s_waitcnt vmcnt + raw s_barrier), so a K step never waits for a load it
+// has just issued; one workgroup (two waves per SIMD) per CU.
 //
 // LDS image: [row][8 chunks of 16 bytes], chunk c of row r stored at c ^ f(r),
 //   f(r) = ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1).
@@ -68,13 +69,18 @@ struct TileGemmArgs {
 };
 
 // TI: operand element type (bf16_t / f16_t / uint8_t = e4m3); TO: output type.
+// 8 waves as 4 (weight rows) x 2 (activation rows); three LDS stages, the fill of step kt + 2 in flight
+// across the barrier that ends step kt (counted s_waitcnt, raw s_barrier: a __syncthreads() would drain it).
 template <typename TI, typename TO, int EPI, bool GROUPED, int SC, int TN>
-__global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs a) {
+__global__ __launch_bounds__(512, 1) void tile_gemm_kernel(const TileGemmArgs a) {
   using V4 = typename Vec<TO>::v4;
   constexpr int EB = sizeof(TI);             // bytes per operand element
   constexpr int XR = 32 * TN;                // activation rows per tile
-  constexpr int WBYTES = 128 * 128, XBYTES = XR * 128;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * (WBYTES + XBYTES)];
+  constexpr int WBYTES = 256 * 128, XBYTES = XR * 128, STAGE = WBYTES + XBYTES;
+  constexpr int XROUNDS = XR / 64;           // 64 rows per fill round (512 threads x 16 bytes)
+  constexpr int NG = 4 + XROUNDS;            // global -> LDS pieces per thread and K step
+  static_assert(TN == 2 || TN == 4, "activation rows per tile: 64 or 128");
+  __shared__ __attribute__((aligned(16))) uint8_t lds[3 * STAGE];
 
   // ---- which tile ----------------------------------------------------------------------------
   // block ids are dealt round-robin to the 8 XCDs; the 64 consecutive blocks an XCD receives form an
@@ -98,26 +104,26 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
-  const int n0 = ni * (EPI == EPI_GATE_UP ? 64 : 128);
+  const int n0 = ni * (EPI == EPI_GATE_UP ? 128 : 256);
   const int w_rows = EPI == EPI_GATE_UP ? 2 * a.N : a.N;
   const long kbytes = (long)a.K * EB;
   const uint8_t* wbase = reinterpret_cast<const uint8_t*>(a.w) + (long)e * a.w_expert_stride * EB;
   const uint8_t* xbase = reinterpret_cast<const uint8_t*>(a.x);
 
-  // ---- staging roles: thread t of round j fills LDS row 32 j + (t >> 3), slot t & 7 -----------------
+  // ---- staging roles: thread t of round j fills LDS row 64 j + (t >> 3), slot t & 7 -----------------
   const int srow = tid >> 3, slot = tid & 7;
   const uint8_t* wsrc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int rho = 32 * j + srow;
-    int row = EPI == EPI_GATE_UP ? (rho < 64 ? n0 + rho : a.N + n0 + rho - 64) : n0 + rho;
+    const int rho = 64 * j + srow;
+    int row = EPI == EPI_GATE_UP ? (rho < 128 ? n0 + rho : a.N + n0 + rho - 128) : n0 + rho;
     row = min(row, w_rows - 1);
     wsrc[j] = wbase + (long)row * kbytes + ((slot ^ swz(rho)) << 4);
   }
-  const uint8_t* xsrc[TN];
+  const uint8_t* xsrc[XROUNDS];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int tau = 32 * j + srow;
+  for (int j = 0; j < XROUNDS; ++j) {
+    const int tau = 64 * j + srow;
     const int pos = beg + min(tau, cnt - 1);
     long row = pos;
     if (GROUPED) {
@@ -126,21 +132,23 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs a)
     }
     xsrc[j] = xbase + row * a.x_stride * EB + ((slot ^ swz(tau)) << 4);
   }
-  auto stage = [&](int buf, int kt) {
-    uint8_t* lw = lds + buf * (WBYTES + XBYTES) + wave * 1024;
+  const int nk = (int)(kbytes >> 7);
+  auto stage = [&](int kt) {                  // ring slot kt % 3 <- K step min(kt, nk - 1) (a re-fill of the
+    uint8_t* lw = lds + (kt % 3) * STAGE + wave * 1024;      // last step keeps the operation count uniform)
     uint8_t* lx = lw + WBYTES;
-    const long ko = (long)kt * 128;
+    const long ko = (long)min(kt, nk - 1) * 128;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      glds16(wsrc[j] + ko, lw + j * 4096);
+      glds16(wsrc[j] + ko, lw + j * 8192);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-      glds16(xsrc[j] + ko, lx + j * 4096);
+    for (int j = 0; j < XROUNDS; ++j)
+      glds16(xsrc[j] + ko, lx + j * 8192);
   };
 
   // ---- compute roles -----------------------------------------------------------------------------------
-  // weight m-tile mt of this wave starts at LDS row:
-  auto wrow = [&](int mt) { return EPI == EPI_GATE_UP ? (mt < 2 ? 32 * wr + 16 * mt : 64 + 32 * wr + 16 * (mt - 2))
+  // weight m-tile mt (0..3) of this wave starts at LDS row: gate/up tiles hold 128 gate rows, then the 128 up
+  // rows of the same columns, and a wave takes two gate tiles and the up tiles of the same 32 columns
+  auto wrow = [&](int mt) { return EPI == EPI_GATE_UP ? (mt < 2 ? 32 * wr + 16 * mt : 128 + 32 * wr + 16 * (mt - 2))
                                                       : 64 * wr + 16 * mt; };
   const int f = swz(r);                        // tile rows start at multiples of 16: f depends on r only
   const int c0 = ((2 * g) ^ f) << 4, c1 = ((2 * g + 1) ^ f) << 4;
@@ -176,19 +184,18 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs a)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int rho = wrow(mt);
-      int row = EPI == EPI_GATE_UP ? (rho < 64 ? n0 + rho : a.N + n0 + rho - 64) : n0 + rho;
+      int row = EPI == EPI_GATE_UP ? (rho < 128 ? n0 + rho : a.N + n0 + rho - 128) : n0 + rho;
       row = min(row, w_rows - 1);
       ws_row[mt] = a.w_scale + ((long)e * nblocks + (row >> 7)) * kblocks;
     }
   }
 
-  const int nk = (int)(kbytes >> 7);
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  stage(0);
+  stage(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");          // step 0 has landed, step 1 is in flight
+  __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
+    stage(kt + 2);                             // into the slot read during step kt - 1 (all waves are past it)
     float sx[TN], sw[4];
     if (SC == SC_BLOCK) {
 #pragma unroll
@@ -196,22 +203,22 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs a)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) sw[mt] = ws_row[mt][kt];
     }
-    const uint8_t* base = lds + buf * (WBYTES + XBYTES);
+    const uint8_t* base = lds + (kt % 3) * STAGE;
     i32x4 wa[4][2], xb[TN][2];
-#pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-      xb[nt][0] = *reinterpret_cast<const i32x4*>(base + xoff[nt] + c0);
-      xb[nt][1] = *reinterpret_cast<const i32x4*>(base + xoff[nt] + c1);
-    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       wa[mt][0] = *reinterpret_cast<const i32x4*>(base + woff[mt] + c0);
       wa[mt][1] = *reinterpret_cast<const i32x4*>(base + woff[mt] + c1);
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int nt = 0; nt < TN; ++nt) {
+      xb[nt][0] = *reinterpret_cast<const i32x4*>(base + xoff[nt] + c0);
+      xb[nt][1] = *reinterpret_cast<const i32x4*>(base + xoff[nt] + c1);
+    }
 #pragma unroll
-      for (int nt = 0; nt < TN; ++nt) {
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
         if (SC == SC_BLOCK) {
           const f32x4 p = mma(wa[mt][0], wa[mt][1], xb[nt][0], xb[nt][1], f32x4{0, 0, 0, 0}, TI{});
           const float s = sw[mt] * sx[nt];
@@ -221,8 +228,11 @@ __global__ __launch_bounds__(256, 2) void tile_gemm_kernel(const TileGemmArgs a)
           acc[mt][nt] = mma(wa[mt][0], wa[mt][1], xb[nt][0], xb[nt][1], acc[mt][nt], TI{});
         }
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // step kt + 1 must have landed before anyone reads it; the fill of step kt + 2 stays in flight.
+    // (SC_BLOCK reads its scales with ordinary loads: they are older than that fill and done by now.)
+    // This step's LDS reads are retired too (lgkmcnt): the next step's fill overwrites the slot they read.
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NG) : "memory");
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- epilogue: lane holds out[token tau(nt)][n(mt) + 4 g + i] -----------------------------------------
@@ -393,7 +403,7 @@ VDA_EXPORT int vda_moe_align_large(int* sorted, int* offsets, int* counts, int* 
 template <typename TI, typename TO, int SC>
 static int launch_tile_gemm(const TileGemmArgs& a, int epi, bool grouped, int rows_per_tile, hipStream_t st) {
   const int pm = (a.m_tiles + 7) / 8, pn = (a.n_tiles + 7) / 8;
-  const dim3 grid((unsigned)((pm * pn + 7) / 8 * 8 * 64)), block(256);
+  const dim3 grid((unsigned)((pm * pn + 7) / 8 * 8 * 64)), block(512);
 #define LAUNCH(EPI, GR, TN) hipLaunchKernelGGL((tile_gemm_kernel<TI, TO, EPI, GR, SC, TN>), grid, block, 0, st, a)
 #define BY_TN(EPI, GR) do { if (rows_per_tile == 128) LAUNCH(EPI, GR, 4); else LAUNCH(EPI, GR, 2); } while (0)
   if (grouped) {
@@ -432,7 +442,7 @@ VDA_EXPORT int vda_tile_gemm(void* out, const void* x, const void* w, const floa
   a.sorted = sorted; a.tile_expert = tile_expert; a.tile_beg = tile_beg; a.tile_end = tile_end; a.num_tiles = num_tiles;
   a.M = M; a.N = N; a.K = K; a.top_k = top_k > 0 ? top_k : 1;
   a.m_tiles = grouped ? max_m_tiles : (M + rows_per_tile - 1) / rows_per_tile;
-  a.n_tiles = epi == EPI_GATE_UP ? N / 64 : (N + 127) / 128;
+  a.n_tiles = epi == EPI_GATE_UP ? (N + 127) / 128 : (N + 255) / 256;
   a.x_stride = x_stride; a.out_stride = out_stride; a.w_expert_stride = w_expert_stride;
   int rc;
 #define BY_SC(TI, TO) (scale_mode == SC_NONE ? launch_tile_gemm<TI, TO, SC_NONE>(a, epi, grouped, rows_per_tile, st) \
