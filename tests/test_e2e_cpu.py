@@ -42,6 +42,43 @@ def _save_tiny(tmp, kind):
             for n, p_ in m.named_parameters():
                 if "router" in n or "experts" in n:
                     p_.normal_(0, 0.08)
+    elif kind == "ernie45":
+        cfg = tf.Ernie4_5Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=256,
+                                use_bias=True, tie_word_embeddings=True)
+        m = tf.Ernie4_5ForCausalLM(cfg)
+    elif kind == "ernie45_moe":
+        cfg = tf.Ernie4_5_MoeConfig(vocab_size=320, hidden_size=128, intermediate_size=256, moe_intermediate_size=64,
+                                    num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=1,
+                                    max_position_embeddings=256, moe_num_experts=4, moe_k=2, moe_num_shared_experts=1,
+                                    moe_layer_start_index=1, moe_layer_interval=1, tie_word_embeddings=True)
+        m = tf.Ernie4_5_MoeForCausalLM(cfg)
+        with torch.no_grad():
+            for n, p_ in m.named_parameters():
+                if "e_score_correction_bias" in n:
+                    p_.normal_(0, 0.2)
+    elif kind == "dots1":
+        cfg = tf.Dots1Config(vocab_size=320, hidden_size=128, intermediate_size=256, moe_intermediate_size=64,
+                             num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=1, head_dim=64,
+                             n_routed_experts=8, n_shared_experts=1, num_experts_per_tok=2, first_k_dense_replace=1,
+                             n_group=2, topk_group=1, norm_topk_prob=True, routed_scaling_factor=1.5,
+                             max_position_embeddings=256)
+        m = tf.Dots1ForCausalLM(cfg)
+        with torch.no_grad():
+            for n, b in m.named_buffers():
+                if "e_score_correction_bias" in n:
+                    b.normal_(0, 0.2)
+    elif kind in ("hunyuan_dense", "hunyuan_moe"):
+        kw = dict(vocab_size=320, hidden_size=128, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                  num_key_value_heads=1, head_dim=64, max_position_embeddings=256)
+        if kind == "hunyuan_moe":
+            m = tf.HunYuanMoEV1ForCausalLM(tf.HunYuanMoEV1Config(num_experts=4, moe_topk=2, **kw))
+        else:
+            m = tf.HunYuanDenseV1ForCausalLM(tf.HunYuanDenseV1Config(**kw))
+    elif kind == "persimmon":
+        cfg = tf.PersimmonConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                 num_attention_heads=2, max_position_embeddings=256)
+        m = tf.PersimmonForCausalLM(cfg)
     elif kind == "mixtral":
         cfg = tf.MixtralConfig(vocab_size=320, hidden_size=128, intermediate_size=128, num_hidden_layers=2,
                                num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -300,7 +337,8 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2"])
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
+                                  "dots1", "hunyuan_dense", "hunyuan_moe", "persimmon"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 40, [1, 2, 3]]

@@ -14,6 +14,17 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
     "Llama4ForCausalLM": ("llama4", "Llama4ForCausalLM"),
     "Llama4ForConditionalGeneration": ("llama4", "Llama4ForConditionalGeneration"),
+    "QuantMixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
+    "InternLMForCausalLM": ("llama", "LlamaForCausalLM"),
+    "Ernie4_5ForCausalLM": ("more_decoders", "Ernie4_5ForCausalLM"),
+    "Ernie4_5_ForCausalLM": ("more_decoders", "Ernie4_5ForCausalLM"),
+    "Ernie4_5_MoeForCausalLM": ("more_decoders", "Ernie4_5_MoeForCausalLM"),
+    "Dots1ForCausalLM": ("more_decoders", "Dots1ForCausalLM"),
+    "HunYuanDenseV1ForCausalLM": ("more_decoders", "HunYuanDenseV1ForCausalLM"),
+    "HunYuanMoEV1ForCausalLM": ("more_decoders", "HunYuanMoEV1ForCausalLM"),
+    "MiMoForCausalLM": ("more_decoders", "MiMoForCausalLM"),
+    "MiniCPMForCausalLM": ("more_decoders", "MiniCPMForCausalLM"),
+    "PersimmonForCausalLM": ("more_decoders", "PersimmonForCausalLM"),
     "Qwen2MoeForCausalLM": ("mixtral", "Qwen2MoeForCausalLM"),
     "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
     "PhiMoEForCausalLM": ("mixtral", "PhiMoEForCausalLM"),
