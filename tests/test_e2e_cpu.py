@@ -356,6 +356,30 @@ def test_greedy_matches_hf(tmp_path, kind):
     llm.shutdown()
 
 
+@pytest.mark.parametrize("head_dim", [32, 80, 96, 112, 192])
+def test_head_sizes_outside_the_kernel_set_match_hf(tmp_path, head_dim):
+    """Heads of 80 / 96 / 112 / 192 (and small ones) run zero-padded to 64 / 128 / 256."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.LlamaConfig(vocab_size=320, hidden_size=2 * head_dim, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256, head_dim=head_dim,
+                         tie_word_embeddings=False)
+    hf = tf.LlamaForCausalLM(cfg).float().eval()
+    path = os.path.join(tmp_path, "m")
+    hf.save_pretrained(path, safe_serialization=True)
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 40]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=10,
+                                                                                   ignore_eos=True))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=10, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref
+
+
 def test_chunked_prefill_prefix_cache_and_preemption_same_tokens(tmp_path):
     path, hf = _save_tiny(str(tmp_path), "llama")
     prompts = [[(i * 7 + j) % 300 for j in range(50)] for i in range(6)] + [[3] * 60, [3] * 60]

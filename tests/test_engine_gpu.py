@@ -58,6 +58,32 @@ def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     assert worst < 0.08, worst
 
 
+@pytest.mark.parametrize("head_dim", [80, 192])
+def test_gpu_padded_head_sizes_match_hf(tmp_path, head_dim):
+    """Head sizes the MFMA kernels are not built for run zero-padded (80 -> 128, 192 -> 256), graphs on."""
+    import transformers as tf
+    from vllm_distributed_amd import SamplingParams
+    torch.manual_seed(0)
+    cfg = tf.LlamaConfig(vocab_size=320, hidden_size=2 * head_dim, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256, head_dim=head_dim,
+                         tie_word_embeddings=False)
+    hf = tf.LlamaForCausalLM(cfg).float().eval()
+    path = os.path.join(tmp_path, "m")
+    hf.save_pretrained(path, safe_serialization=True)
+    llm = _llm(path)
+    outs = llm.generate(prompt_token_ids=PROMPTS,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=10, ignore_eos=True, logprobs=0))
+    llm.shutdown()
+    worst = 0.0
+    for p, o in zip(PROMPTS, outs):
+        gen = list(o.outputs[0].token_ids)
+        with torch.no_grad():
+            lp = torch.log_softmax(hf(torch.tensor([p + gen])).logits[0].float(), -1)
+        for k, t in enumerate(gen):
+            worst = max(worst, abs(float(lp[len(p) + k - 1, t]) - o.outputs[0].logprobs[k][t].logprob))
+    assert worst < 0.08, worst
+
+
 def test_sleep_allocator_keeps_addresses(tmp_path):
     from vllm_distributed_amd.device_allocator import SleepAllocator
     dev = torch.device("cuda:0")

@@ -191,3 +191,33 @@ def test_qwen2_reward_heads(tmp_path, arch):
             if n == 2:
                 ref = torch.softmax(ref, -1)
         torch.testing.assert_close(o.outputs.data.float().view(len(p), n), ref, atol=2e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("kind", ["gpt2", "gemma", "jamba"])
+def test_sequence_classification_adapters_match_hf(tmp_path, kind):
+    """Classification heads on decoders other than Llama (GPT-2, Gemma, the hybrid Jamba)."""
+    import transformers as tf
+    torch.manual_seed(0)
+    if kind == "gpt2":
+        hf = tf.GPT2ForSequenceClassification(tf.GPT2Config(vocab_size=320, n_embd=128, n_layer=2, n_head=2,
+                                                            n_positions=256, num_labels=3, pad_token_id=0))
+    elif kind == "gemma":
+        hf = tf.GemmaForSequenceClassification(tf.GemmaConfig(
+            vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+            num_key_value_heads=1, head_dim=64, max_position_embeddings=256, num_labels=4, pad_token_id=0))
+    else:
+        hf = tf.JambaForSequenceClassification(tf.JambaConfig(
+            vocab_size=320, hidden_size=128, intermediate_size=128, num_hidden_layers=4, num_attention_heads=2,
+            num_key_value_heads=1, attn_layer_period=2, attn_layer_offset=1, expert_layer_period=2,
+            expert_layer_offset=1, num_experts=4, num_experts_per_tok=2, mamba_d_state=8, mamba_d_conv=4,
+            mamba_expand=2, mamba_dt_rank=8, use_mamba_kernels=False, num_labels=2, pad_token_id=0))
+    hf = hf.float().eval()
+    path = os.path.join(tmp_path, kind)
+    hf.save_pretrained(path, safe_serialization=True)
+    llm = LLM(model=path, task="classify", **KW)
+    outs = llm.classify([{"prompt_token_ids": p} for p in PROMPTS])
+    llm.shutdown()
+    for p, o in zip(PROMPTS, outs):
+        with torch.no_grad():
+            ref = torch.softmax(hf(torch.tensor([p])).logits[0], dim=-1)
+        torch.testing.assert_close(torch.tensor(o.outputs.probs), ref, atol=2e-4, rtol=2e-3)

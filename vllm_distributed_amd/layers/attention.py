@@ -28,6 +28,14 @@ class Attention(nn.Module):
         # [p - p % local_chunk, p] only; the runner supplies the per-chunk virtual batch
         # (reference: vllm/v1/attention/backends/utils.py:242 make_local_attention_virtual_batches)
         self.local_chunk = int(local_chunk or 0)
+        # The MFMA kernels are built for heads of 64, 128 and 256 values.  Other sizes (80, 96, 112, 192, ...)
+        # run zero-padded to the next of these: padding adds nothing to q.k, and the padded output values
+        # are zero and cut off again (reference head sizes: csrc/attention/paged_attention_v1.cu:150-188).
+        self.true_head_size = int(head_size)
+        if head_size not in (64, 128, 256):
+            if head_size > 256:
+                raise ValueError(f"head size {head_size} is beyond the MFMA attention kernels (at most 256)")
+            head_size = 64 if head_size < 64 else 128 if head_size < 128 else 256
         self.num_heads, self.head_size, self.scale = num_heads, head_size, float(scale)
         self.causal = causal          # False: encoder models, every token sees its whole sequence
         self.num_kv_heads = num_kv_heads or num_heads
@@ -50,8 +58,6 @@ class Attention(nn.Module):
         # bound by the model runner after KV memory planning
         self.k_cache: Optional[torch.Tensor] = None
         self.v_cache: Optional[torch.Tensor] = None
-        if head_size not in (64, 128, 256):
-            raise ValueError(f"head size {head_size} is not supported by the MFMA attention kernels (64/128/256)")
 
     def get_kv_cache_spec(self, block_size: int, dtype: torch.dtype) -> KVCacheSpec:
         if self.sliding_window:
@@ -65,6 +71,19 @@ class Attention(nn.Module):
 
     def forward(self, qkv: torch.Tensor, positions: Optional[torch.Tensor] = None, rotary=None) -> torch.Tensor:
         """qkv: [T, (Hq + 2 Hkv) * D] fused projection output.  Returns [T, Hq * D]."""
+        D0, D = self.true_head_size, self.head_size
+        if D0 == D:
+            return self._forward_native(qkv, positions, rotary)
+        T = qkv.shape[0]
+        Hq, Hkv = self.num_heads, self.num_kv_heads
+        if rotary is not None and positions is not None:
+            rotary(positions[:T], qkv[:, : Hq * D0], qkv[:, Hq * D0: (Hq + Hkv) * D0])
+        padded = qkv.new_zeros((T, Hq + 2 * Hkv, D))
+        padded[:, :, :D0] = qkv.view(T, Hq + 2 * Hkv, D0)
+        out = self._forward_native(padded.view(T, -1), None, None)
+        return out.view(T, Hq, D)[:, :, :D0].reshape(T, Hq * D0)
+
+    def _forward_native(self, qkv: torch.Tensor, positions: Optional[torch.Tensor] = None, rotary=None) -> torch.Tensor:
         ctx = get_forward_context()
         md: Optional[AttentionMetadata] = ctx.attn_metadata
         T = qkv.shape[0]

@@ -99,6 +99,11 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Qwen3ForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
     "LlamaForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
     "Qwen2ForSequenceClassification": ("pooling", "LlamaForSequenceClassification"),
+    "GPT2ForSequenceClassification": ("pooling", "GPT2ForSequenceClassification"),
+    "GemmaForSequenceClassification": ("pooling", "GemmaForSequenceClassification"),
+    "JambaForSequenceClassification": ("pooling", "JambaForSequenceClassification"),
+    "Gemma2Model": ("pooling", "Gemma2EmbeddingModel"),
+    "InternLM2ForRewardModel": ("pooling", "InternLM2ForRewardModel"),
     "EagleLlamaForCausalLM": ("eagle", "EagleLlamaForCausalLM"),
     "LlamaForCausalLMEagle": ("eagle", "EagleLlamaForCausalLM"),
     "MedusaModel": ("eagle", "MedusaModel"),

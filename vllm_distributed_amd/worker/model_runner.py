@@ -181,6 +181,10 @@ class ModelRunner:
                     or getattr(m, "is_mla", False)}
         for n, m in self.attn_layers.items():
             m.layer_name = n
+        # heads of a size the kernels do not have run zero-padded (layers/attention.py): size buffers for that
+        padded = [m.head_size for m in self.attn_layers.values() if isinstance(m, Attention)]
+        if padded:
+            self.head_size = max(self.head_size, max(padded))
         self._init_hybrid_state()
         self._init_local_attention()
         self.uses_mrope = bool(getattr(self.model, "uses_mrope", False))
