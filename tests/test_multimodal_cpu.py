@@ -211,3 +211,82 @@ def test_qwen2_5_vl_matches_hf(tmp_path):
                           )[0, len(ids):].tolist()
     assert list(o.outputs[0].token_ids) == ref
     llm.shutdown()
+
+
+def test_qwen2_audio_matches_hf(tmp_path):
+    """Audio clips of different lengths through the Whisper-style encoder (padded frames masked), pooled and
+    projected into a Qwen2 decoder: greedy tokens equal transformers'."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.Qwen2AudioConfig(
+        audio_config=dict(num_mel_bins=128, d_model=64, encoder_layers=2, encoder_attention_heads=2,
+                          encoder_ffn_dim=128, max_source_positions=1500),
+        text_config=dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=1024,
+                         tie_word_embeddings=False),
+        audio_token_index=300)
+    hf = tf.Qwen2AudioForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2 and "audio_tower" in n:
+                p.mul_(3.0)                      # make the clip matter for the next tokens
+    hf = hf.float().eval()
+    path = os.path.join(tmp_path, "qwen2audio")
+    hf.save_pretrained(path, safe_serialization=True)
+    rng = np.random.default_rng(3)
+    clips = [rng.standard_normal(16000 * 2).astype(np.float32) * 0.1, rng.standard_normal(9000).astype(np.float32) * 0.1]
+    prompts = [[5, 17, 300, 99, 3], [300, 7, 8, 9], [1, 2, 3, 4]]
+    mm = [{"audio": clips[0]}, {"audio": (clips[1], 16000)}, None]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=8,
+              max_num_batched_tokens=256)
+    reqs = [{"prompt_token_ids": p, **({"multi_modal_data": m} if m else {})} for p, m in zip(prompts, mm)]
+    sp = SamplingParams(temperature=0, max_tokens=8, ignore_eos=True)
+    outs = llm.generate(reqs, sp)
+    llm.shutdown()
+    from vllm_distributed_amd.multimodal import AudioTokenProcessor
+    proc = AudioTokenProcessor(300, 128)
+    for p, m, o in zip(prompts, mm, outs):
+        kw, ids = {}, list(p)
+        if m:
+            feats, mel = proc.features(m["audio"])
+            n = proc.num_tokens(mel)
+            ids = []
+            for t in p:
+                ids.extend([300] * n if t == 300 else [t])
+            mask = torch.zeros(1, feats.shape[-1], dtype=torch.long)
+            mask[0, :mel] = 1
+            kw = dict(input_features=feats.unsqueeze(0), feature_attention_mask=mask)
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), attention_mask=torch.ones(1, len(ids), dtype=torch.long),
+                              max_new_tokens=8, do_sample=False, pad_token_id=0, eos_token_id=None,
+                              **kw)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, p
+
+
+def test_chat_audio_parts_decode_to_waveforms():
+    """OpenAI ``input_audio`` and ``audio_url`` content parts: WAV bytes become (waveform, rate) clips and leave
+    an audio placeholder in the text."""
+    import base64
+    import io
+
+    from scipy.io import wavfile
+
+    from vllm_distributed_amd.entrypoints.chat_utils import load_media, parse_chat_messages
+    buf = io.BytesIO()
+    wavfile.write(buf, 8000, (np.sin(np.arange(8000) / 10) * 20000).astype(np.int16))
+    b64 = base64.b64encode(buf.getvalue()).decode()
+    msgs = [{"role": "user", "content": [
+        {"type": "text", "text": "what is this"},
+        {"type": "input_audio", "input_audio": {"data": b64, "format": "wav"}},
+        {"type": "audio_url", "audio_url": {"url": "data:audio/wav;base64," + b64}}]}]
+    conv, media = parse_chat_messages(msgs)
+    assert conv[0]["content"].count("<audio>") == 2
+    mm = load_media(media)
+    assert len(mm["audio"]) == 2
+    wave, rate = mm["audio"][0]
+    assert rate == 8000 and wave.shape == (8000,) and 0.5 < float(np.abs(wave).max()) <= 1.0
+    # another sampling rate is resampled by the audio processor
+    from vllm_distributed_amd.multimodal import AudioTokenProcessor
+    proc = AudioTokenProcessor(300, 128)
+    feats, mel = proc.features((wave, rate))
+    assert feats.shape == (128, 3000) and mel == 100          # 1 s of audio = 100 mel frames

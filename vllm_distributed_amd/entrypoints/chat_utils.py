@@ -10,6 +10,7 @@ _FALLBACK_TEMPLATE = (
 
 
 IMAGE_PLACEHOLDER = "<image>"       # replaced by the model's image token string before tokenisation
+AUDIO_PLACEHOLDER = "<audio>"
 
 
 def load_image(url: str):
@@ -27,16 +28,60 @@ def load_image(url: str):
     raise ValueError("image_url must be a data: URL or a file:// path (remote fetching is disabled)")
 
 
+def _decode_wav(raw: bytes):
+    """WAV bytes -> (mono float32 waveform in [-1, 1], sampling rate)."""
+    import io
+
+    import numpy as np
+    from scipy.io import wavfile
+    rate, data = wavfile.read(io.BytesIO(raw))
+    if data.dtype.kind == "i":
+        data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
+    elif data.dtype.kind == "u":                    # 8-bit PCM is unsigned
+        data = (data.astype(np.float32) - 128.0) / 128.0
+    data = data.astype(np.float32)
+    if data.ndim > 1:
+        data = data.mean(axis=1)
+    return data, int(rate)
+
+
+def load_audio(url: str):
+    """``data:`` URLs (base64 WAV) and local ``file://`` paths to WAV files."""
+    import base64
+    if url.startswith("data:"):
+        head, _, payload = url.partition(",")
+        return _decode_wav(base64.b64decode(payload) if ";base64" in head else payload.encode())
+    if url.startswith("file://"):
+        with open(url[len("file://"):], "rb") as f:
+            return _decode_wav(f.read())
+    raise ValueError("audio_url must be a data: URL or a file:// path (remote fetching is disabled)")
+
+
 def load_media(parts: list[dict]) -> dict:
     """Media content parts -> ``multi_modal_data``."""
-    images = []
+    import base64
+    images, clips = [], []
     for part in parts:
-        if part.get("type") == "image_url":
+        t = part.get("type")
+        if t == "image_url":
             u = part["image_url"]
             images.append(load_image(u["url"] if isinstance(u, dict) else u))
+        elif t == "audio_url":
+            u = part["audio_url"]
+            clips.append(load_audio(u["url"] if isinstance(u, dict) else u))
+        elif t == "input_audio":                        # OpenAI form: {"data": base64, "format": "wav"}
+            a = part["input_audio"]
+            if str(a.get("format", "wav")).lower() != "wav":
+                raise ValueError("input_audio: only WAV data can be decoded here")
+            clips.append(_decode_wav(base64.b64decode(a["data"])))
         else:
-            raise ValueError(f"{part.get('type')} inputs are not supported by this model")
-    return {"image": images} if images else {}
+            raise ValueError(f"{t} inputs are not supported by this model")
+    out = {}
+    if images:
+        out["image"] = images
+    if clips:
+        out["audio"] = clips
+    return out
 
 
 def _flatten_content(content: Any) -> tuple[str, list[dict]]:
@@ -58,6 +103,8 @@ def _flatten_content(content: Any) -> tuple[str, list[dict]]:
             media.append(part)
             if t == "image_url":
                 texts.append(IMAGE_PLACEHOLDER)
+            elif t in ("audio_url", "input_audio"):
+                texts.append(AUDIO_PLACEHOLDER)
         elif t == "refusal":
             texts.append(part.get("refusal", ""))
         else:

@@ -72,6 +72,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Qwen2VLForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "Qwen2_5_VLForConditionalGeneration": ("qwen2_vl", "Qwen2_5_VLForConditionalGeneration"),
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
+    "MantisForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
+    "Qwen2AudioForConditionalGeneration": ("qwen2_audio", "Qwen2AudioForConditionalGeneration"),
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "BambaForCausalLM": ("jamba", "BambaForCausalLM"),
     "NemotronHForCausalLM": ("jamba", "NemotronHForCausalLM"),

@@ -271,3 +271,81 @@ def _qwen2_vl_processor(vllm_config):
 
 MULTIMODAL_REGISTRY.register_processor("Qwen2VLForConditionalGeneration", _qwen2_vl_processor)
 MULTIMODAL_REGISTRY.register_processor("Qwen2_5_VLForConditionalGeneration", _qwen2_vl_processor)
+
+
+# ---- audio: log-mel features for Whisper-style encoders ------------------------------------------------
+class AudioTokenProcessor:
+    """Prompts mark each clip with an audio placeholder token (one, or an already expanded run); the run is
+    resized to the number of embeddings the encoder will produce for the clip:
+    mel frames -> (frames - 1) // 2 + 1 after the strided convolution -> (that - 2) // 2 + 1 after pooling.
+    ``mm_data["audio"]``: a waveform (1-D float array at the model's sampling rate), a (waveform, rate) pair,
+    or a list of either.  Reference: vllm/model_executor/models/qwen2_audio.py (:130-250)."""
+
+    def __init__(self, audio_token_id: int, n_mels: int, sampling_rate: int = 16000, chunk_seconds: int = 30):
+        from transformers import WhisperFeatureExtractor
+        self.audio_token_id = audio_token_id
+        self.rate = sampling_rate
+        self.extractor = WhisperFeatureExtractor(feature_size=n_mels, sampling_rate=sampling_rate,
+                                                 chunk_length=chunk_seconds)
+
+    def _waveform(self, a):
+        import numpy as np
+        rate = self.rate
+        if isinstance(a, (tuple, list)) and len(a) == 2 and not hasattr(a[1], "__len__"):
+            a, rate = a
+        w = np.asarray(a.cpu() if torch.is_tensor(a) else a, dtype=np.float32).reshape(-1)
+        if int(rate) != self.rate:          # linear resampling: enough for a front end without extra packages
+            n = max(int(round(len(w) * self.rate / float(rate))), 1)
+            w = np.interp(np.linspace(0, len(w) - 1, n), np.arange(len(w)), w).astype(np.float32)
+        return w
+
+    def features(self, a) -> tuple[torch.Tensor, int]:
+        w = self._waveform(a)
+        out = self.extractor(w, sampling_rate=self.rate, return_attention_mask=True, padding="max_length",
+                             return_tensors="pt")
+        return out["input_features"][0].float(), int(out["attention_mask"][0].sum())
+
+    @staticmethod
+    def num_tokens(mel_frames: int) -> int:
+        return ((mel_frames - 1) // 2 + 1 - 2) // 2 + 1
+
+    def __call__(self, prompt_token_ids: list[int], mm_data: dict):
+        clips = mm_data.get("audio")
+        if clips is None:
+            raise ValueError("multi_modal_data needs an 'audio' entry")
+        if not isinstance(clips, list):
+            clips = [clips]
+        runs, prev = [], -2
+        for i, t in enumerate(prompt_token_ids):
+            if t != self.audio_token_id:
+                continue
+            if i != prev + 1:
+                runs.append([i, 1])
+            else:
+                runs[-1][1] += 1
+            prev = i
+        if len(runs) != len(clips):
+            raise ValueError(f"prompt has {len(runs)} audio placeholders but {len(clips)} clips were given")
+        out, positions, inputs, hashes = [], [], [], []
+        cur = 0
+        for (start, n), clip in zip(runs, clips):
+            feats, mel = self.features(clip)
+            ntok = self.num_tokens(mel)
+            out.extend(prompt_token_ids[cur:start])
+            positions.append(PlaceholderRange(offset=len(out), length=ntok))
+            out.extend([self.audio_token_id] * ntok)
+            cur = start + n
+            inputs.append([feats, torch.tensor(mel, dtype=torch.int64)])
+            hashes.append(hash_item(self._waveform(clip)))
+        out.extend(prompt_token_ids[cur:])
+        return out, inputs, hashes, positions
+
+
+def _qwen2_audio_processor(vllm_config):
+    hf = vllm_config.model_config.hf_config
+    ac = hf.audio_config if isinstance(hf.audio_config, dict) else hf.audio_config.to_dict()
+    return AudioTokenProcessor(int(getattr(hf, "audio_token_index", None) or getattr(hf, "audio_token_id", 151646)),
+                               int(ac.get("num_mel_bins", 128)))
+
+
+MULTIMODAL_REGISTRY.register_processor("Qwen2AudioForConditionalGeneration", _qwen2_audio_processor)
