@@ -263,3 +263,45 @@ def test_encoder_only_embeddings_on_gpu(tmp_path):
             ref = torch.nn.functional.normalize(hf(torch.tensor([p])).last_hidden_state[0, 0], dim=-1)
         got = torch.as_tensor(o.outputs.embedding).float()
         assert float(torch.dot(got, ref)) > 0.995, float(torch.dot(got, ref))
+
+
+def test_whisper_and_qwen2_audio_on_gpu(tmp_path):
+    """Audio models on the GPU: Whisper's cross-attention runs through the paged MFMA kernels over the
+    per-slot cross cache (hipGraph decode included); log-probabilities against transformers in fp32."""
+    import numpy as np
+    import transformers as tf
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.multimodal import AudioTokenProcessor
+    torch.manual_seed(0)
+    cfg = tf.WhisperConfig(vocab_size=320, num_mel_bins=80, d_model=128, encoder_layers=2, encoder_attention_heads=2,
+                           decoder_layers=2, decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256,
+                           max_source_positions=1500, max_target_positions=64, pad_token_id=0, bos_token_id=1,
+                           eos_token_id=2, decoder_start_token_id=3, suppress_tokens=None, begin_suppress_tokens=None)
+    hf = tf.WhisperForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+    hf = hf.float().eval()
+    path = os.path.join(tmp_path, "whisper")
+    hf.save_pretrained(path, safe_serialization=True)
+    rng = np.random.default_rng(5)
+    clips = [rng.standard_normal(n).astype(np.float32) * 0.2 for n in (48000, 20000, 5000, 30000)]
+    dec_prompts = [[3, 10, 11, 12], [3, 10], [3, 20, 21, 22, 23, 24], [3]]
+    llm = _llm(path, max_model_len=64)
+    mr = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+    reqs = [{"prompt_token_ids": p, "multi_modal_data": {"audio": c}} for p, c in zip(dec_prompts, clips)]
+    outs = llm.generate(reqs, SamplingParams(temperature=0, max_tokens=10, ignore_eos=True, logprobs=0))
+    assert mr.graphs, "decode graphs expected"
+    llm.shutdown()
+    proc = AudioTokenProcessor(-1, 80)
+    worst = 0.0
+    for p, c, o in zip(dec_prompts, clips, outs):
+        gen = list(o.outputs[0].token_ids)
+        feats, _ = proc.features(c)
+        with torch.no_grad():
+            lg = hf(input_features=feats.unsqueeze(0), decoder_input_ids=torch.tensor([p + gen])).logits[0]
+        lp = torch.log_softmax(lg.float(), -1)
+        for k, t in enumerate(gen):
+            worst = max(worst, abs(float(lp[len(p) + k - 1, t]) - o.outputs[0].logprobs[k][t].logprob))
+    assert worst < 0.1, worst

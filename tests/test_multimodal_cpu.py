@@ -290,3 +290,51 @@ def test_chat_audio_parts_decode_to_waveforms():
     proc = AudioTokenProcessor(300, 128)
     feats, mel = proc.features((wave, rate))
     assert feats.shape == (128, 3000) and mel == 100          # 1 s of audio = 100 mel frames
+
+
+def test_whisper_matches_hf(tmp_path):
+    """Encoder-decoder: the audio encoder output reaches the decoder through the paged cross-attention cache
+    (written with the first decoder step, read at every later one).  Greedy tokens equal transformers'."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.WhisperConfig(vocab_size=320, num_mel_bins=80, d_model=128, encoder_layers=2, encoder_attention_heads=2,
+                           decoder_layers=2, decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256,
+                           max_source_positions=1500, max_target_positions=64, pad_token_id=0, bos_token_id=1,
+                           eos_token_id=2, decoder_start_token_id=3, suppress_tokens=None, begin_suppress_tokens=None)
+    hf = tf.WhisperForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)                      # let the audio decide the tokens
+    hf = hf.float().eval()
+    hf.generation_config = tf.GenerationConfig(pad_token_id=0, eos_token_id=None, decoder_start_token_id=3)
+    path = os.path.join(tmp_path, "whisper")
+    hf.save_pretrained(path, safe_serialization=True)
+    rng = np.random.default_rng(5)
+    clips = [rng.standard_normal(16000 * 3).astype(np.float32) * 0.2, rng.standard_normal(20000).astype(np.float32) * 0.2,
+             rng.standard_normal(5000).astype(np.float32) * 0.2]
+    dec_prompts = [[3, 10, 11, 12], [3, 10], [3, 20, 21, 22, 23, 24]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=64, max_num_seqs=8,
+              max_num_batched_tokens=64)
+    reqs = [{"prompt_token_ids": p, "multi_modal_data": {"audio": c}} for p, c in zip(dec_prompts, clips)]
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    outs = llm.generate(reqs, sp)
+    # a second wave reuses batch slots: their cross-attention caches must be rewritten
+    outs2 = llm.generate([reqs[2], reqs[0]], sp)
+    llm.shutdown()
+    from vllm_distributed_amd.multimodal import AudioTokenProcessor
+    proc = AudioTokenProcessor(-1, 80)
+    refs = []
+    for p, c in zip(dec_prompts, clips):
+        feats, _ = proc.features(c)
+        ids, ref = list(p), []
+        with torch.no_grad():                       # plain greedy loop (Whisper's generate() post-processes its output)
+            enc = hf.model.encoder(feats.unsqueeze(0)).last_hidden_state
+            for _ in range(10):
+                lg = hf(encoder_outputs=(enc,), decoder_input_ids=torch.tensor([ids])).logits[0, -1]
+                ref.append(int(lg.argmax()))
+                ids.append(ref[-1])
+        refs.append(ref)
+    for o, ref in zip(outs, refs):
+        assert list(o.outputs[0].token_ids) == ref
+    assert list(outs2[0].outputs[0].token_ids) == refs[2] and list(outs2[1].outputs[0].token_ids) == refs[0]

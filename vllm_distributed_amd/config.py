@@ -136,6 +136,11 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
         d = copy.deepcopy(PRESETS[key])
     if "text_config" in d and "hidden_size" not in d:
         d = {**d, **d["text_config"]}
+    if d.get("model_type") == "whisper" and "hidden_size" not in d:
+        # encoder-decoder configs name the decoder's sizes differently: give them the names the engine reads
+        d = {**d, "hidden_size": d["d_model"], "num_attention_heads": d["decoder_attention_heads"],
+             "num_key_value_heads": d["decoder_attention_heads"], "num_hidden_layers": d["decoder_layers"],
+             "max_position_embeddings": d.get("max_target_positions", 448)}
     if overrides:
         d.update(overrides)
     return HFConfig(d)
@@ -286,7 +291,9 @@ class ModelConfig:
     def is_hybrid(self) -> bool:
         """Attention and state-space layers in one stack: paged KV for the former, one state slot per
         request for the latter; recurrent state rules out prefix reuse."""
-        return any(a in ("JambaForCausalLM", "BambaForCausalLM", "GraniteMoeHybridForCausalLM", "NemotronHForCausalLM") for a in self.architectures)
+        return any(a in ("JambaForCausalLM", "BambaForCausalLM", "GraniteMoeHybridForCausalLM", "NemotronHForCausalLM",
+                         # encoder-decoder: the cross-attention cache is per-request state of the same kind
+                         "WhisperForConditionalGeneration") for a in self.architectures)
 
     def get_total_num_attention_heads(self) -> int:
         if self.is_attention_free:

@@ -74,6 +74,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlavaForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "MantisForConditionalGeneration": ("llava", "LlavaForConditionalGeneration"),
     "Qwen2AudioForConditionalGeneration": ("qwen2_audio", "Qwen2AudioForConditionalGeneration"),
+    "WhisperForConditionalGeneration": ("whisper", "WhisperForConditionalGeneration"),
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "BambaForCausalLM": ("jamba", "BambaForCausalLM"),
     "NemotronHForCausalLM": ("jamba", "NemotronHForCausalLM"),

@@ -349,3 +349,29 @@ def _qwen2_audio_processor(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("Qwen2AudioForConditionalGeneration", _qwen2_audio_processor)
+
+
+class WhisperAudioProcessor(AudioTokenProcessor):
+    """Encoder-decoder: the clip does not replace prompt tokens.  It is tied to the first decoder token (a
+    placeholder range of one token at offset 0), so the encoder is scheduled with the step that holds it."""
+
+    def __call__(self, prompt_token_ids: list[int], mm_data: dict):
+        clips = mm_data.get("audio")
+        if clips is None:
+            raise ValueError("an encoder-decoder audio model needs multi_modal_data with an 'audio' entry")
+        if isinstance(clips, list):
+            if len(clips) != 1:
+                raise ValueError("one audio clip per request")
+            clips = clips[0]
+        if not prompt_token_ids:
+            raise ValueError("the decoder prompt is empty (start-of-transcript and task tokens expected)")
+        feats, _ = self.features(clips)
+        return list(prompt_token_ids), [[feats]], [hash_item(self._waveform(clips))], [PlaceholderRange(0, 1)]
+
+
+def _whisper_processor(vllm_config):
+    hf = vllm_config.model_config.hf_config
+    return WhisperAudioProcessor(-1, int(getattr(hf, "num_mel_bins", 80)))
+
+
+MULTIMODAL_REGISTRY.register_processor("WhisperForConditionalGeneration", _whisper_processor)

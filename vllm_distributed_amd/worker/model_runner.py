@@ -329,10 +329,11 @@ class ModelRunner:
         with self._sleep_pool("kv_cache"):
             for n, m in ss.items():
                 conv_shape, ssm_shape = m.state_shapes()
-                conv = torch.zeros((nslots, *conv_shape), dtype=m.conv_dtype, device=self.device)
-                ssm = torch.zeros((nslots, *ssm_shape), dtype=torch.float32, device=self.device)
+                dt0, dt1 = getattr(m, "state_dtypes", (m.conv_dtype, torch.float32))
+                conv = torch.zeros((nslots, *conv_shape), dtype=dt0, device=self.device)
+                ssm = torch.zeros((nslots, *ssm_shape), dtype=dt1, device=self.device)
                 m.bind_kv_cache(conv, ssm)
-                total += conv.numel() * conv.element_size() + ssm.numel() * 4
+                total += conv.numel() * conv.element_size() + ssm.numel() * ssm.element_size()
                 del self.attn_layers[n]
             self.state_table = torch.zeros((nslots - 1, 1), dtype=torch.int32, device=self.device)
         self.state_layers = ss
@@ -835,11 +836,19 @@ class ModelRunner:
         self._next_stage()
         req_ids, rows, n_sched, cu, S, T, logits_idx, att, tmd = self._prepare_inputs(so)
         inputs_embeds = None
+        encoder_outputs = ()
         if getattr(self.model, "is_multimodal", False):
             self._run_mm_encoder(so)
-            mm_e, mm_mask = self._gather_mm_embeddings(req_ids, rows, n_sched, cu)
-            if mm_e is not None:
-                inputs_embeds = self.model.get_input_embeddings(self.input_ids[:T], mm_e, mm_mask)
+            if getattr(self.model, "is_encoder_decoder", False):
+                # the encoder output feeds the decoder's cross-attention (written to its cache in the step
+                # that holds the request's first token), not the token embeddings
+                encoder_outputs = [(k, self.encoder_cache[rid][0]) for k, rid in enumerate(req_ids)
+                                   if self.input_batch.num_computed[rows[k]] == 0
+                                   and 0 in self.encoder_cache.get(rid, {})]
+            else:
+                mm_e, mm_mask = self._gather_mm_embeddings(req_ids, rows, n_sched, cu)
+                if mm_e is not None:
+                    inputs_embeds = self.model.get_input_embeddings(self.input_ids[:T], mm_e, mm_mask)
         S_a, T_a, nd, ndt, max_seq, max_q = att        # what THIS rank attends for (== the batch without TKNP)
         ib = self.input_batch
         pure_decode = nd == S and max_q == 1
@@ -902,7 +911,9 @@ class ModelRunner:
             if self.async_tp and T >= envs.VDA_ASYNC_TP_MIN_TOKENS and conn is None and self.lora_manager is None \
                     and inputs_embeds is None and T_in == T and not P and not self.local_chunk:
                 mbs = self._make_micro_batches(rows, n_sched, cu, S, T, nd)
-            with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T, micro_batches=mbs):
+            with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T, micro_batches=mbs) as fctx:
+                if encoder_outputs:
+                    fctx.extra["encoder_outputs"] = encoder_outputs
                 if conn is not None:
                     conn.start_load_kv()
                 extra = {}
