@@ -203,3 +203,70 @@ def test_disaggregated_proxy_end_to_end(tmp_path):
         for e in engines:
             e.shutdown()
         loop.close()
+
+
+def test_audio_transcription_endpoint(tmp_path):
+    """POST /v1/audio/transcriptions with a multipart WAV upload against a tiny Whisper: the text is what the
+    engine generates from the task prompt for that clip (json and text response formats, 2 windows for a
+    clip longer than the encoder window)."""
+    import asyncio
+    import io
+
+    import httpx
+    import numpy as np
+    import torch
+    import transformers as tf
+    from scipy.io import wavfile
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    from vllm_distributed_amd.engine.arg_utils import AsyncEngineArgs
+    from vllm_distributed_amd.engine.async_llm import AsyncLLM
+    from vllm_distributed_amd.entrypoints.openai.api_server import build_app, make_arg_parser
+    torch.manual_seed(0)
+    cfg = tf.WhisperConfig(vocab_size=320, num_mel_bins=80, d_model=128, encoder_layers=1, encoder_attention_heads=2,
+                           decoder_layers=1, decoder_attention_heads=2, encoder_ffn_dim=128, decoder_ffn_dim=128,
+                           max_source_positions=1500, max_target_positions=32, pad_token_id=319, bos_token_id=317,
+                           eos_token_id=318, decoder_start_token_id=310, suppress_tokens=None,
+                           begin_suppress_tokens=None)
+    path = os.path.join(tmp_path, "whisper")
+    tf.WhisperForConditionalGeneration(cfg).float().eval().save_pretrained(path, safe_serialization=True)
+    vocab = {f"w{i}": i for i in range(310)}
+    vocab.update({"<|startoftranscript|>": 310, "<|en|>": 311, "<|transcribe|>": 312, "<|translate|>": 313,
+                  "<|notimestamps|>": 314, "<|de|>": 315, "<unk>": 316, "<s>": 317, "</s>": 318, "<pad>": 319})
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>",
+                            pad_token="<pad>").save_pretrained(path)
+    args = make_arg_parser().parse_args(["--model", path, "--dtype", "float32", "--device", "cpu", "--max-model-len", "32",
+                                         "--max-num-seqs", "4", "--max-num-batched-tokens", "64",
+                                         "--served-model-name", "tiny-whisper"])
+    engine = AsyncLLM.from_engine_args(AsyncEngineArgs.from_cli_args(args))
+    app = build_app(args, engine)
+
+    def wav(seconds):
+        buf = io.BytesIO()
+        wavfile.write(buf, 16000, (np.sin(np.arange(int(16000 * seconds)) / 9.0) * 12000).astype(np.int16))
+        return buf.getvalue()
+
+    async def go():
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://t") as c:
+            a = await c.post("/v1/audio/transcriptions", files={"file": ("a.wav", wav(1.0), "audio/wav")},
+                             data={"model": "tiny-whisper", "language": "en"})
+            b = await c.post("/v1/audio/transcriptions", files={"file": ("a.wav", wav(1.0), "audio/wav")},
+                             data={"model": "tiny-whisper", "response_format": "text"})
+            long = await c.post("/v1/audio/translations", files={"file": ("b.wav", wav(31.0), "audio/wav")},
+                                data={"language": "de", "response_format": "verbose_json"})
+            bad = await c.post("/v1/audio/transcriptions", files={"file": ("a.wav", wav(0.5), "audio/wav")},
+                               data={"language": "xx"})
+            return a, b, long, bad
+    loop = asyncio.new_event_loop()
+    try:
+        a, b, long, bad = loop.run_until_complete(asyncio.wait_for(go(), timeout=200))
+    finally:
+        engine.shutdown()
+        loop.close()
+    assert a.status_code == 200 and isinstance(a.json()["text"], str) and a.json()["text"]
+    assert b.status_code == 200 and b.text == a.json()["text"]            # same clip, greedy
+    assert long.status_code == 200 and long.json()["task"] == "translate" and long.json()["duration"] == 31.0
+    assert bad.status_code == 400 and "xx" in bad.json()["message"]

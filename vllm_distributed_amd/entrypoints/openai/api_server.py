@@ -23,7 +23,7 @@ from typing import Any, Optional
 from fastapi import FastAPI, Request
 from fastapi.exceptions import RequestValidationError
 from fastapi.middleware.cors import CORSMiddleware
-from fastapi.responses import JSONResponse, Response, StreamingResponse
+from fastapi.responses import JSONResponse, PlainTextResponse, Response, StreamingResponse
 
 from ... import envs
 from ...engine.arg_utils import AsyncEngineArgs
@@ -35,7 +35,8 @@ from .protocol import (ChatCompletionRequest, ClassificationRequest, CompletionR
                        EmbeddingRequest, ErrorResponse, LoadLoRAAdapterRequest, PoolingRequest, RerankRequest,
                        ResponsesRequest, ScoreRequest, TokenizeRequest, UnloadLoRAAdapterRequest)
 from .serving import (OpenAIServingChat, OpenAIServingCompletion, OpenAIServingEmbedding, OpenAIServingModels,
-                      OpenAIServingPooling, OpenAIServingResponses, OpenAIServingScores, OpenAIServingTokenization)
+                      OpenAIServingPooling, OpenAIServingResponses, OpenAIServingScores, OpenAIServingTokenization,
+                      OpenAIServingTranscription)
 
 logger = init_logger(__name__)
 
@@ -149,6 +150,8 @@ def build_app(args: argparse.Namespace, engine: AsyncLLM) -> FastAPI:
         if not gen else None
     st.responses = OpenAIServingResponses(engine, mc, models, chat=st.chat, **common) if gen else None
     st.tokenization = OpenAIServingTokenization(engine, mc, models, chat_template=template, **common)
+    speech = any(x == "WhisperForConditionalGeneration" for x in (mc.architectures or []))
+    st.transcription = OpenAIServingTranscription(engine, mc, models, **common) if speech else None
     st.server_load = 0
 
     # ---- middleware ---------------------------------------------------------------
@@ -289,6 +292,22 @@ def build_app(args: argparse.Namespace, engine: AsyncLLM) -> FastAPI:
     async def cancel_response(response_id: str):
         e = _need(st.responses, "the Responses API")
         return _resp(e) if e else _resp(await st.responses.cancel_responses(response_id))
+
+    @app.post("/v1/audio/transcriptions")
+    async def transcriptions(raw: Request):
+        e = _need(st.transcription, "the Transcriptions API")
+        if e:
+            return _resp(e)
+        out = await st.transcription.create(raw, "transcribe")
+        return PlainTextResponse(out) if isinstance(out, str) else _resp(out)
+
+    @app.post("/v1/audio/translations")
+    async def translations(raw: Request):
+        e = _need(st.transcription, "the Translations API")
+        if e:
+            return _resp(e)
+        out = await st.transcription.create(raw, "translate")
+        return PlainTextResponse(out) if isinstance(out, str) else _resp(out)
 
     @app.post("/invocations")
     async def invocations(raw: Request):

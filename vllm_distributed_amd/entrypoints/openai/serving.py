@@ -772,6 +772,81 @@ class OpenAIServingResponses(OpenAIServing):
         return hit[0]          # responses run in the foreground here: nothing is left to cancel
 
 
+def parse_multipart_form(content_type: str, body: bytes) -> dict:
+    """multipart/form-data -> {field: str | (filename, bytes)} with the standard library's MIME parser
+    (no multipart package is installed here)."""
+    from email.parser import BytesParser
+    from email.policy import HTTP
+    if "multipart/form-data" not in (content_type or ""):
+        raise ValueError("expected multipart/form-data")
+    msg = BytesParser(policy=HTTP).parsebytes(b"Content-Type: " + content_type.encode() + b"\r\n\r\n" + body)
+    out: dict = {}
+    for part in msg.iter_parts():
+        name = part.get_param("name", header="content-disposition")
+        if name is None:
+            continue
+        fname = part.get_filename()
+        data = part.get_payload(decode=True) or b""
+        out[name] = (fname, data) if fname is not None else data.decode("utf-8", "replace")
+    return out
+
+
+class OpenAIServingTranscription(OpenAIServing):
+    """/v1/audio/transcriptions and /v1/audio/translations for encoder-decoder speech models (Whisper): the
+    uploaded clip is cut into windows of the encoder's length, every window is decoded from the task prompt
+    ``<|startoftranscript|><|lang|><|transcribe or translate|><|notimestamps|>`` and the texts are joined.
+    Reference: vllm/entrypoints/openai/serving_transcription.py, speech_to_text.py."""
+    WINDOW_S = 30
+
+    async def create(self, raw_request, task: str = "transcribe"):
+        from ..chat_utils import _decode_wav
+        if self.engine_client.errored:
+            raise self.engine_client.dead_error
+        try:
+            form = parse_multipart_form(raw_request.headers.get("content-type", ""), await raw_request.body())
+            if "file" not in form or isinstance(form["file"], str):
+                raise ValueError("the form needs a 'file' part with the audio (WAV)")
+            wave, rate = _decode_wav(form["file"][1])
+            lang = (form.get("language") or "en").strip().lower()
+            fmt = (form.get("response_format") or "json").strip().lower()
+            if fmt not in ("json", "text", "verbose_json"):
+                raise ValueError("response_format must be json, text or verbose_json")
+            temperature = float(form.get("temperature") or 0.0)
+            tok = await self.tokenizer(None)
+            vocab = tok.get_vocab()
+            names = ["<|startoftranscript|>", f"<|{lang}|>", f"<|{task}|>", "<|notimestamps|>"]
+            missing = [n for n in names if n not in vocab]
+            if missing:
+                raise ValueError(f"the tokenizer lacks {missing}: not a speech-to-text model, or an unknown language")
+            prefix = [vocab[n] for n in names]
+            hint = form.get("prompt")
+            if hint and "<|startofprev|>" in vocab:
+                prefix = [vocab["<|startofprev|>"]] + tok.encode(" " + hint.strip(), add_special_tokens=False) + prefix
+        except Exception as e:   # noqa: BLE001 - malformed uploads are client errors
+            return self.error(str(e))
+        win = self.WINDOW_S * rate
+        pieces = [wave[i:i + win] for i in range(0, max(len(wave), 1), win)] or [wave]
+        rid = f"{'transcribe' if task == 'transcribe' else 'translate'}-{random_uuid()}"
+        texts = []
+        for k, piece in enumerate(pieces):
+            sp = SamplingParams(temperature=temperature, max_tokens=max(self.max_model_len - len(prefix), 1))
+            prompt = TokensPrompt(prompt_token_ids=list(prefix), multi_modal_data={"audio": (piece, rate)})
+            final = None
+            try:
+                async for out in self.engine_client.generate(prompt, sp, f"{rid}-{k}"):
+                    final = out
+            except ValueError as e:
+                return self.error(str(e))
+            texts.append(final.outputs[0].text.strip() if final is not None else "")
+        text = " ".join(t for t in texts if t)
+        if fmt == "text":
+            return text
+        body = {"text": text}
+        if fmt == "verbose_json":
+            body.update(task=task, language=lang, duration=round(len(wave) / float(rate), 3))
+        return body
+
+
 class OpenAIServingTokenization(OpenAIServing):
     def __init__(self, *a, chat_template: Optional[str] = None, **kw):
         super().__init__(*a, **kw)
