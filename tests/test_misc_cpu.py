@@ -150,3 +150,42 @@ def test_ray_executor_drives_workers_through_the_actor_protocol(tmp_path, monkey
                           eos_token_id=None)[0, len(p):].tolist()
     assert list(out[0].outputs[0].token_ids) == ref
     llm.shutdown()
+
+
+def test_layerwise_profiler_attributes_time_to_the_module_tree(tmp_path):
+    """Hooks + timers around every module: the tree rows add up (a parent's time covers its children, self
+    time is the remainder), classes are summarised, and the tables export."""
+    import json
+
+    import torch
+
+    from tests.test_e2e_cpu import _save_tiny
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.profiler import layerwise_profile
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4)
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    with layerwise_profile(model, num_running_seqs=2) as prof:
+        llm.generate(prompt_token_ids=[[1, 2, 3, 4], [5, 6, 7]], sampling_params=SamplingParams(max_tokens=3))
+    llm.shutdown()
+    res = prof.results
+    names = [e.name for e in res.model_stats]
+    assert "model.layers.0.self_attn" in names and "model.layers.1.mlp.down_proj" in names
+    by = {e.name: e for e in res.model_stats}
+    layer = by["model.layers.0"]
+    assert layer.calls == 3 and layer.device_time_us > 0
+    kids = sum(e.device_time_us for e in res.model_stats if e.name.startswith("model.layers.0.") and e.depth == layer.depth + 1)
+    assert kids <= layer.device_time_us * 1.001 and abs(layer.device_time_us - kids - layer.self_device_time_us) < 1.0
+    classes = {e.name for e in res.summary_stats}
+    assert {"LlamaDecoderLayer", "RMSNorm", "Attention"} <= classes
+    assert abs(sum(e.pct_device_time for e in res.summary_stats) - 100.0) < 1.0
+    res.export_model_stats_table_csv(str(tmp_path / "m.csv"))
+    res.export_summary_stats_table_csv(str(tmp_path / "s.csv"))
+    d = res.convert_stats_to_dict()
+    json.dumps(d)
+    assert d["metadata"]["num_running_seqs"] == 2 and d["model_stats"] and d["summary_stats"]
+    import io
+    buf = io.StringIO()
+    res.print_model_table(max_depth=3, file=buf)
+    res.print_summary_table(file=buf)
+    assert "self_attn" in buf.getvalue() and "module class" in buf.getvalue()

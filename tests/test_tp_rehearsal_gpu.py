@@ -135,3 +135,25 @@ def test_rccl_wrapper_single_rank_and_graph_capture():
     torch.cuda.synchronize()
     assert torch.all(out == 6.0)
     comm.close()
+
+
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
+    """The driver's multi-GPU launch of bench.py (torch.distributed.run, 8 ranks, external launcher, async
+    TP, peer-memory all-reduce inside decode graphs) rehearsed on ONE device with a shrunken Llama: the run
+    must finish, every timed round must print a JSON line, and the last line must carry the 8-rank shape."""
+    port = _free_port()
+    over = {"num_hidden_layers": 2, "hidden_size": 1024, "intermediate_size": 2048, "num_attention_heads": 16,
+            "num_key_value_heads": 8, "vocab_size": 32000}
+    env = dict(os.environ, VDA_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "8",
+           "--steps", "2", "--warmup", "1", "--model", "llama-3-8b", "--hf-overrides", json.dumps(over), "--batch", "16",
+           "--input-len", "128", "--output-len", "16", "--max-num-batched-tokens", "1024",
+           "--gpu-memory-utilization", "0.04", "--time-budget", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) >= 2, r.stdout[-1500:]
+    last = lines[-1]
+    assert last["n_gpus"] == 8 and last["steps"] == 2 and last["value"] > 0
+    assert last["config"]["parallelism"] == "tp8"
