@@ -74,3 +74,66 @@ def test_lora_matches_merged_weights_and_mixes_in_a_batch(tmp_path):
         assert [list(o.outputs[0].token_ids) for o in both] == [ref1[0], ref2[1]]
     finally:
         llm.shutdown()
+
+
+def _make_vocab_adapter(tmp, name, hf, seed, r=4, alpha=8.0):
+    """PEFT layout for an adapter on the token embedding (lora_embedding_A [r, vocab], lora_embedding_B
+    [hidden, r]), the output head and one projection."""
+    g = torch.Generator().manual_seed(seed)
+    d = os.path.join(tmp, name)
+    os.makedirs(d)
+    sd = hf.state_dict()
+    merged = {k: v.clone() for k, v in sd.items()}
+    w = {}
+    E = sd["model.embed_tokens.weight"]
+    A = torch.randn(r, E.shape[0], generator=g) * 0.2
+    B = torch.randn(E.shape[1], r, generator=g) * 0.2
+    w["base_model.model.model.embed_tokens.lora_embedding_A"] = A
+    w["base_model.model.model.embed_tokens.lora_embedding_B"] = B
+    merged["model.embed_tokens.weight"] = E + (alpha / r) * (B @ A).t()
+    for k in ("lm_head.weight", "model.layers.0.self_attn.q_proj.weight"):
+        out, inp = sd[k].shape
+        A = torch.randn(r, inp, generator=g) * 0.2
+        B = torch.randn(out, r, generator=g) * 0.2
+        mod = k[: -len(".weight")]
+        w[f"base_model.model.{mod}.lora_A.weight"] = A
+        w[f"base_model.model.{mod}.lora_B.weight"] = B
+        merged[k] = sd[k] + (alpha / r) * (B @ A)
+    save_file(w, os.path.join(d, "adapter_model.safetensors"))
+    json.dump({"r": r, "lora_alpha": alpha, "target_modules": ["embed_tokens", "lm_head", "q_proj"], "peft_type": "LORA"},
+              open(os.path.join(d, "adapter_config.json"), "w"))
+    return d, merged
+
+
+def test_lora_on_embedding_and_output_head(tmp_path):
+    """Adapters on embed_tokens and lm_head: equal to the merged model, also when a batch mixes them with
+    base requests and with an adapter that leaves both alone, and for prompt logprobs (head rows of a
+    prefill chunk)."""
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    av, merged_v = _make_vocab_adapter(str(tmp_path), "adv", hf, 3)
+    a1, merged1 = _make_adapter(str(tmp_path), "ad1", hf, 1)
+    base = _hf_tokens(hf, hf.state_dict(), PROMPTS)
+    refv = _hf_tokens(hf, merged_v, PROMPTS)
+    ref1 = _hf_tokens(hf, merged1, PROMPTS)
+    assert refv != base
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=16, enable_lora=True, max_loras=2, max_cpu_loras=2, max_lora_rank=8)
+    try:
+        rv, r1 = LoRARequest("adv", 1, av), LoRARequest("ad1", 2, a1)
+        got = llm.generate(prompt_token_ids=PROMPTS, sampling_params=SP, lora_request=rv)
+        assert [list(o.outputs[0].token_ids) for o in got] == refv
+        mixed = llm.generate(prompt_token_ids=PROMPTS, sampling_params=SP, lora_request=[r1, rv, None])
+        assert [list(o.outputs[0].token_ids) for o in mixed] == [ref1[0], refv[1], base[2]]
+        # prompt logprobs go through the head for every prompt position
+        import copy
+        m = copy.deepcopy(hf)
+        m.load_state_dict(merged_v)
+        with torch.no_grad():
+            lp = torch.log_softmax(m(torch.tensor([PROMPTS[1]])).logits[0].float(), -1)
+        out = llm.generate(prompt_token_ids=[PROMPTS[1]], lora_request=rv,
+                           sampling_params=SamplingParams(temperature=0, max_tokens=1, prompt_logprobs=0))[0]
+        for pos in range(1, len(PROMPTS[1])):
+            tok = PROMPTS[1][pos]
+            assert abs(out.prompt_logprobs[pos][tok].logprob - float(lp[pos - 1, tok])) < 1e-3
+    finally:
+        llm.shutdown()

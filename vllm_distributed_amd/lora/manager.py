@@ -9,11 +9,17 @@ Tensor parallel: column-parallel layers shard B by output rows, row-parallel lay
 columns and add their partial product before the layer's all-reduce.  Adapters are loaded from PEFT
 checkpoints (adapter_config.json + adapter_model.safetensors), kept in a host LRU
 (``max_cpu_loras``) and paged into device slots (``max_loras``) on demand.
+The token embedding and the output head are adapted too: an embedding adapter (``lora_embedding_A``
+[r, vocab], ``lora_embedding_B`` [hidden, r]) adds ``A^T[ids] B^T`` to the looked-up rows (A is kept
+whole on every rank: a row gather needs no sharding), and the head takes an ordinary low-rank update
+with B sharded by vocabulary rows; the rows fed to the head are a subset of the step's tokens, so the
+runner names them (``head_rows``) and the manager regroups them by adapter.
 Reference: vllm/lora/{models.py (LoRAModelManager :312-720, LRUCache), layers.py, worker_manager.py,
 punica_wrapper/}, vllm/v1/worker/lora_model_runner_mixin.py.
 """
 from __future__ import annotations
 
+import contextlib
 import json
 import math
 import os
@@ -24,7 +30,9 @@ from typing import Optional
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from ..layers.basic import ParallelLMHead, VocabParallelEmbedding
 from ..layers.linear import (ColumnParallelLinear, LinearBase, MergedColumnParallelLinear, QKVParallelLinear,
                              RowParallelLinear)
 from .. import envs, ops
@@ -52,6 +60,8 @@ class LoRAModel:
             raise ValueError(f"LoRA rank {r} exceeds max_lora_rank {max_rank}")
         if cfg.get("use_dora") or cfg.get("modules_to_save"):
             raise ValueError("DoRA adapters and modules_to_save are not supported")
+        if any(os.path.isfile(os.path.join(path, f)) for f in ("new_embeddings.safetensors", "new_embeddings.bin")):
+            raise ValueError("adapters that extend the vocabulary (new_embeddings) are not supported")
         scale = alpha / (math.sqrt(r) if cfg.get("use_rslora") else r)
         st = os.path.join(path, "adapter_model.safetensors")
         if os.path.isfile(st):
@@ -64,10 +74,9 @@ class LoRAModel:
             tensors = torch.load(binp, map_location="cpu", weights_only=True)
         pairs: dict[str, dict[str, torch.Tensor]] = {}
         for name, t in tensors.items():
-            m = re.match(r"(?:base_model\.model\.)?(.*)\.lora_([AB])(?:\.default)?\.weight$", name)
+            m = re.match(r"(?:base_model\.model\.)?(.*)\.lora_([AB])(?:\.default)?\.weight$", name) or \
+                re.match(r"(?:base_model\.model\.)?(.*)\.lora_embedding_([AB])(?:\.default)?$", name)
             if not m:
-                if "lora_embedding" in name or "embed_tokens" in name or "lm_head" in name:
-                    raise ValueError("adapters that modify the embedding or output head are not supported")
                 continue
             pairs.setdefault(m.group(1), {})[m.group(2)] = t
         weights = {}
@@ -93,7 +102,7 @@ class _LoRALinearMethod:
     def apply(self, layer: nn.Module, x: torch.Tensor, bias=None) -> torch.Tensor:
         y = self.base.apply(layer, x, bias)
         groups = self.manager.active_groups
-        if not groups:
+        if not groups or not any(layer.lora_has[slot] for slot, _ in groups):
             return y
         A, B = layer.lora_A, layer.lora_B
         x2 = x.reshape(-1, x.shape[-1])
@@ -132,15 +141,23 @@ class LoRAManager:
         self.free_slots = list(range(self.max_loras))
         self.active_groups: list[tuple[int, Optional[torch.Tensor]]] = []
         self.token_slots: Optional[torch.Tensor] = None       # int32 [T] adapter slot of every token row (-1: none)
+        self.step_slots: Optional[np.ndarray] = None          # host copy of the step's token slots (head_rows)
         self.layers: dict[str, LinearBase] = {}
+        self.embeddings: dict[str, VocabParallelEmbedding] = {}
+        self.heads: dict[str, ParallelLMHead] = {}
         for name, m in model.named_modules():
             if isinstance(m, LinearBase) and "lm_head" not in name and isinstance(
                     m, (ColumnParallelLinear, RowParallelLinear)):
                 self._wrap(name, m)
+            elif isinstance(m, ParallelLMHead):
+                self._wrap_head(name, m)
+            elif isinstance(m, VocabParallelEmbedding):
+                self._wrap_embedding(name, m)
         self.expected = set()
         for name in self.layers:
             leaf = name.rsplit(".", 1)[-1]
             self.expected.update(self.packed.get(leaf, [leaf]))
+        self.expected.update(n.rsplit(".", 1)[-1] for n in list(self.embeddings) + list(self.heads))
         logger.info("LoRA enabled on %d layers: %d device slots, rank <= %d", len(self.layers), self.max_loras,
                     self.r_max)
 
@@ -154,6 +171,69 @@ class LoRAManager:
         m.lora_has = [False] * self.max_loras
         m.quant_method = _LoRALinearMethod(m.quant_method, self)
         self.layers[name] = m
+
+    def _wrap_head(self, name: str, m: ParallelLMHead) -> None:
+        """Output head: A whole [r, hidden], B sharded like the head's vocabulary rows."""
+        m.register_buffer("lora_A", torch.zeros(self.max_loras, self.r_max, m.embedding_dim, dtype=self.dtype,
+                                                device=self.device), persistent=False)
+        m.register_buffer("lora_B", torch.zeros(self.max_loras, m.per_rank, self.r_max, dtype=self.dtype,
+                                                device=self.device), persistent=False)
+        m.lora_has = [False] * self.max_loras
+        m.quant_method = _LoRALinearMethod(m.quant_method, self)
+        self.heads[name] = m
+
+    def _wrap_embedding(self, name: str, m: VocabParallelEmbedding) -> None:
+        """Token embedding: A^T whole [vocab, r] (gathered by token id), B [hidden, r]."""
+        m.register_buffer("lora_A", torch.zeros(self.max_loras, m.num_embeddings, self.r_max, dtype=self.dtype,
+                                                device=self.device), persistent=False)
+        m.register_buffer("lora_B", torch.zeros(self.max_loras, m.embedding_dim, self.r_max, dtype=self.dtype,
+                                                device=self.device), persistent=False)
+        m.lora_has = [False] * self.max_loras
+
+        def add_update(mod, args, out):
+            groups = self.active_groups
+            if not groups:
+                return out
+            ids = args[0].reshape(-1)
+            o2 = out.view(-1, out.shape[-1])
+            if ids.shape[0] != o2.shape[0]:
+                return out
+            for slot, idx in groups:
+                if not mod.lora_has[slot]:
+                    continue
+                sel = ids if idx is None else ids.index_select(0, idx)
+                d = torch.mm(F.embedding(sel, mod.lora_A[slot]), mod.lora_B[slot].t()).to(o2.dtype)
+                if idx is None:
+                    o2 += d
+                else:
+                    o2.index_add_(0, idx, d)
+            return out
+        m.register_forward_hook(add_update)
+        self.embeddings[name] = m
+
+    def _place_vocab_layers(self, lora: LoRAModel, slot: int) -> None:
+        for name, m in self.embeddings.items():
+            ab = lora.weights.get(name)
+            m.lora_has[slot] = ab is not None
+            m.lora_A[slot].zero_()
+            m.lora_B[slot].zero_()
+            if ab is not None:
+                A, B = ab                                   # [r, vocab], [hidden, r]
+                r, v = A.shape[0], min(A.shape[1], m.num_embeddings)
+                m.lora_A[slot][:v, :r].copy_(A[:, :v].t())
+                m.lora_B[slot][:, :r].copy_(B)
+        for name, m in self.heads.items():
+            ab = lora.weights.get(name)
+            m.lora_has[slot] = ab is not None
+            m.lora_A[slot].zero_()
+            m.lora_B[slot].zero_()
+            if ab is not None:
+                A, B = ab                                   # [r, hidden], [vocab, r]
+                r = A.shape[0]
+                lo, hi = m.vocab_start, min(m.vocab_end, B.shape[0])
+                m.lora_A[slot][:r].copy_(A)
+                if hi > lo:
+                    m.lora_B[slot][: hi - lo, :r].copy_(B[lo:hi])
 
     # ---- adapter placement ------------------------------------------------------------------------
     def _shard_into(self, layer: LinearBase, slot: int, parts: list[Optional[tuple[torch.Tensor, torch.Tensor]]]) -> None:
@@ -222,6 +302,7 @@ class LoRAManager:
             else:                                   # the fused kernel reads every slot: no stale weights
                 layer.lora_A[slot].zero_()
                 layer.lora_B[slot].zero_()
+        self._place_vocab_layers(lora, slot)
         self.slot_of[lora.id] = slot
         return slot
 
@@ -249,7 +330,7 @@ class LoRAManager:
         found = self.cpu_cache.pop(lora_id, None) is not None
         slot = self.slot_of.pop(lora_id, None)
         if slot is not None:
-            for layer in self.layers.values():
+            for layer in list(self.layers.values()) + list(self.embeddings.values()) + list(self.heads.values()):
                 layer.lora_has[slot] = False
             self.free_slots.append(slot)
         self.pinned.discard(lora_id)
@@ -269,6 +350,7 @@ class LoRAManager:
         ids = ib.lora_id[rows]
         self.active_groups = []
         self.token_slots = None
+        self.step_slots = None
         if not (ids > 0).any():
             return
         busy = set(int(i) for i in np.unique(ids) if i > 0)
@@ -281,8 +363,13 @@ class LoRAManager:
                 self.add_adapter(ib.reqs[rid].lora_request)
             slot_by_id[lid] = self._activate(self.cpu_cache[lid], busy)
         tok_slot = np.repeat(np.array([slot_by_id.get(int(i), -1) for i in ids], dtype=np.int64), n_sched)
+        self.step_slots = tok_slot
+        self._group(tok_slot)
+
+    def _group(self, tok_slot: np.ndarray) -> None:
+        self.active_groups = []
         self.token_slots = torch.from_numpy(tok_slot.astype(np.int32)).to(self.device, non_blocking=True)
-        for slot in sorted(set(slot_by_id.values())):
+        for slot in sorted(set(int(s) for s in np.unique(tok_slot) if s >= 0)):
             idx = np.nonzero(tok_slot == slot)[0]
             if len(idx) == len(tok_slot):
                 self.active_groups.append((slot, None))
@@ -290,5 +377,18 @@ class LoRAManager:
                 self.active_groups.append((slot, torch.from_numpy(idx).to(self.device, non_blocking=True)))
 
     def clear_active(self) -> None:
+        """End of the forward pass: nothing is adapted until the next ``set_active`` / ``head_rows``."""
         self.active_groups = []
         self.token_slots = None
+
+    @contextlib.contextmanager
+    def head_rows(self, index: np.ndarray):
+        """The rows ``index`` of this step's tokens go through the output head inside this block."""
+        if self.step_slots is None or not self.heads:
+            yield
+            return
+        self._group(self.step_slots[np.asarray(index, dtype=np.int64)])
+        try:
+            yield
+        finally:
+            self.clear_active()

@@ -929,7 +929,7 @@ class ModelRunner:
             conn.wait_for_save()
             conn.clear_connector_metadata()
         if self.lora_manager is not None:
-            self.lora_manager.clear_active()       # the output head and warm-up runs are not adapted
+            self.lora_manager.clear_active()       # warm-up runs are not adapted; the head names its rows
         if self.eplb_state is not None:
             self._eplb_step()
         tk_plain = tmd is not None and self._tknp_plain_step(so, rows, conn)
@@ -967,7 +967,7 @@ class ModelRunner:
         else:
             self._to_dev(self.logits_indices, logits_idx)
             sample_hidden = hidden[self.logits_indices[:S]]
-            logits = self.model.compute_logits(sample_hidden)
+            logits = self._compute_logits(sample_hidden, logits_idx[:S])
             if envs.VLLM_COMPUTE_NANS_IN_LOGITS:
                 self._last_nans = {r: int(x) for r, x in zip(req_ids, logits.isnan().sum(-1).tolist())}
             if so.grammar_bitmask is not None:
@@ -1164,11 +1164,18 @@ class ModelRunner:
             if n_tgt <= 0:
                 continue
             h = hidden[int(cu[i]): int(cu[i]) + n_tgt]
-            lp = torch.log_softmax(self.model.compute_logits(h).float(), dim=-1)
+            lp = torch.log_softmax(self._compute_logits(h, np.arange(int(cu[i]), int(cu[i]) + n_tgt)).float(), dim=-1)
             tgt = torch.from_numpy(ib.token_ids[row, start + 1: start + 1 + n_tgt].astype(np.int64)).to(self.device)
             ids, lps, ranks = Sampler.gather_logprobs(lp, k, tgt)
             out[rid] = LogprobsLists(ids.tolist(), lps.tolist(), ranks.tolist())
         return out
+
+    def _compute_logits(self, hidden_rows: torch.Tensor, index: np.ndarray) -> torch.Tensor:
+        """Logits of rows ``index`` of this step's tokens (the index tells LoRA which adapter each row uses)."""
+        if self.lora_manager is None:
+            return self.model.compute_logits(hidden_rows)
+        with self.lora_manager.head_rows(index):
+            return self.model.compute_logits(hidden_rows)
 
     def _apply_grammar_bitmask(self, so, logits, req_ids) -> None:
         bm = so.grammar_bitmask
@@ -1195,7 +1202,7 @@ class ModelRunner:
             last = int(cu[i + 1]) - 1
             idx.extend(range(last - nd_i, last + 1))
         sel = torch.tensor(idx, dtype=torch.int64, device=self.device)
-        logits = self.model.compute_logits(hidden[sel]).float()
+        logits = self._compute_logits(hidden[sel], np.asarray(idx)).float()
         smd = self._sampling_metadata(req_ids, rows)
         lists = self.rejection_sampler(logits, drafts, smd, self.sampler)
         return None, None, lists
