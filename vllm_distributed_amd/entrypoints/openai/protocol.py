@@ -78,8 +78,10 @@ class StreamOptions(OpenAIBaseModel):
 
 
 class ResponseFormat(OpenAIBaseModel):
-    type: Literal["text", "json_object", "json_schema"]
+    type: Literal["text", "json_object", "json_schema", "structural_tag"]
     json_schema: Optional[dict] = None
+    structures: Optional[list[dict]] = None          # structural_tag: [{"begin", "schema", "end"}]
+    triggers: Optional[list[str]] = None
 
 
 class _SamplingMixin(OpenAIBaseModel):
@@ -130,6 +132,9 @@ class _SamplingMixin(OpenAIBaseModel):
         json_object = None
         rf = self.response_format
         if rf is not None:
+            if rf.type == "structural_tag":
+                return GuidedDecodingParams(structural_tag={"structures": rf.structures, "triggers": rf.triggers},
+                                            backend=self.guided_decoding_backend)
             if rf.type == "json_object":
                 json_object = True
             elif rf.type == "json_schema" and rf.json_schema:

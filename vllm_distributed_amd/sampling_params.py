@@ -36,16 +36,17 @@ class GuidedDecodingParams:
     json_object: Optional[bool] = None
     backend: Optional[str] = None
     whitespace_pattern: Optional[str] = None
+    structural_tag: Optional[Union[str, dict]] = None
 
     def __post_init__(self):
         n = sum(x is not None and x is not False for x in
-                (self.json, self.regex, self.choice, self.grammar, self.json_object))
+                (self.json, self.regex, self.choice, self.grammar, self.json_object, self.structural_tag))
         if n > 1:
-            raise ValueError("only one of json/regex/choice/grammar/json_object may be set")
+            raise ValueError("only one of json/regex/choice/grammar/json_object/structural_tag may be set")
 
     @property
     def kind(self) -> Optional[str]:
-        for k in ("json", "regex", "choice", "grammar"):
+        for k in ("json", "regex", "choice", "grammar", "structural_tag"):
             if getattr(self, k) is not None:
                 return k
         return "json_object" if self.json_object else None

@@ -18,6 +18,7 @@ from typing import Optional
 import numpy as np
 
 from ..logger import init_logger
+from .cfg import CompiledPDA, grammar_to_regex, is_recursive_grammar
 from .json_schema import any_json, schema_to_regex
 from .regex_fsm import DFA, compile_regex
 
@@ -232,52 +233,28 @@ def choice_to_regex(choices: list[str]) -> str:
     return "(" + "|".join(re.escape(c) for c in choices) + ")"
 
 
-def grammar_to_regex(text: str) -> str:
-    """Non-recursive EBNF / GBNF (``name ::= ...`` rules, "literals", [classes], ( ) | * + ?) -> regex.
-    The start rule is ``root`` (or ``start``, or the first rule)."""
-    rules: dict[str, str] = {}
-    cur = None
-    for line in text.splitlines():
-        line = line.split("#", 1)[0].rstrip() if not re.search(r'"[^"]*#', line) else line.rstrip()
-        if not line.strip():
-            continue
-        m = re.match(r"\s*([A-Za-z_][\w\-]*)\s*(::=|:)\s*(.*)", line)
-        if m and not line.lstrip().startswith("|"):
-            cur = m.group(1)
-            rules[cur] = m.group(3)
-        elif cur is not None:
-            rules[cur] += " " + line.strip()
-    if not rules:
-        raise ValueError("empty grammar")
-    start = "root" if "root" in rules else ("start" if "start" in rules else next(iter(rules)))
-    tok = re.compile(r'\s*("(?:[^"\\]|\\.)*"|\[(?:[^\]\\]|\\.)*\]|[A-Za-z_][\w\-]*|[()|*+?])')
-
-    def expand(name: str, stack: tuple) -> str:
-        if name in stack:
-            raise ValueError(f"recursive grammar rule {name!r} cannot be lowered to a finite automaton; "
-                             "use a JSON schema or a regex")
-        if name not in rules:
-            raise ValueError(f"undefined grammar rule {name!r}")
-        out, pos, body = [], 0, rules[name]
-        while pos < len(body):
-            m = tok.match(body, pos)
-            if not m:
-                if body[pos:].strip() == "":
-                    break
-                raise ValueError(f"cannot parse grammar rule {name!r} near {body[pos:pos + 20]!r}")
-            t = m.group(1)
-            pos = m.end()
-            if t[0] == '"':
-                out.append(re.escape(json.loads(t)))
-            elif t[0] == "[":
-                out.append(t)
-            elif t in "()|*+?":
-                out.append(t)
-            else:
-                out.append("(" + expand(t, stack + (name,)) + ")")
-        return "".join(out)
-
-    return expand(start, ())
+def structural_tag_to_regex(spec, any_ws: bool = True) -> str:
+    """``{"structures": [{"begin", "schema", "end"}...], "triggers": [...]}``: free text, and whenever a
+    trigger string starts, one of the structures whose ``begin`` starts with it: begin, a JSON value of its
+    schema, end; then free text again.  Free text may not contain the first character of any trigger (a
+    regular over-approximation of "does not contain a trigger" that keeps the automaton small).
+    Reference: vllm/v1/structured_output/backend_xgrammar.py:107-123."""
+    if isinstance(spec, str):
+        spec = json.loads(spec)
+    structures, triggers = spec.get("structures") or [], spec.get("triggers") or []
+    if not structures or not triggers:
+        raise ValueError("a structural tag needs 'structures' and 'triggers'")
+    firsts = sorted({t[0] for t in triggers if t})
+    if any(ord(c) > 127 for c in firsts):
+        raise ValueError("structural tag triggers must start with an ASCII character")
+    free = "[^" + "".join("\\" + c if c in "\\]^-" else c for c in firsts) + "]*"
+    tagged = []
+    for st in structures:
+        if not any(st["begin"].startswith(t) for t in triggers):
+            raise ValueError(f"structure {st['begin']!r} starts with none of the triggers")
+        body = schema_to_regex(st.get("schema") or {}, any_ws)
+        tagged.append(re.escape(st["begin"]) + "(" + body + ")" + re.escape(st["end"]))
+    return free + "((" + "|".join(tagged) + ")" + free + ")*"
 
 
 class FSMBackend:
@@ -302,18 +279,21 @@ class FSMBackend:
         if gd.grammar is not None:
             return "grammar", grammar_to_regex(gd.grammar)
         if getattr(gd, "structural_tag", None):
-            raise ValueError("structural tags are not supported by the built-in guided-decoding backend")
+            return "structural_tag", structural_tag_to_regex(gd.structural_tag, self.any_ws)
         raise ValueError("empty guided-decoding request")
 
     def compile(self, gd) -> Grammar:
-        kind, rx = self.to_regex(gd)
+        if gd.grammar is not None and gd.json is None and is_recursive_grammar(gd.grammar):
+            kind, rx = "cfg", gd.grammar                 # pushdown matcher (cfg.py)
+        else:
+            kind, rx = self.to_regex(gd)
         key = (kind, rx)
         with self._lock:
             c = self._cache.get(key)
             if c is not None:
                 self._cache.move_to_end(key)
         if c is None:
-            c = CompiledGrammar(compile_regex(rx), self.table)
+            c = CompiledPDA(rx, self.table) if kind == "cfg" else CompiledGrammar(compile_regex(rx), self.table)
             with self._lock:
                 self._cache[key] = c
                 if len(self._cache) > 128:
@@ -322,5 +302,8 @@ class FSMBackend:
 
     def validate(self, gd) -> None:
         """Raise ValueError for constraints this backend cannot enforce (called at request intake)."""
+        if gd.grammar is not None and gd.json is None and is_recursive_grammar(gd.grammar):
+            CompiledPDA(gd.grammar, self.table)
+            return
         kind, rx = self.to_regex(gd)
         compile_regex(rx, max_states=50_000)

@@ -5,6 +5,9 @@ punctuation), ``.``, classes ``[a-z0-9_]`` / ``[^...]``, groups ``( )`` / ``(?: 
 quantifiers ``* + ? {m} {m,} {m,n}`` (lazy suffix ``?`` accepted and ignored: matching is a
 membership test, greediness has no meaning).  The automaton runs over UTF-8 bytes, so it lines
 up with token byte strings; ``.`` and negated classes accept any well-formed multi-byte character.
+
+For context-free grammars (cfg.py) the alphabet can be widened: ``\\R{k}`` in a pattern stands for symbol
+256 + k ("call rule k"), and ``compile_regex(..., extra_symbols=n)`` builds the automaton over 256 + n symbols.
 """
 from __future__ import annotations
 
@@ -137,6 +140,11 @@ class _Parser:
         elif c == "u":
             ch = chr(int(self.p[self.i:self.i + 4], 16))
             self.i += 4
+        elif c == "R" and not in_class and self._peek() == "{":
+            j = self.p.index("}", self.i)
+            k = int(self.p[self.i + 1:j])
+            self.i = j + 1
+            return ("lit", 1 << (256 + k))
         elif c == "b" or c == "B":
             return ("eps",)
         else:
@@ -290,16 +298,17 @@ class DFA:
         return bool(self.accepting[s])
 
 
-def compile_regex(pattern: str, max_states: int = 200_000) -> DFA:
+def compile_regex(pattern: str, max_states: int = 200_000, extra_symbols: int = 0) -> DFA:
     nfa = _NFA()
     start, end = nfa.build(_Parser(pattern).parse())
     n = len(nfa.eps)
     # byte equivalence classes over every mask in use
     masks = sorted({m for tr in nfa.trans for m, _ in tr})
     sig_to_class: dict[tuple, int] = {}
-    byte_class = np.zeros(256, dtype=np.int32)
+    nsym = 256 + extra_symbols
+    byte_class = np.zeros(nsym, dtype=np.int32)
     reps: list[int] = []
-    for b in range(256):
+    for b in range(nsym):
         sig = tuple((m >> b) & 1 for m in masks)
         if sig not in sig_to_class:
             sig_to_class[sig] = len(reps)
@@ -349,7 +358,7 @@ def compile_regex(pattern: str, max_states: int = 200_000) -> DFA:
     table = np.asarray(rows, dtype=np.int32).reshape(ns, len(reps))
     table[table < 0] = ns
     table = np.vstack([table, np.full((1, len(reps)), ns, dtype=np.int32)])
-    trans = table[:, byte_class]                      # [ns + 1, 256]
+    trans = table[:, byte_class]                      # [ns + 1, 256 (+ extra symbols)]
     accepting = np.zeros(ns + 1, dtype=bool)
     for st, j in ids.items():
         if end in st:
