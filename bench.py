@@ -57,6 +57,8 @@ def run_disagg(a) -> None:
         argv.append("--enforce-eager")
     if a.rehearse_on_one_gpu:
         argv.append("--rehearse-on-one-gpu")
+    if a.kv_push:
+        argv.append("--kv-push")
     res = disagg.main(argv)["disagg"]
     print(json.dumps({
         "metric": "disagg_output_tokens_per_s_per_gpu", "value": res["output_tok_s_per_gpu"], "unit": "tokens/s/GPU",
@@ -66,7 +68,8 @@ def run_disagg(a) -> None:
         "ttft_ms": res["ttft_ms"], "itl_ms": res["itl_ms"], "output_tok_s": res["output_tok_s"],
         "num_errors": res["num_errors"],
         "config": {"model": model, "deployment": a.disagg.lower(), "input_len": a.input_len, "output_len": out_len,
-                   "num_prompts": a.num_prompts, "request_rate": res["request_rate"], "connector": "XgmiConnector"},
+                   "num_prompts": a.num_prompts, "request_rate": res["request_rate"],
+                   "connector": "XgmiPushConnector" if a.kv_push else "XgmiConnector"},
     }), flush=True)
 
 
@@ -97,6 +100,7 @@ def main() -> None:
                          "1024-token prompts, 200 generated tokens (benchmarks/disagg.py); needs x + y GPUs unless "
                          "--rehearse-on-one-gpu")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="--disagg: every engine on GPU 0")
+    ap.add_argument("--kv-push", action="store_true", help="--disagg: push blocks while prefilling (landing pool)")
     ap.add_argument("--num-prompts", type=int, default=200, help="--disagg: requests")
     ap.add_argument("--request-rate", type=float, default=float("inf"), help="--disagg: Poisson arrivals per second")
     a = ap.parse_args()

@@ -241,7 +241,8 @@ def test_layout_mismatch_is_refused_at_handshake():
         d.shutdown()
 
 
-def test_disagg_benchmark_harness_on_cpu(tmp_path):
+@pytest.mark.parametrize("mode", ["pull", "push"])
+def test_disagg_benchmark_harness_on_cpu(tmp_path, mode):
     """benchmarks/disagg.py end to end (1 prefill + 1 decode engine process, socket data plane): every
     request completes through the router path and the report carries the metrics of the study."""
     import json
@@ -255,10 +256,95 @@ def test_disagg_benchmark_harness_on_cpu(tmp_path):
                         "--load-format", "auto", "--dtype", "float32", "--device", "cpu", "--prefill", "1",
                         "--decode", "1", "--input-len", "64", "--output-len", "6", "--num-prompts", "5",
                         "--vocab-size", "300", "--max-num-seqs", "8", "--max-num-batched-tokens", "256",
-                        "--request-rate", "50", "--output-json", str(out)],
+                        "--request-rate", "50", "--output-json", str(out)] + (["--kv-push"] if mode == "push" else []),
                        cwd=root, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = json.load(open(out))["disagg"]
     assert res["completed"] == 5 and res["num_errors"] == 0
     assert res["n_gpus"] == 2 and res["output_tok_s"] > 0
     assert res["ttft_ms"]["p99"] >= res["ttft_ms"]["p50"] > 0 and res["itl_ms"]["p50"] > 0
+
+
+def _engine_parts(llm):
+    core = llm.llm_engine.engine_core.engine_core
+    return core.scheduler, core.model_executor.worker.model_runner.kv_connector
+
+
+@pytest.mark.parametrize("send_type", ["PUT", "PUT_ASYNC"])
+def test_push_connector_lands_blocks_before_the_decode_request_arrives(tmp_path, send_type):
+    """Push mode: the prefill instance writes the blocks into the decode instance's landing pool step by step
+    (chunked prefill: 64-token steps), frees its own blocks without waiting for the consumer, and the decode
+    instance moves the slots into the request's blocks when the request shows up."""
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    ref = _ref(path)
+    pport, dport = _free_port(), _free_port()
+    xc = {"send_type": send_type, "mem_pool_size_gb": 0.01}
+    prefill = LLM(model=path, kv_transfer_config=dict(kv_connector="XgmiPushConnector", kv_port=pport,
+                                                      kv_role="kv_producer", kv_connector_extra_config=dict(xc)), **KW)
+    decode = LLM(model=path, kv_transfer_config=dict(kv_connector="P2pNcclConnector", kv_port=dport,
+                                                     kv_role="kv_consumer", kv_connector_extra_config=dict(xc)), **KW)
+    try:
+        sched_p, _ = _engine_parts(prefill)
+        _, conn_d = _engine_parts(decode)
+        assert type(conn_d).__name__ == "XgmiPushConnector"
+        free0 = sched_p.kv_cache_manager.block_pool.get_num_free_blocks()
+        host_free0 = conn_d.pool.num_free()[1]
+        sp1 = SamplingParams(temperature=0, max_tokens=1, ignore_eos=True, extra_args={"kv_transfer_params": {
+            "do_remote_decode": True, "push_host": "127.0.0.1", "push_port": dport}})
+        first = prefill.generate(prompt_token_ids=PROMPTS, sampling_params=sp1)
+        params = [o.kv_transfer_params for o in first]
+        assert all(p["pushed"] and p["transfer_id"] and p["remote_block_ids"] for p in params)
+        # every transfer is complete on the consumer although no decode request exists yet
+        import time
+        t0 = time.time()
+        while time.time() - t0 < 5 and not all(conn_d._rx.get(p["transfer_id"], {}).get("complete") for p in params):
+            time.sleep(0.01)
+        assert all(conn_d._rx[p["transfer_id"]]["complete"] for p in params)
+        assert conn_d.pool.num_free()[1] == host_free0 - sum(len(p["remote_block_ids"]) for p in params)
+        # one more producer step: the blocks are free again, nobody sent DONE
+        prefill.generate(prompt_token_ids=[[1, 2, 3]], sampling_params=SamplingParams(max_tokens=2))
+        assert sched_p.kv_cache_manager.block_pool.get_num_free_blocks() == free0
+        sps = [SamplingParams(temperature=0, max_tokens=8, ignore_eos=True, extra_args={"kv_transfer_params": p})
+               for p in params]
+        outs = decode.generate(prompt_token_ids=PROMPTS, sampling_params=sps)
+        assert [list(o.outputs[0].token_ids) for o in outs] == ref
+        assert all(o.num_cached_tokens >= len(p) - 1 - 16 for o, p in zip(outs, PROMPTS))
+        decode.generate(prompt_token_ids=[[1, 2, 3]], sampling_params=SamplingParams(max_tokens=2))
+        assert conn_d.pool.num_free()[1] == host_free0 and not conn_d._rx
+    finally:
+        prefill.shutdown()
+        decode.shutdown()
+
+
+def test_push_falls_back_to_pull_when_the_landing_pool_is_full(tmp_path):
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    ref = _ref(path)
+    pport, dport = _free_port(), _free_port()
+    prefill = LLM(model=path, kv_transfer_config=dict(kv_connector="XgmiPushConnector", kv_port=pport,
+                                                      kv_role="kv_producer"), **KW)
+    decode = LLM(model=path, kv_transfer_config=dict(kv_connector="XgmiPushConnector", kv_port=dport, kv_role="kv_consumer",
+                                                     kv_connector_extra_config={"mem_pool_size_gb": 0}), **KW)
+    try:
+        _, conn_d = _engine_parts(decode)
+        assert conn_d.pool.num_free() == (0, 0)
+        sp1 = SamplingParams(temperature=0, max_tokens=1, ignore_eos=True, extra_args={"kv_transfer_params": {
+            "do_remote_decode": True, "push_host": "127.0.0.1", "push_port": dport}})
+        params = [o.kv_transfer_params for o in prefill.generate(prompt_token_ids=PROMPTS, sampling_params=sp1)]
+        sps = [SamplingParams(temperature=0, max_tokens=8, ignore_eos=True, extra_args={"kv_transfer_params": p})
+               for p in params]
+        outs = decode.generate(prompt_token_ids=PROMPTS, sampling_params=sps)
+        assert [list(o.outputs[0].token_ids) for o in outs] == ref
+        assert all(o.num_cached_tokens >= len(p) - 1 - 16 for o, p in zip(outs, PROMPTS))      # pulled, not recomputed
+    finally:
+        prefill.shutdown()
+        decode.shutdown()
+
+
+def test_push_metadata_survives_the_wire():
+    from vllm_distributed_amd.engine import serial
+    from vllm_distributed_amd.parallel.kv_transfer.push import LandSpec, PushMetadata, PushSpec
+    from vllm_distributed_amd.parallel.kv_transfer.xgmi import RecvSpec
+    m = PushMetadata(pushes={"a": PushSpec("t1", "h", 5, [3, 4], 1, 2, True)},
+                     lands={"b": LandSpec("t2", RecvSpec([1], [9], "h", 7, "E", "tok", [8, 9], 1))}, aborted=["t3"])
+    back = serial.decode(serial.encode(m))
+    assert back == m

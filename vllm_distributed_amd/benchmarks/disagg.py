@@ -54,6 +54,9 @@ def add_cli_args(p: argparse.ArgumentParser) -> None:
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--rehearse-on-one-gpu", action="store_true",
                    help="every engine on GPU 0 with a share of its memory: exercises the path, measures nothing")
+    p.add_argument("--kv-push", action="store_true",
+                   help="push mode: prefill engines write blocks into the decode engine's landing pool while they "
+                        "compute (XgmiPushConnector) instead of the decode engine pulling them afterwards")
     p.add_argument("--baseline-single", action="store_true",
                    help="also run the same workload on ONE ordinary engine (the study's 'single instance' row)")
     p.add_argument("--output-json", default=None)
@@ -77,8 +80,9 @@ def _make_engine(args, role: Optional[str], gpus: list[int], n_gpus_total: int, 
     if not args.rehearse_on_one_gpu and args.device != "cpu":
         os.environ["HIP_VISIBLE_DEVICES"] = _device_list(gpus, n_gpus_total)
     kt = None
+    port = _free_port()
     if role is not None:
-        kt = dict(kv_connector="XgmiConnector", kv_role=role, kv_port=_free_port())
+        kt = dict(kv_connector="XgmiPushConnector" if args.kv_push else "XgmiConnector", kv_role=role, kv_port=port)
     ea = AsyncEngineArgs(
         model=args.model, load_format=args.load_format, dtype=args.dtype, skip_tokenizer_init=True,
         tensor_parallel_size=args.tensor_parallel_size, max_model_len=args.input_len + args.output_len + 16,
@@ -86,7 +90,9 @@ def _make_engine(args, role: Optional[str], gpus: list[int], n_gpus_total: int, 
         gpu_memory_utilization=share, hf_overrides=args.hf_overrides, enforce_eager=args.enforce_eager,
         enable_prefix_caching=False, kv_transfer_config=kt, seed=args.seed, disable_log_stats=True,
         device=args.device)
-    return AsyncLLM.from_engine_args(ea)
+    eng = AsyncLLM.from_engine_args(ea)
+    eng.kv_port = port
+    return eng
 
 
 async def _drive(args, route, n_gpus: int, label: str) -> dict:
@@ -154,8 +160,10 @@ async def run_disagg(args) -> dict:
         async def route(i: int, prompt: list[int]):
             p, d = P[i % len(P)], D[i % len(D)]
             rid = f"bench-{i}"
-            sp_p = SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True,
-                                  extra_args={"kv_transfer_params": {"do_remote_decode": True}})
+            ktp = {"do_remote_decode": True}
+            if args.kv_push:                    # the router picks the decode engine first: that is where blocks go
+                ktp.update(push_host="127.0.0.1", push_port=d.kv_port)
+            sp_p = SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True, extra_args={"kv_transfer_params": ktp})
             last = None
             async for out in p.generate({"prompt_token_ids": prompt}, sp_p, rid):
                 last = out

@@ -34,6 +34,7 @@ KVConnectorFactory.register_connector("SharedStorageConnector", f"{_PKG}.shared_
 KVConnectorFactory.register_connector("XgmiConnector", f"{_PKG}.xgmi", "XgmiConnector")
 # names used by the reference's GPU-to-GPU connectors map onto the xGMI peer-memory connector
 KVConnectorFactory.register_connector("NixlConnector", f"{_PKG}.xgmi", "XgmiConnector")
-KVConnectorFactory.register_connector("P2pNcclConnector", f"{_PKG}.xgmi", "XgmiConnector")
+KVConnectorFactory.register_connector("XgmiPushConnector", f"{_PKG}.push", "XgmiPushConnector")
+KVConnectorFactory.register_connector("P2pNcclConnector", f"{_PKG}.push", "p2p_connector")
 KVConnectorFactory.register_connector("MultiConnector", f"{_PKG}.multi", "MultiConnector")
 KVConnectorFactory.register_connector("LMCacheConnectorV1", f"{_PKG}.multi", "UnavailableConnector")

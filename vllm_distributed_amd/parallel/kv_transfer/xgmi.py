@@ -539,7 +539,7 @@ def _register_wire_types() -> None:
     from ...engine import serial
     from . import multi, shared_storage
     for i, cls in enumerate((RecvSpec, XgmiMetadata, shared_storage._Req, shared_storage.SharedStorageMetadata,
-                             multi.MultiMetadata), start=60):
+                             multi.MultiMetadata), start=60):            # 65-67: push.py
         serial.wire_struct(i)(cls)
 
 
