@@ -30,6 +30,7 @@ def main():
         ktp.update(push_host="127.0.0.1", push_port=port + 100)
     if role == "producer":
         llm = LLM(model=model, kv_transfer_config=dict(kt, kv_role="kv_producer"), **kw)
+        open(os.path.join(workdir, "producer.up"), "w").close()
         t0 = time.time()
         while push and not os.path.exists(os.path.join(workdir, "consumer.ready")) and time.time() - t0 < 60:
             time.sleep(0.1)
@@ -50,6 +51,9 @@ def main():
                        "landing_mapped": any(getattr(p, "landing", None) is not None for p in conn._peers.values())}, f)
         llm.shutdown()
     else:
+        t0 = time.time()              # one engine at a time measures its memory share
+        while not os.path.exists(os.path.join(workdir, "producer.up")) and time.time() - t0 < 60:
+            time.sleep(0.1)
         ref_llm = LLM(model=model, **kw)
         sp = SamplingParams(temperature=0, max_tokens=8, ignore_eos=True)
         ref = [list(o.outputs[0].token_ids) for o in ref_llm.generate(prompt_token_ids=PROMPTS, sampling_params=sp)]

@@ -27,7 +27,10 @@ send queue; p2p/tensor_memory_pool.py host spill; p2p_nccl_connector.py:240-300 
 """
 from __future__ import annotations
 
+import os
+import queue
 import re
+import socket
 import threading
 import time
 import uuid
@@ -138,6 +141,8 @@ class XgmiPushConnector(XgmiConnector):
         self._rx: dict[str, dict] = {}                           # consumer: transfer id -> state
         self._wanted: dict[str, tuple[LandSpec, float]] = {}     # consumer: rid -> (spec, since)
         self._push_stream = None
+        self._end_q: "queue.Queue[Optional[str]]" = queue.Queue()
+        self._end_thread: Optional[threading.Thread] = None
         self._part_off: Optional[dict[str, list[tuple[int, int]]]] = None
         self.slot_bytes = 0
 
@@ -238,6 +243,9 @@ class XgmiPushConnector(XgmiConnector):
         self.slot_bytes = off
         if runner.is_gpu:
             self._push_stream = torch.cuda.Stream(device=runner.device)
+        if kt.is_kv_producer and self._end_thread is None:
+            self._end_thread = threading.Thread(target=self._end_loop, daemon=True, name="kv-push-end")
+            self._end_thread.start()
         if self.is_consumer:
             dev_slots = min(self.landing_bytes // max(self.slot_bytes, 1), nb) if runner.is_gpu else 0
             if self.landing_slots is not None and runner.is_gpu:
@@ -340,8 +348,10 @@ class XgmiPushConnector(XgmiConnector):
     # ---- producer: sending --------------------------------------------------------------------------------
     def _landing_of(self, peer) -> Optional[torch.Tensor]:
         """The peer's device landing arena, mapped once."""
-        if getattr(peer, "landing", None) is not None or not self.runner.is_gpu or peer.region is None:
+        if getattr(peer, "landing", None) is not None or not self.runner.is_gpu:
             return getattr(peer, "landing", None)
+        if peer.info.get("hostname") != socket.gethostname() or peer.info.get("pid") == os.getpid():
+            return None                                      # another node (or this very process): side channel
         info = peer.info.get("landing") or {}
         if not info.get("handle") or not info.get("dev_slots"):
             return None
@@ -466,9 +476,30 @@ class XgmiPushConnector(XgmiConnector):
                 st["events"].append(ev)
             if spec.last:
                 st["last"] = True
+                self._end_q.put(spec.transfer_id)            # PUT_END leaves as soon as the copies are done
         if self.send_type == "PUT" and self._push_stream is not None:
             self._push_stream.synchronize()
         self._tx_step = []
+
+    def _end_loop(self) -> None:
+        """Completion thread of the producer: waits for a transfer's copy events and tells the consumer that the
+        data is whole.  It does not depend on further engine steps (an idle prefill instance makes none)."""
+        while True:
+            tid = self._end_q.get()
+            if tid is None:
+                return
+            st = self._tx.get(tid)
+            if st is None or st["failed"]:
+                continue
+            try:
+                for ev in list(st["events"]):
+                    ev.synchronize()
+                with st["peer"].lock:
+                    st["peer"].conn.send(("PUT_END", tid))
+                st["ended"] = True
+            except Exception:   # noqa: BLE001 - the consumer is gone: it pulls or prefills on its own
+                logger.exception("could not complete KV transfer %s", tid)
+                st["ended"] = "lost"
 
     # ---- both: progress ------------------------------------------------------------------------------------
     def _finish_sends(self) -> None:
@@ -478,16 +509,11 @@ class XgmiPushConnector(XgmiConnector):
                 if st.get("last") or st["peer"] is None:
                     self._tx.pop(tid)
                 continue
-            if not st.get("last") or not all(ev.query() for ev in st["events"]):
+            if st.get("ended") == "lost":
+                self._tx.pop(tid)
                 continue
             if not st.get("ended"):
-                try:
-                    with st["peer"].lock:
-                        st["peer"].conn.send(("PUT_END", tid))
-                except OSError:
-                    self._tx.pop(tid)
-                    continue
-                st["ended"] = True
+                continue
             # reported once the scheduler has finished the request (it then holds the blocks for export and
             # says so with the step's metadata): they are freed with this report
             with self._lock:
@@ -571,6 +597,7 @@ class XgmiPushConnector(XgmiConnector):
         return super().get_finished(finished_req_ids)
 
     def shutdown(self) -> None:
+        self._end_q.put(None)
         super().shutdown()
         for p in self._peers.values():
             reg = getattr(p, "landing_region", None)
