@@ -93,6 +93,8 @@ def main() -> None:
                          "that would not fit are dropped (never below one warm-up and --min-steps timed rounds) "
                          "and the JSON line reports the rounds really run; 0 = run exactly --steps/--warmup")
     ap.add_argument("--min-steps", type=int, default=3, help="timed rounds that run whatever the budget says")
+    ap.add_argument("--sync-scheduling", action="store_true",
+                    help="schedule step N + 1 only after step N's results are on the host (default: run ahead)")
     ap.add_argument("--hf-overrides", type=json.loads, default=None,
                     help="JSON overrides of the model config (rehearsals of the N-rank launch with a small model)")
     ap.add_argument("--disagg", default=None, metavar="xPyD",
@@ -133,7 +135,8 @@ def main() -> None:
               tensor_parallel_size=a.gpus, max_model_len=a.input_len + a.output_len + 16,
               max_num_seqs=max(a.batch, 8), max_num_batched_tokens=a.max_num_batched_tokens,
               enable_prefix_caching=False, gpu_memory_utilization=a.gpu_memory_utilization,
-              enforce_eager=a.enforce_eager, seed=0, hf_overrides=a.hf_overrides, **kw)
+              enforce_eager=a.enforce_eager, seed=0, hf_overrides=a.hf_overrides,
+              async_scheduling=not a.sync_scheduling, **kw)
     vocab = llm.llm_engine.model_config.get_vocab_size()
     eng = llm.llm_engine
     sp = SamplingParams(temperature=0.0, max_tokens=a.output_len, ignore_eos=True,

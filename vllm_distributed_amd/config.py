@@ -892,9 +892,26 @@ class VllmConfig:
             # ranks exchange rows through peer memory (the runner turns graphs off when they cannot)
             if pc.distributed_executor_backend == "mp":
                 pc.distributed_executor_backend = "external_launcher"
-        if pc.distributed_executor_backend == "external_launcher":
-            # every rank runs its own scheduler: scheduling must be deterministic
-            sc.async_scheduling = False
+        if sc.async_scheduling:
+            # run-ahead scheduling keeps a step's sampled ids on the device of the process that schedules: the
+            # worker must live in the engine-core process (one GPU, or one scheduler per rank under torchrun),
+            # and nothing else may feed on a step's results before the next one starts
+            why = None
+            if pc.world_size > 1 and pc.distributed_executor_backend != "external_launcher":
+                why = "workers run in other processes"
+            elif pc.pipeline_parallel_size > 1:
+                why = "pipeline stages already overlap through the batch queue"
+            elif self.speculative_config is not None:
+                why = "draft tokens of step N + 1 depend on the result of step N"
+            elif self.kv_transfer_config is not None and self.kv_transfer_config.is_kv_transfer_instance:
+                why = "KV transfer bookkeeping rides on every step's result"
+            elif pc.token_parallel_size > 1:
+                why = "token-parallel ranks share sampled ids at the end of every step"
+            elif mc.runner_type == "pooling":
+                why = "pooling models produce no tokens"
+            if why is not None:
+                logger.info("async_scheduling is off: %s", why)
+                sc.async_scheduling = False
         if self.compilation_config.level > 0:
             self.compilation_config.init_with_cudagraph_sizes(sc.max_num_seqs)
         if self.kv_transfer_config is not None and not self.kv_transfer_config.is_kv_transfer_instance:

@@ -57,6 +57,11 @@ class EngineCore:
             logger.info("batch queue enabled with %d slots", self.batch_queue_size)
             self.batch_queue = deque()
         self.step_fn = self.step if self.batch_queue is None else self.step_with_batch_queue
+        self._inflight = None            # run-ahead scheduling: (scheduler output, result handle) of the step in flight
+        self._ready: deque = deque()     # outputs of steps collected ahead of their turn
+        if vllm_config.scheduler_config.async_scheduling and self.batch_queue is None:
+            logger.info("run-ahead scheduling: step N + 1 is scheduled and launched while step N runs")
+            self.step_fn = self.step_run_ahead
 
     def _make_tknp(self, cfg: VllmConfig, num_blocks: int) -> Optional[TokenParallelScheduler]:
         n = cfg.parallel_config.token_parallel_size
@@ -113,6 +118,52 @@ class EngineCore:
             mro = mro.result()
         outs = self.scheduler.update_from_output(so, mro)
         return outs, so.total_num_scheduled_tokens > 0
+
+    def _execute_maybe_deferred(self, so: SchedulerOutput):
+        """Execute ``so``; the result is a ModelRunnerOutput, or a handle whose ``get()`` yields one later."""
+        so.defer_output = self.scheduler.can_run_ahead(so)
+        h = self.execute_model(so)
+        return h.result() if isinstance(h, Future) else h
+
+    def _settle(self, so: SchedulerOutput, h) -> Optional[dict[int, EngineCoreOutputs]]:
+        """Keep a deferred result in flight (returns None) or fold a finished one into the scheduler."""
+        if isinstance(h, ModelRunnerOutput):
+            return self.scheduler.update_from_output(so, h)
+        self._inflight = (so, h)
+        return None
+
+    def step_run_ahead(self) -> tuple[dict[int, EngineCoreOutputs], bool]:
+        """One engine step with the host ahead of the GPU by one step: while step N runs, step N + 1 is scheduled
+        (every request of N that will sample a token holds a stand-in for it), its inputs are prepared, the one
+        unknown input token per request is read from N's result on the device, and N + 1 is launched; only then
+        are N's ids collected and its requests updated.  A request that N finished (stop token, stop string)
+        has then already been given one more token in N + 1, which is dropped.  Steps whose next inputs depend
+        on more than the sampled id (grammars, penalties, ...) are collected before anything else is scheduled.
+        Reference: the async scheduler of vllm/v1/core/sched/async_scheduler.py and EngineCore.step_with_batch_queue
+        (vllm/v1/engine/core.py:245-290); here the ids never leave the device between two steps."""
+        sch = self.scheduler
+        if self._ready:
+            return self._ready.popleft(), True
+        if self._inflight is None:
+            if not sch.has_requests():
+                return {}, False
+            so = sch.schedule()
+            outs = self._settle(so, self._execute_maybe_deferred(so))
+            return (outs if outs is not None else {}), so.total_num_scheduled_tokens > 0
+        so, h = self._inflight
+        self._inflight = None
+        so2 = sch.schedule()
+        if sch.last_schedule_preempted:
+            # a preempted request's blocks and batch row go away: finish N on the host before N + 1 is prepared
+            outs = sch.update_from_output(so, h.get())
+            h2 = self._execute_maybe_deferred(so2)
+        else:
+            h2 = self._execute_maybe_deferred(so2)
+            outs = sch.update_from_output(so, h.get())       # N before N + 1, whichever way N + 1 ran
+        outs2 = self._settle(so2, h2)
+        if outs2:
+            self._ready.append(outs2)
+        return outs, True
 
     def step_with_batch_queue(self) -> tuple[Optional[dict[int, EngineCoreOutputs]], bool]:
         """Keep the pipeline full: schedule a new batch whenever a slot is free, and only

@@ -95,7 +95,7 @@ class EngineCoreProc(EngineCore):
             self._process_engine_step()
 
     def _has_work(self) -> bool:
-        return self.scheduler.has_requests() or bool(self.batch_queue)
+        return self.scheduler.has_requests() or bool(self.batch_queue) or self._inflight is not None or bool(self._ready)
 
     def _process_input_queue(self) -> None:
         waited = False

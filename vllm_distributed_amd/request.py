@@ -188,7 +188,7 @@ class Request:
         "prompt_token_ids", "num_prompt_tokens", "_output_token_ids", "_all_token_ids",
         "spec_token_ids", "num_computed_tokens", "cache_salt", "mm_inputs", "mm_hashes",
         "mm_positions", "num_cached_tokens", "num_preemptions", "block_hashes",
-        "trace_headers", "num_output_placeholders", "use_structured_output",
+        "trace_headers", "num_output_placeholders", "use_structured_output", "plain_sampling",
     )
 
     def __init__(self, request_id: str, prompt_token_ids: list[int],
@@ -234,6 +234,14 @@ class Request:
         self.block_hashes: list = []  # filled lazily by the KV manager
         self.trace_headers = trace_headers
         self.num_output_placeholders = 0
+        # nothing but the sampled token itself carries over from one step of this request to the next
+        # (run-ahead scheduling may then start step N + 1 before the results of step N are on the host)
+        sp = sampling_params
+        self.plain_sampling = bool(
+            sp is not None and not self.use_structured_output and not sp.presence_penalty
+            and not sp.frequency_penalty and sp.repetition_penalty == 1.0 and not sp.bad_words
+            and not sp.min_tokens and sp.prompt_logprobs is None and not getattr(sp, "logits_processors", None)
+            and not kv_transfer_params and not self.mm_inputs)
 
     @classmethod
     def from_engine_core_request(cls, r: EngineCoreRequest, structured_output_request=None) -> "Request":

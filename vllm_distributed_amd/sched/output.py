@@ -72,6 +72,8 @@ class SchedulerOutput:
     grammar_bitmask: Any = None
     kv_connector_metadata: Any = None
     tknp: Optional[TokenParallelAllocation] = None
+    # run-ahead scheduling: the runner may hand back a handle and leave the sampled ids on the device until asked
+    defer_output: bool = False
 
 
 @dataclass

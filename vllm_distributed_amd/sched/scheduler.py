@@ -134,6 +134,8 @@ class Scheduler(SchedulerInterface):
         self.encoder_cache_manager = EncoderCacheManager(sc.encoder_cache_size)
         self.max_num_encoder_input_tokens = sc.max_num_encoder_input_tokens
         self._step = 0
+        self.async_mode = bool(self.scheduler_config.async_scheduling)
+        self.last_schedule_preempted = False
 
     # ------------------------------------------------------------------
     # schedule
@@ -157,6 +159,9 @@ class Scheduler(SchedulerInterface):
         i = 0
         while i < len(self.running) and budget > 0:
             req = self.running[i]
+            if req.num_output_placeholders and self._complete_with_placeholders(req):
+                i += 1               # its last token is in flight: nothing more to compute for it
+                continue
             n_new = req.num_tokens_with_spec + req.num_output_placeholders - req.num_computed_tokens
             thr = self.scheduler_config.long_prefill_token_threshold
             if 0 < thr < n_new:
@@ -378,10 +383,33 @@ class Scheduler(SchedulerInterface):
         # the step is now committed: advance the computed-token counters so the
         # next schedule() (pipeline parallel / async scheduling) starts after it
         for rid, n in num_scheduled.items():
-            self.requests[rid].num_computed_tokens += n
+            req = self.requests[rid]
+            req.num_computed_tokens += n
+            if self.async_mode and req.num_computed_tokens == req.num_tokens + req.num_output_placeholders:
+                # this step samples a token the scheduler will only see one step later: stand-in until then
+                req.num_output_placeholders += 1
+        self.last_schedule_preempted = bool(preempted)
         self.finished_req_ids = set()
         self._step += 1
         return out
+
+    def _complete_with_placeholders(self, req: Request) -> bool:
+        """Run-ahead scheduling: would the tokens already in flight end the request by length?"""
+        n_out = req.num_output_tokens + req.num_output_placeholders
+        return (req.max_tokens is not None and n_out >= req.max_tokens) or \
+            req.num_tokens + req.num_output_placeholders >= self.max_model_len
+
+    def can_run_ahead(self, so: SchedulerOutput) -> bool:
+        """May the next step be scheduled before the results of ``so`` are known?  Only when nothing about the
+        next step's inputs other than the sampled token itself depends on those results: no grammar state, no
+        penalties or token-history processors, no prompt log-probabilities (their extraction synchronises)."""
+        if not self.async_mode or so.total_num_scheduled_tokens == 0:
+            return False
+        for rid in so.num_scheduled_tokens:
+            req = self.requests.get(rid)
+            if req is not None and not req.plain_sampling:
+                return False
+        return True
 
     def _pick_victim(self, current: Request) -> Request:
         if self.tknp is not None:
@@ -401,6 +429,7 @@ class Scheduler(SchedulerInterface):
             self.tknp.release(req.request_id)
         req.status = RequestStatus.PREEMPTED
         req.num_computed_tokens = 0
+        req.num_output_placeholders = 0
         req.spec_token_ids = []
         req.num_preemptions += 1
         if self.log_stats:
@@ -490,6 +519,8 @@ class Scheduler(SchedulerInterface):
 
             finished = False
             kv_params = None
+            if req.num_output_placeholders:
+                req.num_output_placeholders = max(0, req.num_output_placeholders - len(new_ids))
             for n, tok in enumerate(new_ids, 1):
                 req.append_output_token_ids(tok)
                 if check_stop(req, self.max_model_len):

@@ -40,6 +40,43 @@ logger = init_logger(__name__)
 _CAPTURE_STATE_ANCHOR = None      # see ModelRunner.capture_model
 
 
+class DeferredOutput:
+    """Result of a step that the engine collects after it has launched the next one (run-ahead scheduling)."""
+
+    def __init__(self, runner, gen, req_ids, done, buf, S, event, logprobs_t):
+        self.runner, self.gen, self.req_ids, self.done = runner, gen, req_ids, done
+        self.buf, self.S, self.event, self.logprobs_t = buf, S, event, logprobs_t
+
+        self._result: Optional[ModelRunnerOutput] = None
+        self.prev: Optional["DeferredOutput"] = None
+
+    def get(self) -> ModelRunnerOutput:
+        """Wait for the ids, apply them to the runner's host-side token arrays (once) and return the step's
+        result.  Steps are collected in the order they ran."""
+        if self._result is not None:
+            return self._result
+        if self.prev is not None:
+            self.prev.get()
+            self.prev = None
+        r = self.runner
+        if self.event is not None:
+            self.event.synchronize()
+        ids = self.buf[:self.S].tolist()
+        r._check_comm_errors()
+        lists = [[t] if self.done[i] else [] for i, t in enumerate(ids)]
+        r._apply_sampled(self.req_ids, lists)
+        if r._pend_gen == self.gen:             # no later step took over: the host arrays are complete again
+            r._pend_of, r._pend_ids = {}, None
+        if r._deferred_open is self:
+            r._deferred_open = None
+        self._result = ModelRunnerOutput(
+            req_ids=self.req_ids, req_id_to_index={rid: i for i, rid in enumerate(self.req_ids)},
+            sampled_token_ids=lists, spec_token_ids=None, logprobs=Sampler.to_lists(self.logprobs_t),
+            prompt_logprobs_dict={}, finished_sending=None, finished_recving=None, failed_recving=None,
+            num_nans_in_logits=None)
+        return self._result
+
+
 class ModelRunner:
     def __init__(self, vllm_config: VllmConfig, device: torch.device):
         self.vllm_config = vllm_config
@@ -127,6 +164,16 @@ class ModelRunner:
         # one step uploads ~24 bytes per token plus one block-table row per sequence
         self._stage_bytes = int(Tpad * 40 + Spad * (self.max_blocks * 4 + 64) + (1 << 20))
         self.intermediate: Optional[IntermediateTensors] = None
+        # run-ahead scheduling: sampled ids of the step in flight, still on the device, and which request
+        # takes which of them as its next input token
+        self._pend_ids: Optional[torch.Tensor] = None
+        self._pend_of: dict[str, int] = {}
+        self._pend_gen = 0
+        self._pend_dst = torch.zeros(Spad, dtype=torch.int64, device=dev)
+        self._pend_src = torch.zeros(Spad, dtype=torch.int64, device=dev)
+        self._deferred_bufs = None
+        self._sample_pos: Optional[np.ndarray] = None
+        self._deferred_open: Optional[DeferredOutput] = None     # handed out, not collected yet
 
     def _stage(self, src: np.ndarray) -> torch.Tensor:
         """Host array -> a slice of a persistent pinned arena (what an asynchronous upload reads from).
@@ -575,12 +622,32 @@ class ModelRunner:
             tmd, att = self._prepare_token_parallel(so, req_ids, rows, n_sched, req_idx, tok_rows, pos)
         else:
             self._to_dev(self.input_ids, ib.token_ids[tok_rows, pos])
+            if self._pend_of:
+                self._feed_pending_tokens(req_ids, rows, cu)
             if self.uses_mrope:
                 pos = self._mrope_positions(req_ids, rows, n_sched, cu, pos)
             nd, ndt = self._upload_attention_inputs(rows, n_sched, cu, pos, slot, seq_lens)
             att = (S, T, nd, ndt, int(seq_lens.max()) if S else 0, int(n_sched.max()) if S else 0)
         logits_idx = (cu[1:] - 1).astype(np.int64)
         return req_ids, rows, n_sched, cu, S, T, logits_idx, att, tmd
+
+    def _feed_pending_tokens(self, req_ids, rows, cu) -> None:
+        """Run-ahead scheduling: requests whose newest token was sampled by the step still in flight read it
+        from that step's device result (the host copy of the token arrives later)."""
+        ib = self.input_batch
+        dst, src = [], []
+        for i, rid in enumerate(req_ids):
+            j = self._pend_of.get(rid)
+            if j is not None and ib.num_computed[rows[i]] == ib.num_tokens[rows[i]]:
+                dst.append(int(cu[i]))
+                src.append(j)
+        if not dst:
+            return
+        n = len(dst)
+        self._to_dev(self._pend_dst, np.asarray(dst, dtype=np.int64))
+        self._to_dev(self._pend_src, np.asarray(src, dtype=np.int64))
+        vals = self._pend_ids.index_select(0, self._pend_src[:n]).to(self.input_ids.dtype)
+        self.input_ids.index_copy_(0, self._pend_dst[:n], vals)
 
     def _mrope_positions(self, req_ids, rows, n_sched, cu, pos: np.ndarray) -> np.ndarray:
         """Multimodal rotary positions.  Requests with images carry three position rows for their prompt
@@ -972,7 +1039,11 @@ class ModelRunner:
                 self._last_nans = {r: int(x) for r, x in zip(req_ids, logits.isnan().sum(-1).tolist())}
             if so.grammar_bitmask is not None:
                 self._apply_grammar_bitmask(so, logits, req_ids)
+            # index of the token being sampled, from the scheduler's counters (the host-side token count lags
+            # by one under run-ahead scheduling)
+            self._sample_pos = (ib.num_computed[rows] + n_sched).astype(np.int64)
             smd = self._sampling_metadata(req_ids, rows)
+            self._sample_pos = None
             sout = self.sampler(logits, smd)
             sampled = sout.sampled_token_ids[:, 0]
             out = (sampled, sout.logprobs_tensors, None)
@@ -981,6 +1052,13 @@ class ModelRunner:
 
         if tk_plain:
             self._tknp_share_sampled(sampled_t, S)          # device to device, queued before the host sync below
+        done = (ib.num_computed[rows] + n_sched) >= ib.num_tokens[rows]
+        if so.defer_output and multi is None and tmd is None and self.drafter is None and not prompt_lp \
+                and conn is None:
+            return self._defer_output(req_ids, done, sampled_t, logprobs_t, S)
+        if self._deferred_open is not None:
+            self._deferred_open.get()        # the previous step's tokens enter the host arrays before this step's
+        self._pend_of, self._pend_ids = {}, None
         # the one host sync of the step
         if multi is not None:
             sampled_lists = multi
@@ -988,7 +1066,6 @@ class ModelRunner:
             sampled_lists = [[t] for t in sampled_t.tolist()]
         self._check_comm_errors()            # the stream is drained: a timed-out collective has reported by now
         # requests still in the middle of their prompt discard the sample
-        done = (ib.num_computed[rows] + n_sched) >= ib.num_tokens[rows]
         for i in range(len(req_ids)):
             if not done[i]:
                 sampled_lists[i] = []
@@ -1007,6 +1084,31 @@ class ModelRunner:
         if tmd is not None and not tk_plain:
             get_tknp_group().broadcast_object(result, src=0)
         return result
+
+    def _defer_output(self, req_ids, done, sampled_t, logprobs_t, S) -> "DeferredOutput":
+        """End of a step whose results the engine collects later: the ids start their way to a pinned host buffer,
+        the next step (scheduled before they arrive) takes them from ``sampled_t`` on the device."""
+        if self._deferred_bufs is None:
+            self._deferred_bufs = [torch.empty(self.max_num_reqs, dtype=torch.int64, pin_memory=self.pin)
+                                   for _ in range(3)]
+        buf = self._deferred_bufs[self._step % 3]
+        buf[:S].copy_(sampled_t, non_blocking=True)
+        ev = None
+        if self.is_gpu:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._pend_gen += 1
+        self._pend_ids = sampled_t
+        self._pend_of = {rid: i for i, rid in enumerate(req_ids) if done[i]}
+        self._step += 1
+        if self._deferred_open is not None:
+            prev = self._deferred_open
+            out = DeferredOutput(self, self._pend_gen, req_ids, done, buf, S, ev, logprobs_t)
+            out.prev = prev                  # collected first (order of the host-side appends)
+        else:
+            out = DeferredOutput(self, self._pend_gen, req_ids, done, buf, S, ev, logprobs_t)
+        self._deferred_open = out
+        return out
 
     def _check_comm_errors(self) -> None:
         if not self.is_gpu:
@@ -1062,7 +1164,9 @@ class ModelRunner:
         for rid, toks in zip(req_ids, sampled_lists):
             if not toks:
                 continue
-            st = ib.reqs[rid]
+            st = ib.reqs.get(rid)
+            if st is None:
+                continue             # finished or aborted while its step was in flight
             for tok in toks:
                 ib.append_token(st.row, tok)
                 st.output_token_ids.append(tok)
@@ -1106,7 +1210,7 @@ class ModelRunner:
             if (mp > 0).any():
                 md.min_p = dev_t(mp)
             # per-step seeds: seeded requests are reproducible (seed, position); others draw fresh entropy
-            pos = ib.num_tokens[rows].astype(np.int64)
+            pos = self._sample_pos if self._sample_pos is not None else ib.num_tokens[rows].astype(np.int64)
             fresh = self._rng.integers(0, 2**62, size=len(rows), dtype=np.int64)
             seeds = np.where(ib.has_seed[rows], ib.seed[rows] * np.int64(1000003) + pos, fresh)
             md.seeds = dev_t(seeds)
