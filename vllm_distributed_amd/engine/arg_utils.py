@@ -18,6 +18,7 @@ from dataclasses import dataclass, field, fields
 from typing import Any, Optional, Union, get_args, get_origin
 
 from .. import config as C
+from .. import envs
 from ..logger import init_logger
 
 logger = init_logger(__name__)
@@ -107,7 +108,7 @@ class EngineArgs:
     long_prefill_token_threshold: int = 0
     scheduling_policy: str = "fcfs"
     scheduler_cls: str = "vllm_distributed_amd.sched.scheduler.Scheduler"
-    async_scheduling: bool = False
+    async_scheduling: Optional[bool] = None      # None: VDA_ASYNC_SCHEDULING
     disable_chunked_mm_input: bool = False
     # lora
     enable_lora: bool = False
@@ -254,7 +255,8 @@ class EngineArgs:
             enable_chunked_prefill=chunked, max_num_partial_prefills=self.max_num_partial_prefills,
             max_long_partial_prefills=self.max_long_partial_prefills,
             long_prefill_token_threshold=self.long_prefill_token_threshold, policy=self.scheduling_policy,
-            scheduler_cls=self.scheduler_cls, async_scheduling=self.async_scheduling,
+            scheduler_cls=self.scheduler_cls, async_scheduling=(bool(envs.VDA_ASYNC_SCHEDULING) if self.async_scheduling is None
+                                                                    else self.async_scheduling),
             disable_chunked_mm_input=self.disable_chunked_mm_input)
         load = C.LoadConfig(load_format=self.load_format, download_dir=self.download_dir,
                             model_loader_extra_config=self.model_loader_extra_config,
