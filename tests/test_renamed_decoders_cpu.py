@@ -1,0 +1,192 @@
+"""Families that are the Llama (or GLM) block under other checkpoint names: a tiny transformers model is written out
+in the family's own layout (names, fused tensors, config keys) and must decode to the tokens transformers produces.
+transformers itself carries none of these architectures (they ship as remote code), so the layouts follow the
+reference's loaders: vllm/model_executor/models/{exaone,telechat2,teleflm,orion,qwen,chatglm}.py."""
+import json
+import os
+
+import pytest
+import torch
+from safetensors.torch import save_file
+
+from vllm_distributed_amd import LLM, SamplingParams
+
+PROMPTS = [[5, 17, 99, 3, 250, 11], [7] * 20, [1, 2, 3], list(range(30, 75))]
+
+
+def _llama(**kw):
+    import transformers as tf
+    torch.manual_seed(0)
+    base = dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                num_key_value_heads=1, max_position_embeddings=256, rms_norm_eps=1e-5, tie_word_embeddings=False,
+                head_dim=64)
+    base.update(kw)
+    m = tf.LlamaForCausalLM(tf.LlamaConfig(**base)).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith(".bias"):
+                p.normal_(0, 0.05)
+    return m
+
+
+def _hf_tokens(m, n=8):
+    out = []
+    with torch.no_grad():
+        for p in PROMPTS:
+            out.append(m.generate(torch.tensor([p]), max_new_tokens=n, do_sample=False, pad_token_id=0,
+                                  eos_token_id=None)[0, len(p):].tolist())
+    return out
+
+
+def _ours(path, n=8):
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4)
+    try:
+        outs = llm.generate(prompt_token_ids=PROMPTS, sampling_params=SamplingParams(temperature=0, max_tokens=n,
+                                                                                     ignore_eos=True))
+        return [list(o.outputs[0].token_ids) for o in outs]
+    finally:
+        llm.shutdown()
+
+
+def _write(tmp, name, config, tensors):
+    d = os.path.join(str(tmp), name)
+    os.makedirs(d)
+    json.dump(config, open(os.path.join(d, "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in tensors.items()}, os.path.join(d, "model.safetensors"))
+    return d
+
+
+def _layers(sd, n_layers):
+    for i in range(n_layers):
+        yield i, {k[len(f"model.layers.{i}."):]: v for k, v in sd.items() if k.startswith(f"model.layers.{i}.")}
+
+
+def test_exaone_layout(tmp_path):
+    m = _llama()
+    sd = m.state_dict()
+    t = {"transformer.wte.weight": sd["model.embed_tokens.weight"], "transformer.ln_f.weight": sd["model.norm.weight"],
+         "lm_head.weight": sd["lm_head.weight"]}
+    for i, L in _layers(sd, 2):
+        p = f"transformer.h.{i}."
+        for a, b in (("q_proj", "q_proj"), ("k_proj", "k_proj"), ("v_proj", "v_proj"), ("o_proj", "out_proj")):
+            t[p + f"attn.attention.{b}.weight"] = L[f"self_attn.{a}.weight"]
+        t[p + "ln_1.weight"], t[p + "ln_2.weight"] = L["input_layernorm.weight"], L["post_attention_layernorm.weight"]
+        t[p + "mlp.c_fc_0.weight"], t[p + "mlp.c_fc_1.weight"] = L["mlp.gate_proj.weight"], L["mlp.up_proj.weight"]
+        t[p + "mlp.c_proj.weight"] = L["mlp.down_proj.weight"]
+    cfg = dict(model_type="exaone", architectures=["ExaoneForCausalLM"], vocab_size=320, hidden_size=128,
+               intermediate_size=256, num_layers=2, num_attention_heads=2, num_key_value_heads=1, head_dim=64,
+               max_position_embeddings=256, layer_norm_epsilon=1e-5, activation_function="silu", rope_theta=10000.0,
+               tie_word_embeddings=False, torch_dtype="float32")
+    assert _ours(_write(tmp_path, "exaone", cfg, t)) == _hf_tokens(m)
+
+
+def test_telechat2_layout(tmp_path):
+    m = _llama(attention_bias=True, mlp_bias=True, num_key_value_heads=2)
+    with torch.no_grad():
+        for n, p in m.named_parameters():          # TeleChat2 has biases on the output projections only
+            if n.endswith(("q_proj.bias", "k_proj.bias", "v_proj.bias", "gate_proj.bias", "up_proj.bias")):
+                p.zero_()
+    sd = m.state_dict()
+    t = {"transformer.word_embeddings.weight": sd["model.embed_tokens.weight"],
+         "transformer.ln_f.weight": sd["model.norm.weight"], "lm_head.weight": sd["lm_head.weight"]}
+    for i, L in _layers(sd, 2):
+        p = f"transformer.h.{i}."
+        t[p + "self_attention.query.weight"] = L["self_attn.q_proj.weight"]
+        k, v = L["self_attn.k_proj.weight"].view(2, 64, 128), L["self_attn.v_proj.weight"].view(2, 64, 128)
+        t[p + "self_attention.key_value.weight"] = torch.stack([k, v], dim=1).reshape(2 * 2 * 64, 128)
+        t[p + "self_attention.dense.weight"], t[p + "self_attention.dense.bias"] = \
+            L["self_attn.o_proj.weight"], L["self_attn.o_proj.bias"]
+        for w in ("input_layernorm.weight", "post_attention_layernorm.weight", "mlp.gate_proj.weight",
+                  "mlp.up_proj.weight", "mlp.down_proj.weight", "mlp.down_proj.bias"):
+            t[p + w] = L[w]
+    cfg = dict(model_type="telechat", architectures=["TeleChat2ForCausalLM"], vocab_size=320, hidden_size=128,
+               ffn_hidden_size=256, n_layer=2, n_head=2, layer_norm_epsilon=1e-5, training_seqlen=256,
+               tie_word_embeddings=False, torch_dtype="float32")
+    assert _ours(_write(tmp_path, "telechat", cfg, t)) == _hf_tokens(m)
+
+
+def test_teleflm_mup_scaling(tmp_path):
+    m = _llama()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    cfg = dict(m.config.to_dict(), model_type="llama", architectures=["TeleFLMForCausalLM"], use_mup=True,
+               input_mult=2.5, output_mult=3.0, mup_scale_factor=4.0, torch_dtype="float32")
+    path = _write(tmp_path, "teleflm", cfg, sd)
+    with torch.no_grad():                           # the same scaling folded into the transformers model
+        m.model.embed_tokens.weight.mul_(2.5)
+        m.lm_head.weight.mul_(3.0 / 4.0)
+    assert _ours(path) == _hf_tokens(m)
+
+
+def test_orion_layernorm_blocks(tmp_path):
+    m = _llama()
+    torch.manual_seed(1)
+    for layer in m.model.layers:
+        layer.input_layernorm = torch.nn.LayerNorm(128, eps=1e-5)
+        layer.post_attention_layernorm = torch.nn.LayerNorm(128, eps=1e-5)
+    m.model.norm = torch.nn.LayerNorm(128, eps=1e-5)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "norm" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+    cfg = dict(m.config.to_dict(), model_type="orion", architectures=["OrionForCausalLM"], torch_dtype="float32")
+    assert _ours(_write(tmp_path, "orion", cfg, m.state_dict())) == _hf_tokens(m)
+
+
+def test_qwen_v1_layout(tmp_path):
+    m = _llama(attention_bias=True, num_key_value_heads=2)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("o_proj.bias"):
+                p.zero_()
+    sd = m.state_dict()
+    t = {"transformer.wte.weight": sd["model.embed_tokens.weight"], "transformer.ln_f.weight": sd["model.norm.weight"],
+         "lm_head.weight": sd["lm_head.weight"]}
+    for i, L in _layers(sd, 2):
+        p = f"transformer.h.{i}."
+        t[p + "attn.c_attn.weight"] = torch.cat([L[f"self_attn.{x}_proj.weight"] for x in "qkv"])
+        t[p + "attn.c_attn.bias"] = torch.cat([L[f"self_attn.{x}_proj.bias"] for x in "qkv"])
+        t[p + "attn.c_proj.weight"] = L["self_attn.o_proj.weight"]
+        t[p + "ln_1.weight"], t[p + "ln_2.weight"] = L["input_layernorm.weight"], L["post_attention_layernorm.weight"]
+        t[p + "mlp.w2.weight"], t[p + "mlp.w1.weight"] = L["mlp.gate_proj.weight"], L["mlp.up_proj.weight"]
+        t[p + "mlp.c_proj.weight"] = L["mlp.down_proj.weight"]
+    cfg = dict(model_type="qwen", architectures=["QWenLMHeadModel"], vocab_size=320, hidden_size=128,
+               intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, kv_channels=64, seq_length=256,
+               layer_norm_epsilon=1e-5, rotary_emb_base=10000, tie_word_embeddings=False, torch_dtype="float32")
+    assert _ours(_write(tmp_path, "qwen", cfg, t)) == _hf_tokens(m)
+
+
+@pytest.mark.parametrize("qkv_bias", [False, True])
+def test_chatglm_layout(tmp_path, qkv_bias):
+    import transformers as tf
+    torch.manual_seed(0)
+    m = tf.GlmForCausalLM(tf.GlmConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                       num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                                       head_dim=64, pad_token_id=0, attention_bias=qkv_bias)).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith(".bias"):
+                p.normal_(0, 0.05)
+    sd = m.state_dict()
+    # the original layout pads the vocabulary: 320 real rows, 384 stored
+    pad = torch.zeros(64, 128)
+    t = {"transformer.embedding.word_embeddings.weight": torch.cat([sd["model.embed_tokens.weight"], pad]),
+         "transformer.encoder.final_layernorm.weight": sd["model.norm.weight"],
+         "transformer.output_layer.weight": torch.cat([sd["lm_head.weight"], pad + 5.0]),
+         "transformer.rotary_pos_emb.inv_freq": torch.ones(16)}
+    for i, L in _layers(sd, 2):
+        p = f"transformer.encoder.layers.{i}."
+        t[p + "self_attention.query_key_value.weight"] = torch.cat([L[f"self_attn.{x}_proj.weight"] for x in "qkv"])
+        if qkv_bias:
+            t[p + "self_attention.query_key_value.bias"] = torch.cat([L[f"self_attn.{x}_proj.bias"] for x in "qkv"])
+        t[p + "self_attention.dense.weight"] = L["self_attn.o_proj.weight"]
+        t[p + "input_layernorm.weight"] = L["input_layernorm.weight"]
+        t[p + "post_attention_layernorm.weight"] = L["post_attention_layernorm.weight"]
+        t[p + "mlp.dense_h_to_4h.weight"] = L["mlp.gate_up_proj.weight"]
+        t[p + "mlp.dense_4h_to_h.weight"] = L["mlp.down_proj.weight"]
+    cfg = dict(model_type="chatglm", architectures=["ChatGLMModel"], vocab_size=320, padded_vocab_size=384,
+               hidden_size=128, ffn_hidden_size=256, num_layers=2, num_attention_heads=2, kv_channels=64,
+               multi_query_attention=True, multi_query_group_num=1, seq_length=256, layernorm_epsilon=m.config.rms_norm_eps,
+               rmsnorm=True, add_bias_linear=False, add_qkv_bias=qkv_bias, post_layer_norm=True,
+               apply_residual_connection_post_layernorm=False, original_rope=True, torch_dtype="float32")
+    # the padded head rows carry large logits: they must never be sampled
+    assert _ours(_write(tmp_path, "chatglm", cfg, t)) == _hf_tokens(m)

@@ -141,6 +141,9 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
         d = {**d, "hidden_size": d["d_model"], "num_attention_heads": d["decoder_attention_heads"],
              "num_key_value_heads": d["decoder_attention_heads"], "num_hidden_layers": d["decoder_layers"],
              "max_position_embeddings": d.get("max_target_positions", 448)}
+    if d.get("model_type") in ("exaone", "telechat", "qwen", "chatglm"):
+        from .models.renamed_decoders import normalise_config
+        d = normalise_config(d)
     if overrides:
         d.update(overrides)
     return HFConfig(d)
@@ -233,7 +236,9 @@ class ModelConfig:
             self.served_model_name = self.model
         if self.task == "auto":
             arch = (self.architectures or [""])[0]
-            generative = "CausalLM" in arch or "LMHead" in arch or "ConditionalGeneration" in arch
+            generative = "CausalLM" in arch or "LMHead" in arch or "ConditionalGeneration" in arch \
+                or arch in ("ChatGLMModel", "GritLM", "MiniCPMV", "MiniCPMO", "Ovis", "NVLM_D", "InternVLChatModel",
+                            "H2OVLChatModel", "SkyworkR1VChatModel", "UltravoxModel", "Qwen2_5OmniModel")
             self.task = ("generate" if generative else "classify" if "SequenceClassification" in arch
                          else "embed" if arch.endswith(("Model", "ForMaskedLM")) else "generate")
 

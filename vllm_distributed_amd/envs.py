@@ -79,7 +79,8 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_DECODE_GEMM_MIN_M": (int, 33),
     "VDA_DECODE_GEMM_MAX_M": (int, 0),           # 0 = never (default: the tuned library GEMMs are faster, see docs/kernels.md)
     "VDA_DECODE_GEMM_WS_MB": (int, 128),         # fp32 split-K workspace per device
-    "VDA_ASYNC_SCHEDULING": (int, 0),            # default of --async-scheduling when the flag is not given
+    "VDA_ASYNC_SCHEDULING": (int, 1),            # default of --async-scheduling when the flag is not given (the
+                                                 # config turns it off again where it cannot apply)
     "VDA_REHEARSE_ON_ONE_GPU": (_bool, False),   # all ranks share cuda:0: gloo groups + peer-memory all-reduce (tests)
     "VDA_GEMM_SELECTIONS": (str, None),          # CSV of library-GEMM algorithm choices; "off" disables
     "VDA_DISABLE_SKINNY_GEMM": (_bool, False),

@@ -25,6 +25,14 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MiMoForCausalLM": ("more_decoders", "MiMoForCausalLM"),
     "MiniCPMForCausalLM": ("more_decoders", "MiniCPMForCausalLM"),
     "PersimmonForCausalLM": ("more_decoders", "PersimmonForCausalLM"),
+    "ExaoneForCausalLM": ("renamed_decoders", "ExaoneForCausalLM"),
+    "TeleChat2ForCausalLM": ("renamed_decoders", "TeleChat2ForCausalLM"),
+    "TeleFLMForCausalLM": ("renamed_decoders", "TeleFLMForCausalLM"),
+    "OrionForCausalLM": ("renamed_decoders", "OrionForCausalLM"),
+    "QWenLMHeadModel": ("renamed_decoders", "QWenLMHeadModel"),
+    "ChatGLMModel": ("renamed_decoders", "ChatGLMModel"),
+    "ChatGLMForConditionalGeneration": ("renamed_decoders", "ChatGLMForConditionalGeneration"),
+    "GritLM": ("renamed_decoders", "GritLM"),
     "Qwen2MoeForCausalLM": ("mixtral", "Qwen2MoeForCausalLM"),
     "Qwen3MoeForCausalLM": ("mixtral", "Qwen3MoeForCausalLM"),
     "PhiMoEForCausalLM": ("mixtral", "PhiMoEForCausalLM"),
