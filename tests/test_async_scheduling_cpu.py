@@ -50,7 +50,7 @@ def _run(path, **kw):
 @pytest.mark.parametrize("kind", ["llama", "mamba2"])
 def test_run_ahead_matches_the_plain_engine(tmp_path, kind):
     path, _ = _save_tiny(str(tmp_path), kind)
-    ref = _run(path, max_num_seqs=6)
+    ref = _run(path, max_num_seqs=6, async_scheduling=False)
     got = _run(path, max_num_seqs=6, async_scheduling=True)
     assert got == ref
 
@@ -58,7 +58,7 @@ def test_run_ahead_matches_the_plain_engine(tmp_path, kind):
 def test_run_ahead_under_preemption(tmp_path):
     """A KV cache too small for the batch: requests are preempted and resumed while steps are in flight."""
     path, _ = _save_tiny(str(tmp_path), "llama")
-    ref = _run(path, max_num_seqs=8, num_gpu_blocks_override=14)
+    ref = _run(path, max_num_seqs=8, num_gpu_blocks_override=14, async_scheduling=False)
     got = _run(path, max_num_seqs=8, num_gpu_blocks_override=14, async_scheduling=True)
     assert got == ref
 

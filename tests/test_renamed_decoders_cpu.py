@@ -190,3 +190,36 @@ def test_chatglm_layout(tmp_path, qkv_bias):
                apply_residual_connection_post_layernorm=False, original_rope=True, torch_dtype="float32")
     # the padded head rows carry large logits: they must never be sampled
     assert _ours(_write(tmp_path, "chatglm", cfg, t)) == _hf_tokens(m)
+
+
+def test_minicpm3_latent_attention_and_scaling(tmp_path):
+    """MiniCPM3 = DeepSeek-V2's latent attention with half-split rotary pairs + MiniCPM's scaled branches.  A tiny
+    transformers DeepSeek-V2 (dense) is turned into the equivalent MiniCPM3 checkpoint: rotary rows de-interleaved,
+    and the branch / embedding / logit scales divided out of the weights that the MiniCPM3 config then re-applies."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.DeepseekV2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                              num_attention_heads=4, num_key_value_heads=4, n_routed_experts=4,
+                              first_k_dense_replace=2, moe_intermediate_size=64, kv_lora_rank=32, q_lora_rank=48, qk_rope_head_dim=16,
+                              qk_nope_head_dim=32, v_head_dim=32, max_position_embeddings=256, tie_word_embeddings=False)
+    m = tf.DeepseekV2ForCausalLM(cfg).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    H, nope, rope, R = 4, 32, 16, 32
+    perm = torch.cat([torch.arange(0, rope, 2), torch.arange(1, rope, 2)])
+    scale_emb, scale_depth, base = 4.0, 2.8, 32
+    branch = scale_depth / (2 ** 0.5)
+    for i in range(2):
+        p = f"model.layers.{i}.self_attn."
+        w = sd[p + "q_b_proj.weight"].view(H, nope + rope, -1)
+        w[:, nope:] = w[:, nope:][:, perm]
+        sd[p + "q_b_proj.weight"] = w.reshape(H * (nope + rope), -1)
+        w = sd[p + "kv_a_proj_with_mqa.weight"]
+        w[R:] = w[R:][perm]
+        sd[p + "o_proj.weight"] /= branch
+        sd[f"model.layers.{i}.mlp.down_proj.weight"] /= branch
+    sd["model.embed_tokens.weight"] /= scale_emb
+    sd["lm_head.weight"] /= base / 128
+    out = dict({k: v for k, v in cfg.to_dict().items() if k not in ("n_routed_experts", "n_shared_experts")},
+               model_type="minicpm3", architectures=["MiniCPM3ForCausalLM"], scale_emb=scale_emb,
+               scale_depth=scale_depth, dim_model_base=base, torch_dtype="float32")
+    assert _ours(_write(tmp_path, "minicpm3", out, sd)) == _hf_tokens(m)

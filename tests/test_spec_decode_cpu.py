@@ -107,3 +107,99 @@ def test_rejection_sampler_greedy_and_distribution():
     assert torch.allclose(freq, p, atol=0.03), freq
     acc = sum(len(o) == 2 for o in outs) / N
     assert abs(acc - 0.3) < 0.03          # P(accept draft token 1) = p(1) for a one-hot draft
+
+
+def _proposals(path, **kw):
+    """(tokens, number of drafted tokens the engine verified)."""
+    llm = LLM(model=path, **KW, **kw)
+    n = [0]
+    sch = llm.llm_engine.engine_core.engine_core.scheduler
+    orig = sch.update_from_output
+
+    def spy(so, mro):
+        n[0] += sum(len(v) for v in so.scheduled_spec_decode_tokens.values())
+        return orig(so, mro)
+    sch.update_from_output = spy
+    outs = llm.generate(prompt_token_ids=PROMPTS, sampling_params=SP)
+    llm.shutdown()
+    return [list(o.outputs[0].token_ids) for o in outs], n[0]
+
+
+def test_mlp_speculator_same_tokens(tmp_path):
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    ref, _ = _gen(path)
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    H, V, inner, k = cfg["hidden_size"], cfg["vocab_size"], 64, 3
+    d = os.path.join(str(tmp_path), "speculator")
+    os.makedirs(d)
+    g = torch.Generator().manual_seed(1)
+    w = {}
+    for i in range(k):
+        w[f"speculator.emb.{i}.weight"] = torch.randn(V, inner, generator=g) * 0.05
+        w[f"speculator.proj.{i}.weight"] = torch.randn(inner, H if i == 0 else inner, generator=g) * 0.05
+        w[f"speculator.head.{i}.weight"] = torch.randn(V, inner, generator=g) * 0.05
+        w[f"speculator.ln.{i}.weight"], w[f"speculator.ln.{i}.bias"] = torch.ones(inner), torch.zeros(inner)
+    json.dump({"architectures": ["MLPSpeculatorPreTrainedModel"], "model_type": "mlp_speculator", "vocab_size": V,
+               "emb_dim": H, "inner_dim": inner, "n_predict": k, "scale_input": True, "tie_weights": False,
+               "hidden_size": H}, open(os.path.join(d, "config.json"), "w"))
+    save_file(w, os.path.join(d, "model.safetensors"))
+    got, n = _proposals(path, speculative_config={"method": "mlp_speculator", "model": d, "num_speculative_tokens": k})
+    assert got == ref and n > 0
+
+
+def test_mimo_multi_token_prediction_layer_drafts(tmp_path):
+    """A MiMo checkpoint (Qwen2 weights + ``model.mtp_layers.0``) drafts with its own prediction layer."""
+    from safetensors.torch import load_file
+    path, _ = _save_tiny(str(tmp_path), "qwen2")
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    hd = H // nh
+    w = load_file(os.path.join(path, "model.safetensors"))
+    g = torch.Generator().manual_seed(2)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.05      # noqa: E731
+    p = "model.mtp_layers.0."
+    w.update({p + "token_layernorm.weight": torch.ones(H), p + "hidden_layernorm.weight": torch.ones(H),
+              p + "input_proj.weight": r(H, 2 * H), p + "final_layernorm.weight": torch.ones(H),
+              p + "input_layernorm.weight": torch.ones(H), p + "post_attention_layernorm.weight": torch.ones(H),
+              p + "self_attn.q_proj.weight": r(nh * hd, H), p + "self_attn.q_proj.bias": r(nh * hd),
+              p + "self_attn.k_proj.weight": r(nkv * hd, H), p + "self_attn.k_proj.bias": r(nkv * hd),
+              p + "self_attn.v_proj.weight": r(nkv * hd, H), p + "self_attn.v_proj.bias": r(nkv * hd),
+              p + "self_attn.o_proj.weight": r(H, nh * hd), p + "mlp.gate_proj.weight": r(I, H),
+              p + "mlp.up_proj.weight": r(I, H), p + "mlp.down_proj.weight": r(H, I)})
+    d = os.path.join(str(tmp_path), "mimo")
+    os.makedirs(d)
+    cfg.update(architectures=["MiMoForCausalLM"], model_type="mimo", num_nextn_predict_layers=1)
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    save_file(w, os.path.join(d, "model.safetensors"))
+    ref, _ = _gen(d)
+    got, n = _proposals(d, speculative_config={"method": "mtp", "num_speculative_tokens": 2})
+    assert got == ref and n > 0
+
+
+def test_deepseek_v3_multi_token_prediction_layer_drafts(tmp_path):
+    """``model.layers.<num_hidden_layers>`` of a DeepSeek-V3 checkpoint (enorm / hnorm / eh_proj / shared_head +
+    a decoder layer with experts) drafts for its own model."""
+    from safetensors.torch import load_file
+    path, _ = _save_tiny(str(tmp_path), "deepseek_v3")
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    w = load_file(os.path.join(path, "model.safetensors"))
+    H, V, L = cfg["hidden_size"], cfg["vocab_size"], cfg["num_hidden_layers"]
+    g = torch.Generator().manual_seed(3)
+    src, dst = f"model.layers.{L - 1}.", f"model.layers.{L}."
+    extra = {dst + k[len(src):]: v.clone() + torch.randn(v.shape, generator=g) * 0.01
+             for k, v in w.items() if k.startswith(src)}
+    extra.update({dst + "enorm.weight": torch.ones(H), dst + "hnorm.weight": torch.ones(H),
+                  dst + "eh_proj.weight": torch.randn(H, 2 * H, generator=g) * 0.05,
+                  dst + "shared_head.norm.weight": torch.ones(H),
+                  dst + "shared_head.head.weight": torch.randn(V, H, generator=g) * 0.05,
+                  dst + "embed_tokens.weight": w["model.embed_tokens.weight"].clone()})
+    w.update(extra)
+    d = os.path.join(str(tmp_path), "dsv3_mtp")
+    os.makedirs(d)
+    cfg.update(num_nextn_predict_layers=1)
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    save_file(w, os.path.join(d, "model.safetensors"))
+    ref, _ = _gen(d)
+    got, n = _proposals(d, speculative_config={"method": "mtp", "num_speculative_tokens": 2})
+    assert got == ref and n > 0

@@ -657,7 +657,8 @@ class SpeculativeConfig:
             return
         if self.method is None:
             self.method = "ngram" if self.model in (None, "ngram", "[ngram]") else "eagle"
-        if self.method not in ("ngram", "eagle", "eagle3", "medusa", "draft_model"):
+        if self.method not in ("ngram", "eagle", "eagle3", "medusa", "draft_model", "mtp", "deepseek_mtp", "mimo_mtp",
+                               "mlp_speculator"):
             raise ValueError(f"unknown speculative method {self.method!r}")
         if self.num_speculative_tokens < 1:
             raise ValueError("num_speculative_tokens must be >= 1")
@@ -668,7 +669,7 @@ class SpeculativeConfig:
                 self.prompt_lookup_min = min(2, self.prompt_lookup_max)
             if self.prompt_lookup_min > self.prompt_lookup_max or self.prompt_lookup_min < 1:
                 raise ValueError("need 1 <= prompt_lookup_min <= prompt_lookup_max")
-        elif self.model is None:
+        elif self.model is None and self.method not in ("mtp", "deepseek_mtp", "mimo_mtp"):
             raise ValueError(f"method {self.method} needs a draft model path")
 
     @property
@@ -676,7 +677,7 @@ class SpeculativeConfig:
         return self.method is not None
 
     def use_eagle(self) -> bool:
-        return self.method in ("eagle", "eagle3")
+        return self.method in ("eagle", "eagle3", "mtp", "deepseek_mtp", "mimo_mtp")
 
 
 @dataclass
@@ -890,6 +891,9 @@ class VllmConfig:
             self.speculative_config = None
         if self.speculative_config is not None:
             sc.num_lookahead_slots = self.speculative_config.num_speculative_tokens
+            if self.speculative_config.model is None and self.speculative_config.method in ("mtp", "deepseek_mtp",
+                                                                                            "mimo_mtp"):
+                self.speculative_config.model = mc.model       # the prediction layers ship inside the target
         if self.device_config.device == "cpu" or mc.enforce_eager:
             self.compilation_config.level = 0
         if pc.token_parallel_size > 1:

@@ -78,8 +78,9 @@ class DeepseekAttention(nn.Module):
             if rs.get("mscale_all_dim"):
                 m = yarn_mscale(factor, float(rs["mscale_all_dim"]))
                 scale = scale * m * m
-        # the rotary pairs are interleaved (x0,x1),(x2,x3),... in these checkpoints
-        self.rotary_emb = get_rope(self.rope_dim, self.rope_dim, vllm_config.model_config.max_model_len, theta, False,
+        # the rotary pairs are interleaved (x0,x1),(x2,x3),... in DeepSeek checkpoints, split in halves in MiniCPM3
+        neox = getattr(config, "model_type", "") == "minicpm3"
+        self.rotary_emb = get_rope(self.rope_dim, self.rope_dim, vllm_config.model_config.max_model_len, theta, neox,
                                    rope_cfg)
         # Latent cache + absorbed projections when the kernel is built for these sizes and kv_b_proj keeps
         # 16-bit weights (its two halves become W_UK and W_UV); expanded, padded heads otherwise.

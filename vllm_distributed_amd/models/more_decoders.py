@@ -337,6 +337,44 @@ class MiniCPMForCausalLM(LlamaForCausalLM):
         return base / config.hidden_size if base else 1.0
 
 
+# ---- MiniCPM3 -----------------------------------------------------------------------------------------
+class MiniCPM3DecoderLayer(nn.Module):
+    """MiniCPM's scaled residual branches around multi-head latent attention (the DeepSeek-V2 attention with
+    half-split rotary pairs) and a dense gated MLP.  Reference: vllm/model_executor/models/minicpm3.py."""
+    make_norm = classmethod(lambda cls, config: RMSNorm(config.hidden_size, getattr(config, "rms_norm_eps", 1e-6)))
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = ""):
+        super().__init__()
+        from .deepseek import DeepseekAttention
+        from .llama import LlamaMLP
+        self.self_attn = DeepseekAttention(config, vllm_config, quant_config, f"{prefix}.self_attn")
+        self.mlp = LlamaMLP(config.hidden_size, config.intermediate_size, False, quant_config, f"{prefix}.mlp")
+        self.input_layernorm = self.make_norm(config)
+        self.post_attention_layernorm = self.make_norm(config)
+        self.branch_scale = float(getattr(config, "scale_depth", 1.0)) / math.sqrt(config.num_hidden_layers)
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states) * self.branch_scale
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.mlp(hidden_states) * self.branch_scale, residual
+
+
+class MiniCPM3Model(MiniCPMModel):
+    layer_cls = MiniCPM3DecoderLayer
+
+
+class MiniCPM3ForCausalLM(MiniCPMForCausalLM):
+    model_cls = MiniCPM3Model
+    stacked_params_mapping = [(".gate_up_proj", ".gate_proj", 0), (".gate_up_proj", ".up_proj", 1)]
+    packed_modules_mapping = {"gate_up_proj": ["gate_proj", "up_proj"]}
+    supports_lora = False
+
+
 # ---- Persimmon ----------------------------------------------------------------------------------------
 class PersimmonAttention(nn.Module):
     def __init__(self, config, vllm_config, quant_config=None, prefix: str = ""):

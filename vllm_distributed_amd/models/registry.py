@@ -25,6 +25,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MiMoForCausalLM": ("more_decoders", "MiMoForCausalLM"),
     "MiniCPMForCausalLM": ("more_decoders", "MiniCPMForCausalLM"),
     "PersimmonForCausalLM": ("more_decoders", "PersimmonForCausalLM"),
+    "MiniCPM3ForCausalLM": ("more_decoders", "MiniCPM3ForCausalLM"),
     "ExaoneForCausalLM": ("renamed_decoders", "ExaoneForCausalLM"),
     "TeleChat2ForCausalLM": ("renamed_decoders", "TeleChat2ForCausalLM"),
     "TeleFLMForCausalLM": ("renamed_decoders", "TeleFLMForCausalLM"),
@@ -118,6 +119,10 @@ _MODELS: dict[str, tuple[str, str]] = {
     "EagleLlamaForCausalLM": ("eagle", "EagleLlamaForCausalLM"),
     "LlamaForCausalLMEagle": ("eagle", "EagleLlamaForCausalLM"),
     "MedusaModel": ("eagle", "MedusaModel"),
+    "EAGLEModel": ("eagle", "EagleLlamaForCausalLM"),
+    "DeepSeekMTPModel": ("mtp", "DeepSeekMTPModel"),
+    "MiMoMTPModel": ("mtp", "MiMoMTPModel"),
+    "MLPSpeculatorPreTrainedModel": ("mtp", "MLPSpeculatorPreTrainedModel"),
 }
 _CUSTOM: dict[str, Union[str, type]] = {}
 

@@ -71,7 +71,11 @@ def _load_draft(vllm_config: VllmConfig, runner, archs_default: str):
     hf = load_hf_config(sc.model)
     cfg.model_config.hf_config = hf
     archs = list(getattr(hf, "architectures", None) or [archs_default])
-    if archs_default == "EagleLlamaForCausalLM" and not any("Eagle" in a for a in archs):
+    # checkpoints that carry their own multi-token-prediction layers draft with those
+    mtp = {"DeepseekV3ForCausalLM": "DeepSeekMTPModel", "MiMoForCausalLM": "MiMoMTPModel"}
+    if archs and archs[0] in mtp and int(getattr(hf, "num_nextn_predict_layers", 0) or 0) > 0:
+        archs = [mtp[archs[0]]]
+    elif archs_default == "EagleLlamaForCausalLM" and not any("Eagle" in a or "MTP" in a for a in archs):
         archs = [archs_default]
     hf.architectures = archs
     cfg.model_config.quantization = None
@@ -100,6 +104,32 @@ class MedusaProposer:
         return [toks[i] if (sampled_lists[i] and lens[i] + self.k < self.max_model_len) else [] for i in range(S)]
 
 
+class MLPSpeculatorProposer:
+    """Stage-wise MLP speculator on the target's last hidden state and the token just sampled."""
+
+    def __init__(self, vllm_config: VllmConfig, runner):
+        self.k = vllm_config.speculative_config.num_speculative_tokens
+        self.model, _ = _load_draft(vllm_config, runner, "MLPSpeculatorPreTrainedModel")
+        self.max_model_len = vllm_config.model_config.max_model_len
+
+    @torch.inference_mode()
+    def propose(self, runner, req_ids, rows, sampled_lists, hidden, cu, n_sched=None, so=None) -> list[list[int]]:
+        S = len(req_ids)
+        drafts = [len(so.scheduled_spec_decode_tokens.get(r, ())) for r in req_ids]
+        v = accepted_bounds(n_sched, drafts, sampled_lists)
+        want = [i for i in range(S) if sampled_lists[i]
+                and runner.input_batch.num_tokens[rows[i]] + self.k < self.max_model_len]
+        out: list[list[int]] = [[] for _ in range(S)]
+        if not want:
+            return out
+        idx = torch.from_numpy((cu[:-1].astype(np.int64) + v - 1)[want]).to(hidden.device)
+        last = torch.tensor([sampled_lists[i][-1] for i in want], dtype=torch.int64, device=hidden.device)
+        toks = self.model.propose(last, hidden.index_select(0, idx), self.k).tolist()
+        for n, i in enumerate(want):
+            out[i] = toks[n]
+        return out
+
+
 class EagleProposer:
     """One-layer draft transformer fed with the target's hidden states (EAGLE).  The draft layer
     keeps its own KV cache in the same blocks as the target (the scheduler reserves k look-ahead
@@ -116,8 +146,8 @@ class EagleProposer:
             self.model.set_shared(target.model.embed_tokens, target.lm_head, target.logits_processor)
 
     def attention_layers(self) -> dict:
-        from ..layers.attention import Attention
-        return {f"draft.{n}": m for n, m in self.model.named_modules() if isinstance(m, Attention)}
+        from ..layers.attention import Attention, MLAAttention
+        return {f"draft.{n}": m for n, m in self.model.named_modules() if isinstance(m, (Attention, MLAAttention))}
 
     def _run(self, runner, ids: np.ndarray, hidden: torch.Tensor, rows, n_q: np.ndarray, start: np.ndarray,
              decode: bool) -> torch.Tensor:
@@ -198,6 +228,8 @@ def make_proposer(vllm_config: VllmConfig, runner):
         return NgramProposer(vllm_config)
     if m == "medusa":
         return MedusaProposer(vllm_config, runner)
-    if m in ("eagle", "eagle3", "draft_model"):
+    if m == "mlp_speculator":
+        return MLPSpeculatorProposer(vllm_config, runner)
+    if m in ("eagle", "eagle3", "draft_model", "mtp", "deepseek_mtp", "mimo_mtp"):
         return EagleProposer(vllm_config, runner)
     raise ValueError(f"unknown speculative method {m!r}")
