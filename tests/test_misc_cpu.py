@@ -189,3 +189,42 @@ def test_layerwise_profiler_attributes_time_to_the_module_tree(tmp_path):
     res.print_model_table(max_depth=3, file=buf)
     res.print_summary_table(file=buf)
     assert "self_attn" in buf.getvalue() and "module class" in buf.getvalue()
+
+
+def test_streamed_safetensors_loader(tmp_path):
+    """The native range reader returns every tensor of a multi-file checkpoint bit for bit (windows smaller than the
+    checkpoint, tensors larger than a read piece, odd dtypes), and an engine loaded through it decodes like one
+    loaded the ordinary way."""
+    import torch
+    from safetensors.torch import save_file
+
+    from tests.test_e2e_cpu import _save_tiny
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.models.loader import streamed_safetensors_iterator
+    g = torch.Generator().manual_seed(0)
+    a = {"big": torch.randn(3000, 3001, generator=g), "half": torch.randn(17, 5, generator=g).half(),
+         "bf": torch.randn(129, generator=g).bfloat16(), "i8": torch.randint(-100, 100, (7, 9), dtype=torch.int8),
+         "flag": torch.tensor([True, False, True]), "scalar": torch.tensor(3.5)}
+    b = {"f8": torch.randn(64, 32, generator=g).to(torch.float8_e4m3fn), "idx": torch.arange(1000, dtype=torch.int64),
+         "empty": torch.zeros(0, 4)}
+    save_file(a, str(tmp_path / "a.safetensors"))
+    save_file(b, str(tmp_path / "b.safetensors"))
+    got = {}
+    for name, t in streamed_safetensors_iterator([str(tmp_path / "a.safetensors"), str(tmp_path / "b.safetensors")],
+                                                 concurrency=5, window_bytes=1 << 20):
+        got[name] = t.clone()
+    want = {**a, **b}
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape
+        assert got[k].reshape(-1).view(torch.uint8).tolist() == v.reshape(-1).view(torch.uint8).tolist() \
+            if v.numel() < 10000 else torch.equal(got[k], v), k
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    sp = SamplingParams(temperature=0, max_tokens=6)
+    kw = dict(skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=64, max_num_seqs=2)
+    outs = []
+    for fmt in ("auto", "fastsafetensors", "runai_streamer"):
+        llm = LLM(model=path, load_format=fmt, model_loader_extra_config={"concurrency": 3}, **kw)
+        outs.append(list(llm.generate(prompt_token_ids=[[5, 6, 7, 8]], sampling_params=sp)[0].outputs[0].token_ids))
+        llm.shutdown()
+    assert outs[0] == outs[1] == outs[2]

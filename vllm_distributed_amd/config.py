@@ -429,7 +429,8 @@ class CacheConfig:
 
 @dataclass
 class LoadConfig:
-    #: auto | safetensors | pt | dummy | sharded_state | npcache
+    #: auto | safetensors | pt | dummy | sharded_state | npcache | fastsafetensors | runai_streamer (the last two:
+    #: the native multi-threaded range reader; extra config "concurrency", "memory_limit")
     load_format: str = "auto"
     #: Directory for downloaded weights (unused: no hub access).
     download_dir: Optional[str] = None
@@ -444,7 +445,8 @@ class LoadConfig:
 
     def __post_init__(self):
         self.load_format = self.load_format.lower()
-        ok = ("auto", "safetensors", "pt", "bin", "dummy", "sharded_state", "npcache")
+        ok = ("auto", "safetensors", "pt", "bin", "dummy", "sharded_state", "npcache", "fastsafetensors",
+              "runai_streamer")
         if self.load_format not in ok:
             raise ValueError(f"load_format must be one of {ok}")
         if self.ignore_patterns is None:

@@ -100,6 +100,81 @@ def safetensors_iterator(files: list[str]) -> Iterator[tuple[str, torch.Tensor]]
                 yield name, f.get_tensor(name)
 
 
+_ST_DTYPES = {"F64": torch.float64, "F32": torch.float32, "F16": torch.float16, "BF16": torch.bfloat16,
+              "I64": torch.int64, "I32": torch.int32, "I16": torch.int16, "I8": torch.int8, "U8": torch.uint8,
+              "BOOL": torch.bool, "F8_E4M3": torch.float8_e4m3fn, "F8_E5M2": torch.float8_e5m2}
+
+
+def read_safetensors_header(path: str) -> tuple[dict, int]:
+    """(tensor table {name: {dtype, shape, data_offsets}}, byte offset of the data section)."""
+    with open(path, "rb") as f:
+        n = int.from_bytes(f.read(8), "little")
+        if n <= 0 or n > 1 << 30:
+            raise ValueError(f"{path}: not a safetensors file")
+        table = json.loads(f.read(n))
+    table.pop("__metadata__", None)
+    return table, 8 + n
+
+
+def streamed_safetensors_iterator(files: list[str], concurrency: int = 16, window_bytes: int = 1 << 30,
+                                  pin: bool = False) -> Iterator[tuple[str, torch.Tensor]]:
+    """Tensors of safetensors files read by the native range reader (runtime/csrc/weight_reader.cpp): a window of
+    tensors at a time, by ``concurrency`` threads, into one of two (pinned) host buffers, the next window being read
+    while the caller consumes this one.  A yielded tensor stays valid until the caller has taken every tensor of
+    the following window.  Role of the reference's fastsafetensors / Run:ai streamer loaders
+    (vllm/model_executor/model_loader/weight_utils.py:480-560, runai_streamer_loader.py)."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    from ..runtime.shm_ring import host_library
+    lib = host_library()
+    lib.vda_read_ranges.restype = ctypes.c_int
+    lib.vda_read_ranges.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_int]
+    windows: list[tuple[str, list]] = []             # (file, [(name, dtype, shape, file offset, nbytes, window offset)])
+    for path in files:
+        table, base = read_safetensors_header(path)
+        items = sorted(table.items(), key=lambda kv: kv[1]["data_offsets"][0])
+        cur, used = [], 0
+        for name, meta in items:
+            lo, hi = meta["data_offsets"]
+            if meta["dtype"] not in _ST_DTYPES:
+                raise ValueError(f"{path}: tensor {name} has unsupported dtype {meta['dtype']}")
+            nb = hi - lo
+            off = (used + 63) // 64 * 64
+            if cur and off + nb > window_bytes:
+                windows.append((path, cur))
+                cur, off = [], 0
+            cur.append((name, _ST_DTYPES[meta["dtype"]], meta["shape"], base + lo, nb, off))
+            used = off + nb
+        if cur:
+            windows.append((path, cur))
+    if not windows:
+        return
+    cap = max(max(it[5] + it[4] for it in w) for _, w in windows)
+    bufs = [torch.empty(max(cap, 64), dtype=torch.uint8, pin_memory=pin) for _ in range(min(2, len(windows)))]
+
+    def fill(k: int):
+        path, items = windows[k]
+        buf = bufs[k % len(bufs)]
+        n = len(items)
+        offs = (ctypes.c_uint64 * n)(*[it[3] for it in items])
+        sizes = (ctypes.c_uint64 * n)(*[it[4] for it in items])
+        dsts = (ctypes.c_void_p * n)(*[buf.data_ptr() + it[5] for it in items])
+        rc = lib.vda_read_ranges(path.encode(), n, offs, sizes, dsts, int(concurrency))
+        if rc != 0:
+            raise OSError(-rc, f"reading {path}: {os.strerror(-rc)}")
+        return buf
+
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="weights") as pool:
+        fut = pool.submit(fill, 0)
+        for k, (_, items) in enumerate(windows):
+            buf = fut.result()
+            if k + 1 < len(windows):
+                fut = pool.submit(fill, k + 1)
+            for name, dtype, shape, _, nb, off in items:
+                yield name, buf[off:off + nb].view(dtype).view(shape)
+
+
 def pt_iterator(files: list[str]) -> Iterator[tuple[str, torch.Tensor]]:
     for path in files:
         state = torch.load(path, map_location="cpu", weights_only=True)
@@ -158,7 +233,14 @@ class DefaultModelLoader(BaseModelLoader):
         if folder.endswith(".gguf") and os.path.isfile(folder):
             from .gguf import gguf_weights_iterator
             return gguf_weights_iterator(folder, vllm_config.model_config.dtype)
-        files, is_st = find_weight_files(folder, self.load_config.load_format, self.load_config.ignore_patterns)
+        fmt = self.load_config.load_format
+        streamed = fmt in ("fastsafetensors", "runai_streamer")
+        files, is_st = find_weight_files(folder, "safetensors" if streamed else fmt, self.load_config.ignore_patterns)
+        if streamed:
+            xc = self.load_config.model_loader_extra_config or {}
+            return streamed_safetensors_iterator(
+                files, int(xc.get("concurrency", 16)), int(xc.get("memory_limit", 1 << 30)),
+                pin=vllm_config.device_config.device != "cpu")
         return safetensors_iterator(files) if is_st else pt_iterator(files)
 
     def load_weights(self, model: nn.Module, vllm_config: VllmConfig) -> None:
