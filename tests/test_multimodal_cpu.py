@@ -338,3 +338,61 @@ def test_whisper_matches_hf(tmp_path):
     for o, ref in zip(outs, refs):
         assert list(o.outputs[0].token_ids) == ref
     assert list(outs2[0].outputs[0].token_ids) == refs[2] and list(outs2[1].outputs[0].token_ids) == refs[0]
+
+
+@pytest.mark.parametrize("family", ["next", "onevision"])
+def test_llava_next_and_onevision_match_hf(tmp_path, family):
+    """Any-resolution images: tiles + base image through the tower, the tile map unpadded (and, for OneVision, capped)
+    with a newline vector per row.  Images of three aspect ratios, so that padding is cut from rows and from columns;
+    the processor's own tiles are fed to transformers as well (its image processor needs torchvision)."""
+    import transformers as tf
+    from vllm_distributed_amd.models.llava_next import AnyResImageProcessor, anyres_num_tokens
+    torch.manual_seed(0)
+    pins = [[28, 28], [28, 56], [56, 28], [56, 56], [28, 84]]
+    tc = tf.LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, head_dim=64)
+    if family == "next":
+        vc = tf.CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                                 image_size=28, patch_size=7, projection_dim=64)
+        cfg = tf.LlavaNextConfig(vision_config=vc, text_config=tc, image_token_index=300, vision_feature_layer=-2,
+                                 vision_feature_select_strategy="default", image_grid_pinpoints=pins)
+        hf = tf.LlavaNextForConditionalGeneration(cfg).float().eval()
+        max_tiles = 0
+    else:
+        vc = tf.SiglipVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                                   image_size=28, patch_size=7)
+        cfg = tf.LlavaOnevisionConfig(vision_config=vc, text_config=tc, image_token_index=300, vision_feature_layer=-1,
+                                      vision_feature_select_strategy="full", image_grid_pinpoints=pins,
+                                      vision_aspect_ratio="anyres_max_2")
+        hf = tf.LlavaOnevisionForConditionalGeneration(cfg).float().eval()
+        max_tiles = 2
+    with torch.no_grad():
+        hf.model.image_newline.normal_(0, 0.5)
+    path = os.path.join(tmp_path, family)
+    hf.save_pretrained(path, safe_serialization=True)
+    rng = np.random.default_rng(1)
+    imgs = [(rng.random(s + (3,)) * 255).astype(np.uint8) for s in ((40, 90), (100, 35), (50, 52))]
+    prompts = [[5, 17, 300, 99, 3], [300, 7, 8, 9, 10, 11, 12], [4, 300, 6]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=8,
+              max_num_batched_tokens=128)
+    reqs = [{"prompt_token_ids": p, "multi_modal_data": {"image": im}} for p, im in zip(prompts, imgs)]
+    sp = SamplingParams(temperature=0, max_tokens=6, ignore_eos=True)
+    outs = llm.generate(reqs, sp)
+    llm.shutdown()
+    proc = AnyResImageProcessor(300, 28, 7, pins, (0.5,) * 3, (0.5,) * 3, max_tiles) if family == "onevision" else None
+    if proc is None:
+        from vllm_distributed_amd.multimodal import CLIP_MEAN, CLIP_STD
+        proc = AnyResImageProcessor(300, 28, 7, pins, CLIP_MEAN, CLIP_STD, 0)
+    lens = set()
+    for p, im, o in zip(prompts, imgs, outs):
+        tiles, size = proc.tiles(im)
+        n_img = anyres_num_tokens((int(size[0]), int(size[1])), pins, 28, 7, max_tiles)
+        lens.add(n_img)
+        ids = []
+        for t in p:
+            ids.extend([300] * n_img if t == 300 else [t])
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=tiles[None], image_sizes=size[None],
+                              max_new_tokens=6, do_sample=False, pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, (family, im.shape)
+    assert len(lens) == 3                       # three different token counts: the geometry was really exercised

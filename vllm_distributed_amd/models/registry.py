@@ -118,6 +118,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "InternLM2ForRewardModel": ("pooling", "InternLM2ForRewardModel"),
     "EagleLlamaForCausalLM": ("eagle", "EagleLlamaForCausalLM"),
     "LlamaForCausalLMEagle": ("eagle", "EagleLlamaForCausalLM"),
+    "LlavaNextForConditionalGeneration": ("llava_next", "LlavaNextForConditionalGeneration"),
+    "LlavaOnevisionForConditionalGeneration": ("llava_next", "LlavaOnevisionForConditionalGeneration"),
     "MedusaModel": ("eagle", "MedusaModel"),
     "EAGLEModel": ("eagle", "EagleLlamaForCausalLM"),
     "DeepSeekMTPModel": ("mtp", "DeepSeekMTPModel"),

@@ -143,6 +143,15 @@ def _llava_processor(vllm_config):
 MULTIMODAL_REGISTRY.register_processor("LlavaForConditionalGeneration", _llava_processor)
 
 
+def _anyres(vllm_config):
+    from ..models.llava_next import _anyres_processor
+    return _anyres_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("LlavaNextForConditionalGeneration", _anyres)
+MULTIMODAL_REGISTRY.register_processor("LlavaOnevisionForConditionalGeneration", _anyres)
+
+
 # ---- Qwen2-VL: variable-size patch grids ------------------------------------------------------------
 def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56,
                  max_pixels: int = 14 * 14 * 4 * 1280) -> tuple[int, int]:
