@@ -396,3 +396,44 @@ def test_llava_next_and_onevision_match_hf(tmp_path, family):
                               max_new_tokens=6, do_sample=False, pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref, (family, im.shape)
     assert len(lens) == 3                       # three different token counts: the geometry was really exercised
+
+
+def test_fuyu_matches_hf(tmp_path):
+    """Patches projected straight into the decoder's input, rows closed by the newline token."""
+    import transformers as tf
+    from vllm_distributed_amd.models.fuyu import IMAGE_TOKEN_ID, NEWLINE_TOKEN_ID, FuyuImageProcessor
+    torch.manual_seed(0)
+    tc = dict(vocab_size=71100, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+              max_position_embeddings=256, qk_layernorm=True, model_type="persimmon")
+    cfg = tf.FuyuConfig(vocab_size=71100, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, max_position_embeddings=256, patch_size=6, text_config=tc)
+    hf = tf.FuyuForCausalLM(cfg).float().eval()
+    path = os.path.join(tmp_path, "fuyu")
+    hf.save_pretrained(path, safe_serialization=True)
+    rng = np.random.default_rng(1)
+    imgs = [(rng.random(s + (3,)) * 255).astype(np.uint8) for s in ((13, 20), (6, 31))]
+    prompts = [[5, 17, IMAGE_TOKEN_ID, 99, 3], [IMAGE_TOKEN_ID, 7, 8, 9]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=128)
+    sp = SamplingParams(temperature=0, max_tokens=6, ignore_eos=True)
+    outs = llm.generate([{"prompt_token_ids": p, "multi_modal_data": {"image": im}} for p, im in zip(prompts, imgs)], sp)
+    llm.shutdown()
+    proc = FuyuImageProcessor(6)
+    for p, im, o in zip(prompts, imgs, outs):
+        patches, grid = proc.patches(im)
+        rows, cols = int(grid[0]), int(grid[1])
+        ids, idx, k = [], [], 0
+        for t in p:
+            if t == IMAGE_TOKEN_ID:
+                for _ in range(rows):
+                    ids += [IMAGE_TOKEN_ID] * cols + [NEWLINE_TOKEN_ID]
+                    idx += list(range(k, k + cols)) + [-1]
+                    k += cols
+            else:
+                ids.append(t)
+                idx.append(-1)
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), image_patches=patches[None],
+                              image_patches_indices=torch.tensor([idx]), max_new_tokens=6, do_sample=False,
+                              pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, im.shape

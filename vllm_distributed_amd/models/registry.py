@@ -120,6 +120,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlamaForCausalLMEagle": ("eagle", "EagleLlamaForCausalLM"),
     "LlavaNextForConditionalGeneration": ("llava_next", "LlavaNextForConditionalGeneration"),
     "LlavaOnevisionForConditionalGeneration": ("llava_next", "LlavaOnevisionForConditionalGeneration"),
+    "FuyuForCausalLM": ("fuyu", "FuyuForCausalLM"),
     "MedusaModel": ("eagle", "MedusaModel"),
     "EAGLEModel": ("eagle", "EagleLlamaForCausalLM"),
     "DeepSeekMTPModel": ("mtp", "DeepSeekMTPModel"),

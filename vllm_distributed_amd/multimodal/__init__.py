@@ -384,3 +384,11 @@ def _whisper_processor(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("WhisperForConditionalGeneration", _whisper_processor)
+
+
+def _fuyu(vllm_config):
+    from ..models.fuyu import FuyuImageProcessor
+    return FuyuImageProcessor(int(getattr(vllm_config.model_config.hf_config, "patch_size", 30)))
+
+
+MULTIMODAL_REGISTRY.register_processor("FuyuForCausalLM", _fuyu)
