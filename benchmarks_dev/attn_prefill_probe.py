@@ -1,4 +1,4 @@
-"""Prefill attention: LDS-staged kernel vs the direct-to-register form."""
+"""Prefill attention: direct-to-register form (0) vs 4-wave LDS-staged form (2) vs wide 8-wave form (3)."""
 import math
 import os
 import sys
@@ -38,7 +38,7 @@ def bench(fn, iters=20):
 
 CASES = [(16, 1024, 32, 8, 128, 16, 0), (16, 1024, 64, 8, 128, 16, 0), (4, 4096, 32, 8, 128, 16, 0),
                                     (2, 2048, 32, 8, 128, 16, 6144), (16, 1024, 32, 32, 128, 16, 0), (16, 1024, 12, 12, 64, 16, 0),
-                                    (16, 1024, 64, 8, 128, 32, 0)]
+                                    (16, 1024, 64, 8, 128, 32, 0), (1, 8192, 32, 8, 128, 16, 24576), (8, 2048, 64, 8, 128, 16, 0)]
 ONLY = os.environ.get("CASE")
 REPS = int(os.environ.get("REPS", "20"))
 for (S, L, Hq, Hkv, D, bs, ctx) in (CASES if ONLY is None else [CASES[int(ONLY)]]):
@@ -48,11 +48,15 @@ for (S, L, Hq, Hkv, D, bs, ctx) in (CASES if ONLY is None else [CASES[int(ONLY)]
     flops = 4.0 * S * Hq * D * (L * (L + 1) / 2 + L * ctx)
     res = []
     outs = []
-    for v in ((0, 1) if os.environ.get("VARIANT") is None else (int(os.environ["VARIANT"]),) * 2):
+    variants = (0, 2, 3) if os.environ.get("VARIANT") is None else tuple(int(v) for v in os.environ["VARIANT"].split(","))
+    for v in variants:
         N.call("vda_set_prefill_variant", v)
         t = bench(lambda: ops.paged_attention_prefill(out, q, kc, vc, bt, sl, qsl, scale), REPS)
         res.append(t)
         outs.append(out.clone())
-    err = (outs[0].float() - outs[1].float()).abs().max().item()
-    print(f"S={S} L={L} ctx={ctx} Hq={Hq} Hkv={Hkv} D={D} bs={bs}: direct {res[0] * 1e3:.3f} ms ({flops / res[0] / 1e12:.0f} TF/s) | "
-          f"lds {res[1] * 1e3:.3f} ms ({flops / res[1] / 1e12:.0f} TF/s) | max diff {err:.4f}", flush=True)
+    N.call("vda_set_prefill_variant", 1)
+    err = max((outs[0].float() - o.float()).abs().max().item() for o in outs)
+    names = {0: "direct", 2: "lds", 3: "wide"}
+    print(f"S={S} L={L} ctx={ctx} Hq={Hq} Hkv={Hkv} D={D} bs={bs}: " + " | ".join(
+        f"{names[v]} {t * 1e3:.3f} ms ({flops / t / 1e12:.0f} TF/s)" for v, t in zip(variants, res)) +
+        f" | max diff {err:.4f}", flush=True)

@@ -319,4 +319,8 @@ def get_model_loader(load_config) -> BaseModelLoader:
 
 
 def get_model(vllm_config: VllmConfig, device=None) -> nn.Module:
+    # rotary modules are shared between the layers of ONE model; a second model in this process (a draft
+    # model, a CPU engine beside a GPU one) must not pick up buffers that the first one moved to its device
+    from ..layers import rotary
+    rotary._CACHE.clear()
     return get_model_loader(vllm_config.load_config).load_model(vllm_config, device)

@@ -51,7 +51,7 @@ LIBS = {
 # mla.hip: 3296 accumulator moves in six kernels, 400 -> 269 registers).  Measured neutral on the
 # memory-bound skinny GEMMs, which therefore keep the default.
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-EXTRA_FLAGS = {f: _VGPR_FORM for f in ("attention.hip", "mla.hip")}
+EXTRA_FLAGS = {f: _VGPR_FORM for f in ("attention.hip", "attention_prefill.hip", "mla.hip")}
 
 
 def _hipcc() -> str:

@@ -20,34 +20,7 @@
 //                       = one 16-byte load from the V layout above), B = P^T which
 //                       is exactly the 8 probabilities the lane already holds.
 // Nothing goes through LDS except the final cross-wave merge of the decode form.
-#include "common.h"
-
-// 2^x as the bare v_exp_f32 instruction.  fexp2() wraps it in a range check and a rescale for results
-// below the smallest normal float (seven instructions instead of one); softmax terms that small are
-// zero for every purpose here.
-__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-struct AttnParams {
-  const void* q;            // [T, Hq, D]
-  const void* k_cache;
-  const void* v_cache;
-  void* out;                // [T, Hq, D]
-  float* part_out;          // [T, Hq, nsplit, D]   (split mode only)
-  float* part_lse;          // [T, Hq, nsplit]      log2-domain log-sum-exp
-  const int* block_table;   // [S, max_blocks]
-  const int* seq_lens;      // [S] keys visible to the LAST query token of the sequence
-  const int* q_start_loc;   // [S+1]
-  const float* alibi;       // [Hq] or nullptr
-  int num_seqs, Hq, Hkv, max_blocks, nsplit;
-  long q_stride, out_stride;   // elements between consecutive tokens
-  float scale, softcap;    // scale already includes the K-cache scale of an fp8 cache
-  float v_scale;            // V-cache scale (1 for 16-bit caches)
-  int window;               // sliding window size, 0 = none
-  int q_tile;               // query tokens per workgroup (prefill form)
-  int causal;               // 1: query token i sees keys up to its own position; 0: every key of the sequence
-  int num_tokens;           // T (row length of lse_out)
-  float* lse_out;           // [Hq, T] natural-log log-sum-exp per (head, token), or nullptr (prefill form)
-};
+#include "attention.h"
 
 template <typename T, int D, int BS, int NCT, bool SPLIT, bool F8>
 __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
@@ -773,9 +746,13 @@ VDA_EXPORT int vda_paged_attention_decode(
   return 0;
 }
 
-// 1 (default): K/V staged through LDS; 0: direct-to-register form (kept for A/B measurements)
+// 1 (default): the wide form where it applies, else the 4-wave form with K/V staged through LDS;
+// 0: direct-to-register form, 2: always the 4-wave LDS form, 3: the wide form whenever the shape allows
+// (0 / 2 / 3 are for A/B measurements and tests)
 static int g_prefill_variant = 1;
+static long g_prefill_wide_min_wgs = 192;
 VDA_EXPORT int vda_set_prefill_variant(int v) { g_prefill_variant = v; return 0; }
+VDA_EXPORT int vda_set_prefill_wide_min_wgs(long n) { g_prefill_wide_min_wgs = n; return 0; }
 
 // Varlen attention of new tokens against the paged cache (the new tokens' own K/V must already be in
 // the cache): causal, or bidirectional within each sequence (encoder models; the shared-prefix pass of
@@ -796,6 +773,16 @@ VDA_EXPORT int vda_paged_attention_prefill(
   AttnParams p{q, k_cache, v_cache, out, nullptr, nullptr, block_table, seq_lens, q_start_loc, alibi,
                num_seqs, Hq, Hkv, max_blocks, 1, q_stride, out_stride, scale * (kv_fp8 ? k_scale : 1.f), softcap,
                kv_fp8 ? v_scale : 1.f, window, q_tile, causal, num_tokens, lse_out};
+  // Wide form (8 waves, 256 columns, 64-key tiles): head size 128 and enough query tiles to occupy the
+  // chip (one workgroup per CU); short chunks keep the 4-wave form, which cuts them into more workgroups.
+  if (D == 128 && 256 % G == 0 && (g_prefill_variant == 1 || g_prefill_variant == 3)) {
+    const int wide_tile = 256 / G;
+    const long wgs = (long)(num_tokens / wide_tile) * Hkv;
+    if (g_prefill_variant == 3 || wgs >= g_prefill_wide_min_wgs) {
+      p.q_tile = wide_tile;
+      return vda_launch_prefill_wide(p, block_size, dtype, kv_fp8, st);
+    }
+  }
   const int grid_x = num_tokens / q_tile + num_seqs;
   const int form = g_prefill_variant == 0 ? 2 : 3;
   return dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, form, grid_x, st, kv_fp8)

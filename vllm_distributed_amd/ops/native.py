@@ -42,6 +42,7 @@ _SIGS = {
     "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, I, P,
                                     P],
     "vda_set_prefill_variant": [I],
+    "vda_set_prefill_wide_min_wgs": [L],
     "vda_merge_attn_states": [P, P, P, P, P, P, I, I, I, I, P],
     "vda_argmax": [P, P, I, I, L, I, P],
     "vda_sample": [P, P, P, P, P, P, P, I, I, L, P],
