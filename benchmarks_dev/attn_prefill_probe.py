@@ -41,6 +41,7 @@ CASES = [(16, 1024, 32, 8, 128, 16, 0), (16, 1024, 64, 8, 128, 16, 0), (4, 4096,
                                     (16, 1024, 64, 8, 128, 32, 0), (1, 8192, 32, 8, 128, 16, 24576), (8, 2048, 64, 8, 128, 16, 0)]
 ONLY = os.environ.get("CASE")
 REPS = int(os.environ.get("REPS", "20"))
+MAXQ = int(os.environ.get("MAXQ", "1"))      # 0: do not tell the kernel the longest query run (linear tile order)
 for (S, L, Hq, Hkv, D, bs, ctx) in (CASES if ONLY is None else [CASES[int(ONLY)]]):
     q, kc, vc, bt, sl, qsl = problem(S, L, Hq, Hkv, D, bs, torch.bfloat16, ctx)
     out = torch.empty_like(q)
@@ -51,7 +52,7 @@ for (S, L, Hq, Hkv, D, bs, ctx) in (CASES if ONLY is None else [CASES[int(ONLY)]
     variants = (0, 2, 3) if os.environ.get("VARIANT") is None else tuple(int(v) for v in os.environ["VARIANT"].split(","))
     for v in variants:
         N.call("vda_set_prefill_variant", v)
-        t = bench(lambda: ops.paged_attention_prefill(out, q, kc, vc, bt, sl, qsl, scale), REPS)
+        t = bench(lambda: ops.paged_attention_prefill(out, q, kc, vc, bt, sl, qsl, scale, max_q_len=MAXQ * L), REPS)
         res.append(t)
         outs.append(out.clone())
     N.call("vda_set_prefill_variant", 1)

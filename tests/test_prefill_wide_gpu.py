@@ -38,6 +38,21 @@ def test_wide_prefill_mixed_batch(dt, Hq, Hkv, bs):
     torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
 
 
+@pytest.mark.parametrize("q_lens,seq_lens", [([300, 300, 300], [300, 300, 300]), ([5, 130, 44, 77, 1, 100], [5, 130, 300, 77, 1, 257]),
+                                             ([700, 3, 64], [900, 3, 128])])
+def test_wide_prefill_level_order(q_lens, seq_lens):
+    """Longest query run known on the host: workgroups walk (level from the end, sequence); every tile of
+    every sequence must still be produced, also when the bound is loose or the batch is ragged."""
+    dt, Hq, Hkv, bs = torch.bfloat16, 16, 4, 16
+    q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, q_lens, Hq, Hkv, 128, bs, dt)
+    scale = 1.0 / math.sqrt(128)
+    ref = R.paged_attention(q, kc, vc, bt, sl, qsl, scale)
+    for bound in (max(q_lens), max(q_lens) + 100):
+        out = torch.full_like(q, float("nan"))
+        ops.paged_attention_prefill(out, q, kc, vc, bt, sl, qsl, scale, max_q_len=bound)
+        torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
 def test_wide_equals_four_wave_form_on_long_prompts():
     dt, Hq, Hkv, bs = torch.bfloat16, 32, 8, 16
     q, kc, vc, bt, sl, qsl = _paged_problem([2048, 1500 + 700], [2048, 700], Hq, Hkv, 128, bs, dt)

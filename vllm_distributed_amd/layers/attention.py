@@ -135,7 +135,8 @@ class Attention(nn.Module):
                 ops.paged_attention_prefill(out[ndt:e], q[ndt:e], self.k_cache, self.v_cache, bt[nd:nd + n_pre],
                                             sl[nd:nd + n_pre], pqsl, self.scale,
                                             window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
-                                            k_scale=ksc, v_scale=vsc, causal=self.causal)
+                                            k_scale=ksc, v_scale=vsc, causal=self.causal,
+                                            max_q_len=md.max_query_len)
         if conn is not None:
             conn.save_kv_layer(self.layer_name, (self.k_cache, self.v_cache), md)
         return out.view(T, qs)

@@ -239,10 +239,12 @@ def paged_attention_decode(out, q, k_cache, v_cache, block_table, seq_lens, q_st
 def paged_attention_prefill(out, q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale: float,
                             window: int = 0, softcap: float = 0.0, alibi: Optional[torch.Tensor] = None,
                             k_scale: float = 1.0, v_scale: float = 1.0, causal: bool = True,
-                            return_lse: bool = False):
+                            return_lse: bool = False, max_q_len: int = 0):
     """Varlen attention of new tokens against the paged cache.  ``causal=False``: every query token sees
     all ``seq_lens[s]`` keys of its sequence (encoder models, the shared-prefix pass of cascade
-    attention).  ``return_lse``: also return the log-sum-exp [Hq, T] (natural log) of every row."""
+    attention).  ``return_lse``: also return the log-sum-exp [Hq, T] (natural log) of every row.
+    ``max_q_len``: the longest query run of the batch when the caller knows it on the host (0 = unknown);
+    the wide kernel then starts the longest causal tiles of all sequences first."""
     T, Hq, D = q.shape
     if not _dev(q):
         o, lse = R.paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, window,
@@ -255,7 +257,7 @@ def paged_attention_prefill(out, q, k_cache, v_cache, block_table, seq_lens, q_s
            block_table.data_ptr(), seq_lens.data_ptr(), q_start_loc.data_ptr(), N.ptr(alibi), seq_lens.shape[0], T,
            Hq, k_cache.shape[1], D, k_cache.shape[2], block_table.stride(0), q.stride(0), out.stride(0), scale,
            softcap, window, N.dt(q.dtype), _kv_fp8(k_cache), k_scale, v_scale, int(bool(causal)), N.ptr(lse),
-           N.stream())
+           int(max_q_len), N.stream())
     return (out, lse) if return_lse else out
 
 

@@ -27,6 +27,7 @@ struct AttnParams {
   int causal;               // 1: query token i sees keys up to its own position; 0: every key of the sequence
   int num_tokens;           // T (row length of lse_out)
   float* lse_out;           // [Hq, T] natural-log log-sum-exp per (head, token), or nullptr (prefill form)
+  int max_q_len;            // longest query run of the batch when the host knows it, else 0 (wide prefill form)
 };
 
 // Wide prefill form (attention_prefill.hip): 512 threads, 256 query columns per workgroup, head size 128.

@@ -764,7 +764,7 @@ VDA_EXPORT int vda_paged_attention_prefill(
     const int* seq_lens, const int* q_start_loc, const float* alibi, int num_seqs, int num_tokens,
     int Hq, int Hkv, int D, int block_size, int max_blocks, long q_stride, long out_stride, float scale,
     float softcap, int window, int dtype, int kv_fp8, float k_scale, float v_scale, int causal, float* lse_out,
-    hipStream_t st) {
+    int max_q_len, hipStream_t st) {
   if (Hq % Hkv) return -1;
   const int G = Hq / Hkv;
   if (G > 128) return -4;
@@ -772,7 +772,7 @@ VDA_EXPORT int vda_paged_attention_prefill(
   const int q_tile = 128 / G;     // 4 waves x 32 columns
   AttnParams p{q, k_cache, v_cache, out, nullptr, nullptr, block_table, seq_lens, q_start_loc, alibi,
                num_seqs, Hq, Hkv, max_blocks, 1, q_stride, out_stride, scale * (kv_fp8 ? k_scale : 1.f), softcap,
-               kv_fp8 ? v_scale : 1.f, window, q_tile, causal, num_tokens, lse_out};
+               kv_fp8 ? v_scale : 1.f, window, q_tile, causal, num_tokens, lse_out, max_q_len};
   // Wide form (8 waves, 256 columns, 64-key tiles): head size 128 and enough query tiles to occupy the
   // chip (one workgroup per CU); short chunks keep the 4-wave form, which cuts them into more workgroups.
   if (D == 128 && 256 % G == 0 && (g_prefill_variant == 1 || g_prefill_variant == 3)) {

@@ -57,13 +57,16 @@ __device__ __forceinline__ float pair_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+#ifndef PW_GLOAD_LATE
+#define PW_GLOAD_LATE 1
+#endif
 constexpr int WD = 128;              // head size
 constexpr int KT = 64;               // keys per tile
 constexpr int K_BYTES = KT * 256;    // one K image
 constexpr int V_BYTES = WD * 128;    // one V image
 
 template <typename T, int BS, bool F8, bool GENERAL>
-__global__ __launch_bounds__(512) void paged_prefill_wide_kernel(AttnParams p, int ntiles) {
+__global__ __launch_bounds__(512) void paged_prefill_wide_kernel(AttnParams p, int ntiles, int levels) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   using CT = typename KVElem<T, F8>::type;
@@ -78,16 +81,33 @@ __global__ __launch_bounds__(512) void paged_prefill_wide_kernel(AttnParams p, i
   const int c32 = lane & 31, hi = lane >> 5;
   const int G = p.Hq / p.Hkv;
   const int kvh = blockIdx.x % p.Hkv;
-  const int tile = ntiles - 1 - (int)(blockIdx.x / p.Hkv);
-
-  int lo = 0, hs = p.num_seqs;
-  while (lo < hs) {
-    int mid = (lo + hs + 1) >> 1;
-    if (mid < p.num_seqs && p.q_start_loc[mid] / p.q_tile + mid <= tile) lo = mid; else hs = mid - 1;
+  int seq, q0;
+  if (levels > 0) {
+    // Host knows the longest query run: workgroup rank r -> (level j = r / S counted from the END of every
+    // sequence, sequence r % S).  The longest causal tiles of all sequences start first, and no search.
+    const int r = blockIdx.x / p.Hkv;
+    seq = r % p.num_seqs;
+    const int n_s = (p.q_start_loc[seq + 1] - p.q_start_loc[seq] + p.q_tile - 1) / p.q_tile;
+    const int j = r / p.num_seqs;
+    if (j >= n_s) return;                   // uniform over the workgroup
+    q0 = (n_s - 1 - j) * p.q_tile;
+  } else {
+    const int tile = ntiles - 1 - (int)(blockIdx.x / p.Hkv);
+    // tile -> sequence: the largest s whose first tile, q_start_loc[s] / q_tile + s (increasing in s), is not
+    // behind this one; 64 candidates per load instead of one dependent load per bisection step
+    seq = 0;
+    for (int base = 0; base < p.num_seqs; base += 64) {
+      const int s = base + lane;
+      const bool ok = s < p.num_seqs && p.q_start_loc[s] / p.q_tile + s <= tile;
+      const unsigned long long mask = __ballot(ok);
+      if (mask == 0) break;
+      seq = base + 63 - __builtin_clzll(mask);
+      if (mask != ~0ull) break;
+    }
+    seq = __builtin_amdgcn_readfirstlane(seq);
+    q0 = (tile - (p.q_start_loc[seq] / p.q_tile + seq)) * p.q_tile;
   }
-  const int seq = lo;
   const int qs = p.q_start_loc[seq];
-  const int q0 = (tile - (qs / p.q_tile + seq)) * p.q_tile;
   const int q_len = p.q_start_loc[seq + 1] - qs;
   const int seq_len = p.seq_lens[seq];
   if (q0 >= q_len) return;                  // uniform over the workgroup
@@ -196,46 +216,42 @@ __global__ __launch_bounds__(512) void paged_prefill_wide_kernel(AttnParams p, i
 
   const float sl2 = p.scale * 1.4426950408889634f;
 
+  // A tile is worked in two halves of 32 keys, each with its own online-softmax update, ordered so that the
+  // vector ALU and the matrix pipe have independent work inside one wave:
+  //     scores(0) . scores(1) || softmax(0) . rescale . P.V(0) || softmax(1) . rescale . P.V(1)
+  // (a || b: same basic block, no dependence).  MODE 0: no masking, scale folded into the exponent's fma;
+  // 1: causal / window masking only; 2: soft-cap and ALiBi as well (its own kernel instance, GENERAL, so
+  // that the common instance does not pay for its registers).
   f32x16 S[2];
-  auto scores = [&](int buf) {
-    const unsigned char* kb_ = sKb + buf * K_BYTES;
+  auto qk_half = [&](int buf, int kb) {
+    const unsigned char* kb_ = sKb + buf * K_BYTES + kb * 8192;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int r = 0; r < 16; ++r) S[kb][r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[kb][r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const V8 a = *reinterpret_cast<const V8*>(kb_ + kb * 8192 + k_rd[s]);
-        S[kb] = Mfma32<V8>::run(a, qf[s], S[kb]);
-      }
+    for (int s = 0; s < 8; ++s) {
+      const V8 a = *reinterpret_cast<const V8*>(kb_ + k_rd[s]);
+      S[kb] = Mfma32<V8>::run(a, qf[s], S[kb]);
     }
   };
-  // MODE 0: no masking, scale folded into the exponent's fma; 1: causal / window masking only;
-  // 2: soft-cap and ALiBi as well (its own kernel instance, GENERAL, so that the common instance does not
-  // pay for its registers).
-  auto finish = [&](int kt, int buf, auto mode) {
+  auto softmax_half = [&](int tb, int kb, V8 (&pb)[2], auto mode) -> float {
     constexpr int MODE = decltype(mode)::value;
-    const int tb0 = kt * KT;
-    const unsigned char* vb_ = sVb + buf * V_BYTES;
     float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float x = S[kb][r];
-        if constexpr (MODE >= 1) {
-          const int tok = tb0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if constexpr (MODE == 2) {
-            x *= p.scale;
-            if (p.softcap > 0.f) x = p.softcap * tanhf(x / p.softcap);
-            x += slope * (float)(tok - (limit - 1));
-            x *= 1.4426950408889634f;
-          }
-          x = (tok < limit && tok >= lower) ? x : -INFINITY;
+    for (int r = 0; r < 16; ++r) {
+      float x = S[kb][r];
+      if constexpr (MODE >= 1) {
+        const int tok = tb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if constexpr (MODE == 2) {
+          x *= p.scale;
+          if (p.softcap > 0.f) x = p.softcap * tanhf(x / p.softcap);
+          x += slope * (float)(tok - (limit - 1));
+          x *= 1.4426950408889634f;
         }
-        if constexpr (MODE >= 1) S[kb][r] = x;
-        mx = fmaxf(mx, x);
+        x = (tok < limit && tok >= lower) ? x : -INFINITY;
+        S[kb][r] = x;
       }
+      mx = fmaxf(mx, x);
+    }
     const float mul = MODE == 2 ? 1.f : sl2;
     if constexpr (MODE != 2) mx *= sl2;          // the scale is positive
     mx = pair_max(mx);
@@ -244,29 +260,77 @@ __global__ __launch_bounds__(512) void paged_prefill_wide_kernel(AttnParams p, i
     const float alpha = fexp2(m - m_use);
     m = m_new;
     float ps = 0.f;
-    V8 pb[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float e = fexp2(fmaf(S[t >> 1][8 * (t & 1) + j], mul, -m_use));
+        const float e = fexp2(fmaf(S[kb][8 * t + j], mul, -m_use));
         ps += e;
         pb[t][j] = (T)e;
       }
     l = l * alpha + ps;
+    return alpha;
+  };
+  auto rescale = [&](float alpha) {
     if (__any(alpha != 1.f)) {          // the running maximum settles early: most tiles need no rescale
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[db][r] *= alpha;
     }
+  };
+  auto pv_half = [&](int buf, int kb, const V8 (&pb)[2]) {
+    const unsigned char* vb_ = sVb + buf * V_BYTES;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const V8 a = *reinterpret_cast<const V8*>(vb_ + db * 4096 + v_rd[t]);
+      for (int t = 0; t < 2; ++t) {
+        const V8 a = *reinterpret_cast<const V8*>(vb_ + db * 4096 + v_rd[2 * kb + t]);
         acc[db] = Mfma32<V8>::run(a, pb[t], acc[db]);
       }
+    }
+  };
+  // request for tile t+2 (and the block numbers of tile t+3)
+  auto issue_next = [&](int kt) {
+    if (kt + 2 < kt_hi) gload();
+    if (kt + 3 < kt_hi) bload(kt + 3);
+  };
+  auto tile_compute = [&](int kt, int buf, auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    const int tb0 = kt * KT;
+    V8 p0[2], p1[2];
+    // second half wholly above every column's causal limit (diagonal tiles): nothing to do for it
+    const bool second = MODE != 1 || tb0 + 32 < wave_hi;
+    // The probabilities are pinned before each rescale branch (otherwise their exponentials sink behind
+    // it, out of the block that holds the products they should overlap), and in the unmasked mode the
+    // scheduler is told the interleave: one MFMA, then a slice of the softmax.
+    auto pin = [](V8 (&pb)[2]) { asm volatile("" : "+v"(pb[0]), "+v"(pb[1])); };
+    auto interleave = [] {
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);    // VALU
+        }
+      }
+    };
+    qk_half(buf, 0);
+    if constexpr (MODE == 0) __builtin_amdgcn_sched_barrier(0);
+    if (second) qk_half(buf, 1);
+#if PW_GLOAD_LATE
+    issue_next(kt);
+#endif
+    const float a0 = softmax_half(tb0, 0, p0, mode);
+    pin(p0);
+    interleave();
+    rescale(a0);
+    pv_half(buf, 0, p0);
+    if (second) {
+      const float a1 = softmax_half(tb0 + 32, 1, p1, mode);
+      pin(p1);
+      interleave();
+      rescale(a1);
+      pv_half(buf, 1, p1);
     }
   };
 
@@ -287,20 +351,20 @@ __global__ __launch_bounds__(512) void paged_prefill_wide_kernel(AttnParams p, i
     const int tb0 = kt * KT;
     const bool active = tb0 < wave_hi && tb0 + KT > wave_lo;   // wave-uniform: tile inside this wave's key range
     if (kt + 1 < kt_hi) sstore(buf ^ 1);
+#if !PW_GLOAD_LATE
+    issue_next(kt);
+#endif
     __builtin_amdgcn_sched_barrier(0);
-    if (active) scores(buf);
-    // the request for tile t+2 goes out behind the score products: their K operands may use the staging
-    // registers, and the loads still have the rest of this iteration and the head of the next to land
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < kt_hi) gload();
-    if (kt + 3 < kt_hi) bload(kt + 3);
-    __builtin_amdgcn_sched_barrier(0);
-    if (active) {
+    if (!active) {
+#if PW_GLOAD_LATE
+      issue_next(kt);
+#endif
+    } else {
       if constexpr (GENERAL) {
-        finish(kt, buf, std::integral_constant<int, 2>{});
+        tile_compute(kt, buf, std::integral_constant<int, 2>{});
       } else {
-        if (tb0 + KT <= full_hi && tb0 >= full_lo) finish(kt, buf, std::integral_constant<int, 0>{});
-        else finish(kt, buf, std::integral_constant<int, 1>{});
+        if (tb0 + KT <= full_hi && tb0 >= full_lo) tile_compute(kt, buf, std::integral_constant<int, 0>{});
+        else tile_compute(kt, buf, std::integral_constant<int, 1>{});
       }
     }
     __syncthreads();
@@ -309,15 +373,25 @@ __global__ __launch_bounds__(512) void paged_prefill_wide_kernel(AttnParams p, i
   l = pair_sum(l);
   if (col_off < 0) return;
   const float inv = l > 0.f ? p.v_scale / l : 0.f;
-  T* op = (T*)p.out + col_off * p.out_stride + (long)head * D + 4 * hi;
+  // Lane l holds d = 8k + 4hi .. +3 of its row for the sixteen groups k = 4db + rr; a half-swap per pair of
+  // groups gives every lane 16 contiguous bytes, so the row leaves in 8 stores of 16 bytes, not 16 of 8.
+  T* op = (T*)p.out + col_off * p.out_stride + (long)head * D + 8 * hi;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      V4 o;
+    for (int rr = 0; rr < 4; rr += 2) {
+      V4 oa, ob;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (T)(acc[db][4 * rr + i] * inv);
-      *reinterpret_cast<V4*>(op + 32 * db + 8 * rr) = o;
+      for (int i = 0; i < 4; ++i) {
+        oa[i] = (T)(acc[db][4 * rr + i] * inv);
+        ob[i] = (T)(acc[db][4 * rr + 4 + i] * inv);
+      }
+      u32x2 a = __builtin_bit_cast(u32x2, oa), b = __builtin_bit_cast(u32x2, ob);
+      auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+      u32x4 w;
+      w[0] = r0[0]; w[1] = r1[0]; w[2] = r0[1]; w[3] = r1[1];
+      *reinterpret_cast<u32x4*>(op + 32 * db + 8 * rr) = w;
     }
   if (p.lse_out && hi == 0)
     p.lse_out[(long)head * p.num_tokens + col_off] =
@@ -326,11 +400,15 @@ __global__ __launch_bounds__(512) void paged_prefill_wide_kernel(AttnParams p, i
 
 template <typename T, bool F8, bool GENERAL>
 int launch_bs(const AttnParams& p, int bs, int ntiles, hipStream_t st) {
-  const dim3 grid((unsigned)ntiles * p.Hkv), block(512);
+  // level order when the host passed the longest query run and the (level, sequence) grid is not much
+  // larger than the number of real tiles (a batch of one long and many short prompts keeps the linear order)
+  int levels = p.max_q_len > 0 ? (p.max_q_len + p.q_tile - 1) / p.q_tile : 0;
+  if ((long)levels * p.num_seqs > 2L * ntiles) levels = 0;
+  const dim3 grid((unsigned)(levels > 0 ? levels * p.num_seqs : ntiles) * p.Hkv), block(512);
   switch (bs) {
-    case 16: hipLaunchKernelGGL((paged_prefill_wide_kernel<T, 16, F8, GENERAL>), grid, block, 0, st, p, ntiles); break;
-    case 32: hipLaunchKernelGGL((paged_prefill_wide_kernel<T, 32, F8, GENERAL>), grid, block, 0, st, p, ntiles); break;
-    case 64: hipLaunchKernelGGL((paged_prefill_wide_kernel<T, 64, F8, GENERAL>), grid, block, 0, st, p, ntiles); break;
+    case 16: hipLaunchKernelGGL((paged_prefill_wide_kernel<T, 16, F8, GENERAL>), grid, block, 0, st, p, ntiles, levels); break;
+    case 32: hipLaunchKernelGGL((paged_prefill_wide_kernel<T, 32, F8, GENERAL>), grid, block, 0, st, p, ntiles, levels); break;
+    case 64: hipLaunchKernelGGL((paged_prefill_wide_kernel<T, 64, F8, GENERAL>), grid, block, 0, st, p, ntiles, levels); break;
     default: return -2;
   }
   VDA_CHECK_LAUNCH();

@@ -40,7 +40,7 @@ _SIGS = {
     "vda_gather_cache": [P, P, P, P, P, I, I, I, I, I, P],
     "vda_paged_attention_decode": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, P],
     "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, I, P,
-                                    P],
+                                    I, P],
     "vda_set_prefill_variant": [I],
     "vda_set_prefill_wide_min_wgs": [L],
     "vda_merge_attn_states": [P, P, P, P, P, P, I, I, I, I, P],
