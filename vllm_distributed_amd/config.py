@@ -165,6 +165,10 @@ class ModelConfig:
     tokenizer_mode: str = "auto"
     #: Allow custom code from the checkpoint directory (never executed here; kept for CLI parity).
     trust_remote_code: bool = False
+    #: "auto": this package's own model code, the transformers fallback for architectures it lacks;
+    #: "vllm": own model code only; "transformers": always the fallback (transformers' module code around
+    #: this package's attention, KV cache and parallel layers).
+    model_impl: str = "auto"
     #: Weight/activation dtype: auto, bfloat16, float16 or float32.
     dtype: Union[str, torch.dtype] = "auto"
     #: Seed for sampling and for dummy-weight initialisation.

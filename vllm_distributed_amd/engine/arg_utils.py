@@ -50,6 +50,7 @@ class EngineArgs:
     enable_sleep_mode: bool = False
     tokenizer_mode: str = "auto"
     trust_remote_code: bool = False
+    model_impl: str = "auto"
     dtype: str = "auto"
     seed: int = 0
     max_model_len: Optional[int] = None
@@ -191,7 +192,7 @@ class EngineArgs:
     def create_model_config(self) -> C.ModelConfig:
         return C.ModelConfig(
             model=self.model, tokenizer=self.tokenizer, skip_tokenizer_init=self.skip_tokenizer_init, enable_sleep_mode=self.enable_sleep_mode,
-            tokenizer_mode=self.tokenizer_mode, trust_remote_code=self.trust_remote_code, dtype=self.dtype,
+            tokenizer_mode=self.tokenizer_mode, trust_remote_code=self.trust_remote_code, model_impl=self.model_impl, dtype=self.dtype,
             seed=self.seed, max_model_len=self.max_model_len, quantization=self.quantization,
             enforce_eager=self.enforce_eager, max_seq_len_to_capture=self.max_seq_len_to_capture,
             max_logprobs=self.max_logprobs, served_model_name=self.served_model_name, revision=self.revision,

@@ -44,7 +44,17 @@ def _quant_config(vllm_config: VllmConfig):
 
 
 def initialize_model(vllm_config: VllmConfig, prefix: str = "") -> nn.Module:
-    cls, arch = ModelRegistry.resolve_model_cls(vllm_config.model_config.architectures)
+    mc = vllm_config.model_config
+    impl = getattr(mc, "model_impl", "auto")
+    if impl not in ("auto", "vllm", "transformers"):
+        raise ValueError(f"model_impl must be auto, vllm or transformers, not {impl!r}")
+    archs = mc.architectures
+    if impl == "transformers" or (impl == "auto" and not any(ModelRegistry.is_supported(a) for a in archs)
+                                  and ModelRegistry.is_text_generation_model(archs)):
+        if impl == "auto":
+            logger.warning("no native implementation of %s: running it through the transformers fallback", archs)
+        archs = ["TransformersForCausalLM"]
+    cls, arch = ModelRegistry.resolve_model_cls(archs)
     vllm_config.quant_config = _quant_config(vllm_config)
     if vllm_config.parallel_config.token_parallel_size > 1:
         from ..parallel.state import is_tknp_root

@@ -122,6 +122,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlavaOnevisionForConditionalGeneration": ("llava_next", "LlavaOnevisionForConditionalGeneration"),
     "FuyuForCausalLM": ("fuyu", "FuyuForCausalLM"),
     "MedusaModel": ("eagle", "MedusaModel"),
+    "TransformersForCausalLM": ("transformers_backend", "TransformersForCausalLM"),
     "EAGLEModel": ("eagle", "EagleLlamaForCausalLM"),
     "DeepSeekMTPModel": ("mtp", "DeepSeekMTPModel"),
     "MiMoMTPModel": ("mtp", "MiMoMTPModel"),
