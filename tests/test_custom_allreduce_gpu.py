@@ -43,6 +43,12 @@ def test_custom_allreduce_shared_gpu(world):
     _run_ranks(world, "car_worker.py")
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_fused_allreduce_rmsnorm_shared_gpu(world):
+    """all-reduce + residual add + RMSNorm in one kernel: the bits of the unfused pair, graph replay."""
+    _run_ranks(world, "far_worker.py")
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_quantised_allreduce_shared_gpu(world):
     """int8 / int4 two-shot all-reduce: error within the two-rounding-step bound, graph replay."""

@@ -102,6 +102,8 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VLLM_DISABLE_CUSTOM_ALL_REDUCE": (_bool, False),
     "VDA_CUSTOM_AR_MAX_BYTES": (int, 16 * 1024 * 1024),
     "VDA_CUSTOM_AR_ONESHOT_BYTES": (int, 512 * 1024),
+    # all-reduce + residual add + RMSNorm in one peer-memory kernel for batches of up to this many tokens (0: off)
+    "VDA_FUSED_AR_NORM_MAX_TOKENS": (int, 512),
     "VDA_CUSTOM_AR_CHUNKED": (_bool, False),     # messages beyond one arena: chunk through it instead of RCCL
     "VDA_MOE_ROWS_FORM": (int, -1),              # grouped expert GEMM: 0 K-split kernel, 1 / 2 row-split kernel (64 / 128 tokens per pass), -1 by shape
     "VDA_CASCADE_MIN_PREFIX": (int, 256),        # cascade attention: shortest common prefix (tokens) worth a shared pass

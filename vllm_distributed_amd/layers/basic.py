@@ -34,6 +34,14 @@ class RMSNorm(nn.Module):
         return ops.rms_norm(x, self.weight, self.eps, residual, self.weight_bias), residual
 
 
+    def forward_reduce(self, x_partial: torch.Tensor, residual: torch.Tensor):
+        """``x_partial`` holds this tensor-parallel rank's partial sums of a row-parallel layer:
+        residual += all_reduce(x_partial); returns (norm(residual), residual).  One peer-memory kernel
+        for decode-sized batches (parallel/csrc/custom_allreduce.hip far_kernel)."""
+        from ..parallel.state import get_tp_group
+        return get_tp_group().all_reduce_rms_norm(x_partial, residual, self.weight, self.eps, self.weight_bias)
+
+
 class GemmaRMSNorm(RMSNorm):
     def __init__(self, hidden_size: int, eps: float = 1e-6, dtype=None):
         super().__init__(hidden_size, eps, dtype, weight_bias=1.0)

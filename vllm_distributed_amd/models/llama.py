@@ -241,6 +241,12 @@ class LlamaModel(nn.Module):
         self.norm = self.layer_cls.make_norm(config) if pp.is_last_rank else PPMissingLayer()
         self.embed_scale = float(self.embed_scale_of(config))
         self.tp = get_tensor_model_parallel_world_size()
+        # all-reduce + add + norm in one kernel (decode-sized batches): the standard block only -- families that
+        # override the block's forward, its MLP or its norm class keep the separate reductions
+        self.fuse_reduce_norm_ok = bool(
+            getattr(self.layer_cls, "supports_sequence_parallel", False)
+            and self.layer_cls.forward is LlamaDecoderLayer.forward and isinstance(self.norm, RMSNorm)
+            and not vllm_config.parallel_config.enable_token_parallel)
         # sequence parallelism: dense Llama-style layers only (the MoE blocks reduce on their own)
         self.sequence_parallel = bool(vllm_config.compilation_config.enable_sequence_parallelism and self.tp > 1
                                       and getattr(self.layer_cls, "supports_sequence_parallel", False)
@@ -263,6 +269,8 @@ class LlamaModel(nn.Module):
         mbs = get_forward_context().micro_batches if (self.tp > 1 and has_forward_context()) else None
         if mbs and not sp and getattr(self.layer_cls, "supports_sequence_parallel", False):
             hidden, residual = self._forward_micro_batched(positions, hidden, residual, mbs)
+        elif not sp and self._fuse_reduce_norm(hidden):
+            return self._forward_fused_reduce(positions, hidden, residual)
         elif not sp:
             for layer in self.layers[self.start_layer:self.end_layer]:
                 hidden, residual = layer(positions, hidden, residual)
@@ -287,6 +295,47 @@ class LlamaModel(nn.Module):
             return IntermediateTensors({"hidden_states": hidden, "residual": residual})
         hidden, _ = self.norm(hidden, residual)
         return hidden
+
+
+def _fuse_reduce_norm(self, hidden) -> bool:
+    """Decode-sized batch of a dense Llama-style stack under tensor parallelism, peer-memory kernel up."""
+    return (self.tp > 1 and self.fuse_reduce_norm_ok and get_tp_group().can_fuse_reduce_norm(hidden))
+
+
+def _forward_fused_reduce(self, positions, hidden, residual):
+    """Every tensor-parallel all-reduce of the stack is followed by a residual add and an RMSNorm: the
+    row-parallel layers hand over their partial sums and the three run as one peer-memory kernel
+    (``RMSNorm.forward_reduce``).  Role of the reference's all-reduce + norm fusion pass
+    (vllm/compilation/collective_fusion.py), chosen at run time by batch size."""
+    pp = get_pp_group()
+    partial = False                 # is ``hidden`` an un-reduced partial sum?
+    old = set_defer_reduce(True)
+    try:
+        for layer in self.layers[self.start_layer:self.end_layer]:
+            if residual is None:
+                residual, h = hidden, layer.input_layernorm(hidden)
+            elif partial:
+                h, residual = layer.input_layernorm.forward_reduce(hidden, residual)
+            else:
+                h, residual = layer.input_layernorm(hidden, residual)
+            o = layer.self_attn(positions, h)
+            h, residual = layer.post_attention_layernorm.forward_reduce(o, residual)
+            hidden, partial = layer.mlp(h), True
+    finally:
+        set_defer_reduce(old)
+    if not pp.is_last_rank:
+        if partial:
+            hidden = get_tp_group().all_reduce(hidden)
+        return IntermediateTensors({"hidden_states": hidden, "residual": residual})
+    if partial:
+        hidden, _ = self.norm.forward_reduce(hidden, residual)
+    else:
+        hidden, _ = self.norm(hidden, residual)
+    return hidden
+
+
+LlamaModel._fuse_reduce_norm = _fuse_reduce_norm
+LlamaModel._forward_fused_reduce = _forward_fused_reduce
 
 
 def _forward_micro_batched(self, positions, hidden, residual, mbs):

@@ -235,6 +235,142 @@ VDA_EXPORT int vda_car_allreduce(void* ctx, const void* in, void* out, size_t nb
 
 
 // ---------------------------------------------------------------------------
+// Fused all-reduce + residual add + RMSNorm for decode-sized batches:
+//     s = sum over ranks of in;  residual += s;  out = rmsnorm(residual) * (w + wbias)
+// in ONE kernel, where the unfused path runs the one-shot all-reduce, writes the sum, and the norm kernel
+// reads it back together with the residual (two launches, one extra round trip of [M, H] through memory).
+// Role of the reference's all-reduce + RMSNorm fusion pass (vllm/compilation/collective_fusion.py,
+// AllReduceRMSNormPattern / AllReduceFusedAddRMSNormPattern, which lowers to a flashinfer kernel there).
+//
+// Whole ROWS are owned by workgroups: row r belongs to workgroup r mod MAX_BLOCKS on every rank, and its
+// staging copy lives in that workgroup's own region of the staging half (region b = bytes
+// [b * region, (b + 1) * region), row r at slot r / MAX_BLOCKS), whatever M and H a call has.  A
+// workgroup thus only ever touches its own region, locally and on the peers, which is the ownership
+// rule that makes the parity-selected halves safe without an end-of-call barrier (see car_kernel); the
+// element-strided ownership of car_kernel is a different partition, so this kernel has a context
+// (arena, counters) of its own.  Rounding follows the unfused path exactly: the sum is rounded to T,
+// added to the residual in fp32 and rounded again, statistics are taken from the rounded values.
+template <typename T, int EMAX>
+__global__ __launch_bounds__(512) void far_kernel(CarArgs a, const u32x4* __restrict__ in, u32x4* __restrict__ residual,
+                                                  const u32x4* __restrict__ weight, u32x4* __restrict__ out, int M,
+                                                  int row16, int H, float eps, float wbias, size_t region) {
+  Signal* me = a.sig[a.rank];
+  __shared__ uint32_t s_cnt, s_call;
+  __shared__ float red[8];
+  if (threadIdx.x == 0) { s_cnt = me->counter[blockIdx.x]; s_call = me->calls[blockIdx.x]; }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;
+  const size_t off = (size_t)(s_call & 1) * a.half_bytes + (size_t)blockIdx.x * region;
+  constexpr int N = 16 / sizeof(T);
+
+  // 0) my partial rows -> my region of my staging half
+  u32x4* mine = reinterpret_cast<u32x4*>(a.data[a.rank] + off);
+  int slot = 0;
+  for (int r = blockIdx.x; r < M; r += MAX_BLOCKS, ++slot)
+    for (int e = threadIdx.x; e < row16; e += 512) mine[(size_t)slot * row16 + e] = in[(size_t)r * row16 + e];
+  const bool ok = cross_barrier(a, cnt + 1);
+
+  if (ok) {
+    slot = 0;
+    for (int r = blockIdx.x; r < M; r += MAX_BLOCKS, ++slot) {
+      float x[EMAX][N];
+      float ss = 0.f;
+#pragma unroll
+      for (int v = 0; v < EMAX; ++v) {
+        const int e = threadIdx.x + v * 512;
+        if (e < row16) {
+          u32x4 pv[MAX_RANKS];
+#pragma unroll
+          for (int q = 0; q < MAX_RANKS; ++q)
+            if (q < a.world) pv[q] = reinterpret_cast<const u32x4*>(a.data[q] + off)[(size_t)slot * row16 + e];
+          float acc[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[k] = 0.f;
+#pragma unroll
+          for (int q = 0; q < MAX_RANKS; ++q)
+            if (q < a.world) acc_add<T>(acc, pv[q]);
+          u32x4 rraw = residual[(size_t)r * row16 + e];
+          T* rp = reinterpret_cast<T*>(&rraw);
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const T s = (T)acc[k];                          // what the unfused all-reduce would have stored
+            const T t = (T)((float)s + (float)rp[k]);
+            rp[k] = t;
+            x[v][k] = (float)t;
+            ss += x[v][k] * x[v][k];
+          }
+          residual[(size_t)r * row16 + e] = rraw;
+        }
+      }
+      // block-wide sum of squares
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      __syncthreads();                       // red[] of the previous row has been read by everyone
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tot += red[w];
+      const float rstd = rsqrtf(tot / (float)H + eps);
+#pragma unroll
+      for (int v = 0; v < EMAX; ++v) {
+        const int e = threadIdx.x + v * 512;
+        if (e < row16) {
+          const u32x4 wraw = weight[e];
+          const T* wp = reinterpret_cast<const T*>(&wraw);
+          u32x4 oraw;
+          T* op = reinterpret_cast<T*>(&oraw);
+#pragma unroll
+          for (int k = 0; k < N; ++k) op[k] = (T)((float)(T)(x[v][k] * rstd) * ((float)wp[k] + wbias));
+          out[(size_t)r * row16 + e] = oraw;
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0) { me->counter[blockIdx.x] = cnt + 1; me->calls[blockIdx.x] = s_call + 1; }
+}
+
+// A context of this kernel is a CarCtx whose in_bytes field holds the bytes of one workgroup region.
+VDA_EXPORT void* vda_far_create(int rank, int world, void** peer_data, void** peer_sig, size_t half_bytes,
+                                unsigned long long spin_limit) {
+  if (world < 2 || world > MAX_RANKS) return nullptr;
+  CarCtx* c = new CarCtx();
+  c->rank = rank; c->world = world; c->half_bytes = half_bytes;
+  c->in_bytes = half_bytes / MAX_BLOCKS / 16 * 16;
+  if (c->in_bytes == 0) { delete c; return nullptr; }
+  for (int i = 0; i < world; ++i) { c->data[i] = (char*)peer_data[i]; c->sig[i] = (Signal*)peer_sig[i]; }
+  c->spin_limit = spin_limit;
+  c->host_err = alloc_host_err();
+  return c;
+}
+
+// in: [M, H] partial sums; residual: [M, H] updated in place; weight: [H]; out: [M, H]; all contiguous and of
+// `dtype` (0 bf16, 1 f16).  Returns -1 when the shape does not fit (the caller takes the unfused path; the
+// answer depends on M, H and the context only, so every rank decides alike).
+VDA_EXPORT int vda_far_run(void* ctx, const void* in, void* residual, const void* weight, void* out, int M, int H,
+                           float eps, float wbias, int dtype, hipStream_t st) {
+  CarCtx* c = (CarCtx*)ctx;
+  if (dtype != 0 && dtype != 1) return -1;
+  const size_t row_bytes = (size_t)H * 2;
+  if (M <= 0 || H <= 0 || row_bytes % 16) return -1;
+  const int row16 = (int)(row_bytes / 16);
+  const size_t slots = ((size_t)M + MAX_BLOCKS - 1) / MAX_BLOCKS;
+  if (row16 > 4 * 512 || slots * row_bytes > c->in_bytes) return -1;
+  CarArgs a;
+  for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
+  a.rank = c->rank; a.world = c->world; a.half_bytes = c->half_bytes; a.in_bytes = c->in_bytes;
+  a.spin_limit = c->spin_limit; a.host_err = c->host_err;
+#define L(T, E) hipLaunchKernelGGL((far_kernel<T, E>), dim3(MAX_BLOCKS), dim3(512), 0, st, a, (const u32x4*)in, \
+                                   (u32x4*)residual, (const u32x4*)weight, (u32x4*)out, M, row16, H, eps, wbias, c->in_bytes)
+  const int emax = (row16 + 511) / 512;
+  if (dtype == 0) { if (emax <= 1) L(bf16_t, 1); else if (emax <= 2) L(bf16_t, 2); else L(bf16_t, 4); }
+  else { if (emax <= 1) L(f16_t, 1); else if (emax <= 2) L(f16_t, 2); else L(f16_t, 4); }
+#undef L
+  return (int)hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------
 // Quantised two-shot all-reduce ("quick reduce"): the bytes that cross xGMI are int8 or int4
 // with one fp32 scale per 32 values, so a bandwidth-bound all-reduce moves 1.8x / 3.2x less.
 // Both shots carry quantised data: inputs are quantised into the staging half, the reducer

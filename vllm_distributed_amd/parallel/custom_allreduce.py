@@ -52,6 +52,9 @@ def comm_library() -> ctypes.CDLL:
         lib.vda_qr_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), sz, i32, u64]
         lib.vda_qr_create.restype = vp
         lib.vda_qr_allreduce.argtypes = [vp, vp, vp, sz, i32, i32, vp]
+        lib.vda_far_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), sz, u64]
+        lib.vda_far_create.restype = vp
+        lib.vda_far_run.argtypes = [vp, vp, vp, vp, vp, i32, i32, ctypes.c_float, ctypes.c_float, i32, vp]
         lib.vda_a2a_half_bytes.argtypes = [i32, i32, i32]
         lib.vda_a2a_half_bytes.restype = sz
         lib.vda_a2a_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), i32, i32, u64]
@@ -201,6 +204,106 @@ class CustomAllReduce:
                 self.lib.vda_car_close(p)
             self.lib.vda_car_free(*self._own)
         self.disabled = True
+
+
+class FusedAllReduceNorm(CustomAllReduce):
+    """All-reduce + residual add + RMSNorm in one peer-memory kernel (``far_kernel``) for decode-sized
+    batches: every TP all-reduce of a dense decoder layer is followed by exactly that, so the fusion
+    saves one launch and one round trip of the [tokens, hidden] activations per reduction.  Rounding is
+    the unfused path's, bit for bit.  Own arena and counters: its workgroups own whole rows, the plain
+    kernel's own strided elements.  Reference role: vllm/compilation/collective_fusion.py
+    (AllReduceFusedAddRMSNormPattern)."""
+    SUPPORTED_WORLD = (2, 3, 4, 5, 6, 7, 8)
+
+    def __init__(self, cpu_group, device: torch.device):
+        self.lib = comm_library()
+        self.group = cpu_group
+        self.device = device
+        self.rank = dist.get_rank(cpu_group)
+        self.world = dist.get_world_size(cpu_group)
+        self.disabled = True
+        self.max_tokens = envs.VDA_FUSED_AR_NORM_MAX_TOKENS
+        # 64 workgroup regions, each holding ceil(max_tokens / 64) rows of up to 16384 16-bit values
+        region = -(-self.max_tokens // 64) * 16384 * 2
+        self.half_bytes = 64 * region
+        self.region_bytes = region
+        pd, ps = self._exchange_arena(2 * self.half_bytes)
+        spins = int(envs.VDA_COMM_SPIN_TIMEOUT_MS * 1e4)
+        self.ctx = self.lib.vda_far_create(self.rank, self.world, pd, ps, self.half_bytes, spins)
+        if not self.ctx:
+            raise RuntimeError("could not create the fused all-reduce + norm context")
+        self.max_bytes = self.half_bytes
+        dist.barrier(group=cpu_group)
+        self.disabled = False
+
+    def fits(self, x: torch.Tensor) -> bool:
+        """Pure function of shape and dtype: every rank answers alike."""
+        if self.disabled or x.dim() != 2 or x.dtype not in (torch.bfloat16, torch.float16):
+            return False
+        M, H = x.shape
+        return 0 < M <= self.max_tokens and H % 8 == 0 and H <= 16384 and -(-M // 64) * H * 2 <= self.region_bytes
+
+    def run(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+            weight_bias: float = 0.0) -> Optional[torch.Tensor]:
+        """residual += sum over ranks of x (in place); returns rmsnorm(residual) * (weight + weight_bias), or
+        None when the shape is outside the kernel (nothing has been touched then)."""
+        if not self.fits(x) or not (x.is_contiguous() and residual.is_contiguous() and weight.is_contiguous()) \
+                or residual.shape != x.shape or residual.dtype != x.dtype or weight.dtype != x.dtype:
+            return None
+        out = torch.empty_like(x)
+        rc = self.lib.vda_far_run(self.ctx, x.data_ptr(), residual.data_ptr(), weight.data_ptr(), out.data_ptr(),
+                                  x.shape[0], x.shape[1], float(eps), float(weight_bias), _DT[x.dtype],
+                                  torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(f"fused all-reduce + norm launch failed with {rc}")
+        return out
+
+    def _self_test(self) -> bool:
+        from .. import ops
+        for M, H in ((1, 4096), (70, 8192), (130, 1024)):
+            g = torch.Generator(device="cpu").manual_seed(1234 + self.rank)
+            x = torch.randn(M, H, generator=g).to(self.device, torch.bfloat16)
+            res0 = torch.randn(M, H, generator=torch.Generator(device="cpu").manual_seed(99)).to(self.device, torch.bfloat16)
+            w = (torch.randn(H, generator=torch.Generator(device="cpu").manual_seed(7)) * 0.1 + 1).to(self.device, torch.bfloat16)
+            tot = x.float().cpu()
+            dist.all_reduce(tot, group=self.group)
+            ref_res = res0.clone()
+            ref_out = ops.rms_norm(tot.to(self.device, torch.bfloat16), w, 1e-5, ref_res)
+            for _ in range(3):          # consecutive calls exercise both staging halves
+                res = res0.clone()
+                out = self.run(x, res, w, 1e-5)
+                torch.cuda.synchronize(self.device)
+                if out is None or self.lib.vda_car_error(self.ctx) != 0:
+                    return False
+                # gloo sums in another order than rank 0..n-1: allow one rounding step of the sum
+                if not (torch.allclose(res.float(), ref_res.float(), atol=0.07, rtol=0.02)
+                        and torch.allclose(out.float(), ref_out.float(), atol=0.07, rtol=0.02)):
+                    return False
+        return True
+
+    @classmethod
+    def maybe_create(cls, cpu_group, device: torch.device) -> Optional["FusedAllReduceNorm"]:
+        world = dist.get_world_size(cpu_group)
+        if world not in cls.SUPPORTED_WORLD or envs.VDA_FUSED_AR_NORM_MAX_TOKENS <= 0:
+            return None
+        ok, obj, err = 1, None, ""
+        try:
+            obj = cls(cpu_group, device)
+            ok = int(obj._self_test())
+        except Exception as e:  # noqa: BLE001 - any failure just disables this path
+            ok, err = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
+        if int(flag.item()) == 0:
+            if dist.get_rank(cpu_group) == 0:
+                logger.warning("fused all-reduce + norm disabled (%s)", err or "self-test failed on a peer")
+            if obj is not None:
+                obj.disabled = True
+            return None
+        if dist.get_rank(cpu_group) == 0:
+            logger.info("fused all-reduce + RMSNorm enabled: %d ranks, batches of up to %d tokens", world,
+                        obj.max_tokens)
+        return obj
 
 
 class QuickAllReduce(CustomAllReduce):

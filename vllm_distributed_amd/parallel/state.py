@@ -71,6 +71,7 @@ class GroupCoordinator:
         self.device = torch.device(f"cuda:{local_rank}") if backend == "nccl" else \
             (torch.device("cuda:0") if self.staged else torch.device("cpu"))
         self.ca_comm = None       # peer-memory all-reduce
+        self.far_comm = None      # peer-memory all-reduce fused with residual add + RMSNorm
         self.ca_comm_async = None # second context (own arena, own call counters) for the communication stream
         self.qr_comm = None       # quantised peer-memory all-reduce (opt-in)
         self.rccl_comm = None     # stream-explicit RCCL (graph capturable)
@@ -105,6 +106,13 @@ class GroupCoordinator:
             except Exception as e:
                 logger.warning("peer-memory all-reduce disabled for group %s: %s", self.name, e)
                 self.ca_comm = None
+            if self.ca_comm is not None:
+                try:
+                    from .custom_allreduce import FusedAllReduceNorm
+                    self.far_comm = FusedAllReduceNorm.maybe_create(self.cpu_group, self.device)
+                except Exception as e:
+                    logger.warning("fused all-reduce + norm disabled for group %s: %s", self.name, e)
+                    self.far_comm = None
             if envs.VLLM_ROCM_QUICK_REDUCE_QUANTIZATION not in ("NONE", "FP"):
                 try:
                     from .custom_allreduce import QuickAllReduce
@@ -174,6 +182,23 @@ class GroupCoordinator:
             x.copy_(h)
         return x
 
+    def can_fuse_reduce_norm(self, x: torch.Tensor) -> bool:
+        """Whether ``all_reduce_rms_norm`` would take the one-kernel path for this tensor (a pure function
+        of shape and dtype, so every rank answers alike)."""
+        return self.world_size > 1 and x.is_cuda and self.far_comm is not None and self.far_comm.fits(x)
+
+    def all_reduce_rms_norm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                            weight_bias: float = 0.0) -> tuple[torch.Tensor, torch.Tensor]:
+        """``residual += all_reduce(x)`` (in place) and ``rmsnorm(residual)``: one peer-memory kernel where
+        the shape fits, all-reduce followed by the fused add + norm kernel otherwise (same bits)."""
+        if self.can_fuse_reduce_norm(x):
+            out = self.far_comm.run(x, residual, weight, eps, weight_bias)
+            if out is not None:
+                return out, residual
+        from .. import ops
+        x = self.all_reduce(x)
+        return ops.rms_norm(x, weight, eps, residual, weight_bias), residual
+
     def all_reduce_async(self, x: torch.Tensor) -> "AsyncWork":
         """Start the all-reduce of ``x`` on this group's communication stream and return at once; the
         caller keeps issuing independent kernels on its own stream and calls ``wait()`` where the sum is
@@ -205,7 +230,7 @@ class GroupCoordinator:
         whose barrier timed out skipped its reads, so the step that contained it produced garbage: the
         worker must die (the engine then reports ENGINE_CORE_DEAD) rather than serve it.  Reads pinned
         host words only; call after the stream has been synchronised (the sampled-token read-back)."""
-        for name in ("ca_comm", "ca_comm_async", "qr_comm"):
+        for name in ("ca_comm", "ca_comm_async", "qr_comm", "far_comm"):
             c = getattr(self, name, None)
             if c is not None and not c.disabled:
                 e = c.check_error()
@@ -435,6 +460,9 @@ class GroupCoordinator:
         if self.ca_comm is not None:
             self.ca_comm.close()
             self.ca_comm = None
+        if self.far_comm is not None:
+            self.far_comm.close()
+            self.far_comm = None
         if self.rccl_comm is not None:
             self.rccl_comm.close()
             self.rccl_comm = None
