@@ -610,6 +610,45 @@ def test_int8_quant_dynamic_and_static(dt, H):
     assert int((q2.int() - q2r.int()).abs().max()) <= 1
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H", [128, 4096, 11008])
+def test_int8_quant_asymmetric(dt, H):
+    """Zero-point int8 (reference: tests/kernels/quantization/test_int8_quant.py, the azp cases)."""
+    x = (torch.randn(37, H, device=DEV) * 3 + 1.5).to(dt)
+    q, s, z = ops.int8_quant_azp(x)
+    qr, sr, zr = R.int8_quant_azp(x)
+    torch.testing.assert_close(s, sr, rtol=1e-6, atol=0)
+    assert int((z - zr).abs().max()) <= 1
+    assert int((q.int() - qr.int()).abs().max()) <= 1 and float((q != qr).float().mean()) < 2e-3
+    # the quantised rows reproduce the input to half a step
+    back = (q.float() - z.float()) * s
+    assert float((back - x.float()).abs().max()) <= float(s.max()) * 0.51 + 2e-2
+    st, sz = torch.tensor([0.04], device=DEV), torch.tensor([-9], device=DEV, dtype=torch.int32)
+    q2, _, _ = ops.int8_quant_azp(x, st, sz)
+    q2r, _, _ = R.int8_quant_azp(x, st, sz)
+    assert int((q2.int() - q2r.int()).abs().max()) <= 1
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(1, 128), (33, 4096), (7, 1000)])
+def test_permute_cols(dt, rows, cols):
+    x = torch.randn(rows, cols, device=DEV).to(dt)
+    perm = torch.randperm(cols, device=DEV).int()
+    assert torch.equal(ops.permute_cols(x, perm), x[:, perm.long()])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_convert_fp8_both_directions(dt):
+    x = torch.randn(40, 8, 128, device=DEV).to(dt)
+    q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=DEV)
+    ops.convert_fp8(q, x, 0.05)
+    torch.testing.assert_close(q.float(), (x.float() / 0.05).clamp(-448, 448).to(torch.float8_e4m3fn).float(),
+                               rtol=0.07, atol=1e-3)
+    back = torch.empty_like(x)
+    ops.convert_fp8(back, q, 0.05)
+    torch.testing.assert_close(back.float(), q.float() * 0.05, rtol=1e-2, atol=1e-3)
+
+
 @pytest.mark.parametrize("M", [1, 17, 300])
 def test_int8_linear_matches_integer_reference(M):
     from vllm_distributed_amd.layers.quant import _int8_matmul

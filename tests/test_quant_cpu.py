@@ -244,6 +244,61 @@ def test_int8_w8a8_checkpoint(tmp_path, strategy):
         assert list(o.outputs[0].token_ids) == ref, (strategy, p)
 
 
+@pytest.mark.parametrize("dynamic", [True, False])
+def test_int8_w8a8_asymmetric_activations(tmp_path, dynamic):
+    """compressed-tensors int8 W8A8 whose activations carry a zero point (dynamic per token, or a static
+    scale + zero point from calibration): the correction by azp x column sums of the weight must make the
+    engine's greedy tokens equal a plain PyTorch emulation of the same arithmetic through the HF model."""
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    out = {}
+    for name, t in sd.items():
+        if not (name.endswith("_proj.weight") and t.dim() == 2):
+            out[name] = t
+            continue
+        prefix = name[: -len(".weight")]
+        s = (t.abs().amax(1, keepdim=True) / 127.0).clamp(min=1e-8).float()
+        q = torch.round(t / s).clamp(-128, 127).to(torch.int8)
+        out[name], out[prefix + ".weight_scale"] = q, s
+        if not dynamic:
+            out[prefix + ".input_scale"] = torch.tensor([0.06])
+            out[prefix + ".input_zero_point"] = torch.tensor([-7], dtype=torch.int8)
+        mod = hf.get_submodule(prefix)
+        wq, ws = q.float(), s.reshape(1, -1)
+
+        def fwd(x, wq=wq, ws=ws):
+            if dynamic:
+                mx, mn = x.amax(-1, keepdim=True), x.amin(-1, keepdim=True)
+                xs = ((mx - mn) / 255.0).clamp(min=1e-10)
+                z = torch.round(-128.0 - mn / xs)
+            else:
+                xs, z = torch.tensor(0.06), torch.tensor(-7.0)
+            xq = (torch.round(x / xs) + z).clamp(-128, 127)
+            return ((xq - z) @ wq.t()) * xs * ws
+        mod.forward = fwd
+    save_file(out, os.path.join(path, "model.safetensors"))
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    cfg["quantization_config"] = {
+        "quant_method": "compressed-tensors", "format": "int-quantized", "ignore": ["lm_head"],
+        "config_groups": {"group_0": {"targets": ["Linear"],
+                                      "weights": {"num_bits": 8, "type": "int", "symmetric": True, "strategy": "channel"},
+                                      "input_activations": {"num_bits": 8, "type": "int", "symmetric": False,
+                                                            "dynamic": dynamic,
+                                                            "strategy": "token" if dynamic else "tensor"}}}}
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, (dynamic, p)
+
+
 _NF4 = [-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635,
         -0.18477343022823334, -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725,
         0.24611230194568634, 0.33791524171829224, 0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0]

@@ -115,10 +115,13 @@ class Int8Config(QuantizationConfig):
     FUSED = Fp8Config.FUSED
 
     def __init__(self, weight_strategy: str = "channel", dynamic_activations: bool = True,
-                 ignored_layers: Optional[list[str]] = None):
+                 ignored_layers: Optional[list[str]] = None, symmetric_activations: bool = True):
         if weight_strategy not in ("channel", "tensor"):
             raise ValueError(f"int8: unsupported weight strategy {weight_strategy!r}")
         self.weight_strategy, self.dynamic = weight_strategy, dynamic_activations
+        # False: activations carry a zero point (q = round(x / s) + azp); the GEMM result is corrected by
+        # azp times the column sums of the weight (reference: cutlass_scaled_mm_azp, scaled_mm_entry.cu)
+        self.symmetric = symmetric_activations
         self.ignored_layers = ignored_layers or []
 
     def get_quant_method(self, layer: nn.Module, prefix: str):
@@ -176,6 +179,10 @@ class Int8LinearMethod:
             ins = nn.Parameter(torch.ones(n_shards, dtype=torch.float32), requires_grad=False)
             set_weight_attrs(ins, {"per_shard_scalar": n_shards > 1})
             layer.register_parameter("input_scale", ins)
+            if not self.cfg.symmetric:
+                zp = nn.Parameter(torch.zeros(n_shards, dtype=torch.int8), requires_grad=False)
+                set_weight_attrs(zp, {"per_shard_scalar": n_shards > 1})
+                layer.register_parameter("input_zero_point", zp)
 
     def process_weights_after_loading(self, layer: nn.Module) -> None:
         ws = layer.weight_scale.data.float()
@@ -184,14 +191,31 @@ class Int8LinearMethod:
                 if ws.numel() > 1 else ws.reshape(1).expand(layer.weight.shape[0])
         layer.weight_scale = nn.Parameter(ws.reshape(1, -1).contiguous(), requires_grad=False)     # [1, N]
         ins = getattr(layer, "input_scale", None)
-        layer.input_scale = nn.Parameter(ins.data.float().max().reshape(1), requires_grad=False) \
-            if ins is not None else None
+        if ins is not None and not self.cfg.symmetric:
+            # fused shards (q/k/v) were calibrated separately: one range covering all of them
+            zp = layer.input_zero_point.data.float()
+            lo, hi = (ins.data.float() * (-128 - zp)).min(), (ins.data.float() * (127 - zp)).max()
+            sc = ((hi - lo) / 255.0).clamp(min=1e-10)
+            layer.input_scale = nn.Parameter(sc.reshape(1), requires_grad=False)
+            layer.input_zero_point = nn.Parameter(torch.round(-128 - lo / sc).to(torch.int32).reshape(1),
+                                                  requires_grad=False)
+        else:
+            layer.input_scale = nn.Parameter(ins.data.float().max().reshape(1), requires_grad=False) \
+                if ins is not None else None
+        if not self.cfg.symmetric:
+            layer.azp_adj = nn.Parameter(layer.weight.data.to(torch.int32).sum(dim=1).float().reshape(1, -1),
+                                         requires_grad=False)                   # [1, N] column sums
 
     def apply(self, layer: nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
-        xq, xs = ops.int8_quant(x2, getattr(layer, "input_scale", None))
-        acc = _int8_matmul(xq, layer.weight)
+        if self.cfg.symmetric:
+            xq, xs = ops.int8_quant(x2, getattr(layer, "input_scale", None))
+            acc = _int8_matmul(xq, layer.weight)
+        else:
+            xq, xs, azp = ops.int8_quant_azp(x2, getattr(layer, "input_scale", None),
+                                             getattr(layer, "input_zero_point", None))
+            acc = _int8_matmul(xq, layer.weight) - azp.float().reshape(-1, 1) * layer.azp_adj
         y = acc * (xs.float().reshape(-1, 1) if xs.numel() > 1 else xs.float().reshape(1, 1)) * layer.weight_scale
         if bias is not None:
             y = y + bias.float()
@@ -241,11 +265,10 @@ def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
         if groups and kinds == {("int", 8)}:
             g0 = next(iter(groups.values()))
             act = g0.get("input_activations") or {}
-            if int(act.get("num_bits", 8)) != 8 or not act.get("symmetric", True) \
-                    or not g0["weights"].get("symmetric", True):
-                raise ValueError(f"{q}: only symmetric W8A8 int8 schemes are supported")
+            if int(act.get("num_bits", 8)) != 8 or not g0["weights"].get("symmetric", True):
+                raise ValueError(f"{q}: W8A8 int8 needs 8-bit activations and symmetric weights")
             return Int8Config(str(g0["weights"].get("strategy", "channel")), bool(act.get("dynamic", True)),
-                              (hf_q or {}).get("ignore"))
+                              (hf_q or {}).get("ignore"), symmetric_activations=bool(act.get("symmetric", True)))
         ok = all(str(g.get("weights", {}).get("type", "")).startswith("float") and
                  int(g.get("weights", {}).get("num_bits", 8)) == 8 for g in groups.values())
         if not groups or not ok:

@@ -401,6 +401,53 @@ def int8_quant(x: torch.Tensor, scale: Optional[torch.Tensor] = None):
     return out.view(x.shape), (scales.view(*x.shape[:-1], 1) if scale is None else scale)
 
 
+def int8_quant_azp(x: torch.Tensor, scale: Optional[torch.Tensor] = None, azp: Optional[torch.Tensor] = None):
+    """Asymmetric int8 quantisation of the last dimension's rows: q = clamp(round(x / scale) + azp).
+    Dynamic per token when ``scale`` is None (scale = (max - min) / 255, azp = round(-128 - min / scale),
+    both returned with a trailing dimension of 1), the given scalar scale / int32 zero point otherwise.
+    Reference: vllm/_custom_ops.py scaled_int8_quant(symmetric=False)."""
+    if not _dev(x) or x.shape[-1] % 8 or x.shape[-1] > 65536:
+        return R.int8_quant_azp(x, scale, azp)
+    H = x.shape[-1]
+    x2 = _contig_last(x).view(-1, H)
+    out = torch.empty(x2.shape, dtype=torch.int8, device=x.device)
+    dyn = scale is None
+    scales = torch.empty((x2.shape[0], 1), dtype=torch.float32, device=x.device) if dyn else scale
+    azps = torch.empty((x2.shape[0], 1), dtype=torch.int32, device=x.device) if dyn else azp
+    N.call("vda_int8_quant_azp", out.data_ptr(), scales.data_ptr(), N.ptr(azps), x2.data_ptr(), N.ptr(scale),
+           N.ptr(azp), x2.shape[0], H, x2.stride(0), out.stride(0), N.dt(x.dtype), N.stream())
+    if dyn:
+        return out.view(x.shape), scales.view(*x.shape[:-1], 1), azps.view(*x.shape[:-1], 1)
+    return out.view(x.shape), scale, azp
+
+
+def permute_cols(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    """``x[:, perm]`` for a 16-bit matrix [rows, cols] (perm int32 [cols]).  Reference: csrc/permute_cols.cu."""
+    if not _dev(x) or x.element_size() != 2 or x.dim() != 2 or x.stride(1) != 1:
+        return x[:, perm.long()]
+    out = torch.empty((x.shape[0], perm.shape[0]), dtype=x.dtype, device=x.device)
+    if out.stride(0) % 8:
+        return x[:, perm.long()]
+    N.call("vda_permute_cols", out.data_ptr(), x.data_ptr(), perm.to(torch.int32).contiguous().data_ptr(), x.shape[0],
+           perm.shape[0], x.stride(0), out.stride(0), N.stream())
+    return out
+
+
+def convert_fp8(dst: torch.Tensor, src: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """Cache-dtype conversion in either direction (reference: csrc/cache_kernels.cu convert_fp8):
+    16-bit / fp32 -> e4m3 stores ``src / scale``, e4m3 -> 16-bit / fp32 stores ``src * scale``."""
+    f8 = torch.float8_e4m3fn
+    s = torch.tensor([scale], dtype=torch.float32, device=src.device)
+    if dst.dtype == f8 and src.dtype != f8:
+        q, _ = scaled_fp8_quant(src.reshape(-1, src.shape[-1]), s)
+        dst.copy_(q.view(dst.shape))
+    elif src.dtype == f8 and dst.dtype != f8:
+        dst.copy_(fp8_dequant(src.contiguous(), s, dst.dtype).view(dst.shape))
+    else:
+        raise ValueError(f"convert_fp8: exactly one side must be float8_e4m3fn, got {src.dtype} -> {dst.dtype}")
+    return dst
+
+
 def fp8_dequant(q: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype):
     if not _dev(q) or q.numel() % 8:
         return R.fp8_dequant(q, scale, dtype)

@@ -240,6 +240,115 @@ __global__ __launch_bounds__(1024) void quant_int8_kernel(int8_t* __restrict__ o
   }
 }
 
+// Asymmetric int8 (zero point): q = clamp(rn(x / scale) + azp, -128, 127).  Dynamic per token:
+// scale = (max - min) / 255, azp = rn(-128 - min / scale); static: one scale and one zero point.
+// Reference: csrc/quantization/compressed_tensors/int8_quant_kernels.cu (the *_azp_* kernels).
+template <typename T, int MAXV>
+__global__ __launch_bounds__(1024) void quant_int8_azp_kernel(int8_t* __restrict__ out, float* __restrict__ scales,
+                                                              int32_t* __restrict__ azps, const T* __restrict__ in,
+                                                              const float* static_scale, const int32_t* static_azp,
+                                                              int H, long in_stride, long out_stride) {
+  using V8 = typename Vec<T>::v8;
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const int nvec = H >> 3;
+  V8 x[MAXV];
+  float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int i = threadIdx.x + v * blockDim.x;
+    if (i < nvec) {
+      x[v] = ld16<V8>(in + row * in_stride + 8 * i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)x[v][j]; mx = fmaxf(mx, f); mn = fminf(mn, f); }
+    }
+  }
+  float sc;
+  int azp;
+  if (static_scale) {
+    sc = *static_scale;
+    azp = static_azp ? *static_azp : 0;
+  } else {
+    mx = block_max(mx, red);
+    mn = -block_max(-mn, red);
+    sc = fmaxf((mx - mn) / 255.f, 1e-10f);
+    azp = __float2int_rn(-128.f - mn / sc);
+    if (threadIdx.x == 0) { scales[row] = sc; azps[row] = azp; }
+  }
+  const float inv = 1.f / sc;
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    const int i = threadIdx.x + v * blockDim.x;
+    if (i < nvec) {
+      u32x2 pk;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int q = __float2int_rn((float)x[v][h * 4 + j] * inv) + azp;
+          q = q < -128 ? -128 : (q > 127 ? 127 : q);
+          w |= (uint32_t)(q & 0xFF) << (8 * j);
+        }
+        pk[h] = w;
+      }
+      *reinterpret_cast<u32x2*>(out + row * out_stride + 8 * i) = pk;
+    }
+  }
+}
+
+VDA_EXPORT int vda_int8_quant_azp(void* out, float* scales, int32_t* azps, const void* in, const float* static_scale,
+                                  const int32_t* static_azp, int rows, int H, long in_stride, long out_stride,
+                                  int dtype, hipStream_t st) {
+  if (H % 8) return -1;
+  if (rows == 0) return 0;
+  const int nvec = H / 8;
+  int threads = ((nvec + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  const int need = (nvec + threads - 1) / threads;
+  if (need > 8) return -2;
+  dim3 grid(rows), block(threads);
+#define L(TT, MV) hipLaunchKernelGGL((quant_int8_azp_kernel<TT, MV>), grid, block, 0, st, (int8_t*)out, scales, azps, \
+                                     (const TT*)in, static_scale, static_azp, H, in_stride, out_stride)
+#define BY(TT) do { if (need <= 1) L(TT, 1); else if (need <= 2) L(TT, 2); else if (need <= 4) L(TT, 4); else L(TT, 8); } while (0)
+  if (dtype == VDA_BF16) BY(bf16_t); else if (dtype == VDA_F16) BY(f16_t); else return -3;
+#undef BY
+#undef L
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[r, c] = in[r, perm[c]] for 16-bit elements (activation reordering in front of act-order GPTQ layers).
+// Reference: csrc/permute_cols.cu.  One workgroup per row; 8 output columns (16 bytes) per thread and step.
+__global__ __launch_bounds__(256) void permute_cols_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ in,
+                                                           const int* __restrict__ perm, int cols, long in_stride,
+                                                           long out_stride) {
+  const long row = blockIdx.x;
+  const uint16_t* ip = in + row * in_stride;
+  uint16_t* op = out + row * out_stride;
+  const int nvec = cols >> 3;
+  for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+    u32x4 w;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const uint32_t lo = ip[perm[8 * i + 2 * h]], hi = ip[perm[8 * i + 2 * h + 1]];
+      w[h] = lo | (hi << 16);
+    }
+    *reinterpret_cast<u32x4*>(op + 8 * i) = w;
+  }
+  for (int c = (nvec << 3) + threadIdx.x; c < cols; c += blockDim.x) op[c] = ip[perm[c]];
+}
+
+VDA_EXPORT int vda_permute_cols(void* out, const void* in, const int* perm, int rows, int cols, long in_stride,
+                                long out_stride, hipStream_t st) {
+  if (rows == 0 || cols == 0) return 0;
+  if (out_stride % 8) return -1;           // 16-byte stores
+  hipLaunchKernelGGL(permute_cols_kernel, dim3(rows), dim3(256), 0, st, (uint16_t*)out, (const uint16_t*)in, perm, cols,
+                     in_stride, out_stride);
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
 // scales: [rows] written when static_scale is null, ignored otherwise.
 VDA_EXPORT int vda_int8_quant(void* out, float* scales, const void* in, const float* static_scale, int rows, int H,
                               long in_stride, long out_stride, int dtype, hipStream_t st) {

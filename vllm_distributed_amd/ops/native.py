@@ -42,6 +42,8 @@ _SIGS = {
     "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, I, P,
                                     I, P],
     "vda_set_prefill_variant": [I],
+    "vda_int8_quant_azp": [P, P, P, P, P, P, I, I, L, L, I, P],
+    "vda_permute_cols": [P, P, P, I, I, L, L, P],
     "vda_set_prefill_wide_min_wgs": [L],
     "vda_merge_attn_states": [P, P, P, P, P, P, I, I, I, I, P],
     "vda_argmax": [P, P, I, I, L, I, P],

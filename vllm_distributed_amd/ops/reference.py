@@ -355,6 +355,20 @@ def int8_quant(x, scale=None):
     return q, (s if scale is None else scale)
 
 
+def int8_quant_azp(x, scale=None, azp=None):
+    xf = x.float()
+    if scale is None:
+        mx, mn = xf.amax(-1, keepdim=True), xf.amin(-1, keepdim=True)
+        s = ((mx - mn) / 255.0).clamp(min=1e-10)
+        z = torch.round(-128.0 - mn / s).to(torch.int32)
+        q = (torch.round(xf / s) + z).clamp(-128, 127).to(torch.int8)
+        return q, s, z
+    s = scale.float().reshape(())
+    z = azp.reshape(()).to(torch.int32) if azp is not None else torch.zeros((), dtype=torch.int32, device=x.device)
+    q = (torch.round(xf / s) + z).clamp(-128, 127).to(torch.int8)
+    return q, scale, azp
+
+
 # ---- state-space layers ---------------------------------------------------------------------------
 def causal_conv1d(x, weight, bias, conv_state, qsl, seq_lens, block_table, activation=True):
     T, C = x.shape
