@@ -437,3 +437,55 @@ def test_fuyu_matches_hf(tmp_path):
                               image_patches_indices=torch.tensor([idx]), max_new_tokens=6, do_sample=False,
                               pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref, im.shape
+
+
+@pytest.mark.parametrize("family", ["mistral3", "pixtral_llava"])
+def test_pixtral_tower_models_match_hf(tmp_path, family):
+    """Pixtral tower (images of any size, 2-D rotary positions, block-diagonal attention) under Mistral-3's
+    norm + 2x2 patch merger + projector and under LLaVA's plain projector; image rows closed by break / end tokens
+    that keep their text embeddings.  Three image shapes; the processor's own pixels are fed to transformers too."""
+    import transformers as tf
+    from vllm_distributed_amd.models.pixtral import PixtralImageProcessor
+    from vllm_distributed_amd.multimodal import CLIP_MEAN, CLIP_STD
+    torch.manual_seed(0)
+    vc = tf.PixtralVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                                image_size=64, patch_size=4, head_dim=32)
+    tc = tf.MistralConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                          num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=1024, head_dim=64,
+                          sliding_window=None)
+    if family == "mistral3":
+        cfg = tf.Mistral3Config(vision_config=vc, text_config=tc, image_token_index=300, spatial_merge_size=2,
+                                vision_feature_layer=-1)
+        hf = tf.Mistral3ForConditionalGeneration(cfg).float().eval()
+        merge, arch = 2, None
+    else:
+        cfg = tf.LlavaConfig(vision_config=vc, text_config=tc, image_token_index=300, vision_feature_layer=-1,
+                             vision_feature_select_strategy="full")
+        hf = tf.LlavaForConditionalGeneration(cfg).float().eval()
+        merge, arch = 1, None           # resolved from the vision tower's model type under LLaVA's own name
+    path = os.path.join(tmp_path, family)
+    hf.save_pretrained(path, safe_serialization=True)
+    overrides = {"image_break_token_id": 301, "image_end_token_id": 302}
+    if arch:
+        overrides["architectures"] = [arch]
+    rng = np.random.default_rng(2)
+    imgs = [(rng.random(s + (3,)) * 255).astype(np.uint8) for s in ((20, 41), (100, 30), (16, 16))]
+    prompts = [[5, 17, 300, 99, 3], [300, 7, 8, 9, 10, 11, 12], [4, 300, 6]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=1024, max_num_seqs=8,
+              max_num_batched_tokens=256, hf_overrides=overrides)
+    reqs = [{"prompt_token_ids": p, "multi_modal_data": {"image": im}} for p, im in zip(prompts, imgs)]
+    outs = llm.generate(reqs, SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    llm.shutdown()
+    proc = PixtralImageProcessor(300, 301, 302, 4, merge, 64, CLIP_MEAN, CLIP_STD)
+    shapes = set()
+    for p, im, o in zip(prompts, imgs, outs):
+        ids, inputs, _, ranges = proc(p, {"image": im})
+        px = inputs[0][0]
+        shapes.add(tuple(px.shape))
+        assert ranges[0].length == (px.shape[1] // (4 * merge)) * (px.shape[2] // (4 * merge) + 1)
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=px[None],
+                              image_sizes=torch.tensor([list(px.shape[1:])]), max_new_tokens=6, do_sample=False,
+                              pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, (family, im.shape)
+    assert len(shapes) == 3

@@ -81,6 +81,14 @@ class LlavaForConditionalGeneration(nn.Module):
     supports_pp = False
     supports_lora = False
 
+    def __new__(cls, vllm_config: Optional[VllmConfig] = None, prefix: str = ""):
+        # a LLaVA checkpoint over the Pixtral tower (images of any size, break / end tokens) is another model
+        if cls is LlavaForConditionalGeneration and vllm_config is not None \
+                and _cfg(vllm_config.model_config.hf_config.vision_config).get("model_type") == "pixtral":
+            from .pixtral import PixtralForConditionalGeneration
+            return PixtralForConditionalGeneration(vllm_config, prefix)
+        return super().__new__(cls)
+
     def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
         super().__init__()
         hf = vllm_config.model_config.hf_config

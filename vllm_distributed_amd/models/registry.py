@@ -122,6 +122,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlavaOnevisionForConditionalGeneration": ("llava_next", "LlavaOnevisionForConditionalGeneration"),
     "FuyuForCausalLM": ("fuyu", "FuyuForCausalLM"),
     "MedusaModel": ("eagle", "MedusaModel"),
+    "Mistral3ForConditionalGeneration": ("pixtral", "Mistral3ForConditionalGeneration"),
+    "PixtralForConditionalGeneration": ("pixtral", "PixtralForConditionalGeneration"),
     "TransformersForCausalLM": ("transformers_backend", "TransformersForCausalLM"),
     "EAGLEModel": ("eagle", "EagleLlamaForCausalLM"),
     "DeepSeekMTPModel": ("mtp", "DeepSeekMTPModel"),

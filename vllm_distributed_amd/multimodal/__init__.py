@@ -132,6 +132,9 @@ def process_multimodal(vllm_config, prompt_token_ids: list[int], mm_data: dict):
 def _llava_processor(vllm_config):
     hf = vllm_config.model_config.hf_config
     vc = hf.vision_config if isinstance(hf.vision_config, dict) else hf.vision_config.to_dict()
+    if vc.get("model_type") == "pixtral":
+        from ..models.pixtral import pixtral_processor
+        return pixtral_processor(vllm_config)
     size, patch = int(vc.get("image_size", 336)), int(vc.get("patch_size", 14))
     n = (size // patch) ** 2
     if getattr(hf, "vision_feature_select_strategy", "default") == "full":
@@ -392,3 +395,12 @@ def _fuyu(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("FuyuForCausalLM", _fuyu)
+
+
+def _pixtral(vllm_config):
+    from ..models.pixtral import pixtral_processor
+    return pixtral_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("Mistral3ForConditionalGeneration", _pixtral)
+MULTIMODAL_REGISTRY.register_processor("PixtralForConditionalGeneration", _pixtral)
