@@ -489,3 +489,97 @@ def test_pixtral_tower_models_match_hf(tmp_path, family):
                               pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref, (family, im.shape)
     assert len(shapes) == 3
+
+
+@pytest.mark.parametrize("layout", ["transformers", "original"])
+def test_internvl_matches_hf(tmp_path, layout):
+    """InternViT tower (layer scale, query / key norm) + pixel shuffle + projector over a Qwen2 decoder, dynamic tiling
+    with a thumbnail.  ``original``: the same weights re-laid-out the way the InternVLChatModel checkpoints store
+    them (fused qkv, mlp1.*, language_model.*, llm_config) must load and decode identically."""
+    import json
+    import transformers as tf
+    from safetensors.torch import load_file, save_file
+    from vllm_distributed_amd.models.internvl import InternVLImageProcessor
+    torch.manual_seed(0)
+    vc = tf.InternVLVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                                 image_size=[28, 28], patch_size=[7, 7], use_qk_norm=True, attention_bias=True,
+                                 layer_scale_init_value=0.5)
+    tc = tf.Qwen2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512,
+                        tie_word_embeddings=False)
+    cfg = tf.InternVLConfig(vision_config=vc, text_config=tc, image_token_id=300, downsample_ratio=0.5)
+    hf = tf.InternVLForConditionalGeneration(cfg).float().eval()
+    with torch.no_grad():
+        for n, p_ in hf.named_parameters():
+            if "lambda_" in n or "position_embeddings" in n or "cls_token" in n:
+                p_.normal_(0, 0.5)
+    path = os.path.join(tmp_path, layout)
+    hf.save_pretrained(path, safe_serialization=True)
+    overrides = {}
+    if layout == "original":
+        sd = load_file(os.path.join(path, "model.safetensors"))
+        out, qkv = {}, {}
+        ren = (("embeddings.cls_token", "embeddings.class_embedding"),
+               ("embeddings.patch_embeddings.projection.", "embeddings.patch_embedding."),
+               ("embeddings.position_embeddings", "embeddings.position_embedding"), ("encoder.layer.", "encoder.layers."),
+               (".attention.projection_layer.", ".attn.proj."), (".attention.q_norm.", ".attn.q_norm."),
+               (".attention.k_norm.", ".attn.k_norm."), (".lambda_1", ".ls1"), (".lambda_2", ".ls2"),
+               (".layernorm_before.", ".norm1."), (".layernorm_after.", ".norm2."))
+        for n, t in sd.items():
+            if n.startswith("model.") and not n.startswith("model.language_model."):
+                n = n[6:]
+            if n.startswith("language_model."):
+                out[n] = t
+            elif n.startswith("model.language_model."):
+                out["language_model.model." + n[len("model.language_model."):]] = t
+            elif n.startswith("lm_head."):
+                out["language_model." + n] = t
+            elif n.startswith("multi_modal_projector."):
+                n = n[len("multi_modal_projector."):]
+                for a, b in (("layer_norm.", "0."), ("linear_1.", "1."), ("linear_2.", "3.")):
+                    if n.startswith(a):
+                        n = b + n[len(a):]
+                out["mlp1." + n] = t
+            elif n.startswith("vision_tower."):
+                n = n[len("vision_tower."):]
+                for a, b in ren:
+                    n = n.replace(a, b)
+                hit = next((s for s in ("q_proj", "k_proj", "v_proj") if f".attention.{s}." in n), None)
+                if hit:
+                    qkv.setdefault(n.replace(f".attention.{hit}.", ".attn.qkv."), {})[hit] = t
+                elif not n.startswith("layernorm."):
+                    out["vision_model." + n] = t
+        for n, d in qkv.items():
+            out["vision_model." + n] = torch.cat((d["q_proj"], d["k_proj"], d["v_proj"]), dim=0)
+        save_file(out, os.path.join(path, "model.safetensors"))
+        c = json.load(open(os.path.join(path, "config.json")))
+        v = c["vision_config"]
+        new = {"architectures": ["InternVLChatModel"], "model_type": "internvl_chat", "downsample_ratio": 0.5,
+               "select_layer": -1, "ps_version": "v2", "dynamic_image_size": True, "max_dynamic_patch": 12,
+               "min_dynamic_patch": 1, "use_thumbnail": True,
+               "llm_config": dict(c["text_config"], architectures=["Qwen2ForCausalLM"]),
+               "vision_config": {"hidden_size": 64, "intermediate_size": 128, "num_hidden_layers": 3,
+                                 "num_attention_heads": 2, "image_size": 28, "patch_size": 7, "qk_normalization": True,
+                                 "qkv_bias": True, "norm_type": v.get("norm_type", "layer_norm"),
+                                 "layer_norm_eps": v.get("layer_norm_eps", 1e-6), "hidden_act": "gelu"}}
+        json.dump(new, open(os.path.join(path, "config.json"), "w"))
+        overrides = {"image_token_id": 300}
+    rng = np.random.default_rng(3)
+    imgs = [(rng.random(s + (3,)) * 255).astype(np.uint8) for s in ((30, 95), (100, 35), (28, 28))]
+    prompts = [[5, 17, 300, 99, 3], [300, 7, 8, 9, 10, 11, 12], [4, 300, 6]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=8,
+              max_num_batched_tokens=128, hf_overrides=overrides)
+    reqs = [{"prompt_token_ids": p, "multi_modal_data": {"image": im}} for p, im in zip(prompts, imgs)]
+    outs = llm.generate(reqs, SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    llm.shutdown()
+    proc = InternVLImageProcessor(300, 28, 4, 1, 12, True, True)
+    counts = set()
+    for p, im, o in zip(prompts, imgs, outs):
+        ids, inputs, _, _ = proc(p, {"image": im})
+        tiles = inputs[0][0]
+        counts.add(tiles.shape[0])
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=tiles, max_new_tokens=6, do_sample=False,
+                              pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, (layout, im.shape)
+    assert counts == {4, 1}            # 3 x 1 and 1 x 3 grids + thumbnail, and a single tile

@@ -136,6 +136,8 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
         d = copy.deepcopy(PRESETS[key])
     if "text_config" in d and "hidden_size" not in d:
         d = {**d, **d["text_config"]}
+    elif "llm_config" in d and "hidden_size" not in d:          # InternVL's original layout
+        d = {**d, **{k: v for k, v in d["llm_config"].items() if k not in ("architectures", "model_type")}}
     if d.get("model_type") == "whisper" and "hidden_size" not in d:
         # encoder-decoder configs name the decoder's sizes differently: give them the names the engine reads
         d = {**d, "hidden_size": d["d_model"], "num_attention_heads": d["decoder_attention_heads"],

@@ -122,6 +122,10 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlavaOnevisionForConditionalGeneration": ("llava_next", "LlavaOnevisionForConditionalGeneration"),
     "FuyuForCausalLM": ("fuyu", "FuyuForCausalLM"),
     "MedusaModel": ("eagle", "MedusaModel"),
+    "InternVLChatModel": ("internvl", "InternVLChatModel"),
+    "InternVLForConditionalGeneration": ("internvl", "InternVLForConditionalGeneration"),
+    "SkyworkR1VChatModel": ("internvl", "InternVLChatModel"),
+    "H2OVLChatModel": ("internvl", "InternVLChatModel"),
     "Mistral3ForConditionalGeneration": ("pixtral", "Mistral3ForConditionalGeneration"),
     "PixtralForConditionalGeneration": ("pixtral", "PixtralForConditionalGeneration"),
     "TransformersForCausalLM": ("transformers_backend", "TransformersForCausalLM"),

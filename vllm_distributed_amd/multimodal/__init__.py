@@ -404,3 +404,12 @@ def _pixtral(vllm_config):
 
 MULTIMODAL_REGISTRY.register_processor("Mistral3ForConditionalGeneration", _pixtral)
 MULTIMODAL_REGISTRY.register_processor("PixtralForConditionalGeneration", _pixtral)
+
+
+def _internvl(vllm_config):
+    from ..models.internvl import internvl_processor
+    return internvl_processor(vllm_config)
+
+
+for _a in ("InternVLChatModel", "InternVLForConditionalGeneration", "SkyworkR1VChatModel", "H2OVLChatModel"):
+    MULTIMODAL_REGISTRY.register_processor(_a, _internvl)
