@@ -596,3 +596,45 @@ def test_gemma3_multimodal_checkpoint_served_as_text(tmp_path):
                               eos_token_id=None)[0, len(p):].tolist()
         assert list(o.outputs[0].token_ids) == ref
     llm.shutdown()
+
+
+def test_fairseq2_llama_checkpoint(tmp_path):
+    """A Llama checkpoint re-written the way fairseq2 stores it (its names, the interleaved rotary row order of the
+    q / k projections, the {"model_key": ...} wrapper in a .pt file) decodes the same tokens as the original."""
+    import json
+    from safetensors.torch import load_file
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    hd = 64
+    ren = (("model.embed_tokens.", "decoder_frontend.embed."), ("lm_head.", "final_proj."), ("model.", "decoder."))
+    sub = ((".input_layernorm.", ".self_attn_layer_norm."), (".post_attention_layernorm.", ".ffn_layer_norm."),
+           (".self_attn.o_proj.", ".self_attn.output_proj."), (".mlp.gate_proj.", ".ffn.gate_proj."),
+           (".mlp.up_proj.", ".ffn.inner_proj."), (".mlp.down_proj.", ".ffn.output_proj."), ("decoder.norm.", "decoder.layer_norm."))
+    out = {}
+    for n, t in sd.items():
+        if ".q_proj." in n or ".k_proj." in n:          # half-split -> interleaved pairs
+            heads = t.shape[0] // hd
+            t = t.view(heads, 2, hd // 2, t.shape[1]).transpose(1, 2).reshape(t.shape).contiguous()
+        for a, b in ren:
+            if n.startswith(a):
+                n = b + n[len(a):]
+                break
+        for a, b in sub:
+            n = n.replace(a, b)
+        out[n] = t
+    fs2 = os.path.join(str(tmp_path), "fs2")
+    os.makedirs(fs2)
+    torch.save({"model_key": "model", "model": out}, os.path.join(fs2, "model.pt"))
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    cfg["architectures"] = ["Fairseq2LlamaForCausalLM"]
+    json.dump(cfg, open(os.path.join(fs2, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 40]
+    llm = LLM(model=fs2, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=10,
+                                                                                   ignore_eos=True))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=10, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref

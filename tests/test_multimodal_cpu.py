@@ -583,3 +583,49 @@ def test_internvl_matches_hf(tmp_path, layout):
                               pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref, (layout, im.shape)
     assert counts == {4, 1}            # 3 x 1 and 1 x 3 grids + thumbnail, and a single tile
+
+
+def test_llava_next_video_matches_hf(tmp_path):
+    """Frames through the tower, stride-2 average pooling of every frame's feature map, projector; one request with
+    a video, one with an image (the LLaVA-NeXT path of the same checkpoint), one with both."""
+    import transformers as tf
+    from vllm_distributed_amd.models.llava_next import FrameVideoProcessor
+    from vllm_distributed_amd.multimodal import CLIP_MEAN, CLIP_STD
+    torch.manual_seed(0)
+    pins = [[28, 28], [28, 56], [56, 28]]
+    tc = tf.LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, head_dim=64)
+    vc = tf.CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                             image_size=28, patch_size=7, projection_dim=64)
+    cfg = tf.LlavaNextVideoConfig(vision_config=vc, text_config=tc, image_token_index=300, video_token_index=301,
+                                  vision_feature_layer=-2, vision_feature_select_strategy="default",
+                                  image_grid_pinpoints=pins, spatial_pool_mode="average", spatial_pool_stride=2)
+    hf = tf.LlavaNextVideoForConditionalGeneration(cfg).float().eval()
+    with torch.no_grad():
+        hf.model.image_newline.normal_(0, 0.5)
+    path = os.path.join(tmp_path, "lnv")
+    hf.save_pretrained(path, safe_serialization=True)
+    rng = np.random.default_rng(4)
+    video = (rng.random((3, 40, 52, 3)) * 255).astype(np.uint8)
+    image = (rng.random((40, 90, 3)) * 255).astype(np.uint8)
+    reqs = [{"prompt_token_ids": [5, 17, 301, 99, 3], "multi_modal_data": {"video": video}},
+            {"prompt_token_ids": [300, 7, 8, 9], "multi_modal_data": {"image": image}},
+            {"prompt_token_ids": [4, 300, 6, 301, 8], "multi_modal_data": {"image": image, "video": video}}]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=8,
+              max_num_batched_tokens=128)
+    outs = llm.generate(reqs, SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    llm.shutdown()
+    proc = FrameVideoProcessor(300, 28, 7, pins, CLIP_MEAN, CLIP_STD, 0, video_token_id=301, pool_stride=2)
+    for r, o in zip(reqs, outs):
+        ids, inputs, _, ranges = proc(r["prompt_token_ids"], r["multi_modal_data"])
+        kw = {}
+        for it in inputs:
+            if len(it) == 1:
+                kw["pixel_values_videos"] = it[0][None]
+            else:
+                kw["pixel_values"], kw["image_sizes"] = it[0][None], it[1][None]
+        assert sum(rg.length for rg in ranges) == sum(t in (300, 301) for t in ids)
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), max_new_tokens=6, do_sample=False, pad_token_id=0,
+                              eos_token_id=None, **kw)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, list(r["multi_modal_data"])

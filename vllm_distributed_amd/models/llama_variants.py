@@ -443,3 +443,34 @@ class Gemma3TextOnlyFromMultimodal(Gemma3ForCausalLM):
                     yield name, t
                 # vision_tower.*, multi_modal_projector.*: not part of the text path
         return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)
+
+
+# ---- Llama checkpoints written by fairseq2 --------------------------------------------------------------------
+class Fairseq2LlamaForCausalLM(LlamaForCausalLM):
+    """Llama weights in fairseq2's naming (``decoder_frontend.embed``, ``decoder.layers.N.ffn.inner_proj``,
+    ``final_proj`` ...) inside its ``{"model_key": name, name: state_dict}`` wrapper (unwrapped by the .pt reader),
+    with q / k projection rows in the interleaved rotary order: they are permuted to the half-split order the
+    rotary kernel uses.  Reference: vllm/model_executor/models/fairseq2_llama.py:48-152."""
+    _PREFIX = (("decoder_frontend.embed.", "model.embed_tokens."), ("decoder.", "model."), ("final_proj.", "lm_head."))
+    _SUBSTR = ((".self_attn_layer_norm.", ".input_layernorm."), (".ffn_layer_norm.", ".post_attention_layernorm."),
+               (".self_attn.output_proj.", ".self_attn.o_proj."), (".ffn.gate_proj.", ".mlp.gate_proj."),
+               (".ffn.inner_proj.", ".mlp.up_proj."), (".ffn.output_proj.", ".mlp.down_proj."),
+               (".layer_norm.", ".norm."))
+
+    def load_weights(self, weights):
+        c = self.config
+        hd = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+
+        def convert():
+            for n, t in weights:
+                for a, b in self._PREFIX:
+                    if n.startswith(a):
+                        n = b + n[len(a):]
+                        break
+                for a, b in self._SUBSTR:
+                    n = n.replace(a, b)
+                if ".q_proj." in n or ".k_proj." in n:
+                    heads = t.shape[0] // hd
+                    t = t.view(heads, hd // 2, 2, *t.shape[1:]).transpose(1, 2).reshape(t.shape)
+                yield n, t
+        return super().load_weights(convert())

@@ -308,3 +308,129 @@ def _anyres_processor(vllm_config):
     return AnyResImageProcessor(int(getattr(hf, "image_token_index", None) or getattr(hf, "image_token_id", 32000)),
                                 int(vc.get("image_size", 336)), int(vc.get("patch_size", 14)),
                                 [list(p) for p in hf.image_grid_pinpoints], mean, std, max_tiles)
+
+
+# ---- LLaVA-NeXT-Video -----------------------------------------------------------------------------------------
+class LlavaNextVideoForConditionalGeneration(LlavaNextForConditionalGeneration):
+    """LLaVA-NeXT plus videos: every frame goes through the tower at the encoder's own size, its feature map is
+    pooled with stride ``spatial_pool_stride`` (average, max or a learned convolution) and projected; the frames'
+    tokens follow each other in the prompt in place of a run of video tokens (no newline vectors).  A video item
+    reaches the model as [frames [F, 3, S, S]], an image item as LLaVA-NeXT's [tiles, size].
+    Reference: vllm/model_executor/models/llava_next_video.py (LlavaNextVideoPooler :155-193, video path :360-420)."""
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        hf = self.config
+        mode, stride = str(getattr(hf, "spatial_pool_mode", "average")), int(getattr(hf, "spatial_pool_stride", 2))
+        self.video_token_id = int(getattr(hf, "video_token_index", None) or getattr(hf, "video_token_id", 32000))
+        self.vision_resampler = nn.Module()
+        if mode == "average":
+            self.vision_resampler.pool = nn.AvgPool2d(stride, stride)
+        elif mode == "max":
+            self.vision_resampler.pool = nn.MaxPool2d(stride, stride)
+        elif mode == "conv":
+            H = self.vc.hidden_size
+            self.vision_resampler.pool = nn.Conv2d(H, int(getattr(hf, "spatial_pool_out_channels", H)), stride, stride)
+        else:
+            raise ValueError(f"unknown spatial_pool_mode {mode!r}")
+
+    def _video_features(self, frames: torch.Tensor) -> torch.Tensor:
+        feats = self.vision_tower.vision_model(frames.to(self.image_newline.dtype))
+        if self.select == "default" and self.has_cls:
+            feats = feats[:, 1:]
+        n, t, d = feats.shape
+        side = int(math.sqrt(t))
+        pooled = self.vision_resampler.pool(feats.view(n, side, side, d).permute(0, 3, 1, 2))
+        p = self.multi_modal_projector
+        return p.linear_2(self.proj_act(p.linear_1(pooled.flatten(2).transpose(1, 2)))).flatten(0, 1)
+
+    def encode_mm_items(self, items: list[list[torch.Tensor]]) -> list[torch.Tensor]:
+        images = [(i, it) for i, it in enumerate(items) if len(it) == 2]
+        out: list = [None] * len(items)
+        if images:
+            for (i, _), f in zip(images, super().encode_mm_items([it for _, it in images])):
+                out[i] = f
+        for i, it in enumerate(items):
+            if len(it) == 1:
+                out[i] = self._video_features(it[0])
+        return out
+
+
+class FrameVideoProcessor(AnyResImageProcessor):
+    """Adds videos to the any-resolution image processor: frames [F, H, W, 3] are resized (shortest side to the
+    encoder size, centre crop) and normalised; a run of video tokens becomes F * (side / stride)^2 of them.
+    Pre-processed input: {"pixel_values_videos": [F, 3, S, S]}."""
+
+    def __init__(self, *a, video_token_id: int, pool_stride: int, **kw):
+        super().__init__(*a, **kw)
+        self.video_token_id, self.stride = video_token_id, pool_stride
+
+    def frames(self, video: Any) -> torch.Tensor:
+        if isinstance(video, dict):
+            return torch.as_tensor(video["pixel_values_videos"]).float()
+        t = torch.as_tensor(np.asarray(video)).permute(0, 3, 1, 2).float()
+        H, W = t.shape[-2:]
+        S = self.S
+        s = S / min(H, W)
+        nh, nw = max(S, round(H * s)), max(S, round(W * s))
+        t = torch.nn.functional.interpolate(t, size=(nh, nw), mode="bicubic", align_corners=False,
+                                            antialias=True).clamp(0, 255)
+        top, left = (nh - S) // 2, (nw - S) // 2
+        t = t[:, :, top:top + S, left:left + S] / 255.0
+        m, sd = torch.tensor(self.mean).view(1, 3, 1, 1), torch.tensor(self.std).view(1, 3, 1, 1)
+        return (t - m) / sd
+
+    def __call__(self, prompt_token_ids: list[int], mm_data: dict):
+        from ..multimodal import PlaceholderRange, hash_item
+        videos = mm_data.get("video")
+        if videos is None:
+            return super().__call__(prompt_token_ids, mm_data)
+        if not isinstance(videos, (list, tuple)):
+            videos = [videos]
+        # videos first pass: expand their runs; images (if any) are expanded afterwards on the result
+        runs, prev = [], -2
+        for i, tok in enumerate(prompt_token_ids):
+            if tok == self.video_token_id:
+                if i != prev + 1:
+                    runs.append([i, 1])
+                else:
+                    runs[-1][1] += 1
+                prev = i
+        if len(runs) != len(videos):
+            raise ValueError(f"prompt has {len(runs)} video placeholders but {len(videos)} videos were given")
+        per_frame = (self.S // self.P // self.stride) ** 2
+        out, vid, cur = [], [], 0
+        for (start, n), v in zip(runs, videos):
+            fr = self.frames(v)
+            out.extend(prompt_token_ids[cur:start])
+            vid.append((len(out), fr.shape[0] * per_frame, fr))
+            out.extend([self.video_token_id] * (fr.shape[0] * per_frame))
+            cur = start + n
+        out.extend(prompt_token_ids[cur:])
+        entries = [(off, PlaceholderRange(offset=off, length=ln), [fr], hash_item(fr)) for off, ln, fr in vid]
+        if mm_data.get("image") is not None:
+            out2, inputs, hashes, positions = super().__call__(out, {"image": mm_data["image"]})
+            # image expansion shifted everything behind each image run: recompute the video offsets by scanning
+            entries, k = [], 0
+            i = 0
+            while i < len(out2) and k < len(vid):
+                if out2[i] == self.video_token_id:
+                    ln, fr = vid[k][1], vid[k][2]
+                    entries.append((i, PlaceholderRange(offset=i, length=ln), [fr], hash_item(fr)))
+                    i += ln
+                    k += 1
+                else:
+                    i += 1
+            entries += [(p.offset, p, inp, h) for p, inp, h in zip(positions, inputs, hashes)]
+            out = out2
+        entries.sort(key=lambda e: e[0])
+        return out, [e[2] for e in entries], [e[3] for e in entries], [e[1] for e in entries]
+
+
+def _video_processor(vllm_config):
+    base = _anyres_processor(vllm_config)
+    hf = vllm_config.model_config.hf_config
+    return FrameVideoProcessor(base.image_token_id, base.S, base.P, base.pinpoints, base.mean, base.std, base.max_tiles,
+                               video_token_id=int(getattr(hf, "video_token_index", None)
+                                                  or getattr(hf, "video_token_id", 32000)),
+                               pool_stride=int(getattr(hf, "spatial_pool_stride", 2)))

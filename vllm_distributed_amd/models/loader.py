@@ -190,6 +190,8 @@ def pt_iterator(files: list[str]) -> Iterator[tuple[str, torch.Tensor]]:
         state = torch.load(path, map_location="cpu", weights_only=True)
         if "state_dict" in state and isinstance(state["state_dict"], dict):
             state = state["state_dict"]
+        elif isinstance(state.get("model_key"), str) and isinstance(state.get(state["model_key"]), dict):
+            state = state[state["model_key"]]          # fairseq2: {"model_key": name, name: state_dict}
         yield from state.items()
         del state
 

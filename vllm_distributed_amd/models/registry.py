@@ -122,6 +122,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlavaOnevisionForConditionalGeneration": ("llava_next", "LlavaOnevisionForConditionalGeneration"),
     "FuyuForCausalLM": ("fuyu", "FuyuForCausalLM"),
     "MedusaModel": ("eagle", "MedusaModel"),
+    "LlavaNextVideoForConditionalGeneration": ("llava_next", "LlavaNextVideoForConditionalGeneration"),
+    "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),
     "InternVLChatModel": ("internvl", "InternVLChatModel"),
     "InternVLForConditionalGeneration": ("internvl", "InternVLForConditionalGeneration"),
     "SkyworkR1VChatModel": ("internvl", "InternVLChatModel"),

@@ -413,3 +413,11 @@ def _internvl(vllm_config):
 
 for _a in ("InternVLChatModel", "InternVLForConditionalGeneration", "SkyworkR1VChatModel", "H2OVLChatModel"):
     MULTIMODAL_REGISTRY.register_processor(_a, _internvl)
+
+
+def _llava_next_video(vllm_config):
+    from ..models.llava_next import _video_processor
+    return _video_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("LlavaNextVideoForConditionalGeneration", _llava_next_video)
