@@ -348,3 +348,62 @@ def test_push_metadata_survives_the_wire():
                      lands={"b": LandSpec("t2", RecvSpec([1], [9], "h", 7, "E", "tok", [8, 9], 1))}, aborted=["t3"])
     back = serial.decode(serial.encode(m))
     assert back == m
+
+
+# ---------------------------------------------------------------------------------------------------------
+# KV offloading to host memory
+# ---------------------------------------------------------------------------------------------------------
+def test_host_offload_connector_serves_evicted_prefixes(tmp_path):
+    """Prompts are copied to the host pool when their prefill completes.  With the HBM prefix cache off every later
+    request is served from the host pool: same tokens, block-aligned prefixes (also of LONGER prompts that merely
+    share a prefix) counted as cached."""
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    ref = _ref(path)
+    kt = dict(kv_connector="HostOffloadConnector", kv_role="kv_both", kv_connector_extra_config={"host_blocks": 64})
+    sp = SamplingParams(temperature=0, max_tokens=8, ignore_eos=True)
+    llm = LLM(model=path, kv_transfer_config=kt, enable_prefix_caching=False, **KW)
+    first = llm.generate(prompt_token_ids=PROMPTS, sampling_params=sp)
+    assert [list(o.outputs[0].token_ids) for o in first] == ref
+    assert all(o.num_cached_tokens == 0 for o in first)
+    again = llm.generate(prompt_token_ids=PROMPTS, sampling_params=sp)
+    assert [list(o.outputs[0].token_ids) for o in again] == ref
+    assert all(o.num_cached_tokens == (len(p) - 1) // 16 * 16 for o, p in zip(again, PROMPTS))
+    # a longer prompt that shares a prefix: the shared full blocks come from the host pool
+    longest = max(PROMPTS, key=len)
+    ext = longest + [11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
+    base = LLM(model=path, enable_prefix_caching=False, **KW)
+    want = list(base.generate(prompt_token_ids=[ext], sampling_params=sp)[0].outputs[0].token_ids)
+    base.shutdown()
+    got = llm.generate(prompt_token_ids=[ext], sampling_params=sp)[0]
+    assert list(got.outputs[0].token_ids) == want
+    assert got.num_cached_tokens == (len(longest) - 1) // 16 * 16 > 0
+    llm.shutdown()
+
+
+def test_host_offload_index_evicts_least_recently_used():
+    from vllm_distributed_amd.parallel.kv_transfer.host_offload import HostOffloadConnector
+    cfg = SimpleNamespace(kv_transfer_config=SimpleNamespace(kv_connector_extra_config={"host_blocks": 3}),
+                          cache_config=SimpleNamespace(block_size=4, prefix_caching_hash_algo="builtin"))
+    c = HostOffloadConnector(cfg, KVConnectorRole.SCHEDULER)
+
+    def step(new=(), cached=(), finished=()):
+        so = SimpleNamespace(
+            scheduled_new_reqs=[SimpleNamespace(req_id=r, prompt_token_ids=t, block_ids=b, num_computed_tokens=0)
+                                for r, t, b in new],
+            scheduled_cached_reqs=SimpleNamespace(req_ids=[], resumed_from_preemption=[], new_block_ids=[],
+                                                  num_computed_tokens=[]),
+            num_scheduled_tokens={r: len(t) for r, t, _ in new}, finished_req_ids=set(finished))
+        return c.build_connector_meta(so)
+    a, b = list(range(100, 109)), list(range(200, 209))        # two full blocks each (the ninth token is computed)
+    m = step(new=[("a", a, [7, 8, 9])])
+    assert [blk for _, blk in m.stores] == [7, 8] and len(c.index) == 2
+    m = step(new=[("b", b, [3, 4, 5])])
+    assert len(m.stores) == 2 and len(c.index) == 3 and c.stats["evicted_blocks"] == 1
+    # a's first block was the oldest: gone, so nothing of a matches any more (the chain starts at block 0)
+    req = SimpleNamespace(request_id="a2", prompt_token_ids=a, mm_inputs=None)
+    assert c.get_num_new_matched_tokens(req, 0) == (0, False)
+    req = SimpleNamespace(request_id="b2", prompt_token_ids=b, mm_inputs=None)
+    assert c.get_num_new_matched_tokens(req, 0) == (8, False)
+    c.update_state_after_alloc(req, [11, 12, 13], 8)
+    m = step()
+    assert [blk for _, blk in m.loads] == [11, 12] and not m.stores

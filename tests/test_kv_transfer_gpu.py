@@ -72,3 +72,27 @@ def test_push_into_the_landing_pool_over_peer_memory(tmp_path):
     assert all(n >= 96 for n in c["cached"])
     assert c["pulled"] == 0, "the consumer fell back to pulling"
     assert c["pool_free_after"][0] == 24
+
+
+def test_host_offload_connector_on_gpu(tmp_path):
+    """Prompt blocks go to the pinned host pool after their prefill and come back with host -> device copies (the HBM
+    prefix cache is off, so every repeat is served from the host pool); tokens equal the plain engine's, graphs on."""
+    os.environ.setdefault("VLLM_ENABLE_V1_MULTIPROCESSING", "0")
+    from tests.test_e2e_cpu import _save_tiny
+    from vllm_distributed_amd import LLM, SamplingParams
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    prompts = [[(7 * i + 3 * j) % 300 + 1 for j in range(40 + 23 * i)] for i in range(4)]
+    sp = SamplingParams(temperature=0, max_tokens=8, ignore_eos=True)
+    kw = dict(skip_tokenizer_init=True, dtype="bfloat16", max_model_len=256, max_num_seqs=8, gpu_memory_utilization=0.1,
+              enable_prefix_caching=False)
+    base = LLM(model=path, **kw)
+    ref = [list(o.outputs[0].token_ids) for o in base.generate(prompt_token_ids=prompts, sampling_params=sp)]
+    base.shutdown()
+    llm = LLM(model=path, kv_transfer_config=dict(kv_connector="HostOffloadConnector", kv_role="kv_both",
+                                                  kv_connector_extra_config={"host_blocks": 64}), **kw)
+    first = llm.generate(prompt_token_ids=prompts, sampling_params=sp)
+    again = llm.generate(prompt_token_ids=prompts, sampling_params=sp)
+    llm.shutdown()
+    assert [list(o.outputs[0].token_ids) for o in first] == ref
+    assert [list(o.outputs[0].token_ids) for o in again] == ref
+    assert all(o.num_cached_tokens == (len(p) - 1) // 16 * 16 for o, p in zip(again, prompts))

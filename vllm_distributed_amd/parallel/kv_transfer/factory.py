@@ -37,4 +37,8 @@ KVConnectorFactory.register_connector("NixlConnector", f"{_PKG}.xgmi", "XgmiConn
 KVConnectorFactory.register_connector("XgmiPushConnector", f"{_PKG}.push", "XgmiPushConnector")
 KVConnectorFactory.register_connector("P2pNcclConnector", f"{_PKG}.push", "p2p_connector")
 KVConnectorFactory.register_connector("MultiConnector", f"{_PKG}.multi", "MultiConnector")
-KVConnectorFactory.register_connector("LMCacheConnectorV1", f"{_PKG}.multi", "UnavailableConnector")
+# KV offloading to host memory, in-tree; the names of the reference's adapters around external stores (LMCache,
+# Mooncake) resolve to it as well: those packages are not part of this build
+KVConnectorFactory.register_connector("HostOffloadConnector", f"{_PKG}.host_offload", "HostOffloadConnector")
+KVConnectorFactory.register_connector("LMCacheConnectorV1", f"{_PKG}.host_offload", "HostOffloadConnector")
+KVConnectorFactory.register_connector("MooncakeStoreConnector", f"{_PKG}.host_offload", "HostOffloadConnector")
