@@ -1,5 +1,6 @@
 """Small runtime pieces: the stateless process group, plugin loading and the local usage record."""
 import json
+import pytest
 import multiprocessing as mp
 import os
 import socket
@@ -228,3 +229,32 @@ def test_streamed_safetensors_loader(tmp_path):
         outs.append(list(llm.generate(prompt_token_ids=[[5, 6, 7, 8]], sampling_params=sp)[0].outputs[0].token_ids))
         llm.shutdown()
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_tensorizer_loader_round_trip(tmp_path):
+    """Serialise a loaded model the way it sits in memory, start a second engine from that one file through the
+    native streamed reader with hash verification: same greedy tokens; a flipped byte is caught."""
+    import torch
+    from tests.test_e2e_cpu import _save_tiny
+    from vllm_distributed_amd import LLM, SamplingParams
+    from vllm_distributed_amd.models.loader import TensorizerLoader
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    kw = dict(skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4)
+    sp = SamplingParams(temperature=0, max_tokens=8, ignore_eos=True)
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 20]
+    a = LLM(model=path, **kw)
+    ref = [list(o.outputs[0].token_ids) for o in a.generate(prompt_token_ids=prompts, sampling_params=sp)]
+    model = a.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    uri = str(tmp_path / "ser" / "model-rank-%03d.tensors")
+    TensorizerLoader.tensorize_model(model, uri % 0)
+    a.shutdown()
+    extra = {"tensorizer_uri": uri, "verify_hash": True, "num_readers": 4}
+    b = LLM(model=path, load_format="tensorizer", model_loader_extra_config=extra, **kw)
+    got = [list(o.outputs[0].token_ids) for o in b.generate(prompt_token_ids=prompts, sampling_params=sp)]
+    b.shutdown()
+    assert got == ref
+    raw = bytearray(open(uri % 0, "rb").read())
+    raw[-5] ^= 0x40
+    open(uri % 0, "wb").write(bytes(raw))
+    with pytest.raises(Exception, match="recorded hash"):
+        LLM(model=path, load_format="tensorizer", model_loader_extra_config=extra, **kw)

@@ -599,3 +599,35 @@ def test_block_scaled_fp8_checkpoint_runs_natively(tmp_path, kind, monkeypatch):
     # fp32 accumulation order differs: allow a late near-tie (more of them where the reference does not
     # round the experts' activations)
     assert same >= (0.9 if emulated_all else 0.6) * total, (same, total)
+
+
+def test_bitsandbytes_in_flight_nf4(tmp_path):
+    """quantization="bitsandbytes" on a 16-bit checkpoint: weights become NF4 while loading (packed bytes + one
+    absmax per 64 values in memory); greedy tokens equal the HF model whose projections were replaced by the
+    NF4-rounded weights; the code book round-trips its own values exactly."""
+    from vllm_distributed_amd.layers.quant import NF4_CODE, nf4_dequantize, nf4_quantize
+    code = torch.tensor(NF4_CODE)
+    w = (code[torch.randint(0, 16, (8, 128))] * 0.37)
+    w[:, ::64] = 0.37                                   # every block's absmax is the same scale
+    p, a = nf4_quantize(w)
+    assert p.shape == (8, 64) and a.shape == (8, 2)
+    torch.testing.assert_close(nf4_dequantize(p, a, torch.float32), w, rtol=1e-6, atol=1e-7)
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    with torch.no_grad():
+        for name, mod in hf.named_modules():
+            if isinstance(mod, torch.nn.Linear) and name != "lm_head":
+                mod.weight.copy_(nf4_dequantize(*nf4_quantize(mod.weight.data), torch.float32))
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64, quantization="bitsandbytes")
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    qkv = model.model.layers[0].self_attn.qkv_proj
+    assert qkv.weight.dtype == torch.uint8 and qkv.weight.shape[1] * 2 == 128 and qkv.absmax.shape[1] == 2
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    llm.shutdown()
+    for pr, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([pr]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(pr):].tolist()
+        assert list(o.outputs[0].token_ids) == ref

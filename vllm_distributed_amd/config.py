@@ -436,7 +436,9 @@ class CacheConfig:
 @dataclass
 class LoadConfig:
     #: auto | safetensors | pt | dummy | sharded_state | npcache | fastsafetensors | runai_streamer (the last two:
-    #: the native multi-threaded range reader; extra config "concurrency", "memory_limit")
+    #: the native multi-threaded range reader; extra config "concurrency", "memory_limit") | tensorizer (one
+    #: pre-sharded, post-processed file per rank written by ``TensorizerLoader.tensorize_model``; extra config
+    #: "tensorizer_uri", "verify_hash", "num_readers")
     load_format: str = "auto"
     #: Directory for downloaded weights (unused: no hub access).
     download_dir: Optional[str] = None
@@ -452,7 +454,7 @@ class LoadConfig:
     def __post_init__(self):
         self.load_format = self.load_format.lower()
         ok = ("auto", "safetensors", "pt", "bin", "dummy", "sharded_state", "npcache", "fastsafetensors",
-              "runai_streamer")
+              "runai_streamer", "tensorizer")
         if self.load_format not in ok:
             raise ValueError(f"load_format must be one of {ok}")
         if self.ignore_patterns is None:

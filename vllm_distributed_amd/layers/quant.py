@@ -222,6 +222,71 @@ class Int8LinearMethod:
         return y.to(x.dtype).view(*shape[:-1], -1)
 
 
+# ---- bitsandbytes-style NF4, quantised in flight ------------------------------------------------------------
+NF4_CODE = (-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635,
+            -0.18477343022823334, -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725,
+            0.24611230194568634, 0.33791524171829224, 0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0)
+
+
+def nf4_quantize(w: torch.Tensor, block: int = 64) -> tuple[torch.Tensor, torch.Tensor]:
+    """[N, K] -> (codes packed two per byte [N, K / 2] (first element in the high nibble), absmax [N, K / block])."""
+    N, K = w.shape
+    g = w.float().reshape(N, K // block, block)
+    absmax = g.abs().amax(-1).clamp(min=1e-12)
+    code = torch.tensor(NF4_CODE, device=w.device)
+    # nearest code: the codebook is sorted, so a search over the midpoints finds it
+    mids = (code[1:] + code[:-1]) / 2
+    idx = torch.bucketize((g / absmax[..., None]).reshape(N, K), mids).to(torch.uint8)
+    return (idx[:, 0::2] << 4) | idx[:, 1::2], absmax
+
+
+def nf4_dequantize(packed: torch.Tensor, absmax: torch.Tensor, dtype: torch.dtype, block: int = 64) -> torch.Tensor:
+    N = packed.shape[0]
+    code = torch.tensor(NF4_CODE, device=packed.device, dtype=torch.float32)
+    idx = torch.stack((packed >> 4, packed & 15), dim=-1).reshape(N, -1).long()
+    return (code[idx].reshape(N, -1, block) * absmax[..., None]).reshape(N, -1).to(dtype)
+
+
+class Bnb4InflightConfig(QuantizationConfig):
+    """``quantization="bitsandbytes"`` on an unquantised checkpoint: every linear layer's weight is quantised to
+    NF4 (blocks of 64 values, one fp32 absmax each: 4.5 bits per weight in HBM) right after it is loaded, and
+    expanded to the activation dtype in front of its GEMM.  Reference:
+    vllm/model_executor/model_loader/bitsandbytes_loader.py (in-flight path :418-520) and
+    layers/quantization/bitsandbytes.py; the bitsandbytes package itself is not part of this build, the NF4 code
+    book and blocking are its published ones (pre-quantised checkpoints: models/dequant.py)."""
+    name = "bitsandbytes"
+    FUSED = Fp8Config.FUSED
+
+    def get_quant_method(self, layer: nn.Module, prefix: str):
+        if isinstance(layer, LinearBase):
+            return UnquantizedLinearMethod() if prefix.endswith("lm_head") else Bnb4LinearMethod()
+        return None
+
+
+class Bnb4LinearMethod:
+    BLOCK = 64
+
+    def create_weights(self, layer: nn.Module, in_per_rank: int, out_per_rank: int, dtype: torch.dtype) -> None:
+        w = nn.Parameter(torch.empty(out_per_rank, in_per_rank, dtype=dtype), requires_grad=False)
+        set_weight_attrs(w, {"input_dim": 1, "output_dim": 0})
+        layer.register_parameter("weight", w)
+        layer.orig_dtype = dtype
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        w = layer.weight.data
+        if w.dtype == torch.uint8 or w.shape[1] % self.BLOCK:
+            return                                   # already processed, or a width the blocking does not divide
+        packed, absmax = nf4_quantize(w, self.BLOCK)
+        layer.weight = nn.Parameter(packed, requires_grad=False)
+        layer.absmax = nn.Parameter(absmax, requires_grad=False)
+
+    def apply(self, layer: nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        w = layer.weight
+        if w.dtype == torch.uint8:
+            w = nf4_dequantize(w, layer.absmax, x.dtype, self.BLOCK)
+        return torch.nn.functional.linear(x, w, bias)
+
+
 def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
     mc = vllm_config.model_config
     q = mc.quantization
@@ -230,8 +295,7 @@ def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
     hf_q = mc.hf_config.get("quantization_config") if hasattr(mc.hf_config, "get") else \
         getattr(mc.hf_config, "quantization_config", None)
     if q == "bitsandbytes" and not hf_q:
-        raise ValueError("bitsandbytes: only pre-quantised checkpoints are supported (their weights are expanded "
-                         "to 16 bit while loading); for on-the-fly quantisation use quantization='fp8'")
+        return Bnb4InflightConfig()          # 16-bit checkpoint, quantised to NF4 while loading
     if q == "modelopt_fp4":
         if int((hf_q or {}).get("group_size", 16) or 16) != 16:
             raise ValueError("modelopt fp4: only groups of 16 (NVFP4) are supported")

@@ -10,6 +10,7 @@ from __future__ import annotations
 import contextlib
 import fnmatch
 import glob
+import hashlib
 import json
 import os
 import time
@@ -321,8 +322,72 @@ class ShardedStateLoader(BaseModelLoader):
             save_file(cur, os.path.join(path, pattern.format(rank=rank, part=part)))
 
 
+class TensorizerLoader(BaseModelLoader):
+    """One file per rank holding the model exactly as it sits in memory after loading (tensor-parallel shards cut,
+    fused projections stacked, quantised weights processed): start-up is a straight streamed read by the native
+    range reader into the parameters, with no per-tensor routing and no re-slicing, and an optional SHA-256 check
+    of every tensor.  ``tensorizer_uri`` may contain ``%03d`` (or ``{rank}``) for the rank; default
+    ``<model dir>/model-rank-%03d.tensors``.  The container is safetensors' (8-byte header length, JSON table, raw
+    data), so other tools can read the files too.  Layers whose post-load processing changes parameter shapes
+    (some quantisation methods) keep the default loader: the shapes in the file would not match a fresh model.
+    Reference: vllm/model_executor/model_loader/tensorizer.py (TensorizerConfig :163-260, serialize_vllm_model
+    :625-660, deserialisation :491-560) and tensorizer_loader.py; encryption (libsodium) is not available."""
+
+    def _uri(self, vllm_config, rank: int) -> str:
+        extra = self.load_config.model_loader_extra_config or {}
+        if extra.get("encryption_keyfile"):
+            raise ValueError("encrypted tensorizer files are not supported in this build")
+        uri = extra.get("tensorizer_uri") or os.path.join(vllm_config.model_config.model, "model-rank-%03d.tensors")
+        return uri.replace("{rank}", str(rank)) % rank if "%" in uri else uri.replace("{rank}", str(rank))
+
+    def load_weights(self, model, vllm_config):
+        from ..parallel.state import get_world_group
+        extra = self.load_config.model_loader_extra_config or {}
+        path = self._uri(vllm_config, get_world_group().rank)
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"{path}: write it with TensorizerLoader.tensorize_model(model, path)")
+        want = {}
+        if extra.get("verify_hash"):
+            with open(path, "rb") as f:
+                want = json.loads(f.read(int.from_bytes(f.read(8), "little"))).get("__metadata__") or {}
+            if not want:
+                raise ValueError(f"{path} carries no tensor hashes to verify")
+        state = model.state_dict()
+        for name, t in streamed_safetensors_iterator([path], concurrency=int(extra.get("num_readers", 16))):
+            if name not in state:
+                raise KeyError(f"unexpected tensor {name} in {path}")
+            if want:
+                got = hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+                if want.get(name) != got:
+                    raise ValueError(f"{path}: tensor {name} does not match its recorded hash")
+            state.pop(name).copy_(t)
+        ptrs = {}
+        for k, p in model.state_dict().items():         # tied tensors were written once
+            ptrs.setdefault(p.data_ptr(), k)
+        missing = [k for k in state if ptrs.get(model.state_dict()[k].data_ptr()) == k]
+        if missing:
+            raise ValueError(f"tensors missing from {path}: {sorted(missing)[:8]}")
+
+    @staticmethod
+    def tensorize_model(model: nn.Module, path: str) -> None:
+        """Write this rank's model state to ``path`` (with per-tensor hashes in the file's metadata)."""
+        from safetensors.torch import save_file
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        out, meta, seen = {}, {}, set()
+        for k, t in model.state_dict().items():
+            if t.data_ptr() in seen:
+                continue
+            seen.add(t.data_ptr())
+            c = t.detach().cpu().contiguous()
+            out[k] = c
+            meta[k] = hashlib.sha256(c.view(torch.uint8).numpy().tobytes()).hexdigest()
+        save_file(out, path, metadata=meta)
+
+
 def get_model_loader(load_config) -> BaseModelLoader:
     fmt = load_config.load_format
+    if fmt == "tensorizer":
+        return TensorizerLoader(load_config)
     if fmt == "dummy":
         return DummyModelLoader(load_config)
     if fmt == "sharded_state":
