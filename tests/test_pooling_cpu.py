@@ -221,3 +221,25 @@ def test_sequence_classification_adapters_match_hf(tmp_path, kind):
         with torch.no_grad():
             ref = torch.softmax(hf(torch.tensor([p])).logits[0], dim=-1)
         torch.testing.assert_close(torch.tensor(o.outputs.probs), ref, atol=2e-4, rtol=2e-3)
+
+
+def test_nomic_bert_rotary_encoder_matches_hf(tmp_path):
+    """Rotary BERT with a gated MLP: mean-pooled, normalised sentence embeddings equal transformers' hidden states
+    pooled the same way (bidirectional attention with the fused rotary + cache write in front)."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.NomicBertConfig(vocab_size=320, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                             intermediate_size=256, max_position_embeddings=128, head_dim=64)
+    hf = tf.NomicBertModel(cfg).float().eval()
+    path = os.path.join(tmp_path, "nomic")
+    hf.save_pretrained(path, safe_serialization=True)
+    prompts = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 11, [2, 3]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128,
+              max_num_seqs=8, block_size=16)
+    outs = llm.embed(None, prompt_token_ids=prompts)
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf(torch.tensor([p])).last_hidden_state[0].mean(0)
+        ref = torch.nn.functional.normalize(ref, dim=-1)
+        torch.testing.assert_close(torch.as_tensor(o.outputs.embedding), ref, atol=2e-4, rtol=1e-3)

@@ -192,3 +192,115 @@ class RobertaForSequenceClassification(RobertaEmbeddingModel):
         if name.startswith("classifier.out_proj."):
             return "head_out." + name[len("classifier.out_proj."):]
         return super()._route(name)
+
+
+# ---- rotary encoders (Nomic BERT) -----------------------------------------------------------------------------
+class NomicBertLayer(nn.Module):
+    """Post-norm block with rotary positions and a gated MLP, no biases:
+    x = LN(x + o(attn(rope(q, k), v)));  x = LN(x + down(act(gate(x)) * up(x)))."""
+
+    def __init__(self, config, vllm_config: VllmConfig, prefix: str, rotary):
+        super().__init__()
+        from ..layers.basic import get_act_and_mul_fn
+        from ..layers.linear import MergedColumnParallelLinear
+        d, H = config.hidden_size, config.num_attention_heads
+        D = getattr(config, "head_dim", None) or d // H
+        tp = get_tensor_model_parallel_world_size()
+        eps = config.layer_norm_eps
+        self.rotary = rotary
+        self.qkv_proj = QKVParallelLinear(d, D, H, H, bias=False, prefix=f"{prefix}.self_attn.qkv_proj")
+        self.attn = Attention(H // tp, D, D ** -0.5, H // tp, prefix=f"{prefix}.self_attn.attn",
+                              cache_dtype=vllm_config.cache_config.cache_dtype, causal=False)
+        self.o_proj = RowParallelLinear(H * D, d, bias=False, prefix=f"{prefix}.self_attn.o_proj")
+        self.post_attention_layernorm = LayerNorm(d, eps)
+        self.gate_up_proj = MergedColumnParallelLinear(d, [config.intermediate_size] * 2, bias=False,
+                                                       prefix=f"{prefix}.mlp.gate_up_proj")
+        self.down_proj = RowParallelLinear(config.intermediate_size, d, bias=False, prefix=f"{prefix}.mlp.down_proj")
+        self.post_mlp_layernorm = LayerNorm(d, eps)
+        self.act = get_act_and_mul_fn(getattr(config, "hidden_act", "silu"))
+
+    def forward(self, x, positions):
+        x = self.post_attention_layernorm(x + self.o_proj(self.attn(self.qkv_proj(x), positions, self.rotary)))
+        return self.post_mlp_layernorm(x + self.down_proj(self.act(self.gate_up_proj(x))))
+
+
+class NomicBertBackbone(nn.Module):
+    def __init__(self, vllm_config: VllmConfig):
+        super().__init__()
+        from ..layers.rotary import get_rope
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        d = config.hidden_size
+        D = getattr(config, "head_dim", None) or d // config.num_attention_heads
+        rp = getattr(config, "rope_parameters", None) or {}
+        theta = float(getattr(config, "rope_theta", None) or getattr(config, "rotary_emb_base", None)
+                      or rp.get("rope_theta", 10000.0))
+        rotary = get_rope(D, D, config.max_position_embeddings, theta, True)
+        self.word_embeddings = VocabParallelEmbedding(config.vocab_size, d)
+        self.token_type_embeddings = nn.Embedding(max(int(getattr(config, "type_vocab_size", 1) or 1), 1), d)
+        self.token_type_embeddings.weight.requires_grad_(False)
+        self.embed_norm = LayerNorm(d, config.layer_norm_eps)
+        self.layers = nn.ModuleList([NomicBertLayer(config, vllm_config, f"encoder.layers.{i}", rotary)
+                                     for i in range(config.num_hidden_layers)])
+
+    def forward(self, input_ids, positions, token_type_ids: Optional[torch.Tensor] = None, inputs_embeds=None):
+        x = inputs_embeds if inputs_embeds is not None else self.word_embeddings(input_ids)
+        x = x + (self.token_type_embeddings.weight[0] if token_type_ids is None
+                 else self.token_type_embeddings(token_type_ids))
+        x = self.embed_norm(x)
+        for layer in self.layers:
+            x = layer(x, positions)
+        return x
+
+
+class NomicBertModel(BertEmbeddingModel):
+    """Sentence embeddings from a rotary BERT (mean pooling, L2-normalised), in the layout transformers writes:
+    ``embeddings.{word,token_type}_embeddings``, ``encoder.layers.N.self_attn.{q,k,v,o}_proj``,
+    ``mlp.{gate,up,down}_proj``, ``post_{attention,mlp}_layernorm``.
+    Reference: vllm/model_executor/models/bert_with_rope.py (NomicBertModel :520-600)."""
+    backbone_cls = NomicBertBackbone
+    uses_token_type_ids = True
+    _NB_STACKED = [(".qkv_proj", ".q_proj", "q"), (".qkv_proj", ".k_proj", "k"), (".qkv_proj", ".v_proj", "v"),
+                   (".gate_up_proj", ".gate_proj", 0), (".gate_up_proj", ".up_proj", 1)]
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        self.pooler = Pooler.from_config(getattr(vllm_config.model_config, "pooler_config", None), PoolingType.MEAN,
+                                         normalize=True, softmax=False)
+
+    # original (nomic-ai) names -> the module tree above; transformers writes these names too when it saves
+    _ORIG = (("emb_ln.", "embeddings.LayerNorm."), (".attn.out_proj.", ".self_attn.o_proj."), (".mlp.fc11.", ".mlp.up_proj."),
+             (".mlp.fc12.", ".mlp.gate_proj."), (".mlp.fc2.", ".mlp.down_proj."), (".norm1.", ".post_attention_layernorm."),
+             (".norm2.", ".post_mlp_layernorm."))
+
+    def _route(self, name: str) -> Optional[str]:
+        for p in ("nomic_bert.", "bert.", "model."):
+            if name.startswith(p):
+                name = name[len(p):]
+                break
+        for a, b in self._ORIG:
+            name = name.replace(a, b)
+        if name.startswith("layers."):
+            name = "encoder." + name
+        if name.startswith("embeddings."):
+            name = name[len("embeddings."):].replace("LayerNorm.", "embed_norm.")
+            return None if name.startswith(("position_ids", "token_type_ids")) else "model." + name
+        if name.startswith("encoder.layers."):
+            name = "layers." + name[len("encoder.layers."):]
+            for a, b in ((".self_attn.q_proj.", ".q_proj."), (".self_attn.k_proj.", ".k_proj."),
+                         (".self_attn.v_proj.", ".v_proj."), (".self_attn.o_proj.", ".o_proj."),
+                         (".mlp.gate_proj.", ".gate_proj."), (".mlp.up_proj.", ".up_proj."),
+                         (".mlp.down_proj.", ".down_proj."), (".attn.Wqkv.", ".Wqkv.")):
+                name = name.replace(a, b)
+            return "model." + name
+        return None                                     # pooler / prediction heads are not used for embeddings
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        def split_fused():
+            for n, t in weights:
+                if ".attn.Wqkv." in n:                  # fused [q; k; v] rows -> the three logical projections
+                    for part, piece in zip(("q_proj", "k_proj", "v_proj"), t.chunk(3, dim=0)):
+                        yield n.replace(".attn.Wqkv.", f".self_attn.{part}."), piece
+                else:
+                    yield n, t
+        return load_weights_with_mapping(self, split_fused(), self._NB_STACKED, rename=self._route)

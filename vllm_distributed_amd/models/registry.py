@@ -123,6 +123,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "FuyuForCausalLM": ("fuyu", "FuyuForCausalLM"),
     "MedusaModel": ("eagle", "MedusaModel"),
     "LlavaNextVideoForConditionalGeneration": ("llava_next", "LlavaNextVideoForConditionalGeneration"),
+    "NomicBertModel": ("bert", "NomicBertModel"),
     "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),
     "InternVLChatModel": ("internvl", "InternVLChatModel"),
     "InternVLForConditionalGeneration": ("internvl", "InternVLForConditionalGeneration"),
