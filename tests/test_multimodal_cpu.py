@@ -629,3 +629,42 @@ def test_llava_next_video_matches_hf(tmp_path):
             ref = hf.generate(input_ids=torch.tensor([ids]), max_new_tokens=6, do_sample=False, pad_token_id=0,
                               eos_token_id=None, **kw)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref, list(r["multi_modal_data"])
+
+
+def test_bart_matches_hf(tmp_path):
+    """Text encoder-decoder: a plain prompt is the encoder input, the decoder starts from its start token and reads
+    the encoder states through cross-attention with per-request source lengths; greedy tokens equal transformers'."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.BartConfig(vocab_size=320, d_model=128, encoder_layers=2, decoder_layers=2, encoder_attention_heads=2,
+                        decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256, max_position_embeddings=128,
+                        decoder_start_token_id=2, forced_bos_token_id=None, forced_eos_token_id=None, pad_token_id=1,
+                        bos_token_id=0, eos_token_id=2, scale_embedding=True)
+    hf = tf.BartForConditionalGeneration(cfg).float().eval()
+    with torch.no_grad():
+        hf.final_logits_bias.normal_(0, 0.3)
+    path = os.path.join(tmp_path, "bart")
+    hf.save_pretrained(path, safe_serialization=True)
+    from safetensors.torch import load_file, save_file
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    sd["final_logits_bias"] = hf.final_logits_bias.detach().clone()       # a buffer transformers does not persist
+    save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    sources = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 13, [4, 6]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=8,
+              max_num_batched_tokens=64)
+    outs = llm.generate(prompt_token_ids=sources, sampling_params=SamplingParams(temperature=0, max_tokens=8,
+                                                                                   ignore_eos=True))
+    # explicit decoder prompt
+    dec = [2, 40, 41]
+    out2 = llm.generate([{"prompt_token_ids": dec, "multi_modal_data": {"encoder_token_ids": sources[1]}}],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))[0]
+    llm.shutdown()
+    for s_, o in zip(sources, outs):
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([s_]), max_new_tokens=8, do_sample=False, num_beams=1,
+                              eos_token_id=None, pad_token_id=1)[0, 1:].tolist()
+        assert list(o.outputs[0].token_ids) == ref, s_
+    with torch.no_grad():
+        ref = hf.generate(input_ids=torch.tensor([sources[1]]), decoder_input_ids=torch.tensor([dec]), max_new_tokens=6,
+                          do_sample=False, num_beams=1, eos_token_id=None, pad_token_id=1)[0, len(dec):].tolist()
+    assert list(out2.outputs[0].token_ids) == ref

@@ -143,6 +143,9 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
         d = {**d, "hidden_size": d["d_model"], "num_attention_heads": d["decoder_attention_heads"],
              "num_key_value_heads": d["decoder_attention_heads"], "num_hidden_layers": d["decoder_layers"],
              "max_position_embeddings": d.get("max_target_positions", 448)}
+    if d.get("model_type") in ("bart", "mbart") and "hidden_size" not in d:
+        d = {**d, "hidden_size": d["d_model"], "num_attention_heads": d["decoder_attention_heads"],
+             "num_key_value_heads": d["decoder_attention_heads"], "num_hidden_layers": d["decoder_layers"]}
     if d.get("model_type") in ("exaone", "telechat", "qwen", "chatglm"):
         from .models.renamed_decoders import normalise_config
         d = normalise_config(d)
@@ -304,7 +307,13 @@ class ModelConfig:
         request for the latter; recurrent state rules out prefix reuse."""
         return any(a in ("JambaForCausalLM", "BambaForCausalLM", "GraniteMoeHybridForCausalLM", "NemotronHForCausalLM",
                          # encoder-decoder: the cross-attention cache is per-request state of the same kind
-                         "WhisperForConditionalGeneration") for a in self.architectures)
+                         "WhisperForConditionalGeneration", "BartForConditionalGeneration", "BartModel")
+                   for a in self.architectures)
+
+    @property
+    def is_text_encoder_decoder(self) -> bool:
+        """Encoder-decoder over text: a request's plain prompt is the encoder's input."""
+        return any(a in ("BartForConditionalGeneration", "BartModel") for a in self.architectures)
 
     def get_total_num_attention_heads(self) -> int:
         if self.is_attention_free:

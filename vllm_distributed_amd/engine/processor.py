@@ -161,6 +161,12 @@ class Processor:
         else:
             pooling = params.clone()
         mm = p.get("multi_modal_data")
+        if not mm and self.vllm_config.model_config.is_text_encoder_decoder:
+            # a plain prompt of a text encoder-decoder is the ENCODER input; the decoder starts from its start token
+            mm = {"encoder_token_ids": list(ids)}
+            ids = [int(self.vllm_config.model_config.hf_config.get("decoder_start_token_id", 2) or 0)]
+            if sampling is not None and p.get("prompt_token_ids") is not None and sampling.max_tokens is not None:
+                sampling.max_tokens = min(sampling.max_tokens, max_len - 1)
         mm_inputs = mm_hashes = mm_pos = None
         if mm:
             from ..multimodal import process_multimodal

@@ -421,3 +421,21 @@ def _llava_next_video(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("LlavaNextVideoForConditionalGeneration", _llava_next_video)
+
+
+class EncoderTextProcessor:
+    """Text encoder-decoder: the source tokens are the request's one encoder item, tied to the first decoder token
+    (they replace no prompt tokens)."""
+
+    def __call__(self, prompt_token_ids: list[int], mm_data: dict):
+        src = mm_data.get("encoder_token_ids")
+        if src is None or len(src) == 0:
+            raise ValueError("a text encoder-decoder needs multi_modal_data with 'encoder_token_ids'")
+        if not prompt_token_ids:
+            raise ValueError("the decoder prompt is empty (the decoder start token is expected)")
+        t = torch.as_tensor(list(src), dtype=torch.int64)
+        return list(prompt_token_ids), [[t]], [hash_item(t)], [PlaceholderRange(0, 1)]
+
+
+for _a in ("BartForConditionalGeneration", "BartModel"):
+    MULTIMODAL_REGISTRY.register_processor(_a, lambda vllm_config: EncoderTextProcessor())
