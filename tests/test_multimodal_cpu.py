@@ -668,3 +668,42 @@ def test_bart_matches_hf(tmp_path):
         ref = hf.generate(input_ids=torch.tensor([sources[1]]), decoder_input_ids=torch.tensor([dec]), max_new_tokens=6,
                           do_sample=False, num_beams=1, eos_token_id=None, pad_token_id=1)[0, len(dec):].tolist()
     assert list(out2.outputs[0].token_ids) == ref
+
+
+def test_tarsier_split_tokens_over_llava(tmp_path):
+    """Tarsier = LLaVA + the text embeddings of a newline token behind every patch row and of an image-end token
+    behind the image.  No transformers class exists for it (parity unpinned): the check is structural, against
+    this package's own LLaVA features of the same checkpoint, plus an end-to-end run."""
+    import json
+    import transformers as tf
+    torch.manual_seed(0)
+    tc = tf.LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, head_dim=64)
+    vc = tf.CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                             image_size=28, patch_size=7, projection_dim=64)
+    cfg = tf.LlavaConfig(vision_config=vc, text_config=tc, image_token_index=300, vision_feature_layer=-2)
+    hf = tf.LlavaForConditionalGeneration(cfg).float().eval()
+    path = os.path.join(tmp_path, "tarsier")
+    hf.save_pretrained(path, safe_serialization=True)
+    c = json.load(open(os.path.join(path, "config.json")))
+    c.update(architectures=["TarsierForConditionalGeneration"], image_newline_idx=301, image_new_idx=302)
+    json.dump(c, open(os.path.join(path, "config.json"), "w"))
+    img = (np.random.default_rng(5).random((40, 52, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=4)
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    from vllm_distributed_amd.models.llava import LlavaForConditionalGeneration
+    from vllm_distributed_amd.multimodal import to_pixel_values
+    px = to_pixel_values(img, 28)[None]
+    with torch.no_grad():
+        t = model.encode_images(px)
+        plain = LlavaForConditionalGeneration.encode_images(model, px)
+        emb = model.language_model.get_input_embeddings(torch.tensor([301, 302]))
+    assert t.shape == (1, 4 * 5 + 1, 128)
+    grid = t[0, :20].view(4, 5, 128)
+    torch.testing.assert_close(grid[:, :4].reshape(16, 128), plain[0])
+    torch.testing.assert_close(grid[:, 4], emb[0].expand(4, 128))
+    torch.testing.assert_close(t[0, 20], emb[1])
+    out = llm.generate([{"prompt_token_ids": [5, 300, 9], "multi_modal_data": {"image": img}}],
+                       SamplingParams(temperature=0, max_tokens=4, ignore_eos=True))[0]
+    assert len(out.prompt_token_ids) == 2 + 21 and len(out.outputs[0].token_ids) == 4
+    llm.shutdown()

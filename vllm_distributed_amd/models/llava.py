@@ -165,3 +165,24 @@ class LlavaForConditionalGeneration(nn.Module):
         loaded = load_weights_with_mapping(self, dec, stacked, tie_lm_head=self.language_model.tie)
         loaded |= load_weights_with_mapping(self, vis, [])
         return loaded
+
+
+class TarsierForConditionalGeneration(LlavaForConditionalGeneration):
+    """Tarsier: LLaVA whose projected patch grid gets the text embedding of a newline token behind every row and
+    of an image-end token behind the last one (h * (w + 1) + 1 positions per image).
+    Reference: vllm/model_executor/models/tarsier.py (_add_tarsier_split_tokens :515-559)."""
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        self.newline_id = int(self.config.image_newline_idx)
+        self.new_id = int(self.config.image_new_idx)
+
+    def encode_images(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        f = super().encode_images(pixel_values)                     # [n, h * w, H]
+        n, t, d = f.shape
+        h = int(t ** 0.5)
+        w = t // h
+        seps = self.language_model.get_input_embeddings(
+            torch.tensor([self.newline_id, self.new_id], device=f.device)).to(f.dtype)
+        grid = torch.cat((f.view(n, h, w, d), seps[0].expand(n, h, 1, d)), dim=2).reshape(n, h * (w + 1), d)
+        return torch.cat((grid, seps[1].expand(n, 1, d)), dim=1)

@@ -124,6 +124,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MedusaModel": ("eagle", "MedusaModel"),
     "LlavaNextVideoForConditionalGeneration": ("llava_next", "LlavaNextVideoForConditionalGeneration"),
     "NomicBertModel": ("bert", "NomicBertModel"),
+    "TarsierForConditionalGeneration": ("llava", "TarsierForConditionalGeneration"),
+    "Tarsier2ForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "BartForConditionalGeneration": ("bart", "BartForConditionalGeneration"),
     "BartModel": ("bart", "BartModel"),
     "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),

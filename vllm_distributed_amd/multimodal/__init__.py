@@ -439,3 +439,14 @@ class EncoderTextProcessor:
 
 for _a in ("BartForConditionalGeneration", "BartModel"):
     MULTIMODAL_REGISTRY.register_processor(_a, lambda vllm_config: EncoderTextProcessor())
+
+
+def _tarsier_processor(vllm_config):
+    base = _llava_processor(vllm_config)
+    side = int(round((base.tokens_per_image) ** 0.5))
+    base.tokens_per_image = side * (side + 1) + 1          # a newline position per row and one image-end position
+    return base
+
+
+MULTIMODAL_REGISTRY.register_processor("TarsierForConditionalGeneration", _tarsier_processor)
+MULTIMODAL_REGISTRY.register_processor("Tarsier2ForConditionalGeneration", _qwen2_vl_processor)
