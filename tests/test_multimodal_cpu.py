@@ -707,3 +707,36 @@ def test_tarsier_split_tokens_over_llava(tmp_path):
                        SamplingParams(temperature=0, max_tokens=4, ignore_eos=True))[0]
     assert len(out.prompt_token_ids) == 2 + 21 and len(out.outputs[0].token_ids) == 4
     llm.shutdown()
+
+
+@pytest.mark.parametrize("text", ["gemma", "gemma2"])
+def test_paligemma_greedy_matches_hf(tmp_path, text):
+    """PaliGemma (Gemma decoder) and PaliGemma 2 (Gemma-2 decoder) against transformers' greedy generation; without
+    ``token_type_ids`` transformers runs the prompt causally, which is what the reference's engine does too."""
+    import transformers as tf
+    torch.manual_seed(0)
+    kw = dict(vocab_size=400, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+              num_key_value_heads=1, max_position_embeddings=512, head_dim=64)
+    tc = tf.GemmaConfig(**kw) if text == "gemma" else tf.Gemma2Config(**kw, sliding_window=64, query_pre_attn_scalar=64)
+    tc.use_bidirectional_attention = False       # transformers' default for this wrapper lets the prompt attend both ways
+    vc = tf.SiglipVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                               image_size=28, patch_size=7, projection_dim=128)
+    cfg = tf.PaliGemmaConfig(vision_config=vc, text_config=tc, image_token_index=399, projection_dim=128,
+                             hidden_size=128, vocab_size=400)
+    hf = tf.PaliGemmaForConditionalGeneration(cfg).float().eval()
+    path = os.path.join(tmp_path, "pg")
+    hf.save_pretrained(path, safe_serialization=True)
+    img = (np.random.default_rng(3).random((33, 47, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4)
+    out = llm.generate([{"prompt_token_ids": [399, 2, 17, 45, 108], "multi_modal_data": {"image": img}}],
+                       SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+    ids = out.prompt_token_ids
+    assert ids.count(399) == 16
+    from vllm_distributed_amd.multimodal import process_multimodal
+    eng = llm.llm_engine
+    _, inputs, _, _ = process_multimodal(eng.vllm_config, [399, 2, 17, 45, 108], {"image": img})
+    with torch.no_grad():
+        ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=inputs[0][None].float(), max_new_tokens=8,
+                          do_sample=False, eos_token_id=None, pad_token_id=0)[0, len(ids):].tolist()
+    assert list(out.outputs[0].token_ids) == ref
+    llm.shutdown()

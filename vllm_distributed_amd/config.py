@@ -134,7 +134,7 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
                 f"{model!r} is neither a local checkpoint directory nor a known preset "
                 f"({', '.join(sorted(PRESETS))})")
         d = copy.deepcopy(PRESETS[key])
-    if "text_config" in d and "hidden_size" not in d:
+    if "text_config" in d and ("hidden_size" not in d or "num_attention_heads" not in d):
         d = {**d, **d["text_config"]}
     elif "llm_config" in d and "hidden_size" not in d:          # InternVL's original layout
         d = {**d, **{k: v for k, v in d["llm_config"].items() if k not in ("architectures", "model_type")}}

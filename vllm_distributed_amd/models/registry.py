@@ -125,6 +125,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "LlavaNextVideoForConditionalGeneration": ("llava_next", "LlavaNextVideoForConditionalGeneration"),
     "NomicBertModel": ("bert", "NomicBertModel"),
     "TarsierForConditionalGeneration": ("llava", "TarsierForConditionalGeneration"),
+    "PaliGemmaForConditionalGeneration": ("paligemma", "PaliGemmaForConditionalGeneration"),
     "Tarsier2ForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "BartForConditionalGeneration": ("bart", "BartForConditionalGeneration"),
     "BartModel": ("bart", "BartModel"),

@@ -450,3 +450,11 @@ def _tarsier_processor(vllm_config):
 
 MULTIMODAL_REGISTRY.register_processor("TarsierForConditionalGeneration", _tarsier_processor)
 MULTIMODAL_REGISTRY.register_processor("Tarsier2ForConditionalGeneration", _qwen2_vl_processor)
+
+
+def _paligemma(vllm_config):
+    from ..models.paligemma import paligemma_processor
+    return paligemma_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("PaliGemmaForConditionalGeneration", _paligemma)
