@@ -305,3 +305,34 @@ def test_whisper_and_qwen2_audio_on_gpu(tmp_path):
         for k, t in enumerate(gen):
             worst = max(worst, abs(float(lp[len(p) + k - 1, t]) - o.outputs[0].logprobs[k][t].logprob))
     assert worst < 0.1, worst
+
+
+@pytest.mark.parametrize("orig_max,head_dim", [(0, 128), (40, 64)])
+def test_gpu_dual_chunk_attention_matches_dense_definition(tmp_path, orig_max, head_dim):
+    """Dual-chunk attention through the paged prefill kernels (three passes per step, merged by log-sum-exp;
+    virtual sequences without older chunks carry zero keys), graphs against eager, and the reported
+    log-probabilities against the dense fp32 form of the definition."""
+    from vllm_distributed_amd import SamplingParams
+    from tests.test_dual_chunk_cpu import dense_dual_chunk_logits, save_tiny_dual_chunk
+    path, hf = save_tiny_dual_chunk(str(tmp_path), orig_max, head_dim)
+    g = torch.Generator().manual_seed(1)
+    prompts = [torch.randint(3, 300, (n,), generator=g).tolist() for n in (150, 37, 101, 46)]
+    sp = SamplingParams(temperature=0, max_tokens=12, ignore_eos=True, logprobs=0)
+    a = _llm(path, max_model_len=512, enable_prefix_caching=False)
+    mr = a.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+    assert mr.dual_chunk and mr.graphs
+    outs_g = a.generate(prompt_token_ids=prompts, sampling_params=sp)
+    a.shutdown()
+    b = _llm(path, max_model_len=512, enable_prefix_caching=False, enforce_eager=True)
+    outs_e = b.generate(prompt_token_ids=prompts, sampling_params=sp)
+    b.shutdown()
+    assert [list(o.outputs[0].token_ids) for o in outs_g] == [list(o.outputs[0].token_ids) for o in outs_e]
+    worst = 0.0
+    for p, o in zip(prompts, outs_g):
+        ids = list(p)
+        with torch.no_grad():
+            for k, t in enumerate(o.outputs[0].token_ids):
+                lp = torch.log_softmax(dense_dual_chunk_logits(hf, ids, 64, 16, orig_max, len(p)).float(), -1)
+                worst = max(worst, abs(float(lp[t]) - o.outputs[0].logprobs[k][t].logprob))
+                ids.append(t)
+    assert worst < 0.08, worst

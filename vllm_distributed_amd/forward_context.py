@@ -58,6 +58,14 @@ class AttentionMetadata:
     local_query_start_loc: Optional[torch.Tensor] = None    # int32 [S_virtual + 1]
     local_prefill_query_start_loc: Optional[torch.Tensor] = None
     local_num_prefill_seqs: int = 0
+    # dual-chunk attention: per virtual sequence (sequence, chunk c) also the keys of chunk c - 1 (table that starts
+    # at that chunk's first block) and of chunks 0 .. c - 2 (the owner's own table), zero keys where there is none
+    dca_succ_block_table: Optional[torch.Tensor] = None     # int32 [S_virtual, chunk / block_size]
+    dca_succ_lens: Optional[torch.Tensor] = None            # int32 [S_virtual]: chunk length or 0
+    dca_inter_block_table: Optional[torch.Tensor] = None    # int32 [S_virtual, blocks of the longest sequence]
+    dca_inter_lens: Optional[torch.Tensor] = None           # int32 [S_virtual]: (c - 1) * chunk length or 0
+    dca_token_scale: Optional[torch.Tensor] = None          # model dtype [T, 1]: length-dependent q / k factor
+    dca_passes: int = 3                                      # 1: no virtual sequence has older chunks (host knows)
     # host copies for connectors / debugging
     seq_lens_cpu: Any = None
     query_start_loc_cpu: Any = None

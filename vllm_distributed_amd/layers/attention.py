@@ -169,6 +169,95 @@ def _cascade(self, out, q, md: AttentionMetadata, n: int, ksc: float, vsc: float
 Attention._cascade = _cascade
 
 
+class DualChunkAttention(Attention):
+    """Dual-chunk attention (Qwen2.5-1M): positions never exceed what the model was trained on.  Keys are rotated
+    with their position inside their chunk of ``chunk_len = chunk_size - local_size`` tokens.  A query sees
+      * the keys of its own chunk, causally, rotated with its own in-chunk position (relative distances exact),
+      * the keys of the chunk before, all of them, rotated with in-chunk position + chunk_len (capped at chunk_size),
+      * all older keys, rotated with one fixed far position,
+    under ONE softmax.  Here that is three passes of the paged prefill kernel over per-(sequence, chunk) virtual
+    sequences -- the own-chunk pass is exactly chunked local attention, the other two read the owner's block table
+    at other offsets without a causal mask -- merged by their log-sum-exp.  Decode steps take the same three
+    launches (one query row per sequence), so they are captured in the decode graphs like any other layer.
+    With ``original_max_position_embeddings`` the reference multiplies queries and keys by
+    0.1 ln(len / original_max) + 1 (at least 1) of their sequence; the runner supplies that factor per token.
+    Reference: vllm/attention/backends/dual_chunk_flash_attn.py (_dual_chunk_flash_attn_prefill_func :705-1145 dense
+    branch, _dual_chunk_flash_attn_decoding :1283-1377), vllm/model_executor/layers/rotary_embedding.py:1679-1845.
+    The reference's sparse (vertical-slash) prefill estimate is not built: every pass is dense."""
+    dual_chunk = True
+
+    def __init__(self, *args, chunk_size: int, local_size: int, original_max_position_embeddings: int = 0, **kw):
+        super().__init__(*args, **kw)
+        if self.sliding_window or self.alibi_slopes is not None:
+            raise ValueError("dual-chunk attention takes neither a sliding window nor ALiBi")
+        self.chunk_size, self.chunk_len = int(chunk_size), int(chunk_size) - int(local_size)
+        self.local_chunk = self.chunk_len           # the runner cuts the step into (sequence, chunk) pairs
+        self.original_max = int(original_max_position_embeddings or 0)
+
+    def _forward_native(self, qkv: torch.Tensor, positions: Optional[torch.Tensor] = None, rotary=None) -> torch.Tensor:
+        ctx = get_forward_context()
+        md: Optional[AttentionMetadata] = ctx.attn_metadata
+        if md is None or self.k_cache is None:
+            return super()._forward_native(qkv, positions, rotary)
+        if md.local_block_table is None or md.dca_succ_lens is None or rotary is None:
+            raise RuntimeError("dual-chunk attention needs the runner's per-chunk batch layout and a rotary table")
+        T = qkv.shape[0]
+        Hq, Hkv, D = self.num_heads, self.num_kv_heads, self.head_size
+        qs, ks = Hq * D, Hkv * D
+        n, L = md.num_actual_tokens, self.chunk_len
+        ksc, vsc = self._k_scale_float, self._v_scale_float
+        conn = ctx.kv_connector
+        if conn is not None:
+            conn.wait_for_layer_load(self.layer_name)
+        if md.dca_token_scale is not None:
+            qkv[:n, :qs + ks] *= md.dca_token_scale[:n]
+        raw = qkv[:n, :qs]
+        q_succ, q_inter = raw.clone(), raw.clone()
+        p_in = positions[:n] % L
+        table, rd, neox = rotary.cos_sin_cache, rotary.rotary_dim, rotary.is_neox_style
+        ops.rope_and_cache(p_in, qkv[:n], table, self.k_cache, self.v_cache, md.slot_mapping[:n], rd, D, Hq, Hkv,
+                           neox, ksc, vsc)
+        out = torch.empty((T, Hq, D), dtype=qkv.dtype, device=qkv.device)
+        if n < T:
+            out[n:].zero_()
+        qsl = md.local_query_start_loc
+        kw = dict(softcap=self.softcap, k_scale=ksc, v_scale=vsc, return_lse=True)
+        q = qkv[:n, :qs].view(n, Hq, D)
+        if md.dca_passes == 1:
+            # no sequence of the step has an older chunk: plain chunked local attention, decode kernel included
+            nd, ndt, n_pre = md.num_decode_seqs, md.num_decode_tokens, md.local_num_prefill_seqs
+            if nd > 0:
+                ops.paged_attention_decode(out[:ndt], q[:ndt], self.k_cache, self.v_cache, md.local_block_table[:nd],
+                                           md.local_seq_lens[:nd], qsl[:nd + 1], self.scale,
+                                           num_splits=md.decode_num_splits, max_q_len=md.max_decode_query_len,
+                                           softcap=self.softcap, workspace=md.decode_workspace, k_scale=ksc,
+                                           v_scale=vsc)
+            if n_pre > 0:
+                e = ndt + md.num_prefill_tokens
+                ops.paged_attention_prefill(out[ndt:e], q[ndt:e], self.k_cache, self.v_cache,
+                                            md.local_block_table[nd:nd + n_pre], md.local_seq_lens[nd:nd + n_pre],
+                                            md.local_prefill_query_start_loc, self.scale, softcap=self.softcap,
+                                            k_scale=ksc, v_scale=vsc, causal=True)
+        else:
+            ops.rotary_embedding((p_in + L).clamp_(max=self.chunk_size), q_succ, None, table, rd, D, neox)
+            ops.rotary_embedding(torch.full_like(p_in, min(2 * L - 1, self.chunk_size)), q_inter, None, table, rd, D,
+                                 neox)
+            o1, l1 = ops.paged_attention_prefill(torch.zeros_like(out[:n]), q, self.k_cache, self.v_cache,
+                                                 md.local_block_table, md.local_seq_lens, qsl, self.scale,
+                                                 causal=True, **kw)
+            o2, l2 = ops.paged_attention_prefill(torch.zeros_like(o1), q_succ.view(n, Hq, D), self.k_cache,
+                                                 self.v_cache, md.dca_succ_block_table, md.dca_succ_lens, qsl,
+                                                 self.scale, causal=False, **kw)
+            o3, l3 = ops.paged_attention_prefill(torch.zeros_like(o1), q_inter.view(n, Hq, D), self.k_cache,
+                                                 self.v_cache, md.dca_inter_block_table, md.dca_inter_lens, qsl,
+                                                 self.scale, causal=False, **kw)
+            o12, l12 = ops.merge_attn_states(o1, l1, o2, l2, return_lse=True)
+            out[:n] = ops.merge_attn_states(o12, l12, o3, l3)
+        if conn is not None:
+            conn.save_kv_layer(self.layer_name, (self.k_cache, self.v_cache), md)
+        return out.view(T, qs)
+
+
 class MLAAttention(nn.Module):
     """Multi-head latent attention over a latent KV cache (DeepSeek-V2 / V3).
 

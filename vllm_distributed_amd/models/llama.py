@@ -69,9 +69,22 @@ class LlamaAttention(nn.Module):
         if alibi_slopes is not None:       # this rank's heads
             r = get_tensor_model_parallel_rank()
             alibi_slopes = list(alibi_slopes)[r * self.num_heads:(r + 1) * self.num_heads]
-        self.attn = Attention(self.num_heads, self.head_dim, scale if scale is not None else self.head_dim ** -0.5,
-                              self.num_kv_heads, alibi_slopes=alibi_slopes, sliding_window=sliding_window,
-                              logits_soft_cap=logits_soft_cap, prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
+        dca = getattr(config, "dual_chunk_attention_config", None)
+        if dca and use_rope:
+            # Qwen2.5-1M: keys rotated with their position inside a chunk, three query rotations (layers/attention.py
+            # ::DualChunkAttention); the table only needs chunk_size + 1 rows and takes no length scaling
+            # (reference: vllm/model_executor/models/qwen2.py:117-175 passes the same dict to rope and attention)
+            from ..layers.attention import DualChunkAttention
+            cs, ls = int(dca.get("chunk_size", 8192)), int(dca.get("local_size", 1024))
+            self.rotary_emb = get_rope(self.head_dim, self.head_dim, cs + 1, rope_theta, neox_style, None, partial)
+            self.attn = DualChunkAttention(
+                self.num_heads, self.head_dim, scale if scale is not None else self.head_dim ** -0.5, self.num_kv_heads,
+                logits_soft_cap=logits_soft_cap, prefix=f"{prefix}.attn", cache_dtype=cache_dtype, chunk_size=cs,
+                local_size=ls, original_max_position_embeddings=int(dca.get("original_max_position_embeddings", 0)))
+        else:
+            self.attn = Attention(self.num_heads, self.head_dim, scale if scale is not None else self.head_dim ** -0.5,
+                                  self.num_kv_heads, alibi_slopes=alibi_slopes, sliding_window=sliding_window,
+                                  logits_soft_cap=logits_soft_cap, prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
         # True: RMSNorm per head (Qwen3); "gemma": the (1 + w) form per head; "full": one RMSNorm over the
         # whole q / k projection (OLMo-2)
         self.qk_norm = qk_norm if not attention_only else False

@@ -138,6 +138,7 @@ class ModelRunner:
         self.encoder_cache: dict[str, dict[int, torch.Tensor]] = {}     # request -> item index -> embeddings
         self.local_chunk = 0           # chunk length of chunked-local attention layers (set by load_model)
         self._l_counts = (0, 0)        # (virtual sequences, virtual prefill-form sequences) of the step
+        self.dual_chunk = False        # some layer runs dual-chunk attention (set by load_model)
         self._init_buffers()
 
     # ------------------------------------------------------------------
@@ -281,6 +282,19 @@ class ModelRunner:
         self.l_qsl = torch.zeros(self.l_max + 1, dtype=torch.int32, device=dev)
         self.l_prefill_qsl = torch.zeros(self.l_max + 1, dtype=torch.int32, device=dev)
         self._stage_bytes += self.l_max * (self.l_width * 4 + 64)
+        # dual-chunk attention (layers/attention.py::DualChunkAttention): the same virtual sequences also read the
+        # chunk before theirs and everything older
+        dca = [m for m in self.attn_layers.values() if getattr(m, "dual_chunk", False)]
+        self.dual_chunk = bool(dca)
+        if dca:
+            self.d_succ_bt = torch.zeros((self.l_max, self.l_width), dtype=torch.int32, device=dev)
+            self.d_succ_lens = torch.zeros(self.l_max, dtype=torch.int32, device=dev)
+            self.d_inter_lens = torch.zeros(self.l_max, dtype=torch.int32, device=dev)
+            self.d_owner = torch.zeros(self.l_max, dtype=torch.int64, device=dev)
+            self.d_orig_max = max(m.original_max for m in dca)
+            self.d_scale = torch.ones((self.max_num_tokens, 1), dtype=self.dtype, device=dev) if self.d_orig_max else None
+            self._d_inter_bt, self._d_passes = None, 3
+            self._stage_bytes += self.l_max * (self.l_width * 4 + 64) + self.max_num_tokens * 4
 
     def _upload_local_attention(self, rows, n_sched, cu, seq_lens, nd: int) -> None:
         """Per-chunk view of the step's sequences (see _init_local_attention)."""
@@ -316,6 +330,27 @@ class ModelRunner:
         if nd < Sv:
             self._to_dev(self.l_prefill_qsl, (l_cu[nd:] - l_cu[nd]).astype(np.int32))
         self._l_counts = (Sv, Sv - nd)
+        if not self.dual_chunk:
+            return
+        prev = chunk - 1
+        self._d_passes = 3 if Sv and int(chunk.max()) >= 1 else 1
+        self._to_dev(self.d_succ_lens, np.where(prev >= 0, C, 0).astype(np.int32))
+        self._to_dev(self.d_inter_lens, (np.maximum(prev, 0) * C).astype(np.int32))
+        if self._d_passes == 3:
+            cols = prev[:, None] * (C // bs) + np.arange(W, dtype=np.int64)[None, :]
+            valid = (prev >= 0)[:, None] & (cols < bt.shape[1])
+            s_bt = np.where(valid, bt[rows[owner][:, None], np.clip(cols, 0, bt.shape[1] - 1)], 0).astype(np.int32)
+            self.d_succ_bt[:Sv].copy_(self._stage(s_bt), non_blocking=True)
+            if Sv == S:                    # every sequence inside one chunk: the step's own table serves
+                self._d_inter_bt = None
+            else:
+                self._to_dev(self.d_owner, owner)
+                self._d_inter_bt = self.block_table.index_select(0, self.d_owner[:Sv])
+        if self.d_scale is not None:
+            # tokens known of the sequence (the whole prompt while it is prefilled, the current length afterwards)
+            known = np.maximum(self.input_batch.num_tokens[rows].astype(np.int64), end)
+            f = np.maximum(0.1 * np.log(np.maximum(known, 1) / self.d_orig_max) + 1.0, 1.0)
+            self._to_dev(self.d_scale.view(-1), np.repeat(f, n).astype(np.float32))
 
     def _init_tknp_exchange(self) -> None:
         """Token parallelism on GPUs of one node: rows travel through the peer-memory all-to-all-v
@@ -812,6 +847,12 @@ class ModelRunner:
             local = dict(local_block_table=self.l_block_table[:Sv], local_seq_lens=self.l_seq_lens[:Sv],
                          local_query_start_loc=self.l_qsl[:Sv + 1], local_num_prefill_seqs=n_pre,
                          local_prefill_query_start_loc=self.l_prefill_qsl[:n_pre + 1] if n_pre else None)
+            if self.dual_chunk:
+                inter = None if decode_only else self._d_inter_bt
+                local.update(dca_succ_block_table=self.d_succ_bt[:Sv], dca_succ_lens=self.d_succ_lens[:Sv],
+                             dca_inter_block_table=inter if inter is not None else self.block_table[:Sv],
+                             dca_inter_lens=self.d_inter_lens[:Sv], dca_token_scale=self.d_scale,
+                             dca_passes=3 if decode_only else self._d_passes)
         return AttentionMetadata(**local,
             num_actual_tokens=T, num_decode_seqs=nd, num_decode_tokens=ndt, num_prefill_seqs=S - nd,
             num_prefill_tokens=T - ndt, slot_mapping=self.slot_mapping, block_table=self.block_table[:S],
@@ -945,6 +986,9 @@ class ModelRunner:
                 if self.local_chunk:
                     self.l_seq_lens[Sg:graph_bs].zero_()
                     self.l_qsl[Sg + 1: graph_bs + 1].copy_(self.query_start_loc[Sg + 1: graph_bs + 1])
+                    if self.dual_chunk:
+                        self.d_succ_lens[Sg:graph_bs].zero_()
+                        self.d_inter_lens[Sg:graph_bs].zero_()
             g, hidden_buf, md = self.graphs[graph_bs]
             with set_forward_context(md, kv_connector=conn, num_tokens=T):
                 if conn is not None:
@@ -1335,6 +1379,9 @@ class ModelRunner:
             if self.local_chunk:
                 self.l_seq_lens[:S].zero_()
                 self.l_qsl[:S + 1].copy_(self.query_start_loc[:S + 1])
+                if self.dual_chunk:
+                    self.d_succ_lens[:S].zero_()
+                    self.d_inter_lens[:S].zero_()
             md = self._build_attn_metadata(S, num_tokens, S, num_tokens, 0, 1, nsplit, decode_only=True)
         with set_forward_context(md, num_tokens=0):
             out = self.model(self.input_ids[:num_tokens], self.positions[:num_tokens], inter, None)
@@ -1386,6 +1433,9 @@ class ModelRunner:
                 if self.local_chunk:
                     self.l_seq_lens[:bs].zero_()
                     self.l_qsl[:bs + 1].copy_(self.query_start_loc[:bs + 1])
+                    if self.dual_chunk:
+                        self.d_succ_lens[:bs].zero_()
+                        self.d_inter_lens[:bs].zero_()
                 md = self._build_attn_metadata(bs, bs, bs, bs, 0, 1, nsplit, decode_only=True)
                 tmd = None
                 if self.tk_rx is not None:
