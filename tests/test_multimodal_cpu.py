@@ -740,3 +740,55 @@ def test_paligemma_greedy_matches_hf(tmp_path, text):
                           do_sample=False, eos_token_id=None, pad_token_id=0)[0, len(ids):].tolist()
     assert list(out.outputs[0].token_ids) == ref
     llm.shutdown()
+
+
+def test_nvlm_d_dummy_heads_and_projector(tmp_path):
+    """NVLM-D = InternVL with 7 all-zero heads beside the tower's own and a bias-free projector as wide as the
+    decoder's MLP.  No transformers class exists (parity unpinned): zero dummy heads must leave the tower's output
+    unchanged, and a dummy-weight engine must run an image request end to end."""
+    import json
+    from vllm_distributed_amd.models.internvl import InternVisionLayer
+    torch.manual_seed(0)
+    a = InternVisionLayer(64, 2, 128, True, False, "layer_norm", 1e-6, "gelu").eval()
+    b = InternVisionLayer(64, 2, 128, True, False, "layer_norm", 1e-6, "gelu", dummy_heads=7).eval()
+    with torch.no_grad():
+        sd = a.state_dict()
+        for n, p in b.named_parameters():
+            if n == "attn.qkv.weight":
+                p.zero_()
+                for i in range(3):
+                    p[i * 288:i * 288 + 64] = sd[n][i * 64:(i + 1) * 64]
+            elif n == "attn.qkv.bias":
+                p.zero_()
+                for i in range(3):
+                    p[i * 288:i * 288 + 64] = sd[n][i * 64:(i + 1) * 64]
+            elif n == "attn.proj.weight":
+                p.zero_()
+                p[:, :64] = sd[n]
+            else:
+                p.copy_(sd[n])
+        x = torch.randn(2, 17, 64)
+        torch.testing.assert_close(b(x), a(x))
+    path = os.path.join(tmp_path, "nvlm")
+    os.makedirs(path)
+    cfg = {"architectures": ["NVLM_D"], "model_type": "NVLM_D", "downsample_ratio": 0.5, "select_layer": -1,
+           "ps_version": "v2", "dynamic_image_size": True, "max_dynamic_patch": 6, "min_dynamic_patch": 1,
+           "use_thumbnail": True, "image_token_id": 300,
+           "llm_config": {"architectures": ["Qwen2ForCausalLM"], "model_type": "qwen2", "vocab_size": 320,
+                          "hidden_size": 128, "intermediate_size": 256, "num_hidden_layers": 2,
+                          "num_attention_heads": 2, "num_key_value_heads": 1, "max_position_embeddings": 512,
+                          "rms_norm_eps": 1e-6, "rope_theta": 10000.0, "tie_word_embeddings": False},
+           "vision_config": {"hidden_size": 64, "intermediate_size": 128, "num_hidden_layers": 2,
+                             "num_attention_heads": 2, "image_size": 28, "patch_size": 7, "qk_normalization": True,
+                             "qkv_bias": False, "norm_type": "rms_norm", "layer_norm_eps": 1e-6, "hidden_act": "gelu"}}
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=4,
+              load_format="dummy")
+    m = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    assert m.vision_model.encoder.layers[0].attn.qkv.weight.shape == (3 * 9 * 32, 64)
+    assert m.mlp1[1].weight.shape == (256, 256) and m.mlp1[1].bias is None and m.mlp1[3].weight.shape == (128, 256)
+    img = (np.random.default_rng(3).random((30, 95, 3)) * 255).astype(np.uint8)
+    out = llm.generate([{"prompt_token_ids": [5, 300, 9], "multi_modal_data": {"image": img}}],
+                       SamplingParams(temperature=0, max_tokens=4, ignore_eos=True))[0]
+    assert len(out.prompt_token_ids) == 2 + 4 * 4 and len(out.outputs[0].token_ids) == 4
+    llm.shutdown()

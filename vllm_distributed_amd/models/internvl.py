@@ -48,14 +48,17 @@ def _norm(kind: str, n: int, eps: float) -> nn.Module:
 
 
 class InternVisionLayer(nn.Module):
-    def __init__(self, H, heads, inter, qkv_bias, qk_norm, norm_type, eps, act):
+    def __init__(self, H, heads, inter, qkv_bias, qk_norm, norm_type, eps, act, dummy_heads: int = 0):
         super().__init__()
-        self.heads, self.hd = heads, H // heads
+        # dummy heads: extra all-zero heads some checkpoints (NVLM-D) carry so that the count divides 8
+        self.hd = H // heads
+        self.heads = heads + dummy_heads
+        A = self.heads * self.hd
         self.attn = nn.Module()
-        self.attn.qkv = nn.Linear(H, 3 * H, bias=qkv_bias)
-        self.attn.proj = nn.Linear(H, H)
+        self.attn.qkv = nn.Linear(H, 3 * A, bias=qkv_bias)
+        self.attn.proj = nn.Linear(A, H)
         if qk_norm:
-            self.attn.q_norm, self.attn.k_norm = _RMS(H, eps), _RMS(H, eps)
+            self.attn.q_norm, self.attn.k_norm = _RMS(A, eps), _RMS(A, eps)
         self.qk_norm = qk_norm
         self.norm1, self.norm2 = _norm(norm_type, H, eps), _norm(norm_type, H, eps)
         self.mlp = nn.Module()
@@ -69,13 +72,13 @@ class InternVisionLayer(nn.Module):
         if self.qk_norm:
             q, k = self.attn.q_norm(q), self.attn.k_norm(k)
         q, k, v = (t.reshape(B, N, self.heads, self.hd).transpose(1, 2) for t in (q, k, v))
-        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, H)
+        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, self.heads * self.hd)
         x = x + self.ls1 * self.attn.proj(o)
         return x + self.ls2 * self.mlp.fc2(self.act(self.mlp.fc1(self.norm2(x))))
 
 
 class InternVisionModel(nn.Module):
-    def __init__(self, vc: dict, select_layer: int):
+    def __init__(self, vc: dict, select_layer: int, dummy_heads: int = 0):
         super().__init__()
         g = vc.get
         H = int(g("hidden_size"))
@@ -94,7 +97,7 @@ class InternVisionModel(nn.Module):
         self.encoder.layers = nn.ModuleList([
             InternVisionLayer(H, int(g("num_attention_heads")), int(g("intermediate_size")), qkv_bias, qk_norm,
                               str(g("norm_type", "layer_norm")), float(g("layer_norm_eps", 1e-6)),
-                              str(g("hidden_act", "gelu"))) for _ in range(keep)])
+                              str(g("hidden_act", "gelu")), dummy_heads) for _ in range(keep)])
 
     def forward(self, px):
         e = self.embeddings
@@ -127,11 +130,16 @@ class InternVLChatModel(nn.Module):
         self.ratio = float(getattr(hf, "downsample_ratio", 0.5))
         self.ps_v2 = str(getattr(hf, "ps_version", "v2")) != "v1"
         select = int(getattr(hf, "select_layer", getattr(hf, "vision_feature_layer", -1)))
-        self.vision_model = InternVisionModel(vc, select)
+        self.vision_model = InternVisionModel(vc, select, self.vision_dummy_heads)
         Hv = int(vc["hidden_size"]) * int(1 / self.ratio) ** 2
-        self.mlp1 = nn.Sequential(nn.LayerNorm(Hv), nn.Linear(Hv, tc.hidden_size), nn.GELU(),
-                                  nn.Linear(tc.hidden_size, tc.hidden_size))
+        self.mlp1 = self._make_projector(Hv, tc)
         self.language_model = build_language_model(vllm_config, tc, maybe_prefix(prefix, "language_model"))
+
+    vision_dummy_heads = 0
+
+    def _make_projector(self, Hv: int, tc) -> nn.Sequential:
+        return nn.Sequential(nn.LayerNorm(Hv), nn.Linear(Hv, tc.hidden_size), nn.GELU(),
+                             nn.Linear(tc.hidden_size, tc.hidden_size))
 
     def encode_mm_items(self, items: list[list[torch.Tensor]]) -> list[torch.Tensor]:
         tiles = torch.cat([it[0] for it in items], dim=0)
@@ -222,6 +230,18 @@ class InternVLChatModel(nn.Module):
             lm.tie = True
             sub.add("lm_head.weight")
         return loaded | {"language_model." + n for n in sub}
+
+
+class NVLM_D_Model(InternVLChatModel):
+    """NVLM-D: InternVL whose InternViT-6B carries 7 all-zero heads beside its 25 (32 divides over 8 ranks) and
+    whose projector is bias-free and as wide as the decoder's MLP.  The tile tags (``<tile_1>`` ... in front of
+    each tile's positions) are text: a prompt that carries them keeps them, this package's processor only expands
+    the image positions.  Reference: vllm/model_executor/models/nvlm_d.py:171-216."""
+    vision_dummy_heads = 7
+
+    def _make_projector(self, Hv: int, tc) -> nn.Sequential:
+        return nn.Sequential(nn.LayerNorm(Hv), nn.Linear(Hv, tc.intermediate_size, bias=False), nn.GELU(),
+                             nn.Linear(tc.intermediate_size, tc.hidden_size, bias=False))
 
 
 class InternVLForConditionalGeneration(InternVLChatModel):

@@ -131,6 +131,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "BartModel": ("bart", "BartModel"),
     "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),
     "InternVLChatModel": ("internvl", "InternVLChatModel"),
+    "NVLM_D": ("internvl", "NVLM_D_Model"),
     "InternVLForConditionalGeneration": ("internvl", "InternVLForConditionalGeneration"),
     "SkyworkR1VChatModel": ("internvl", "InternVLChatModel"),
     "H2OVLChatModel": ("internvl", "InternVLChatModel"),

@@ -411,7 +411,7 @@ def _internvl(vllm_config):
     return internvl_processor(vllm_config)
 
 
-for _a in ("InternVLChatModel", "InternVLForConditionalGeneration", "SkyworkR1VChatModel", "H2OVLChatModel"):
+for _a in ("InternVLChatModel", "InternVLForConditionalGeneration", "SkyworkR1VChatModel", "H2OVLChatModel", "NVLM_D"):
     MULTIMODAL_REGISTRY.register_processor(_a, _internvl)
 
 
