@@ -792,3 +792,42 @@ def test_nvlm_d_dummy_heads_and_projector(tmp_path):
                        SamplingParams(temperature=0, max_tokens=4, ignore_eos=True))[0]
     assert len(out.prompt_token_ids) == 2 + 4 * 4 and len(out.outputs[0].token_ids) == 4
     llm.shutdown()
+
+
+def test_jina_vl_ranking_scores(tmp_path):
+    """jina-reranker-m0's form: Qwen2-VL + two-layer scorer on the last hidden state, sigmoid(logit - 2.65).
+    Checked against transformers' hidden states of the same Qwen2-VL weights and the scorer applied by hand."""
+    import json
+    from safetensors.torch import load_file, save_file
+    path, hf = _tiny_qwen2_vl(str(tmp_path))
+    torch.manual_seed(4)
+    H = hf.config.get_text_config().hidden_size
+    score = torch.nn.Sequential(torch.nn.Linear(H, H), torch.nn.ReLU(), torch.nn.Linear(H, 1)).float()
+    f = [x for x in os.listdir(path) if x.endswith(".safetensors")][0]
+    sd = load_file(os.path.join(path, f))
+    sd.update({"score." + n: t.detach().clone() for n, t in score.state_dict().items()})
+    save_file(sd, os.path.join(path, f))
+    c = json.load(open(os.path.join(path, "config.json")))
+    c.update(architectures=["JinaVLForRanking"], num_labels=1)
+    json.dump(c, open(os.path.join(path, "config.json"), "w"))
+    g = torch.Generator().manual_seed(3)
+    img = {"pixel_values": torch.randn(4 * 6, 1176, generator=g), "image_grid_thw": torch.tensor([1, 4, 6])}
+    prompts = [([5, 17, 302, 300, 303, 9, 11, 100], [img]), ([7, 8, 9, 10, 100], [])]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              enable_prefix_caching=False)
+    outs = llm.classify([{"prompt_token_ids": p, **({"multi_modal_data": {"image": m}} if m else {})}
+                         for p, m in prompts])
+    for (p, ims), o in zip(prompts, outs):
+        ids = []
+        for t in p:
+            ids += [t] * (int(ims[0]["image_grid_thw"].prod()) // 4 if t == 300 else 1)
+        kw = {}
+        if ims:
+            kw = dict(pixel_values=ims[0]["pixel_values"], image_grid_thw=ims[0]["image_grid_thw"][None],
+                      mm_token_type_ids=torch.tensor([[1 if t == 300 else 0 for t in ids]], dtype=torch.int32))
+        with torch.no_grad():
+            h = hf(input_ids=torch.tensor([ids]), output_hidden_states=True, **kw).hidden_states[-1][0, -1]
+            ref = torch.sigmoid(score(h) - 2.65)
+        got = torch.as_tensor(o.outputs.probs if hasattr(o.outputs, "probs") else o.outputs.data).float().view(-1)
+        torch.testing.assert_close(got, ref.view(-1), atol=2e-4, rtol=1e-3)
+    llm.shutdown()

@@ -249,6 +249,7 @@ class ModelConfig:
                 or arch in ("ChatGLMModel", "GritLM", "MiniCPMV", "MiniCPMO", "Ovis", "NVLM_D", "InternVLChatModel",
                             "H2OVLChatModel", "SkyworkR1VChatModel", "UltravoxModel", "Qwen2_5OmniModel")
             self.task = ("generate" if generative else "classify" if "SequenceClassification" in arch
+                         or arch.endswith("ForRanking")
                          else "embed" if arch.endswith(("Model", "ForMaskedLM")) else "generate")
 
     @staticmethod

@@ -201,6 +201,39 @@ class Qwen2VLForConditionalGeneration(nn.Module):
         return loaded
 
 
+class JinaVLForRanking(Qwen2VLForConditionalGeneration):
+    """jina-reranker-m0: Qwen2-VL whose last hidden state goes through a two-layer scorer; the score is
+    sigmoid(logit - 2.65).  Reference: vllm/model_executor/models/jina_vl.py:30-150."""
+    is_pooling_model = True
+    LOGIT_BIAS = 2.65
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        from ..layers.pooler import Pooler, PoolingType
+        H = int(self.config.hidden_size)
+        n = int(getattr(self.config, "num_labels", 1) or 1)
+        self.score = nn.Sequential(nn.Linear(H, H), nn.ReLU(), nn.Linear(H, n))
+        self.pooler = Pooler.from_config(getattr(vllm_config.model_config, "pooler_config", None), PoolingType.LAST,
+                                         normalize=False, softmax=True)
+
+    def pool(self, hidden: torch.Tensor, params=None) -> torch.Tensor:
+        x = self.pooler.extract(hidden)
+        x = self.score(x.unsqueeze(0) if x.dim() == 1 else x).squeeze(0) - self.LOGIT_BIAS
+        return self.pooler.head(x, params)
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        own, rest = {}, []
+        for n, t in weights:
+            (own.__setitem__(n, t) if n.startswith("score.") else rest.append((n, t)))
+        loaded = super().load_weights(rest)
+        params = dict(self.named_parameters())
+        for n, t in own.items():
+            params[n].data.copy_(t)
+            loaded.add(n)
+        loaded |= {n for n in params if n.startswith("language_model.lm_head.")}       # unused head
+        return loaded
+
+
 # ---- Qwen2.5-VL --------------------------------------------------------------------------------------
 class _RMS(nn.Module):
     def __init__(self, dim: int, eps: float = 1e-6):

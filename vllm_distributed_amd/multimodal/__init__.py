@@ -450,6 +450,7 @@ def _tarsier_processor(vllm_config):
 
 MULTIMODAL_REGISTRY.register_processor("TarsierForConditionalGeneration", _tarsier_processor)
 MULTIMODAL_REGISTRY.register_processor("Tarsier2ForConditionalGeneration", _qwen2_vl_processor)
+MULTIMODAL_REGISTRY.register_processor("JinaVLForRanking", _qwen2_vl_processor)
 
 
 def _paligemma(vllm_config):
