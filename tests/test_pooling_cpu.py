@@ -243,3 +243,65 @@ def test_nomic_bert_rotary_encoder_matches_hf(tmp_path):
             ref = hf(torch.tensor([p])).last_hidden_state[0].mean(0)
         ref = torch.nn.functional.normalize(ref, dim=-1)
         torch.testing.assert_close(torch.as_tensor(o.outputs.embedding), ref, atol=2e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("arch", ["GteNewModel", "GteModel"])
+def test_gte_new_encoder_matches_dense_form(tmp_path, arch):
+    """Alibaba-NLP "new" encoder (rotary BERT, biased projections, fused up_gate_proj with the up rows first, GELU
+    gate, fixed-NTK rope, CLS pooling) from a checkpoint in its own naming.  transformers has no class for it (remote
+    code upstream, parity unpinned): the reference is the block written out in fp32 below."""
+    import json
+    from safetensors.torch import save_file
+    torch.manual_seed(0)
+    V, d, H, I, Lr, maxp, theta, factor = 320, 128, 2, 256, 2, 256, 10000.0, 4.0
+    D = d // H
+    g = lambda *s: torch.randn(*s) * 0.05
+    pre = "new." if arch == "GteNewModel" else ""
+    sd = {pre + "embeddings.word_embeddings.weight": g(V, d), pre + "embeddings.token_type_embeddings.weight": g(2, d),
+          pre + "embeddings.LayerNorm.weight": 1 + g(d), pre + "embeddings.LayerNorm.bias": g(d)}
+    for i in range(Lr):
+        p = f"{pre}encoder.layer.{i}."
+        sd.update({p + "attention.qkv_proj.weight": g(3 * d, d), p + "attention.qkv_proj.bias": g(3 * d),
+                   p + "attention.o_proj.weight": g(d, d), p + "attention.o_proj.bias": g(d),
+                   p + "attn_ln.weight": 1 + g(d), p + "attn_ln.bias": g(d),
+                   p + "mlp.up_gate_proj.weight": g(2 * I, d), p + "mlp.down_proj.weight": g(d, I),
+                   p + "mlp.down_proj.bias": g(d), p + "mlp_ln.weight": 1 + g(d), p + "mlp_ln.bias": g(d)})
+    sd[pre + "pooler.dense.weight"] = g(d, d)
+    path = os.path.join(tmp_path, "gte")
+    os.makedirs(path)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    json.dump({"architectures": [arch], "model_type": "new", "vocab_size": V, "hidden_size": d, "num_attention_heads": H,
+               "intermediate_size": I, "num_hidden_layers": Lr, "max_position_embeddings": maxp, "rope_theta": theta,
+               "rope_scaling": {"type": "ntk", "factor": factor}, "hidden_act": "gelu", "layer_norm_eps": 1e-12,
+               "type_vocab_size": 2, "position_embedding_type": "rope", "torch_dtype": "float32"},
+              open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 11, [2, 3]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128,
+              max_num_seqs=8, block_size=16)
+    outs = llm.embed(None, prompt_token_ids=prompts)
+    llm.shutdown()
+    F = torch.nn.functional
+    inv = 1.0 / ((theta * factor) ** (torch.arange(0, D, 2).float() / D)) / factor ** (2 / D)
+
+    def rope(x):                                         # [T, H, D]
+        ang = torch.arange(x.shape[0])[:, None].float() * inv[None]
+        c, s_ = ang.cos()[:, None], ang.sin()[:, None]
+        a, b = x[..., :D // 2], x[..., D // 2:]
+        return torch.cat((a * c - b * s_, b * c + a * s_), -1)
+
+    for p_ids, o in zip(prompts, outs):
+        T = len(p_ids)
+        x = sd[pre + "embeddings.word_embeddings.weight"][p_ids] + sd[pre + "embeddings.token_type_embeddings.weight"][0]
+        x = F.layer_norm(x, (d,), sd[pre + "embeddings.LayerNorm.weight"], sd[pre + "embeddings.LayerNorm.bias"], 1e-12)
+        for i in range(Lr):
+            p = f"{pre}encoder.layer.{i}."
+            q, k, v = (x @ sd[p + "attention.qkv_proj.weight"].T + sd[p + "attention.qkv_proj.bias"]).chunk(3, -1)
+            q, k, v = rope(q.view(T, H, D)), rope(k.view(T, H, D)), v.view(T, H, D)
+            a = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None])
+            a = a[0].transpose(0, 1).reshape(T, d) @ sd[p + "attention.o_proj.weight"].T + sd[p + "attention.o_proj.bias"]
+            x = F.layer_norm(x + a, (d,), sd[p + "attn_ln.weight"], sd[p + "attn_ln.bias"], 1e-12)
+            up, gate = (x @ sd[p + "mlp.up_gate_proj.weight"].T).chunk(2, -1)
+            m = (F.gelu(gate) * up) @ sd[p + "mlp.down_proj.weight"].T + sd[p + "mlp.down_proj.bias"]
+            x = F.layer_norm(x + m, (d,), sd[p + "mlp_ln.weight"], sd[p + "mlp_ln.bias"], 1e-12)
+        ref = F.normalize(x[0], dim=-1)
+        torch.testing.assert_close(torch.as_tensor(o.outputs.embedding), ref, atol=2e-4, rtol=1e-3)

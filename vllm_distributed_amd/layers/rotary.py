@@ -77,6 +77,24 @@ class LinearScalingRotaryEmbedding(RotaryEmbedding):
         return torch.arange(self.max_position, dtype=torch.float32) / self.factor
 
 
+class NTKScalingRotaryEmbedding(RotaryEmbedding):
+    """Fixed NTK scaling (base * factor, every frequency divided by factor^(2 / rotary_dim)) and the "mixed" form
+    whose divisor grows with the frequency index.  Reference: vllm/model_executor/layers/rotary_embedding.py:462-493."""
+
+    def __init__(self, head_size, rotary_dim, max_position, base, is_neox_style, factor: float,
+                 mixed_b: Optional[float] = None):
+        self.factor, self.mixed_b = float(factor), mixed_b
+        super().__init__(head_size, rotary_dim, max_position, base, is_neox_style)
+
+    def _freqs(self):
+        if self.mixed_b is None:
+            return _inv_freq(self.base * self.factor, self.rotary_dim) / self.factor ** (2 / self.rotary_dim)
+        half = self.rotary_dim // 2
+        a = math.log(self.factor) / half ** self.mixed_b
+        lam = (a * torch.arange(1, half + 1).float() ** self.mixed_b).exp()
+        return _inv_freq(self.base, self.rotary_dim) / lam
+
+
 class DynamicNTKScalingRotaryEmbedding(RotaryEmbedding):
     def __init__(self, head_size, rotary_dim, max_position, base, is_neox_style, factor: float):
         self.factor = factor
@@ -220,6 +238,9 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, is
                                      rs["original_max_position_embeddings"])
     elif kind == "linear":
         rope = LinearScalingRotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, rs["factor"])
+    elif kind == "ntk":
+        rope = NTKScalingRotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style, rs["factor"],
+                                         rs.get("mixed_b"))
     elif kind == "dynamic":
         rope = DynamicNTKScalingRotaryEmbedding(head_size, rotary_dim, max_position, base, is_neox_style,
                                                 rs["factor"])

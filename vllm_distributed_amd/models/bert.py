@@ -199,6 +199,9 @@ class NomicBertLayer(nn.Module):
     """Post-norm block with rotary positions and a gated MLP, no biases:
     x = LN(x + o(attn(rope(q, k), v)));  x = LN(x + down(act(gate(x)) * up(x)))."""
 
+    linear_bias = False
+    act_name: Optional[str] = None
+
     def __init__(self, config, vllm_config: VllmConfig, prefix: str, rotary):
         super().__init__()
         from ..layers.basic import get_act_and_mul_fn
@@ -208,16 +211,17 @@ class NomicBertLayer(nn.Module):
         tp = get_tensor_model_parallel_world_size()
         eps = config.layer_norm_eps
         self.rotary = rotary
-        self.qkv_proj = QKVParallelLinear(d, D, H, H, bias=False, prefix=f"{prefix}.self_attn.qkv_proj")
+        b = self.linear_bias          # every projection but the fused gate / up one
+        self.qkv_proj = QKVParallelLinear(d, D, H, H, bias=b, prefix=f"{prefix}.self_attn.qkv_proj")
         self.attn = Attention(H // tp, D, D ** -0.5, H // tp, prefix=f"{prefix}.self_attn.attn",
                               cache_dtype=vllm_config.cache_config.cache_dtype, causal=False)
-        self.o_proj = RowParallelLinear(H * D, d, bias=False, prefix=f"{prefix}.self_attn.o_proj")
+        self.o_proj = RowParallelLinear(H * D, d, bias=b, prefix=f"{prefix}.self_attn.o_proj")
         self.post_attention_layernorm = LayerNorm(d, eps)
         self.gate_up_proj = MergedColumnParallelLinear(d, [config.intermediate_size] * 2, bias=False,
                                                        prefix=f"{prefix}.mlp.gate_up_proj")
-        self.down_proj = RowParallelLinear(config.intermediate_size, d, bias=False, prefix=f"{prefix}.mlp.down_proj")
+        self.down_proj = RowParallelLinear(config.intermediate_size, d, bias=b, prefix=f"{prefix}.mlp.down_proj")
         self.post_mlp_layernorm = LayerNorm(d, eps)
-        self.act = get_act_and_mul_fn(getattr(config, "hidden_act", "silu"))
+        self.act = get_act_and_mul_fn(self.act_name or getattr(config, "hidden_act", "silu"))
 
     def forward(self, x, positions):
         x = self.post_attention_layernorm(x + self.o_proj(self.attn(self.qkv_proj(x), positions, self.rotary)))
@@ -225,6 +229,8 @@ class NomicBertLayer(nn.Module):
 
 
 class NomicBertBackbone(nn.Module):
+    layer_cls = NomicBertLayer
+
     def __init__(self, vllm_config: VllmConfig):
         super().__init__()
         from ..layers.rotary import get_rope
@@ -235,12 +241,13 @@ class NomicBertBackbone(nn.Module):
         rp = getattr(config, "rope_parameters", None) or {}
         theta = float(getattr(config, "rope_theta", None) or getattr(config, "rotary_emb_base", None)
                       or rp.get("rope_theta", 10000.0))
-        rotary = get_rope(D, D, config.max_position_embeddings, theta, True)
+        scaling = getattr(config, "rope_scaling", None) if self.layer_cls is not NomicBertLayer else None
+        rotary = get_rope(D, D, config.max_position_embeddings, theta, True, dict(scaling) if scaling else None)
         self.word_embeddings = VocabParallelEmbedding(config.vocab_size, d)
         self.token_type_embeddings = nn.Embedding(max(int(getattr(config, "type_vocab_size", 1) or 1), 1), d)
         self.token_type_embeddings.weight.requires_grad_(False)
         self.embed_norm = LayerNorm(d, config.layer_norm_eps)
-        self.layers = nn.ModuleList([NomicBertLayer(config, vllm_config, f"encoder.layers.{i}", rotary)
+        self.layers = nn.ModuleList([self.layer_cls(config, vllm_config, f"encoder.layers.{i}", rotary)
                                      for i in range(config.num_hidden_layers)])
 
     def forward(self, input_ids, positions, token_type_ids: Optional[torch.Tensor] = None, inputs_embeds=None):
@@ -304,3 +311,50 @@ class NomicBertModel(BertEmbeddingModel):
                 else:
                     yield n, t
         return load_weights_with_mapping(self, split_fused(), self._NB_STACKED, rename=self._route)
+
+
+class GteNewLayer(NomicBertLayer):
+    linear_bias = True
+    act_name = "gelu"               # gelu(gate) * up
+
+
+class GteNewBackbone(NomicBertBackbone):
+    layer_cls = GteNewLayer
+
+
+class GteNewModel(NomicBertModel):
+    """Alibaba-NLP "new" encoder (gte-multilingual-base ...): rotary BERT with biased projections, a bias-free fused
+    ``up_gate_proj`` (up rows first), GELU gate, optional fixed-NTK rope scaling, CLS pooling.
+    Checkpoint names: ``new.embeddings.*``, ``encoder.layer.N.attention.{qkv_proj,o_proj}``, ``mlp.{up_gate_proj,
+    down_proj}``, ``attn_ln``, ``mlp_ln``.  Reference: vllm/model_executor/models/bert_with_rope.py:487-540,
+    vllm/model_executor/models/config.py:21-40."""
+    backbone_cls = GteNewBackbone
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        self.pooler = Pooler.from_config(getattr(vllm_config.model_config, "pooler_config", None), PoolingType.CLS,
+                                         normalize=True, softmax=False)
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        def rename():
+            for n, t in weights:
+                if n.startswith("new."):
+                    n = n[4:]
+                if n.startswith(("classifier", "pooler")):
+                    continue
+                n = n.replace("encoder.layer.", "encoder.layers.").replace(".attn_ln.", ".post_attention_layernorm.") \
+                     .replace(".mlp_ln.", ".post_mlp_layernorm.").replace(".attention.o_proj.", ".self_attn.o_proj.")
+                if ".attention.qkv_proj." in n:
+                    for part, piece in zip(("q_proj", "k_proj", "v_proj"), t.chunk(3, dim=0)):
+                        yield n.replace(".attention.qkv_proj.", f".self_attn.{part}."), piece
+                elif ".mlp.up_gate_proj." in n:
+                    up, gate = t.chunk(2, dim=0)
+                    yield n.replace(".mlp.up_gate_proj.", ".mlp.up_proj."), up
+                    yield n.replace(".mlp.up_gate_proj.", ".mlp.gate_proj."), gate
+                else:
+                    yield n, t
+        return load_weights_with_mapping(self, rename(), self._NB_STACKED, rename=self._route)
+
+
+class SnowflakeGteNewModel(GteNewModel):
+    """snowflake-arctic-embed-m-v2.0: the same encoder saved without the ``new.`` level (architecture ``GteModel``)."""

@@ -124,6 +124,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "MedusaModel": ("eagle", "MedusaModel"),
     "LlavaNextVideoForConditionalGeneration": ("llava_next", "LlavaNextVideoForConditionalGeneration"),
     "NomicBertModel": ("bert", "NomicBertModel"),
+    "GteNewModel": ("bert", "GteNewModel"),
+    "GteModel": ("bert", "SnowflakeGteNewModel"),
     "TarsierForConditionalGeneration": ("llava", "TarsierForConditionalGeneration"),
     "PaliGemmaForConditionalGeneration": ("paligemma", "PaliGemmaForConditionalGeneration"),
     "Tarsier2ForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
