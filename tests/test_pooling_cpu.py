@@ -305,3 +305,43 @@ def test_gte_new_encoder_matches_dense_form(tmp_path, arch):
             x = F.layer_norm(x + m, (d,), sd[p + "mlp_ln.weight"], sd[p + "mlp_ln.bias"], 1e-12)
         ref = F.normalize(x[0], dim=-1)
         torch.testing.assert_close(torch.as_tensor(o.outputs.embedding), ref, atol=2e-4, rtol=1e-3)
+
+
+def test_modernbert_matches_hf(tmp_path):
+    """ModernBERT: alternating global / local (|i - j| <= 4 here) bidirectional attention with two rope bases, GeGLU
+    MLP, no norm before the first attention.  Embeddings (CLS, normalised) and classification probabilities against
+    transformers; one prompt is longer than the local window so the band matters."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.ModernBertConfig(vocab_size=320, hidden_size=128, num_hidden_layers=4, num_attention_heads=2,
+                              intermediate_size=192, max_position_embeddings=128, local_attention=8,
+                              global_attn_every_n_layers=3, num_labels=3, pad_token_id=0, bos_token_id=1,
+                              eos_token_id=2, cls_token_id=1, sep_token_id=2)
+    hf = tf.ModernBertForSequenceClassification(cfg).float().eval()
+    with torch.no_grad():
+        for n, p_ in hf.named_parameters():
+            if "norm" in n and n.endswith("weight"):
+                p_.add_(torch.randn_like(p_) * 0.1)
+    path = os.path.join(tmp_path, "mb")
+    hf.save_pretrained(path, safe_serialization=True)
+    prompts = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 11, [2, 3]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128,
+              max_num_seqs=8, block_size=16)
+    outs = llm.classify([{"prompt_token_ids": p} for p in prompts])
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf(torch.tensor([p])).logits[0].softmax(-1)
+        torch.testing.assert_close(torch.as_tensor(o.outputs.probs), ref, atol=2e-4, rtol=1e-3)
+    import json
+    c = json.load(open(os.path.join(path, "config.json")))
+    c["architectures"] = ["ModernBertModel"]
+    json.dump(c, open(os.path.join(path, "config.json"), "w"))
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128,
+              max_num_seqs=8, block_size=16)
+    outs = llm.embed(None, prompt_token_ids=prompts)
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = torch.nn.functional.normalize(hf.model(torch.tensor([p])).last_hidden_state[0, 0], dim=-1)
+        torch.testing.assert_close(torch.as_tensor(o.outputs.embedding), ref, atol=2e-4, rtol=1e-3)

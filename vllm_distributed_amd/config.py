@@ -380,7 +380,8 @@ class ModelConfig:
     @property
     def is_encoder_only(self) -> bool:
         """Bidirectional encoders: a prompt runs in one step and its KV blocks are never reused."""
-        return any(a.startswith(("Bert", "Roberta", "XLMRoberta")) for a in self.architectures)
+        return any(a.startswith(("Bert", "Roberta", "XLMRoberta", "NomicBert", "GteNew", "GteModel", "ModernBert"))
+                   for a in self.architectures)
 
     def verify_with_parallel_config(self, pc: "ParallelConfig") -> None:
         heads = self.get_total_num_attention_heads()

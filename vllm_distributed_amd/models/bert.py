@@ -358,3 +358,158 @@ class GteNewModel(NomicBertModel):
 
 class SnowflakeGteNewModel(GteNewModel):
     """snowflake-arctic-embed-m-v2.0: the same encoder saved without the ``new.`` level (architecture ``GteModel``)."""
+
+
+# ---- ModernBERT ---------------------------------------------------------------------------------------------------
+class ModernBertLayer(nn.Module):
+    """Pre-norm block (no norm in front of the first attention), fused Wqkv, GeGLU MLP with a fused ``Wi``
+    (activation half first).  Global layers attend over the whole sequence through the paged kernels; local layers
+    see |i - j| <= local_attention / 2 and compute that band directly on the step's tokens (an encoder runs every
+    prompt in one step, so nothing has to be cached for them)."""
+
+    def __init__(self, config, vllm_config: VllmConfig, idx: int, is_global: bool, rotary):
+        super().__init__()
+        from ..layers.basic import get_act_and_mul_fn
+        from ..layers.linear import MergedColumnParallelLinear
+        d, H = config.hidden_size, config.num_attention_heads
+        if get_tensor_model_parallel_world_size() != 1:
+            raise ValueError("ModernBERT runs on one rank per replica (use data parallelism to scale it)")
+        self.H, self.D = H, d // H
+        eps, nb = float(getattr(config, "norm_eps", 1e-5)), bool(getattr(config, "norm_bias", False))
+        ab, mb = bool(getattr(config, "attention_bias", False)), bool(getattr(config, "mlp_bias", False))
+        self.attn_norm = nn.LayerNorm(d, eps=eps, bias=nb) if idx > 0 else nn.Identity()
+        self.qkv_proj = QKVParallelLinear(d, self.D, H, H, bias=ab, prefix=f"layers.{idx}.attn.Wqkv")
+        self.o_proj = RowParallelLinear(d, d, bias=ab, prefix=f"layers.{idx}.attn.Wo")
+        self.is_global, self.rotary = is_global, rotary
+        self.half_window = int(getattr(config, "local_attention", 128)) // 2
+        if is_global:
+            self.attn = Attention(H, self.D, self.D ** -0.5, H, prefix=f"layers.{idx}.attn.attn",
+                                  cache_dtype=vllm_config.cache_config.cache_dtype, causal=False)
+        self.mlp_norm = nn.LayerNorm(d, eps=eps, bias=nb)
+        self.gate_up_proj = MergedColumnParallelLinear(d, [config.intermediate_size] * 2, bias=mb,
+                                                       prefix=f"layers.{idx}.mlp.Wi")
+        self.down_proj = RowParallelLinear(config.intermediate_size, d, bias=mb, prefix=f"layers.{idx}.mlp.Wo")
+        self.act = get_act_and_mul_fn(getattr(config, "hidden_activation", "gelu"))
+
+    def _local(self, qkv: torch.Tensor, positions: torch.Tensor, band: Optional[torch.Tensor]) -> torch.Tensor:
+        T, d = qkv.shape[0], self.H * self.D
+        q, k = qkv[:, :d].contiguous(), qkv[:, d:2 * d].contiguous()
+        self.rotary(positions[:T], q, k)
+        q, k, v = (t.reshape(T, self.H, self.D).transpose(0, 1)[None] for t in (q, k, qkv[:, 2 * d:]))
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=band)
+        return o[0].transpose(0, 1).reshape(T, d)
+
+    def forward(self, x, positions, band):
+        qkv = self.qkv_proj(self.attn_norm(x))
+        a = self.attn(qkv, positions, self.rotary) if self.is_global else self._local(qkv, positions, band)
+        x = x + self.o_proj(a)
+        return x + self.down_proj(self.act(self.gate_up_proj(self.mlp_norm(x))))
+
+
+class ModernBertBackbone(nn.Module):
+    def __init__(self, vllm_config: VllmConfig):
+        super().__init__()
+        from ..layers.rotary import get_rope
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        d = config.hidden_size
+        D = d // config.num_attention_heads
+        eps, nb = float(getattr(config, "norm_eps", 1e-5)), bool(getattr(config, "norm_bias", False))
+        rp = getattr(config, "rope_parameters", None) or {}
+        g_theta = float((rp.get("full_attention") or {}).get("rope_theta") or getattr(config, "global_rope_theta", 160000.0))
+        l_theta = float((rp.get("sliding_attention") or {}).get("rope_theta")
+                        or getattr(config, "local_rope_theta", None) or g_theta)
+        kinds = list(getattr(config, "layer_types", None) or [])
+        every = int(getattr(config, "global_attn_every_n_layers", 3) or 1)
+        self.word_embeddings = VocabParallelEmbedding(config.vocab_size, d)
+        self.embed_norm = nn.LayerNorm(d, eps=eps, bias=nb)
+        ropes = {True: get_rope(D, D, config.max_position_embeddings, g_theta, True),
+                 False: get_rope(D, D, config.max_position_embeddings, l_theta, True)}
+        self.layers = nn.ModuleList()
+        for i in range(config.num_hidden_layers):
+            is_global = (kinds[i] == "full_attention") if kinds else (i % every == 0)
+            self.layers.append(ModernBertLayer(config, vllm_config, i, is_global, ropes[is_global]))
+        self.final_norm = nn.LayerNorm(d, eps=eps, bias=nb)
+        self.half_window = int(getattr(config, "local_attention", 128)) // 2
+
+    def forward(self, input_ids, positions, token_type_ids: Optional[torch.Tensor] = None, inputs_embeds=None):
+        from ..forward_context import get_forward_context
+        x = self.embed_norm(inputs_embeds if inputs_embeds is not None else self.word_embeddings(input_ids))
+        T = x.shape[0]
+        md = get_forward_context().attn_metadata
+        pos = positions[:T]
+        near = (pos[:, None] - pos[None, :]).abs() <= self.half_window
+        if md is not None:                               # same sequence: tokens between the same two start offsets
+            S = md.num_decode_seqs + md.num_prefill_seqs
+            seq = torch.searchsorted(md.query_start_loc[1:S + 1].to(torch.int64),
+                                     torch.arange(T, device=x.device), right=True)
+            near &= seq[:, None] == seq[None, :]
+        for layer in self.layers:
+            x = layer(x, positions, near)
+        return self.final_norm(x)
+
+
+class ModernBertModel(BertEmbeddingModel):
+    """ModernBERT sentence embeddings (CLS by default).  Checkpoint names: ``model.embeddings.{tok_embeddings,norm}``,
+    ``model.layers.N.{attn_norm,attn.Wqkv,attn.Wo,mlp_norm,mlp.Wi,mlp.Wo}``, ``model.final_norm``.
+    Reference: vllm/model_executor/models/modernbert.py:40-339."""
+    backbone_cls = ModernBertBackbone
+    uses_token_type_ids = False
+    _RENAMES = (("embeddings.tok_embeddings.", "word_embeddings."), ("embeddings.norm.", "embed_norm."),
+                (".attn.Wo.", ".o_proj."), (".mlp.Wo.", ".down_proj."))
+
+    def _route(self, name: str) -> Optional[str]:
+        if name.startswith("model."):
+            name = name[6:]
+        if name.startswith(("head.", "classifier.", "decoder.")):
+            return None
+        for a, b in self._RENAMES:
+            name = name.replace(a, b)
+        return "model." + name
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        def split():
+            for n, t in weights:
+                if ".attn.Wqkv." in n:
+                    for part, piece in zip(("q", "k", "v"), t.chunk(3, dim=0)):
+                        yield n.replace(".attn.Wqkv.", f".{part}_part."), piece
+                elif ".mlp.Wi." in n:                   # activation half first, then the linear half
+                    a, g = t.chunk(2, dim=0)
+                    yield n.replace(".mlp.Wi.", ".act_part."), a
+                    yield n.replace(".mlp.Wi.", ".lin_part."), g
+                else:
+                    yield n, t
+        stacked = [(".qkv_proj", ".q_part", "q"), (".qkv_proj", ".k_part", "k"), (".qkv_proj", ".v_part", "v"),
+                   (".gate_up_proj", ".act_part", 0), (".gate_up_proj", ".lin_part", 1)]
+        return load_weights_with_mapping(self, split(), stacked, rename=self._route)
+
+
+class ModernBertForSequenceClassification(ModernBertModel):
+    """CLS (or mean) -> dense + activation + LayerNorm -> classifier."""
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        c = self.config
+        d = c.hidden_size
+        labels = getattr(c, "id2label", None)
+        n = len(labels) if labels else int(getattr(c, "num_labels", 2) or 2)
+        self.head_dense = nn.Linear(d, d, bias=bool(getattr(c, "classifier_bias", False)))
+        self.head_norm = nn.LayerNorm(d, eps=float(getattr(c, "norm_eps", 1e-5)), bias=bool(getattr(c, "norm_bias", False)))
+        self.head_act = get_act_fn(getattr(c, "classifier_activation", "gelu"))
+        self.classifier = nn.Linear(d, n)
+        kind = PoolingType.MEAN if getattr(c, "classifier_pooling", "cls") == "mean" else PoolingType.CLS
+        self.pooler = Pooler.from_config(getattr(vllm_config.model_config, "pooler_config", None), kind,
+                                         normalize=False, softmax=True)
+
+    def pool(self, hidden: torch.Tensor, params=None) -> torch.Tensor:
+        x = self.pooler.extract(hidden)
+        return self.pooler.head(self.classifier(self.head_norm(self.head_act(self.head_dense(x)))), params)
+
+    def _route(self, name: str) -> Optional[str]:
+        if name.startswith("classifier."):
+            return name
+        if name.startswith("head.dense."):
+            return "head_dense." + name[len("head.dense."):]
+        if name.startswith("head.norm."):
+            return "head_norm." + name[len("head.norm."):]
+        return super()._route(name)

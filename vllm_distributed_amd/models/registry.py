@@ -126,6 +126,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "NomicBertModel": ("bert", "NomicBertModel"),
     "GteNewModel": ("bert", "GteNewModel"),
     "GteModel": ("bert", "SnowflakeGteNewModel"),
+    "ModernBertModel": ("bert", "ModernBertModel"),
+    "ModernBertForSequenceClassification": ("bert", "ModernBertForSequenceClassification"),
     "TarsierForConditionalGeneration": ("llava", "TarsierForConditionalGeneration"),
     "PaliGemmaForConditionalGeneration": ("paligemma", "PaliGemmaForConditionalGeneration"),
     "Tarsier2ForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
