@@ -831,3 +831,37 @@ def test_jina_vl_ranking_scores(tmp_path):
         got = torch.as_tensor(o.outputs.probs if hasattr(o.outputs, "probs") else o.outputs.data).float().view(-1)
         torch.testing.assert_close(got, ref.view(-1), atol=2e-4, rtol=1e-3)
     llm.shutdown()
+
+
+def test_aya_vision_matches_hf(tmp_path):
+    """SigLIP tower -> pixel shuffle -> LayerNorm + SwiGLU projector over a Cohere-2 decoder, one image cut into
+    tiles + thumbnail and one single-tile image: greedy tokens equal transformers'."""
+    import transformers as tf
+    from vllm_distributed_amd.multimodal import process_multimodal
+    torch.manual_seed(0)
+    tc = tf.Cohere2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                          num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, sliding_window=64,
+                          pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    vc = tf.SiglipVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                               image_size=28, patch_size=7)
+    cfg = tf.AyaVisionConfig(vision_config=vc, text_config=tc, image_token_index=300, downsample_factor=2,
+                             vision_feature_select_strategy="full", vision_feature_layer=-1)
+    hf = tf.AyaVisionForConditionalGeneration(cfg).float().eval()
+    path = os.path.join(tmp_path, "aya")
+    hf.save_pretrained(path, safe_serialization=True)
+    rng = np.random.default_rng(3)
+    imgs = [(rng.random(s + (3,)) * 255).astype(np.uint8) for s in ((30, 95), (28, 28))]
+    prompts = [[5, 17, 300, 99, 3], [4, 300, 6]]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=8)
+    reqs = [{"prompt_token_ids": p, "multi_modal_data": {"image": im}} for p, im in zip(prompts, imgs)]
+    outs = llm.generate(reqs, SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    cfg_v = llm.llm_engine.vllm_config
+    for p, im, o in zip(prompts, imgs, outs):
+        ids, inputs, _, _ = process_multimodal(cfg_v, p, {"image": im})
+        tiles = inputs[0][0]
+        assert len(ids) == len(p) - 1 + tiles.shape[0] * 4
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=tiles, max_new_tokens=6, do_sample=False,
+                              pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, im.shape
+    llm.shutdown()

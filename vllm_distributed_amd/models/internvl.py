@@ -268,6 +268,8 @@ class InternVLImageProcessor:
     """Image -> tiles [n, 3, S, S] (grid tiles row-major, then the thumbnail when there is more than one), and the
     prompt's context token -> tokens_per_tile * n copies.  Pre-processed input: {"pixel_values": tiles}."""
 
+    mean, std = IMAGENET_MEAN, IMAGENET_STD
+
     def __init__(self, context_token_id: int, S: int, tokens_per_tile: int, min_num: int, max_num: int,
                  thumbnail: bool, dynamic: bool):
         self.context_token_id, self.S, self.tpt = context_token_id, S, tokens_per_tile
@@ -289,7 +291,7 @@ class InternVLImageProcessor:
         parts = big.unfold(1, S, S).unfold(2, S, S).permute(1, 2, 0, 3, 4).reshape(-1, 3, S, S)
         if self.thumbnail and parts.shape[0] > 1:
             parts = torch.cat((parts, resize(S, S)), dim=0)
-        m, sd = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+        m, sd = torch.tensor(self.mean).view(1, 3, 1, 1), torch.tensor(self.std).view(1, 3, 1, 1)
         return (parts / 255.0 - m) / sd
 
     def __call__(self, prompt_token_ids: list[int], mm_data: dict):

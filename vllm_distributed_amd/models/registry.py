@@ -136,6 +136,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),
     "InternVLChatModel": ("internvl", "InternVLChatModel"),
     "NVLM_D": ("internvl", "NVLM_D_Model"),
+    "AyaVisionForConditionalGeneration": ("aya_vision", "AyaVisionForConditionalGeneration"),
     "JinaVLForRanking": ("qwen2_vl", "JinaVLForRanking"),
     "InternVLForConditionalGeneration": ("internvl", "InternVLForConditionalGeneration"),
     "SkyworkR1VChatModel": ("internvl", "InternVLChatModel"),

@@ -459,3 +459,11 @@ def _paligemma(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("PaliGemmaForConditionalGeneration", _paligemma)
+
+
+def _aya_vision(vllm_config):
+    from ..models.aya_vision import aya_vision_processor
+    return aya_vision_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("AyaVisionForConditionalGeneration", _aya_vision)
