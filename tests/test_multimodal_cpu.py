@@ -865,3 +865,47 @@ def test_aya_vision_matches_hf(tmp_path):
                               pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref, im.shape
     llm.shutdown()
+
+
+@pytest.mark.parametrize("name", ["Idefics3", "SmolVLM"])
+def test_idefics3_smolvlm_match_hf(tmp_path, name):
+    """SigLIP-style tower with its closing norm, pixel shuffle, one projection, Llama decoder; a wide image (tiles +
+    whole image) given as one placeholder, and the same image given the way a chat template expands it (one run of
+    image tokens per tile with text between): greedy tokens equal transformers'."""
+    import transformers as tf
+    from vllm_distributed_amd.multimodal import process_multimodal
+    torch.manual_seed(0)
+    tc = tf.LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, head_dim=64,
+                        pad_token_id=0)
+    Cfg, VCfg, Model = ((tf.Idefics3Config, tf.Idefics3VisionConfig, tf.Idefics3ForConditionalGeneration)
+                        if name == "Idefics3" else
+                        (tf.SmolVLMConfig, tf.SmolVLMVisionConfig, tf.SmolVLMForConditionalGeneration))
+    vc = VCfg(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=28,
+              patch_size=7)
+    cfg = Cfg(vision_config=vc, text_config=tc, image_token_id=300, scale_factor=2, pad_token_id=0)
+    hf = Model(cfg).float().eval()
+    path = os.path.join(tmp_path, name)
+    hf.save_pretrained(path, safe_serialization=True)
+    img = (np.random.default_rng(3).random((24, 80, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=8,
+              hf_overrides={"longest_edge": 84})
+    cfg_v = llm.llm_engine.vllm_config
+    ids1, inputs, _, _ = process_multimodal(cfg_v, [5, 17, 300, 99, 3], {"image": img})
+    tiles = inputs[0][0]
+    assert tiles.shape[0] == 3 + 1 and len(ids1) == 4 + 4 * 4           # 1 x 3 grid + the whole image
+    expanded = [5]
+    for j in range(4):
+        expanded += [310 + j] + [300] * 4                                 # a text tag in front of every tile
+    expanded += [99, 3]
+    reqs = [{"prompt_token_ids": [5, 17, 300, 99, 3], "multi_modal_data": {"image": img}},
+            {"prompt_token_ids": expanded, "multi_modal_data": {"image": img}}]
+    outs = llm.generate(reqs, SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    for ids, o in zip((ids1, expanded), outs):
+        assert list(o.prompt_token_ids) == ids
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=tiles[None],
+                              pixel_attention_mask=torch.ones(1, 4, 28, 28, dtype=torch.bool), max_new_tokens=6,
+                              do_sample=False, pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref
+    llm.shutdown()

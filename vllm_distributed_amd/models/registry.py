@@ -136,6 +136,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),
     "InternVLChatModel": ("internvl", "InternVLChatModel"),
     "NVLM_D": ("internvl", "NVLM_D_Model"),
+    "Idefics3ForConditionalGeneration": ("idefics3", "Idefics3ForConditionalGeneration"),
+    "SmolVLMForConditionalGeneration": ("idefics3", "SmolVLMForConditionalGeneration"),
     "AyaVisionForConditionalGeneration": ("aya_vision", "AyaVisionForConditionalGeneration"),
     "JinaVLForRanking": ("qwen2_vl", "JinaVLForRanking"),
     "InternVLForConditionalGeneration": ("internvl", "InternVLForConditionalGeneration"),

@@ -467,3 +467,12 @@ def _aya_vision(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("AyaVisionForConditionalGeneration", _aya_vision)
+
+
+def _idefics3(vllm_config):
+    from ..models.idefics3 import idefics3_processor
+    return idefics3_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("Idefics3ForConditionalGeneration", _idefics3)
+MULTIMODAL_REGISTRY.register_processor("SmolVLMForConditionalGeneration", _idefics3)
