@@ -207,6 +207,14 @@ def _save_tiny(tmp, kind):
             for n, p in m.named_parameters():
                 if p.dim() >= 2 and "A_log" not in n:
                     p.mul_(1.5)
+    elif kind == "minimax":
+        cfg = tf.MiniMaxConfig(vocab_size=320, hidden_size=128, intermediate_size=192, num_hidden_layers=4,
+                               num_attention_heads=2, num_key_value_heads=1, head_dim=64, num_local_experts=4,
+                               num_experts_per_tok=2, max_position_embeddings=512, block_size=16,
+                               layer_types=["linear_attention", "full_attention", "linear_attention", "linear_attention"],
+                               full_attn_alpha_factor=1.5, full_attn_beta_factor=0.8, linear_attn_alpha_factor=1.3,
+                               linear_attn_beta_factor=0.9, mlp_alpha_factor=1.2, mlp_beta_factor=0.7)
+        m = tf.MiniMaxForCausalLM(cfg)
     elif kind == "bamba":
         cfg = tf.BambaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=4,
                              num_attention_heads=2, num_key_value_heads=1, attn_layer_indices=[1, 3], mamba_n_heads=8,
@@ -337,7 +345,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "minimax", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
                                   "dots1", "hunyuan_dense", "hunyuan_moe", "persimmon"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)

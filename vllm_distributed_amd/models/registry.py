@@ -136,6 +136,9 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),
     "InternVLChatModel": ("internvl", "InternVLChatModel"),
     "NVLM_D": ("internvl", "NVLM_D_Model"),
+    "MiniMaxForCausalLM": ("minimax", "MiniMaxForCausalLM"),
+    "MiniMaxText01ForCausalLM": ("minimax", "MiniMaxText01ForCausalLM"),
+    "MiniMaxM1ForCausalLM": ("minimax", "MiniMaxM1ForCausalLM"),
     "Idefics3ForConditionalGeneration": ("idefics3", "Idefics3ForConditionalGeneration"),
     "SmolVLMForConditionalGeneration": ("idefics3", "SmolVLMForConditionalGeneration"),
     "AyaVisionForConditionalGeneration": ("aya_vision", "AyaVisionForConditionalGeneration"),
