@@ -215,6 +215,16 @@ def _save_tiny(tmp, kind):
                                full_attn_alpha_factor=1.5, full_attn_beta_factor=0.8, linear_attn_alpha_factor=1.3,
                                linear_attn_beta_factor=0.9, mlp_alpha_factor=1.2, mlp_beta_factor=0.7)
         m = tf.MiniMaxForCausalLM(cfg)
+    elif kind == "falcon_h1":
+        cfg = tf.FalconH1Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                                num_attention_heads=2, num_key_value_heads=1, head_dim=64, mamba_d_ssm=128,
+                                mamba_n_heads=4, mamba_d_head=32, mamba_n_groups=1, mamba_d_state=16, mamba_d_conv=4,
+                                mamba_expand=1, mamba_chunk_size=16, mamba_rms_norm=False, max_position_embeddings=256,
+                                embedding_multiplier=1.7, lm_head_multiplier=0.6, mlp_multipliers=[1.3, 0.7],
+                                key_multiplier=0.8, attention_in_multiplier=1.2, attention_out_multiplier=0.9,
+                                ssm_multipliers=[0.9, 1.1, 1.2, 0.8, 1.3], ssm_in_multiplier=1.1,
+                                ssm_out_multiplier=0.85)
+        m = tf.FalconH1ForCausalLM(cfg)
     elif kind == "bamba":
         cfg = tf.BambaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=4,
                              num_attention_heads=2, num_key_value_heads=1, attn_layer_indices=[1, 3], mamba_n_heads=8,
@@ -345,7 +355,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "minimax", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "minimax", "falcon_h1", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
                                   "dots1", "hunyuan_dense", "hunyuan_moe", "persimmon"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)

@@ -22,7 +22,7 @@ def _llm(path, **kw):
 
 @pytest.mark.parametrize("kind", ["llama", "qwen2", "mixtral", "mamba", "mamba2", "deepseek_v2_mla", "bloom", "cohere",
                                   "gemma3", "olmo2", "falcon_new", "jamba", "bamba", "dbrx", "nemotron_h",
-                                  "granitemoehybrid", "llama4", "minimax"])
+                                  "granitemoehybrid", "llama4", "minimax", "falcon_h1"])
 def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     import transformers as tf
     from vllm_distributed_amd import SamplingParams

@@ -213,6 +213,121 @@ class BambaForCausalLM(JambaForCausalLM):
         return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)
 
 
+# ---- Falcon-H1 ------------------------------------------------------------------------------------------------
+class FalconH1Layer(nn.Module):
+    """Attention and a Mamba-2 mixer side by side on the same normalised input, their outputs added to the residual
+    together; then a gated MLP.  The family's fixed multipliers (on the mixer input segments, keys, attention input
+    and output, MLP gate and output) are constants: they are folded into the projection weights while loading.
+    Reference: vllm/model_executor/models/falcon_h1.py (FalconH1ParallelHybrid :360-440, the multipliers :60-110)."""
+
+    def __init__(self, config, vllm_config: VllmConfig, prefix: str):
+        super().__init__()
+        from .mamba import Mamba2Mixer
+        quant_config = getattr(vllm_config, "quant_config", None)
+        d, eps = config.hidden_size, config.rms_norm_eps
+        rp = getattr(config, "rope_parameters", None) or {}
+        theta = float(getattr(config, "rope_theta", None) or rp.get("rope_theta") or 10000.0)
+        ab = bool(getattr(config, "attention_bias", False))
+        self.self_attn = LlamaAttention(config, d, config.num_attention_heads, config.num_key_value_heads, theta, None,
+                                        vllm_config.model_config.max_model_len, bias=ab, o_bias=ab,
+                                        quant_config=quant_config, prefix=f"{prefix}.self_attn",
+                                        cache_dtype=vllm_config.cache_config.cache_dtype)
+        if bool(getattr(config, "mamba_rms_norm", False)) and bool(getattr(config, "mamba_norm_before_gate", False)):
+            raise ValueError("Falcon-H1 with a gated norm applied before the gate is not supported")
+        d_ssm = int(getattr(config, "mamba_d_ssm", None) or config.mamba_expand * d)
+        shim = SimpleNamespace(hidden_size=d, num_heads=config.mamba_n_heads, head_dim=d_ssm // config.mamba_n_heads,
+                               intermediate_size=d_ssm, state_size=config.mamba_d_state,
+                               conv_kernel=config.mamba_d_conv, n_groups=config.mamba_n_groups,
+                               use_bias=bool(config.mamba_proj_bias), use_conv_bias=bool(config.mamba_conv_bias),
+                               layer_norm_epsilon=eps, gated_norm=bool(getattr(config, "mamba_rms_norm", False)),
+                               gated_norm_groups=getattr(config, "gated_norm_groups", None))
+        self.mamba = Mamba2Mixer(shim, f"{prefix}.mamba")
+        self.feed_forward = LlamaMLP(d, config.intermediate_size, bool(getattr(config, "mlp_bias", False)),
+                                     quant_config, f"{prefix}.feed_forward")
+        self.input_layernorm = RMSNorm(d, eps)
+        self.pre_ff_layernorm = RMSNorm(d, eps)
+
+    def forward(self, positions, hidden, residual):
+        if residual is None:
+            residual = hidden
+            hidden = self.input_layernorm(hidden)
+        else:
+            hidden, residual = self.input_layernorm(hidden, residual)
+        hidden = self.self_attn(positions, hidden) + self.mamba(hidden)
+        hidden, residual = self.pre_ff_layernorm(hidden, residual)
+        return self.feed_forward(hidden), residual
+
+
+class FalconH1ForCausalLM(JambaForCausalLM):
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        nn.Module.__init__(self)
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, config.hidden_size)
+        self.embed_scale = float(getattr(config, "embedding_multiplier", 1.0) or 1.0)
+        self.layers = nn.ModuleList([FalconH1Layer(config, vllm_config, f"model.layers.{i}")
+                                     for i in range(config.num_hidden_layers)])
+        self.final_layernorm = RMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.tie = bool(getattr(config, "tie_word_embeddings", False))
+        self.lm_head = ParallelLMHead(config.vocab_size, config.hidden_size)
+        if self.tie:
+            self.lm_head.tie_weights(self.embed_tokens)
+        self.logits_processor = LogitsProcessor(config.vocab_size, config.vocab_size,
+                                                float(getattr(config, "lm_head_multiplier", 1.0) or 1.0))
+
+    forward = None          # set below: GraniteMoeHybridForCausalLM.forward applies the embedding scale
+
+    def _mup_rows(self) -> torch.Tensor:
+        """Per-row factor of the mixer's input projection: [gate | x | B | C | dt] segments."""
+        c = self.config
+        m = list(getattr(c, "ssm_multipliers", None) or [1.0] * 5)
+        d_ssm = int(getattr(c, "mamba_d_ssm", None) or c.mamba_expand * c.hidden_size)
+        gs = int(c.mamba_n_groups) * int(c.mamba_d_state)
+        v = torch.ones(2 * d_ssm + 2 * gs + int(c.mamba_n_heads))
+        v[:d_ssm] *= m[0]
+        v[d_ssm:2 * d_ssm] *= m[1]
+        v[2 * d_ssm:2 * d_ssm + gs] *= m[2]
+        v[2 * d_ssm + gs:2 * d_ssm + 2 * gs] *= m[3]
+        v[2 * d_ssm + 2 * gs:] *= m[4]
+        return v
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        c = self.config
+        f = lambda n, d=1.0: float(getattr(c, n, d) if getattr(c, n, None) is not None else d)
+        gate_m, down_m = (list(getattr(c, "mlp_multipliers", None) or [1.0, 1.0]) + [1.0, 1.0])[:2]
+        a_in, a_out, key_m = f("attention_in_multiplier"), f("attention_out_multiplier"), f("key_multiplier")
+        s_in, s_out = f("ssm_in_multiplier"), f("ssm_out_multiplier")
+        mup = self._mup_rows()
+        names = {".mamba.conv1d.weight": ".mamba.conv_weight", ".mamba.conv1d.bias": ".mamba.conv_bias",
+                 ".mamba.A_log": ".mamba.A", ".mamba.norm.weight": ".mamba.norm_weight"}
+
+        def fix(items):
+            for name, t in items:
+                name = name.removeprefix("model.")
+                w = name.endswith(".weight")
+                if ".mamba.in_proj." in name:
+                    r = mup.to(t.dtype)
+                    t = t * (r[:, None] * s_in if w else r)
+                elif ".mamba.out_proj." in name and w:
+                    t = t * s_out
+                elif ".self_attn.k_proj." in name:
+                    t = t * (a_in * key_m if w else key_m)
+                elif (".self_attn.q_proj." in name or ".self_attn.v_proj." in name) and w:
+                    t = t * a_in
+                elif ".self_attn.o_proj." in name and w:
+                    t = t * a_out
+                elif ".feed_forward.gate_proj." in name:
+                    t = t * gate_m
+                elif ".feed_forward.down_proj." in name and w:
+                    t = t * down_m
+                for a, b in names.items():
+                    if name.endswith(a):
+                        name = name[: -len(a)] + b
+                yield name, t
+
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)
+
+
 # ---- Granite-4 hybrid (GraniteMoeHybrid) -----------------------------------------------------------------
 class GraniteMoeHybridLayer(nn.Module):
     """Mamba-2 mixer or attention (softmax scale and residual scale from the Granite multipliers), then
@@ -415,3 +530,6 @@ class NemotronHForCausalLM(JambaForCausalLM):
                 yield name, t
 
         return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)
+
+
+FalconH1ForCausalLM.forward = GraniteMoeHybridForCausalLM.forward

@@ -168,12 +168,14 @@ class Mamba2Mixer(StateSpaceLayer):
         self.dt_bias = _sharded_param((self.num_heads,), torch.float32, 0, lambda t: t.float())
         self.A = _sharded_param((self.num_heads,), torch.float32, 0, lambda t: -torch.exp(t.float()))
         self.D = _sharded_param((self.num_heads,), torch.float32, 0, lambda t: t.float())
-        self.norm_weight = _sharded_param((self.d_inner,), dtype, 0)
+        if bool(getattr(config, "gated_norm", True)):
+            self.norm_weight = _sharded_param((self.d_inner,), dtype, 0)
         self.norm_eps = float(getattr(config, "layer_norm_epsilon", 1e-5))
         # The gated norm is per B/C group, as in the kernels these checkpoints were trained with (and in the
         # reference, mamba_mixer2.py Mixer2RMSNormGated); transformers' eager path normalises the whole
         # width instead, which ``gated_norm_groups: 1`` in the config reproduces.
         self.norm_groups = int(getattr(config, "gated_norm_groups", None) or self.n_groups)
+        self.use_norm = bool(getattr(config, "gated_norm", True))      # Falcon-H1: y * silu(gate) without a norm
         lim = getattr(config, "time_step_limit", None)
 
         def num(v, default):       # JSON has no infinity: configs carry it as a string or a tagged object
@@ -190,6 +192,8 @@ class Mamba2Mixer(StateSpaceLayer):
 
     def _gated_norm(self, y: torch.Tensor) -> torch.Tensor:
         # y already carries the silu(gate) factor (applied inside the scan kernel)
+        if not self.use_norm:
+            return y
         T = y.shape[0]
         f = y.float().view(T, self.norm_groups, -1)
         f = f * torch.rsqrt(f.pow(2).mean(-1, keepdim=True) + self.norm_eps)
@@ -201,7 +205,7 @@ class Mamba2Mixer(StateSpaceLayer):
         di, cd = self.d_inner, self.conv_dim
         gate, xbc, dt = p[:, :di], p[:, di:di + cd], p[:, di + cd:]
         if md is None or self.conv_state is None:
-            return self.out_proj(self._gated_norm(xbc[:, :di] * gate))
+            return self.out_proj(self._gated_norm((xbc[:, :di] * gate).contiguous()))
         tbl = self.slot_table(md)
         xbc = ops.causal_conv1d(xbc, self.conv_weight, self.conv_bias, self.conv_state, md.query_start_loc,
                                 md.seq_lens, tbl, md.max_query_len)
