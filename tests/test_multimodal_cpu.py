@@ -909,3 +909,76 @@ def test_idefics3_smolvlm_match_hf(tmp_path, name):
                               do_sample=False, pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref
     llm.shutdown()
+
+
+@pytest.mark.parametrize("ln_mid", [False, True])
+def test_ultravox_matches_hf_components(tmp_path, ln_mid):
+    """Ultravox has no transformers class (remote code upstream; parity unpinned as a whole).  The reference here is
+    assembled from transformers' own parts: its Whisper encoder on the clip's valid frames, the frame stacking and
+    projector written out, and its Llama decoder run from input embeddings."""
+    import json
+    import transformers as tf
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.multimodal import process_multimodal
+    torch.manual_seed(0)
+    wc = tf.WhisperConfig(num_mel_bins=80, d_model=64, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=128,
+                          max_source_positions=1500, decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=64,
+                          vocab_size=100, pad_token_id=0, bos_token_id=1, eos_token_id=2, decoder_start_token_id=1)
+    enc = tf.WhisperModel(wc).encoder.float().eval()
+    tc = tf.LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, head_dim=64,
+                        tie_word_embeddings=False)
+    lm = tf.LlamaForCausalLM(tc).float().eval()
+    stack, hid = 8, 96
+    g = lambda *s: torch.randn(*s) * 0.2
+    mid = hid // 2
+    proj = {"ln_pre.weight": 1 + g(64 * stack) * 0.1, "linear_1.weight": g(hid, 64 * stack), "linear_2.weight": g(128, mid),
+            ("ln_mid.weight" if ln_mid else "ln_post.weight"): 1 + g(mid if ln_mid else 128) * 0.1}
+    sd = {"audio_tower." + n: t for n, t in enc.state_dict().items()}
+    sd.update({"multi_modal_projector." + n: t for n, t in proj.items()})
+    sd.update({"language_model." + n: t for n, t in lm.state_dict().items()})
+    path = os.path.join(tmp_path, "uv")
+    os.makedirs(path)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    json.dump({"architectures": ["UltravoxModel"], "model_type": "ultravox", "audio_config": wc.to_dict(),
+               "text_config": tc.to_dict(), "stack_factor": stack, "hidden_size": hid, "projector_act": "swiglu",
+               "projector_ln_mid": ln_mid, "audio_token_index": 300, "torch_dtype": "float32"},
+              open(os.path.join(path, "config.json"), "w"))
+    rng = np.random.default_rng(3)
+    clip = rng.standard_normal(16000 * 2).astype(np.float32) * 0.1
+    prompt = [5, 17, 300, 99, 3]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=4)
+    out = llm.generate([{"prompt_token_ids": prompt, "multi_modal_data": {"audio": clip}}],
+                       SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+    ids, inputs, _, _ = process_multimodal(llm.llm_engine.vllm_config, prompt, {"audio": clip})
+    llm.shutdown()
+    feats, mel = inputs[0][0], int(inputs[0][1])
+    frames = (mel - 1) // 2 + 1
+    ntok = -(-frames // stack)
+    assert list(out.prompt_token_ids) == ids and ids.count(300) == ntok == 13
+    F = torch.nn.functional
+    rms = lambda x, w: x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    with torch.no_grad():
+        # the encoder on the valid frames only equals the padded run with the padding masked out
+        x = F.gelu(enc.conv1(feats[None])); x = F.gelu(enc.conv2(x)).permute(0, 2, 1)
+        x = x + enc.embed_positions.weight[: x.shape[1]]
+        mask = torch.zeros(1, 1, 1, x.shape[1]); mask[..., frames:] = torch.finfo(torch.float32).min
+        for layer in enc.layers:
+            x = layer(x, attention_mask=mask)
+            x = x[0] if isinstance(x, tuple) else x
+        x = enc.layer_norm(x)
+        pad = -x.shape[1] % stack
+        x = F.pad(x, (0, 0, 0, pad)).reshape(1, -1, 64 * stack)
+        hh = rms(x, proj["ln_pre.weight"]) @ proj["linear_1.weight"].T
+        a, b = hh.chunk(2, -1)
+        hh = a * F.silu(b)
+        if ln_mid:
+            hh = rms(hh, proj["ln_mid.weight"])
+        hh = hh @ proj["linear_2.weight"].T
+        if not ln_mid:
+            hh = rms(hh, proj["ln_post.weight"])
+        emb = lm.model.embed_tokens(torch.tensor([ids]))
+        emb[0, torch.tensor(ids) == 300] = hh[0, :ntok]
+        ref = lm.generate(inputs_embeds=emb, max_new_tokens=8, do_sample=False, pad_token_id=0,
+                          eos_token_id=None)[0].tolist()
+    assert list(out.outputs[0].token_ids) == ref[-8:]

@@ -135,7 +135,10 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
                 f"({', '.join(sorted(PRESETS))})")
         d = copy.deepcopy(PRESETS[key])
     if "text_config" in d and ("hidden_size" not in d or "num_attention_heads" not in d):
-        d = {**d, **d["text_config"]}
+        if "hidden_size" in d:                 # a wrapper-level width (Ultravox: its projector's) stays reachable
+            d["top_hidden_size"] = d["hidden_size"]
+        d = {**d, **{k: v for k, v in d["text_config"].items()
+                     if v is not None and not (k == "architectures" and d.get("architectures"))}}
     elif "llm_config" in d and "hidden_size" not in d:          # InternVL's original layout
         d = {**d, **{k: v for k, v in d["llm_config"].items() if k not in ("architectures", "model_type")}}
     if d.get("model_type") == "whisper" and "hidden_size" not in d:

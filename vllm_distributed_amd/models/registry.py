@@ -136,6 +136,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),
     "InternVLChatModel": ("internvl", "InternVLChatModel"),
     "NVLM_D": ("internvl", "NVLM_D_Model"),
+    "UltravoxModel": ("ultravox", "UltravoxModel"),
     "FalconH1ForCausalLM": ("jamba", "FalconH1ForCausalLM"),
     "MiniMaxForCausalLM": ("minimax", "MiniMaxForCausalLM"),
     "MiniMaxText01ForCausalLM": ("minimax", "MiniMaxText01ForCausalLM"),

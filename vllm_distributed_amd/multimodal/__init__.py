@@ -476,3 +476,11 @@ def _idefics3(vllm_config):
 
 MULTIMODAL_REGISTRY.register_processor("Idefics3ForConditionalGeneration", _idefics3)
 MULTIMODAL_REGISTRY.register_processor("SmolVLMForConditionalGeneration", _idefics3)
+
+
+def _ultravox(vllm_config):
+    from ..models.ultravox import ultravox_processor
+    return ultravox_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("UltravoxModel", _ultravox)
