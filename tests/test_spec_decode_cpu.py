@@ -203,3 +203,84 @@ def test_deepseek_v3_multi_token_prediction_layer_drafts(tmp_path):
     ref, _ = _gen(d)
     got, n = _proposals(d, speculative_config={"method": "mtp", "num_speculative_tokens": 2})
     assert got == ref and n > 0
+
+
+def test_eagle3_draft_same_tokens_and_layer_math(tmp_path):
+    """EAGLE-3 draft over a tiny Llama target: (a) speculative greedy decoding emits the target's own tokens and does
+    verify drafted tokens; (b) the draft network's forward (three-depth residual stream -> fc, [normed embedding |
+    normed hidden] -> attention, reduced vocabulary mapped through d2t) equals the block written out by hand.
+    No transformers class exists for the draft (parity unpinned); names follow the published EAGLE-3 checkpoints."""
+    path, hf = _save_tiny(str(tmp_path), "llama")
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    H, I, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    hd, nh, nkv = cfg["head_dim"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    DV = 200
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.05      # noqa: E731
+    ids = torch.sort(torch.randperm(V, generator=g)[:DV]).values
+    w = {"fc.weight": r(H, 3 * H), "midlayer.self_attn.q_proj.weight": r(nh * hd, 2 * H),
+         "midlayer.self_attn.k_proj.weight": r(nkv * hd, 2 * H), "midlayer.self_attn.v_proj.weight": r(nkv * hd, 2 * H),
+         "midlayer.self_attn.o_proj.weight": r(H, nh * hd), "midlayer.mlp.gate_proj.weight": r(I, H),
+         "midlayer.mlp.up_proj.weight": r(I, H), "midlayer.mlp.down_proj.weight": r(H, I),
+         "midlayer.input_layernorm.weight": 1 + r(H), "midlayer.hidden_norm.weight": 1 + r(H),
+         "midlayer.post_attention_layernorm.weight": 1 + r(H), "norm.weight": 1 + r(H), "lm_head.weight": r(DV, H),
+         "d2t": ids - torch.arange(DV), "t2d": torch.zeros(V, dtype=torch.bool)}
+    d = os.path.join(str(tmp_path), "eagle3")
+    os.makedirs(d)
+    cfg.update(architectures=["LlamaForCausalLMEagle3"], num_hidden_layers=1, draft_vocab_size=DV)
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in w.items()}, os.path.join(d, "model.safetensors"))
+    ref, _ = _gen(path)
+    got, n = _proposals(path, speculative_config={"method": "eagle3", "model": d, "num_speculative_tokens": 3})
+    assert got == ref and n > 0
+    # (b) one draft forward on a fresh engine's model object, positions 0..5, against the block by hand
+    llm = LLM(model=path, **KW, speculative_config={"method": "eagle3", "model": d, "num_speculative_tokens": 2})
+    mr = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+    draft = mr.drafter.model
+    assert len(mr.model.model.aux_layers) == 3 and mr.model.model.aux_hidden.shape[1] == 3 * H
+    T = 6
+    tok = torch.arange(3, 3 + T)
+    aux = torch.randn(T, 3 * H, generator=g)
+    rms = lambda x, wt: x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg["rms_norm_eps"]) * wt   # noqa: E731
+    with torch.no_grad():
+        e = hf.model.embed_tokens(tok)
+        hdn = aux @ w["fc.weight"].T
+        x = torch.cat((rms(e, w["midlayer.input_layernorm.weight"]), rms(hdn, w["midlayer.hidden_norm.weight"])), -1)
+        q = (x @ w["midlayer.self_attn.q_proj.weight"].T).view(T, nh, hd)
+        k = (x @ w["midlayer.self_attn.k_proj.weight"].T).view(T, nkv, hd)
+        v = (x @ w["midlayer.self_attn.v_proj.weight"].T).view(T, nkv, hd)
+        theta = cfg.get("rope_theta") or cfg["rope_parameters"]["rope_theta"]
+        inv = 1.0 / (theta ** (torch.arange(0, hd, 2).float() / hd))
+        ang = torch.arange(T)[:, None].float() * inv[None]
+
+        def rope(t):
+            a, b = t[..., : hd // 2], t[..., hd // 2:]
+            c, s_ = ang.cos()[:, None], ang.sin()[:, None]
+            return torch.cat((a * c - b * s_, b * c + a * s_), -1)
+        q, k = rope(q), rope(k).repeat_interleave(nh // nkv, 1)
+        v = v.repeat_interleave(nh // nkv, 1)
+        o = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None],
+                                                             v.transpose(0, 1)[None], is_causal=True)[0]
+        a = o.transpose(0, 1).reshape(T, nh * hd) @ w["midlayer.self_attn.o_proj.weight"].T
+        res = hdn + a
+        y = rms(res, w["midlayer.post_attention_layernorm.weight"])
+        mlp = (torch.nn.functional.silu(y @ w["midlayer.mlp.gate_proj.weight"].T) * (y @ w["midlayer.mlp.up_proj.weight"].T)) \
+            @ w["midlayer.mlp.down_proj.weight"].T
+        want_h = mlp + res
+        want_lg = rms(want_h, w["norm.weight"]) @ w["lm_head.weight"].T
+        # run the draft through the engine's own plumbing: a prefill-form pass over one fresh request row
+        import numpy as np
+        ib = mr.input_batch
+        from vllm_distributed_amd.forward_context import set_forward_context
+        rows = np.array([0], dtype=np.int64)
+        ib.block_tables[0][0, 0] = 5
+        got_h = mr.drafter._run(mr, tok.numpy(), aux, rows, np.array([T], dtype=np.int32), np.array([0], dtype=np.int64),
+                                decode=False)
+        torch.testing.assert_close(got_h, want_h, atol=2e-4, rtol=1e-3)
+        lg = draft.compute_logits(got_h)
+        assert lg.shape == (T, V)
+        torch.testing.assert_close(lg[:, ids], want_lg, atol=2e-4, rtol=1e-3)
+        rest = torch.ones(V, dtype=torch.bool)
+        rest[ids] = False
+        assert torch.isinf(lg[:, rest]).all()
+    llm.shutdown()

@@ -11,7 +11,7 @@ import torch.nn as nn
 from ..config import VllmConfig
 from ..layers.basic import LogitsProcessor, ParallelLMHead, VocabParallelEmbedding
 from ..layers.linear import ReplicatedLinear
-from .llama import LlamaDecoderLayer
+from .llama import LlamaAttention, LlamaDecoderLayer
 from .utils import load_weights_with_mapping, maybe_prefix
 
 
@@ -84,6 +84,102 @@ class EagleLlamaForCausalLM(nn.Module):
                    (".gate_up_proj", ".gate_proj", 0), (".gate_up_proj", ".up_proj", 1)]
         load_weights_with_mapping(self, weights, stacked, rename=rename)
         return None      # embedding / head may legitimately be absent (shared with the target)
+
+
+class _Eagle3Attention(LlamaAttention):
+    """Queries, keys and values are projected from [normed token embedding | normed hidden state] (2 H wide)."""
+
+    def _make_projections(self, hidden_size, num_heads, num_kv_heads, bias, o_bias, quant_config, prefix):
+        from ..layers.linear import QKVParallelLinear, RowParallelLinear
+        self.qkv_proj = QKVParallelLinear(2 * hidden_size, self.head_dim, num_heads, num_kv_heads, bias=bias,
+                                          quant_config=quant_config, prefix=f"{prefix}.qkv_proj")
+        self.o_proj = RowParallelLinear(num_heads * self.head_dim, hidden_size, bias=o_bias,
+                                        quant_config=quant_config, prefix=f"{prefix}.o_proj")
+
+
+class Eagle3LlamaForCausalLM(nn.Module):
+    """EAGLE-3 draft: the target's residual stream at three depths (low / middle / high), concatenated and
+    projected to H, and the embedding of the next token enter ONE decoder layer; later draft steps feed the layer's
+    own un-normalised output back instead.  The head predicts over a reduced vocabulary, ``d2t`` maps its ids back.
+    Reference: vllm/model_executor/models/llama_eagle3.py:28-263, vllm/v1/spec_decode/eagle.py."""
+    share_embeddings = True
+    is_eagle3 = True
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__()
+        from ..layers.basic import RMSNorm
+        from .llama import LlamaMLP
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        H = config.hidden_size
+        Ht = int(getattr(config, "target_hidden_size", None) or H)
+        eps = float(getattr(config, "rms_norm_eps", 1e-6))
+        self.vocab = int(config.vocab_size)
+        self.draft_vocab = int(getattr(config, "draft_vocab_size", None) or self.vocab)
+        self.embed_tokens = VocabParallelEmbedding(self.vocab, H, prefix="draft.embed_tokens")
+        self.fc = ReplicatedLinear(3 * Ht, H, bias=False, prefix="draft.fc")
+        rp = getattr(config, "rope_parameters", None) or {}
+        scaling = getattr(config, "rope_scaling", None)
+        theta = float(getattr(config, "rope_theta", None) or rp.get("rope_theta") or 10000.0)
+        layer = self.midlayer = nn.Module()
+        layer.self_attn = _Eagle3Attention(config, H, config.num_attention_heads,
+                                           getattr(config, "num_key_value_heads", None) or config.num_attention_heads,
+                                           theta, scaling if scaling and ("rope_type" in scaling or "type" in scaling) else None,
+                                           vllm_config.model_config.max_model_len,
+                                           bias=bool(getattr(config, "attention_bias", False)),
+                                           prefix="draft.layers.0.self_attn",
+                                           cache_dtype=vllm_config.cache_config.cache_dtype)
+        layer.mlp = LlamaMLP(H, config.intermediate_size, bool(getattr(config, "mlp_bias", False)), None,
+                             "draft.layers.0.mlp")
+        layer.input_layernorm, layer.hidden_norm = RMSNorm(H, eps), RMSNorm(H, eps)
+        layer.post_attention_layernorm = RMSNorm(H, eps)
+        self.norm = RMSNorm(H, eps)
+        self.lm_head = ParallelLMHead(self.draft_vocab, H, prefix="draft.lm_head")
+        self.logits_processor = LogitsProcessor(self.draft_vocab, self.draft_vocab)
+        self.register_buffer("d2t", torch.zeros(self.draft_vocab, dtype=torch.int64), persistent=False)
+        self._own_embed = False
+
+    def set_shared(self, embed, lm_head, logits_processor) -> None:
+        if not self._own_embed:
+            self.embed_tokens = embed               # the head is always the draft's own
+
+    def forward(self, input_ids, positions, hidden_states):
+        m = self.midlayer
+        e = self.embed_tokens(input_ids)
+        if hidden_states.shape[-1] != e.shape[-1]:
+            hidden_states = self.fc(hidden_states)
+        x = torch.cat((m.input_layernorm(e), m.hidden_norm(hidden_states)), dim=-1)
+        x, residual = m.post_attention_layernorm(m.self_attn.o_proj(m.self_attn.attn(
+            m.self_attn.qkv_proj(x), positions, m.self_attn.rotary_emb)), hidden_states)
+        return m.mlp(x) + residual
+
+    def compute_logits(self, hidden_states):
+        lg = self.logits_processor(self.lm_head, self.norm(hidden_states))
+        if self.draft_vocab == self.vocab:
+            return lg
+        full = torch.full((lg.shape[0], self.vocab), float("-inf"), dtype=lg.dtype, device=lg.device)
+        full[:, torch.arange(self.draft_vocab, device=lg.device) + self.d2t] = lg
+        return full
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        def rename(name: str):
+            if name.startswith("model."):
+                name = name[len("model."):]
+            if name.startswith("layers.0."):
+                name = "midlayer." + name[len("layers.0."):]
+            if name.startswith("embed_tokens."):
+                self._own_embed = True
+            return name
+        rest = []
+        for n, t in weights:
+            if n.endswith("d2t"):
+                self.d2t.copy_(t.to(torch.int64))
+            elif not n.endswith("t2d"):
+                rest.append((n, t))
+        stacked = [(".qkv_proj", ".q_proj", "q"), (".qkv_proj", ".k_proj", "k"), (".qkv_proj", ".v_proj", "v"),
+                   (".gate_up_proj", ".gate_proj", 0), (".gate_up_proj", ".up_proj", 1)]
+        load_weights_with_mapping(self, rest, stacked, rename=rename)
+        return None
 
 
 class _ResidualBlock(nn.Module):

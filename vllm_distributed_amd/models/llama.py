@@ -253,6 +253,8 @@ class LlamaModel(nn.Module):
             lambda p: self.layer_cls(config, vllm_config, quant_config, p), f"{prefix}.layers")
         self.norm = self.layer_cls.make_norm(config) if pp.is_last_rank else PPMissingLayer()
         self.embed_scale = float(self.embed_scale_of(config))
+        self.aux_layers: tuple = ()
+        self.aux_hidden: Optional[torch.Tensor] = None
         self.tp = get_tensor_model_parallel_world_size()
         # all-reduce + add + norm in one kernel (decode-sized batches): the standard block only -- families that
         # override the block's forward, its MLP or its norm class keep the separate reductions
@@ -268,6 +270,17 @@ class LlamaModel(nn.Module):
     def get_input_embeddings(self, input_ids):
         return self.embed_tokens(input_ids)
 
+    def enable_aux_hidden_states(self, layers: tuple, max_tokens: int) -> None:
+        """Keep ``hidden + residual`` as it enters each of ``layers`` in one persistent [max_tokens, n * H] buffer
+        (written inside captured decode graphs too).  Reference: vllm/model_executor/models/llama.py:383-397."""
+        if get_pp_group().world_size > 1 or self.sequence_parallel:
+            raise ValueError("EAGLE-3 drafting needs the whole target stack on one pipeline stage, without "
+                             "sequence parallelism")
+        w = self.embed_tokens.weight
+        self.aux_layers = tuple(int(x) for x in layers)
+        self.aux_hidden = torch.zeros((max_tokens, len(self.aux_layers) * self.config.hidden_size), dtype=w.dtype,
+                                      device=w.device)
+
     def forward(self, input_ids, positions, intermediate_tensors: Optional[IntermediateTensors] = None,
                 inputs_embeds: Optional[torch.Tensor] = None):
         pp = get_pp_group()
@@ -282,6 +295,14 @@ class LlamaModel(nn.Module):
         mbs = get_forward_context().micro_batches if (self.tp > 1 and has_forward_context()) else None
         if mbs and not sp and getattr(self.layer_cls, "supports_sequence_parallel", False):
             hidden, residual = self._forward_micro_batched(positions, hidden, residual, mbs)
+        elif not sp and self.aux_layers:
+            # EAGLE-3 drafting: the residual stream in front of a few layers is kept for the draft network
+            T, H = hidden.shape
+            for i, layer in enumerate(self.layers[self.start_layer:self.end_layer], self.start_layer):
+                for j, a in enumerate(self.aux_layers):
+                    if a == i:
+                        self.aux_hidden[:T, j * H:(j + 1) * H] = hidden if residual is None else hidden + residual
+                hidden, residual = layer(positions, hidden, residual)
         elif not sp and self._fuse_reduce_norm(hidden):
             return self._forward_fused_reduce(positions, hidden, residual)
         elif not sp:

@@ -220,6 +220,28 @@ class EagleProposer:
         return res
 
 
+class Eagle3Proposer(EagleProposer):
+    """EAGLE-3: the draft reads the target's residual stream at three depths instead of its final hidden state.
+    Reference: vllm/v1/spec_decode/eagle.py (use_aux_hidden_state), vllm/v1/worker/gpu_model_runner.py:1340-1380."""
+
+    def __init__(self, vllm_config: VllmConfig, runner):
+        super().__init__(vllm_config, runner)
+        if not getattr(self.model, "is_eagle3", False):
+            raise ValueError("speculative method eagle3 needs an EAGLE-3 draft checkpoint")
+        inner = getattr(runner.model, "model", None)
+        if inner is None or not hasattr(inner, "enable_aux_hidden_states"):
+            raise ValueError(f"{type(runner.model).__name__} cannot hand its intermediate states to an EAGLE-3 draft")
+        n = len(inner.layers)
+        layers = getattr(self.model.config, "eagle_aux_hidden_state_layer_ids", None) or (2, n // 2, n - 3)
+        cap = max(runner.max_num_tokens, max(runner.capture_sizes, default=0))
+        inner.enable_aux_hidden_states(tuple(max(min(int(x), n - 1), 0) for x in layers), cap)
+        self.target_inner = inner
+
+    def propose(self, runner, req_ids, rows, sampled_lists, hidden, cu, n_sched=None, so=None):
+        return super().propose(runner, req_ids, rows, sampled_lists, self.target_inner.aux_hidden[: hidden.shape[0]],
+                               cu, n_sched, so)
+
+
 def make_proposer(vllm_config: VllmConfig, runner):
     m = vllm_config.speculative_config.method
     if vllm_config.parallel_config.token_parallel_size > 1:
@@ -230,6 +252,8 @@ def make_proposer(vllm_config: VllmConfig, runner):
         return MedusaProposer(vllm_config, runner)
     if m == "mlp_speculator":
         return MLPSpeculatorProposer(vllm_config, runner)
-    if m in ("eagle", "eagle3", "draft_model", "mtp", "deepseek_mtp", "mimo_mtp"):
+    if m == "eagle3":
+        return Eagle3Proposer(vllm_config, runner)
+    if m in ("eagle", "draft_model", "mtp", "deepseek_mtp", "mimo_mtp"):
         return EagleProposer(vllm_config, runner)
     raise ValueError(f"unknown speculative method {m!r}")
