@@ -982,3 +982,43 @@ def test_ultravox_matches_hf_components(tmp_path, ln_mid):
         ref = lm.generate(inputs_embeds=emb, max_new_tokens=8, do_sample=False, pad_token_id=0,
                           eos_token_id=None)[0].tolist()
     assert list(out.outputs[0].token_ids) == ref[-8:]
+
+
+def test_minimax_vl_01_runs_llava_next_path_over_minimax_decoder(tmp_path):
+    """MiniMax-VL-01 = LLaVA-NeXT's image path over the MiniMax decoder.  No transformers class (parity unpinned);
+    both halves have their own transformers parity tests, this one checks the composition: a LLaVA-NeXT checkpoint
+    whose text model is transformers' MiniMax, loaded under the MiniMax-VL-01 name, against that same composition
+    run by transformers' LLaVA-NeXT class."""
+    import json
+    import transformers as tf
+    from vllm_distributed_amd.multimodal import process_multimodal
+    torch.manual_seed(0)
+    tc = tf.MiniMaxConfig(vocab_size=320, hidden_size=128, intermediate_size=192, num_hidden_layers=3,
+                          num_attention_heads=2, num_key_value_heads=1, head_dim=64, num_local_experts=4,
+                          num_experts_per_tok=2, max_position_embeddings=512, block_size=16,
+                          layer_types=["linear_attention", "full_attention", "linear_attention"])
+    vc = tf.CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2,
+                             image_size=28, patch_size=7, projection_dim=64)
+    cfg = tf.LlavaNextConfig(vision_config=vc, text_config=tc, image_token_index=300, vision_feature_layer=-2,
+                             image_grid_pinpoints=[[28, 28], [28, 56], [56, 28]])
+    hf = tf.LlavaNextForConditionalGeneration(cfg).float().eval()
+    path = os.path.join(tmp_path, "mmvl")
+    hf.save_pretrained(path, safe_serialization=True)
+    c = json.load(open(os.path.join(path, "config.json")))
+    c["architectures"] = ["MiniMaxVL01ForConditionalGeneration"]
+    json.dump(c, open(os.path.join(path, "config.json"), "w"))
+    img = (np.random.default_rng(5).random((30, 52, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=4)
+    prompt = [5, 17, 300, 99, 3]
+    out = llm.generate([{"prompt_token_ids": prompt, "multi_modal_data": {"image": img}}],
+                       SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))[0]
+    ids, inputs, _, _ = process_multimodal(llm.llm_engine.vllm_config, prompt, {"image": img})
+    llm.shutdown()
+    with torch.no_grad():
+        cur, ref = list(ids), []
+        for _ in range(6):               # no cache: transformers' LLaVA-NeXT wrapper cannot build MiniMax's own
+            lg = hf(input_ids=torch.tensor([cur]), pixel_values=inputs[0][0][None],
+                    image_sizes=torch.tensor([[int(x) for x in inputs[0][1]]]), use_cache=False).logits[0, -1]
+            ref.append(int(lg.argmax()))
+            cur.append(ref[-1])
+    assert list(out.outputs[0].token_ids) == ref

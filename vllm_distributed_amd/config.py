@@ -310,7 +310,7 @@ class ModelConfig:
         """Attention and state-space layers in one stack: paged KV for the former, one state slot per
         request for the latter; recurrent state rules out prefix reuse."""
         return any(a in ("JambaForCausalLM", "BambaForCausalLM", "GraniteMoeHybridForCausalLM", "NemotronHForCausalLM",
-                         "MiniMaxForCausalLM", "MiniMaxText01ForCausalLM", "MiniMaxM1ForCausalLM", "FalconH1ForCausalLM",
+                         "MiniMaxForCausalLM", "MiniMaxText01ForCausalLM", "MiniMaxM1ForCausalLM", "FalconH1ForCausalLM", "MiniMaxVL01ForConditionalGeneration",
                          # encoder-decoder: the cross-attention cache is per-request state of the same kind
                          "WhisperForConditionalGeneration", "BartForConditionalGeneration", "BartModel")
                    for a in self.architectures)

@@ -97,7 +97,8 @@ def build_language_model(vllm_config: VllmConfig, text_config, prefix: str):
     from .registry import ModelRegistry
     by_type = {"llama": "LlamaForCausalLM", "mistral": "MistralForCausalLM", "qwen2": "Qwen2ForCausalLM",
                "qwen3": "Qwen3ForCausalLM", "gemma": "GemmaForCausalLM", "gemma2": "Gemma2ForCausalLM",
-               "cohere2": "Cohere2ForCausalLM", "phi3": "Phi3ForCausalLM", "persimmon": "PersimmonForCausalLM"}
+               "cohere2": "Cohere2ForCausalLM", "phi3": "Phi3ForCausalLM", "persimmon": "PersimmonForCausalLM",
+               "minimax": "MiniMaxForCausalLM", "minimax_text_01": "MiniMaxText01ForCausalLM"}
     archs = list(getattr(text_config, "architectures", None) or [])
     if not archs:
         mt = getattr(text_config, "model_type", "llama")
@@ -434,3 +435,9 @@ def _video_processor(vllm_config):
                                video_token_id=int(getattr(hf, "video_token_index", None)
                                                   or getattr(hf, "video_token_id", 32000)),
                                pool_stride=int(getattr(hf, "spatial_pool_stride", 2)))
+
+
+class MiniMaxVL01ForConditionalGeneration(LlavaNextForConditionalGeneration):
+    """MiniMax-VL-01: the LLaVA-NeXT image path (tower, two-layer projector, any-resolution tiles with a newline
+    embedding per row) in front of the MiniMax-Text-01 decoder (lightning attention state slots + paged KV).
+    Reference: vllm/model_executor/models/minimax_vl_01.py:170-360."""

@@ -153,6 +153,7 @@ def _anyres(vllm_config):
 
 MULTIMODAL_REGISTRY.register_processor("LlavaNextForConditionalGeneration", _anyres)
 MULTIMODAL_REGISTRY.register_processor("LlavaOnevisionForConditionalGeneration", _anyres)
+MULTIMODAL_REGISTRY.register_processor("MiniMaxVL01ForConditionalGeneration", _anyres)
 
 
 # ---- Qwen2-VL: variable-size patch grids ------------------------------------------------------------
