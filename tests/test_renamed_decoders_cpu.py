@@ -223,3 +223,72 @@ def test_minicpm3_latent_attention_and_scaling(tmp_path):
                model_type="minicpm3", architectures=["MiniCPM3ForCausalLM"], scale_emb=scale_emb,
                scale_depth=scale_depth, dim_model_base=base, torch_dtype="float32")
     assert _ours(_write(tmp_path, "minicpm3", out, sd)) == _hf_tokens(m)
+
+
+def test_jais_matches_dense_form(tmp_path):
+    """JAIS (GPT-2 layout, ALiBi, SwiGLU over two up projections, muP scales).  The upstream model is remote code
+    (no transformers class; parity unpinned): the reference is the network written out in fp32."""
+    import json
+    import math
+    from safetensors.torch import save_file
+    from vllm_distributed_amd import LLM, SamplingParams
+    torch.manual_seed(0)
+    V, d, H, I, Lr = 320, 128, 4, 192, 2
+    D = d // H
+    g = lambda *s: torch.randn(*s) * 0.08      # noqa: E731
+    sd = {"transformer.wte.weight": g(V, d), "transformer.ln_f.weight": 1 + g(d), "transformer.ln_f.bias": g(d),
+          "transformer.relative_pe.slopes": torch.zeros(H, 1, 1)}
+    for i in range(Lr):
+        p = f"transformer.h.{i}."
+        sd.update({p + "ln_1.weight": 1 + g(d), p + "ln_1.bias": g(d), p + "ln_2.weight": 1 + g(d), p + "ln_2.bias": g(d),
+                   p + "attn.c_attn.weight": g(d, 3 * d), p + "attn.c_attn.bias": g(3 * d),
+                   p + "attn.c_proj.weight": g(d, d), p + "attn.c_proj.bias": g(d),
+                   p + "mlp.c_fc.weight": g(d, I), p + "mlp.c_fc.bias": g(I), p + "mlp.c_fc2.weight": g(d, I),
+                   p + "mlp.c_fc2.bias": g(I), p + "mlp.c_proj.weight": g(I, d), p + "mlp.c_proj.bias": g(d)})
+    path = os.path.join(tmp_path, "jais")
+    os.makedirs(path)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    cfg = {"architectures": ["JAISLMHeadModel"], "model_type": "jais", "vocab_size": V, "n_embd": d, "n_head": H,
+           "n_layer": Lr, "n_inner": I, "n_positions": 256, "layer_norm_epsilon": 1e-5, "activation_function": "swiglu",
+           "position_embedding_type": "alibi", "mup_embeddings_scale": 9.1, "mup_output_alpha": 1.1,
+           "mup_width_scale": 0.2, "mup_scale_qk_dot_by_d": True, "torch_dtype": "float32",
+           "scale_attn_by_inverse_layer_idx": False}
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 7]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4)
+    outs = llm.generate([{"prompt_token_ids": p} for p in prompts],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    llm.shutdown()
+    F = torch.nn.functional
+
+    def slopes(n):
+        start = 2 ** (-(2 ** -(math.log2(n) - 3)))
+        return torch.tensor([start * start ** i for i in range(n)])
+
+    def logits(ids):
+        T = len(ids)
+        x = sd["transformer.wte.weight"][ids] * 9.1
+        pos = torch.arange(T)
+        bias = -(pos[:, None] - pos[None, :]).float()[None] * slopes(H)[:, None, None]       # [H, T, T]
+        mask = pos[None, :] > pos[:, None]
+        for i in range(Lr):
+            p = f"transformer.h.{i}."
+            h = F.layer_norm(x, (d,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], 1e-5)
+            q, k, v = (h @ sd[p + "attn.c_attn.weight"] + sd[p + "attn.c_attn.bias"]).view(T, 3, H, D).unbind(1)
+            s = torch.einsum("ihd,jhd->hij", q, k) / D + bias
+            s = s.masked_fill(mask[None], float("-inf")).softmax(-1)
+            a = torch.einsum("hij,jhd->ihd", s, v).reshape(T, d)
+            x = x + a @ sd[p + "attn.c_proj.weight"] + sd[p + "attn.c_proj.bias"]
+            h = F.layer_norm(x, (d,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], 1e-5)
+            m = (h @ sd[p + "mlp.c_fc.weight"] + sd[p + "mlp.c_fc.bias"]) * \
+                F.silu(h @ sd[p + "mlp.c_fc2.weight"] + sd[p + "mlp.c_fc2.bias"])
+            x = x + m @ sd[p + "mlp.c_proj.weight"] + sd[p + "mlp.c_proj.bias"]
+        x = F.layer_norm(x, (d,), sd["transformer.ln_f.weight"], sd["transformer.ln_f.bias"], 1e-5)
+        return (x[-1] @ sd["transformer.wte.weight"].T) * (1.1 * 0.2)
+
+    for p, o in zip(prompts, outs):
+        ids = list(p)
+        for tok in o.outputs[0].token_ids:
+            lg = logits(ids)
+            assert tok == int(lg.argmax()) or float(lg.max() - lg[tok]) < 1e-4
+            ids.append(tok)

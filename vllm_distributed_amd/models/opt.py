@@ -218,3 +218,95 @@ class GPT2LMHeadModel(nn.Module):
             getattr(p, "weight_loader", lambda p_, t_: p_.data.copy_(t_))(p, t)
             loaded.add(name)
         return loaded
+
+
+# ---------------------------------------------------------------------------
+def _alibi_slopes(n: int) -> list[float]:
+    import math
+
+    def pow2(m):
+        start = 2 ** (-(2 ** -(math.log2(m) - 3)))
+        return [start * start ** i for i in range(m)]
+    if math.log2(n).is_integer():
+        return pow2(n)
+    c = 2 ** math.floor(math.log2(n))
+    return pow2(c) + _alibi_slopes(2 * c)[0::2][: n - c]
+
+
+class JAISBlock(GPT2Block):
+    """GPT-2 block with ALiBi attention (softmax scale 1/d under muP), and x1 * silu(x2) over two up projections."""
+
+    def __init__(self, config, prefix: str):
+        super().__init__(config, prefix)
+        d, H = config.n_embd, config.n_head
+        tp = get_tensor_model_parallel_world_size()
+        from ..parallel.state import get_tensor_model_parallel_rank
+        r = get_tensor_model_parallel_rank()
+        by_d = bool(getattr(config, "scale_qk_dot_by_d", getattr(config, "mup_scale_qk_dot_by_d", False)))
+        self.attn = Attention(H // tp, d // H, (d // H) ** (-1.0 if by_d else -0.5),
+                              alibi_slopes=_alibi_slopes(H)[r * (H // tp):(r + 1) * (H // tp)], prefix=f"{prefix}.attn")
+        inner = getattr(config, "n_inner", None) or 4 * d
+        self.swiglu = bool(getattr(config, "jais_swiglu", False))
+        if self.swiglu:
+            self.c_fc2 = ColumnParallelLinear(d, inner, bias=True, prefix=f"{prefix}.mlp.c_fc2")
+
+    def forward(self, x):
+        x = x + self.c_proj(self.attn(self.c_attn(self.ln_1(x))))
+        h = self.ln_2(x)
+        h = self.c_fc(h) * torch.nn.functional.silu(self.c_fc2(h)) if self.swiglu else self.act(self.c_fc(h))
+        return x + self.mlp_proj(h)
+
+
+class JAISLMHeadModel(GPT2LMHeadModel):
+    """JAIS: GPT-2 layout with ALiBi instead of learned positions, SwiGLU MLPs and muP scales on the embedding,
+    the attention logits and the output logits.  Reference: vllm/model_executor/models/jais.py:60-373."""
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        nn.Module.__init__(self)
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        self.wte = VocabParallelEmbedding(config.vocab_size, config.n_embd)
+        self.alibi = getattr(config, "position_embedding_type", "alibi") == "alibi"
+        if not self.alibi:
+            self.wpe = nn.Embedding(config.n_positions, config.n_embd)
+            self.wpe.weight.requires_grad_(False)
+        real_act = getattr(config, "activation_function", "swiglu")
+        config.jais_swiglu = real_act == "swiglu"
+        if config.jais_swiglu:
+            config.activation_function = "silu"          # the base block builds an (unused) plain activation
+        self.h = nn.ModuleList([JAISBlock(config, f"transformer.h.{i}") for i in range(config.n_layer)])
+        config.activation_function = real_act
+        self.ln_f = LayerNorm(config.n_embd, config.layer_norm_epsilon)
+        self.lm_head = ParallelLMHead(config.vocab_size, config.n_embd).tie_weights(self.wte)
+        self.embeddings_scale = float(getattr(config, "embeddings_scale", None)
+                                      or getattr(config, "mup_embeddings_scale", 1.0))
+        out_scale = getattr(config, "width_scale", None)
+        if out_scale is None:
+            out_scale = float(getattr(config, "mup_output_alpha", 1.0)) * float(getattr(config, "mup_width_scale", 1.0))
+        self.logits_processor = LogitsProcessor(config.vocab_size, config.vocab_size, float(out_scale))
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None):
+        x = inputs_embeds if inputs_embeds is not None else self.wte(input_ids)
+        if not self.alibi:
+            x = x + self.wpe(positions)
+        x = x * self.embeddings_scale
+        for blk in self.h:
+            x = blk(x)
+        return self.ln_f(x)
+
+    def load_weights(self, weights):
+        def fix():
+            for name, t in weights:
+                if "relative_pe" in name:
+                    continue
+                if ".mlp.c_fc2." in name:
+                    name = name.replace(".mlp.c_fc2.", ".c_fc2.")
+                    t = t.t() if name.endswith(".weight") else t
+                    p = dict(self.named_parameters())[name.removeprefix("transformer.")]
+                    getattr(p, "weight_loader", lambda p_, t_: p_.data.copy_(t_))(p, t)
+                    done.add(name.removeprefix("transformer."))
+                    continue
+                yield name, t
+        done: set[str] = set()
+        loaded = super().load_weights(fix())
+        return loaded | done

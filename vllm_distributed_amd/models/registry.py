@@ -93,6 +93,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Mamba2ForCausalLM": ("mamba", "Mamba2ForCausalLM"),
     "OPTForCausalLM": ("opt", "OPTForCausalLM"),
     "GPT2LMHeadModel": ("opt", "GPT2LMHeadModel"),
+    "JAISLMHeadModel": ("opt", "JAISLMHeadModel"),
     "BertModel": ("bert", "BertEmbeddingModel"),
     "BertForMaskedLM": ("bert", "BertEmbeddingModel"),
     "BertForSequenceClassification": ("bert", "BertForSequenceClassification"),
