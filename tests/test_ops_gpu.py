@@ -808,3 +808,33 @@ def test_mla_attention(dt, DK, DV, H, lens, computed, nsplit):
     ops.mla_attention(out, q, kc, vt, bt, seq, qsl, DK ** -0.5, max(lens), nsplit)
     ref = R.mla_attention(q, kc, vt, bt, seq, qsl, DK ** -0.5)
     torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
+@pytest.mark.parametrize("D,dtype", [(128, torch.bfloat16), (64, torch.float16), (32, torch.float32)])
+def test_lightning_attention_decode_matches_reference(D, dtype):
+    """One-token lightning attention step (state update + q.S in one pass) against the same step in plain PyTorch
+    fp32; rows: ongoing sequences, a sequence at its first token (starts from zero) and a padded row (untouched)."""
+    from vllm_distributed_amd import ops
+    torch.manual_seed(0)
+    S, H, slots = 6, 5, 9
+    dev = "cuda"
+    qkv = (torch.randn(S, H * 3 * D, device=dev) * 0.5).to(dtype)
+    state = torch.randn(slots, H, D, D, device=dev)
+    slope = torch.rand(H, device=dev) * 0.5 + 0.01
+    seq_lens = torch.tensor([7, 1, 30, 0, 2, 1], dtype=torch.int32, device=dev)
+    table = torch.tensor([[3], [1], [8], [0], [5], [2]], dtype=torch.int32, device=dev)
+    ref_state = state.clone()
+    q, k, v = qkv.view(S, H, 3 * D).float().split(D, dim=-1)
+    want = torch.zeros(S, H, D, device=dev)
+    for s in range(S):
+        if int(seq_lens[s]) <= 0:
+            continue
+        slot = int(table[s, 0])
+        prev = ref_state[slot] * (0.0 if int(seq_lens[s]) <= 1 else 1.0) * torch.exp(-slope).view(H, 1, 1)
+        new = prev + k[s].unsqueeze(-1) * v[s].unsqueeze(-2)
+        ref_state[slot] = new
+        want[s] = torch.matmul(q[s].unsqueeze(-2), new).squeeze(-2)
+    got = ops.lightning_attention_decode(qkv, state, slope, seq_lens, table, H, D)
+    live = seq_lens > 0
+    torch.testing.assert_close(got[live], want[live], atol=1e-3, rtol=1e-4)
+    torch.testing.assert_close(state, ref_state, atol=1e-4, rtol=1e-5)

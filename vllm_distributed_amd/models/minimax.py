@@ -15,6 +15,7 @@ from typing import Iterable, Optional
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..config import VllmConfig
 from ..forward_context import get_forward_context
 from ..layers.basic import LogitsProcessor, ParallelLMHead, RMSNorm, VocabParallelEmbedding
@@ -109,12 +110,7 @@ class LightningAttention(StateSpaceLayer):
         state = self.ssm_state
         if nd and ndt == nd:
             # one token per sequence: S <- decay * S + k^T v (a sequence at its first token starts from zero)
-            slots = tbl[:nd, 0].long()
-            fresh = (md.seq_lens[:nd] <= 1).view(nd, 1, 1, 1)
-            s = state[slots] * torch.where(fresh, 0.0, 1.0) * torch.exp(-self.slope).view(1, H, 1, 1)
-            s = s + k[:nd].unsqueeze(-1) * v[:nd].unsqueeze(-2)
-            state[slots] = s
-            out[:nd] = torch.matmul(q[:nd].unsqueeze(-2), s).squeeze(-2)
+            out[:nd] = ops.lightning_attention_decode(qkv[:nd], state, self.slope, md.seq_lens[:nd], tbl[:nd], H, D)
             first = nd
         else:
             first = 0

@@ -905,3 +905,28 @@ def selective_scan(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: tor
            Ch // E, int(A.dim() == 1), Ch // num_groups, int(softplus), chunk, nchunks, N.ptr(ws_p), N.ptr(ws_h),
            N.dt(u.dtype), N.stream())
     return out
+
+
+# ---- lightning (linear) attention -----------------------------------------------------------------------
+def lightning_attention_decode(qkv: torch.Tensor, state: torch.Tensor, slope: torch.Tensor, seq_lens: torch.Tensor,
+                               slot_table: torch.Tensor, num_heads: int, head_dim: int) -> torch.Tensor:
+    """One token per sequence.  qkv [S, H * 3 D] (per head [q | k | v], already activated); state fp32
+    [slots, H, D, D], updated in place: S <- exp(-slope) S + k^T v (from zero when ``seq_lens`` says this is the
+    sequence's first token); slot_table [S, >= 1] int32 with the state slot in column 0.  Returns q S, fp32 [S, H, D]."""
+    S = qkv.shape[0]
+    H, D = num_heads, head_dim
+    out = torch.empty((S, H, D), dtype=torch.float32, device=qkv.device)
+    if _dev(qkv) and qkv.stride(1) == 1 and state.is_contiguous() and D in (16, 32, 64, 128, 256) \
+            and state.dtype == torch.float32 and slope.dtype == torch.float32:
+        N.call("vda_lightning_decode", out.data_ptr(), qkv.data_ptr(), state.data_ptr(), slope.data_ptr(),
+               seq_lens.data_ptr(), slot_table.data_ptr(), slot_table.stride(0), S, H, D, qkv.stride(0),
+               N.dt(qkv.dtype), N.stream())
+        return out
+    q, k, v = qkv.view(S, H, 3 * D).float().split(D, dim=-1)
+    slots = slot_table[:S, 0].long()
+    fresh = (seq_lens[:S] <= 1).view(S, 1, 1, 1)
+    s = state[slots] * torch.where(fresh, 0.0, 1.0) * torch.exp(-slope.float()).view(1, H, 1, 1)
+    s = s + k.unsqueeze(-1) * v.unsqueeze(-2)
+    live = (seq_lens[:S] > 0).view(S, 1, 1, 1)
+    state[slots] = torch.where(live, s, state[slots])
+    return torch.matmul(q.unsqueeze(-2), s).squeeze(-2)

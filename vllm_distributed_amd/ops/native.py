@@ -73,6 +73,7 @@ _SIGS = {
     "vda_lora_shrink": [P, P, P, P, I, I, I, L, I, P],
     "vda_lora_expand": [P, P, P, P, I, I, I, L, I, P],
     "vda_causal_conv1d": [P, P, P, P, P, P, P, P, L, I, I, I, I, L, L, I, I, P],
+    "vda_lightning_decode": [P, P, P, P, P, P, L, I, I, I, L, I, P],
     "vda_selective_scan": [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, L, L, L, L, L, L, I, I, I, I, I, I, P, P,
                            I, P],
 }
