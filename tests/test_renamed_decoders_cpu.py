@@ -292,3 +292,87 @@ def test_jais_matches_dense_form(tmp_path):
             lg = logits(ids)
             assert tok == int(lg.argmax()) or float(lg.max() - lg[tok]) < 1e-4
             ids.append(tok)
+
+
+def test_arctic_matches_dense_form(tmp_path):
+    """Snowflake Arctic: dense layers and expert layers alternate; an expert layer also runs a small dense MLP on the
+    post-attention stream while its experts read the normalised layer input.  No transformers class (remote code
+    upstream, parity unpinned): the reference is the network written out in fp32 from the checkpoint's own names."""
+    torch.manual_seed(0)
+    V, d, H, KV, I, E, Lr = 320, 128, 2, 1, 192, 4, 4
+    D = d // H
+    g = lambda *s: torch.randn(*s) * 0.06      # noqa: E731
+    sd = {"model.embed_tokens.weight": g(V, d), "model.norm.weight": 1 + g(d), "lm_head.weight": g(V, d)}
+    for i in range(Lr):
+        p = f"model.layers.{i}."
+        sd.update({p + "self_attn.q_proj.weight": g(H * D, d), p + "self_attn.k_proj.weight": g(KV * D, d),
+                   p + "self_attn.v_proj.weight": g(KV * D, d), p + "self_attn.o_proj.weight": g(d, H * D),
+                   p + "input_layernorm.weight": 1 + g(d), p + "post_attention_layernorm.weight": 1 + g(d)})
+        if (i + 1) % 2 == 0:
+            sd.update({p + "residual_layernorm.weight": 1 + g(d), p + "residual_mlp.w1.weight": g(d, d),
+                       p + "residual_mlp.w3.weight": g(d, d), p + "residual_mlp.w2.weight": g(d, d),
+                       p + "block_sparse_moe.gate.weight": g(E, d)})
+            for e in range(E):
+                q = p + f"block_sparse_moe.experts.{e}."
+                sd.update({q + "w1.weight": g(I, d), q + "w3.weight": g(I, d), q + "w2.weight": g(d, I)})
+        else:
+            q = p + "block_sparse_moe.mlp."
+            sd.update({q + "w1.weight": g(I, d), q + "w3.weight": g(I, d), q + "w2.weight": g(d, I)})
+    path = os.path.join(tmp_path, "arctic")
+    os.makedirs(path)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    json.dump({"architectures": ["ArcticForCausalLM"], "model_type": "arctic", "vocab_size": V, "hidden_size": d,
+               "num_attention_heads": H, "num_key_value_heads": KV, "intermediate_size": I, "num_hidden_layers": Lr,
+               "num_local_experts": E, "num_experts_per_tok": 2, "moe_layer_frequency": 2, "use_residual": True,
+               "rms_norm_eps": 1e-5, "rope_theta": 10000.0, "max_position_embeddings": 256, "hidden_act": "silu",
+               "tie_word_embeddings": False, "torch_dtype": "float32"}, open(os.path.join(path, "config.json"), "w"))
+    prompts = [[5, 17, 99, 3, 250, 11], [7, 8, 9] * 7]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4)
+    outs = llm.generate([{"prompt_token_ids": p} for p in prompts],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    llm.shutdown()
+    F = torch.nn.functional
+    rms = lambda x, w: x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * w      # noqa: E731
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+
+    def glu(x, q):
+        return (F.silu(x @ sd[q + "w1.weight"].T) * (x @ sd[q + "w3.weight"].T)) @ sd[q + "w2.weight"].T
+
+    def logits(ids):
+        T = len(ids)
+        ang = torch.arange(T)[:, None].float() * inv[None]
+
+        def rope(t):
+            a, b = t[..., : D // 2], t[..., D // 2:]
+            c, s_ = ang.cos()[:, None], ang.sin()[:, None]
+            return torch.cat((a * c - b * s_, b * c + a * s_), -1)
+        x = sd["model.embed_tokens.weight"][ids]
+        for i in range(Lr):
+            p = f"model.layers.{i}."
+            h = rms(x, sd[p + "input_layernorm.weight"])
+            q = rope((h @ sd[p + "self_attn.q_proj.weight"].T).view(T, H, D))
+            k = rope((h @ sd[p + "self_attn.k_proj.weight"].T).view(T, KV, D)).repeat_interleave(H // KV, 1)
+            v = (h @ sd[p + "self_attn.v_proj.weight"].T).view(T, KV, D).repeat_interleave(H // KV, 1)
+            o = F.scaled_dot_product_attention(q.transpose(0, 1)[None], k.transpose(0, 1)[None], v.transpose(0, 1)[None],
+                                               is_causal=True)[0].transpose(0, 1).reshape(T, H * D)
+            attn = x + o @ sd[p + "self_attn.o_proj.weight"].T
+            if (i + 1) % 2 == 0:
+                res = glu(rms(attn, sd[p + "residual_layernorm.weight"]), p + "residual_mlp.")
+                m_in = rms(x, sd[p + "post_attention_layernorm.weight"])
+                w, idx = (m_in @ sd[p + "block_sparse_moe.gate.weight"].T).softmax(-1).topk(2, -1)
+                w = w / w.sum(-1, keepdim=True)
+                moe = torch.zeros_like(m_in)
+                for t in range(T):
+                    for j in range(2):
+                        moe[t] += w[t, j] * glu(m_in[t:t + 1], p + f"block_sparse_moe.experts.{int(idx[t, j])}.")[0]
+                x = attn + res + moe
+            else:
+                x = attn + glu(rms(attn, sd[p + "post_attention_layernorm.weight"]), p + "block_sparse_moe.mlp.")
+        return rms(x[-1], sd["model.norm.weight"]) @ sd["lm_head.weight"].T
+
+    for p, o in zip(prompts, outs):
+        ids = list(p)
+        for tok in o.outputs[0].token_ids:
+            lg = logits(ids)
+            assert tok == int(lg.argmax()) or float(lg.max() - lg[tok]) < 1e-4
+            ids.append(tok)

@@ -391,3 +391,68 @@ class DbrxForCausalLM(MixtralForCausalLM):
         g, d, u = self.expert_names
         experts = FusedMoE.make_expert_params_mapping(g, d, u, E)
         return load_weights_with_mapping(self, fix(weights), [], tie_lm_head=self.tie, expert_mapping=experts)
+
+
+# ---- Snowflake Arctic --------------------------------------------------------------------------------
+class ArcticDecoderLayer(LlamaDecoderLayer):
+    """Every ``moe_layer_frequency``-th layer routes over experts, the others carry a dense gated MLP; with
+    ``use_residual`` an expert layer also runs a small dense MLP on the post-attention stream while the experts read
+    the normalised layer INPUT, and both are added to the post-attention stream.
+    Reference: vllm/model_executor/models/arctic.py:296-360."""
+    supports_sequence_parallel = False
+
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        idx = int(prefix.split(".")[-2])
+        self.is_moe = (idx + 1) % int(getattr(config, "moe_layer_frequency", 2)) == 0
+        self.use_residual = bool(getattr(config, "use_residual", True)) and self.is_moe
+        p = prefix.replace(".mlp", ".block_sparse_moe")
+        if self.use_residual:
+            self.residual_layernorm = self.make_norm(config)
+            self.residual_mlp = LlamaMLP(config.hidden_size, config.hidden_size, False, quant_config,
+                                         prefix.replace(".mlp", ".residual_mlp"))
+        if self.is_moe:
+            return SparseMoeBlock(config.hidden_size, config.intermediate_size, _num_experts(config),
+                                  config.num_experts_per_tok, int(config.num_experts_per_tok) > 1, quant_config, p)
+        m = nn.Module()
+        m.mlp = LlamaMLP(config.hidden_size, config.intermediate_size, False, quant_config, f"{p}.mlp")
+        m.forward = lambda x: m.mlp(x)
+        return m
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = ""):
+        super().__init__(config, vllm_config, quant_config, prefix)
+        self.block_sparse_moe = self.mlp
+        del self.mlp
+
+    def forward(self, positions, hidden_states, residual):
+        x = hidden_states if residual is None else hidden_states + residual          # the layer's input
+        attn = x + self.self_attn(positions, self.input_layernorm(x))
+        if self.use_residual:
+            out = self.residual_mlp(self.residual_layernorm(attn)) + \
+                self.block_sparse_moe(self.post_attention_layernorm(x))
+        else:
+            out = self.block_sparse_moe(self.post_attention_layernorm(attn))
+        return out, attn
+
+
+class ArcticModel(LlamaModel):
+    layer_cls = ArcticDecoderLayer
+
+
+class ArcticForCausalLM(MixtralForCausalLM):
+    model_cls = ArcticModel
+    stacked_params_mapping = MixtralForCausalLM.stacked_params_mapping + [
+        (".gate_up_proj", ".w1", 0), (".gate_up_proj", ".w3", 1)]
+
+    def num_experts(self) -> int:
+        return _num_experts(self.config)
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
+        experts = FusedMoE.make_expert_params_mapping("w1", "w2", "w3", self.num_experts())
+
+        def fix(items):
+            for n, t in items:
+                if (".residual_mlp." in n or ".block_sparse_moe.mlp." in n) and ".w2." in n:
+                    n = n.replace(".w2.", ".down_proj.")
+                yield n, t
+        return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie,
+                                         expert_mapping=experts)

@@ -137,6 +137,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Fairseq2LlamaForCausalLM": ("llama_variants", "Fairseq2LlamaForCausalLM"),
     "InternVLChatModel": ("internvl", "InternVLChatModel"),
     "NVLM_D": ("internvl", "NVLM_D_Model"),
+    "ArcticForCausalLM": ("mixtral", "ArcticForCausalLM"),
     "MiniMaxVL01ForConditionalGeneration": ("llava_next", "MiniMaxVL01ForConditionalGeneration"),
     "Eagle3LlamaForCausalLM": ("eagle", "Eagle3LlamaForCausalLM"),
     "LlamaForCausalLMEagle3": ("eagle", "Eagle3LlamaForCausalLM"),
