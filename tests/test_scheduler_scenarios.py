@@ -757,3 +757,44 @@ def test_remote_prefill_with_a_locally_cached_prefix_asks_for_the_rest_only():
     s.update_from_output(s.schedule(), ModelRunnerOutput(finished_recving={r.request_id}))
     s.schedule()
     assert_scheduler_empty(s)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# run-ahead scheduling: a preempted request whose last token was still in flight
+# ---------------------------------------------------------------------------------------------------------
+def test_run_ahead_preempted_request_finishing_on_its_in_flight_token():
+    """Run-ahead mode schedules step N + 1 before step N's tokens are known.  If that schedule preempts a request
+    and step N's token then ends it (EOS), the request must leave the waiting queue as well: otherwise the next
+    schedule() admits a finished request (reference: stopped_preempted_reqs in Scheduler.update_from_output)."""
+    s = make_scheduler(num_blocks=9, max_num_batched_tokens=64, max_num_seqs=4, async_scheduling=True)
+    assert s.async_mode
+    a, b = make_requests(2, num_tokens=30, max_tokens=40)          # 16-token blocks: two blocks each at first
+    s.add_request(a)
+    s.add_request(b)
+    o0 = s.schedule()                                               # both prefills
+    s.update_from_output(o0, make_runner_output(o0, tokens_by_req={a.request_id: [1], b.request_id: [1]}))
+    # decode steps run ahead: o_next is scheduled before o_prev's tokens arrive
+    o_prev = s.schedule()
+    victim = None
+    for _ in range(40):
+        o_next = s.schedule()
+        if b.status == RequestStatus.PREEMPTED or a.status == RequestStatus.PREEMPTED:
+            victim = b if b.status == RequestStatus.PREEMPTED else a
+            break
+        s.update_from_output(o_prev, make_runner_output(o_prev, token=1))
+        o_prev = o_next
+    assert victim is not None, "the block budget never forced a preemption"
+    assert victim.request_id in o_prev.num_scheduled_tokens          # its token of the previous step is in flight
+    other = a if victim is b else b
+    # that in-flight token is EOS for the victim
+    s.update_from_output(o_prev, make_runner_output(o_prev, tokens_by_req={victim.request_id: [EOS],
+                                                                          other.request_id: [1]}))
+    assert victim.is_finished()
+    assert victim.request_id not in s.requests
+    assert all(r is not victim for r in s.running)
+    assert victim not in list(s.waiting)
+    s.update_from_output(o_next, make_runner_output(o_next, token=1))
+    s.finish_requests([other.request_id], RequestStatus.FINISHED_ABORTED)
+    o = s.schedule()                                                 # must not raise on a finished request
+    assert victim.request_id not in o.num_scheduled_tokens
+    assert_scheduler_empty(s)

@@ -510,6 +510,51 @@ def decode_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+_DENSE_EPI = {"plain": 0, "gate_up": 1}
+
+
+def dense_gemm_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """Operands the ping-pong MFMA GEMM takes: 16-bit, K a multiple of 32, row strides multiples of 8 elements,
+    both operands below 4 GiB (the kernel addresses them with 32-bit byte offsets)."""
+    return (x.dim() == 2 and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and w.is_contiguous()
+            and x.stride(1) == 1 and x.shape[1] % 32 == 0 and x.stride(0) % 8 == 0 and x.shape[0] >= 1
+            and w.numel() * 2 < (1 << 32) and x.shape[0] * x.stride(0) * 2 < (1 << 32))
+
+
+def dense_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, epilogue: str = "plain",
+               out: Optional[torch.Tensor] = None, wt: int = 0, splits: int = 0, variant: int = 0) -> torch.Tensor:
+    """y = epilogue(x @ w.T) with the in-tree ping-pong MFMA kernel (ops/csrc/gemm_dense.hip), any M.
+    ``plain``: y = x @ w.T (+ bias) (+ residual); ``gate_up``: w holds the gate rows followed by the up rows of a
+    gated MLP and y = silu(x @ gate.T) * (x @ up.T) (no separate activation pass).  ``wt`` / ``splits`` override the
+    tile height (2 or 4 = 128 or 256 weight rows), the K split and the kernel form (1 = ring of 32-element K units,
+    2 = 64-element units on 256 x 256 tiles; 0 = chosen by the launcher)."""
+    epi = _DENSE_EPI[epilogue]
+    M, K = x.shape
+    n_out = w.shape[0] // 2 if epi else w.shape[0]
+    if not _dev(x):
+        y = torch.nn.functional.linear(x, w, None if epi else bias)
+        if epi:
+            y = torch.nn.functional.silu(y[:, :n_out]) * y[:, n_out:]
+        elif residual is not None:
+            y = y + residual
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    if not dense_gemm_ok(x, w) or w.shape[1] != K:
+        raise ValueError("dense_gemm: x must be 16-bit [M, K] (K % 32 == 0), w [N, K] contiguous of the same dtype")
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    ws = _DECODE_WS.get(x.device)
+    if ws is None:          # split-K partial sums; one arena per device, reused by every call (stream order)
+        ws = _DECODE_WS[x.device] = torch.empty(envs.VDA_DECODE_GEMM_WS_MB << 18, dtype=torch.float32, device=x.device)
+    N.call("vda_dense_gemm", out.data_ptr(), x.data_ptr(), w.data_ptr(), N.ptr(bias), N.ptr(residual), ws.data_ptr(),
+           ws.numel() * 4, M, n_out, K, x.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0,
+           epi, N.dt(x.dtype), wt, splits, variant, N.stream())
+    return out
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Unquantised linear: skinny MFMA kernel for the smallest M, the weight-streaming split-K kernel for
     decode batches, hipBLASLt otherwise."""

@@ -492,6 +492,7 @@ class Scheduler(SchedulerInterface):
         outputs: dict[int, list[EngineCoreOutput]] = defaultdict(list)
         spec_stats: Optional[SpecDecodingStats] = None
         stopped: list[Request] = []
+        stopped_preempted: list[Request] = []   # run-ahead: finished by a token that was in flight at preemption
 
         for rid, n_sched in num_scheduled.items():
             if n_sched == 0:
@@ -519,6 +520,7 @@ class Scheduler(SchedulerInterface):
 
             finished = False
             kv_params = None
+            was_preempted = req.status == RequestStatus.PREEMPTED
             if req.num_output_placeholders:
                 req.num_output_placeholders = max(0, req.num_output_placeholders - len(new_ids))
             for n, tok in enumerate(new_ids, 1):
@@ -533,7 +535,7 @@ class Scheduler(SchedulerInterface):
                 finished = True
             if finished:
                 kv_params = self._free_request(req)
-                stopped.append(req)
+                (stopped_preempted if was_preempted else stopped).append(req)
 
             new_lp = mro.logprobs.slice(idx, idx + 1) if (mro.logprobs and new_ids and idx is not None
                                                            and sp_logprobs(req)) else None
@@ -557,6 +559,10 @@ class Scheduler(SchedulerInterface):
         if stopped:
             gone = set(id(r) for r in stopped)
             self.running = [r for r in self.running if id(r) not in gone]
+        if stopped_preempted:
+            # the victim went back to the waiting queue while its last token was still in flight: take it out
+            # again, or the next schedule() would admit a finished request
+            self.waiting.remove_requests(stopped_preempted)
 
         self._update_from_kv_xfer_finished(mro)
 
