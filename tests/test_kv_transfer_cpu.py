@@ -4,6 +4,8 @@ instance imports it and must continue with exactly the tokens of a single-instan
 import os
 import socket
 
+import time
+
 import pytest
 
 from tests.test_e2e_cpu import _save_tiny
@@ -165,7 +167,7 @@ def test_pull_with_another_tensor_parallel_degree(ptp, dtp):
         prods.append(c)
     remote = [7, 2, 9]
     local = [1, 5, 3]
-    token = prods[0]._sign("", remote)
+    token = prods[0]._sign("n0", int(time.time()) + 600, remote)
     try:
         for r in range(dtp):
             c, run, _ = _fake_side(dtp, r, "d", port)
@@ -200,9 +202,16 @@ def test_forged_transfer_parameters_are_refused():
         views[0][0].fill_(7)
     d, _, _ = _fake_side(1, 0, "d", port)
     good = [3, 4]
-    token = p._sign("", good)
+    token = p._sign("n1", int(time.time()) + 600, good)
+    expired = p._sign("n2", int(time.time()) - 5, good)
+    with p._lock:
+        p._nonce_of["freed"] = "n3"
+        p._revoke("freed")                      # the export "n3" was released: its token is dead
+    revoked = p._sign("n3", int(time.time()) + 600, good)
     try:
         cases = [
+            RecvSpec([1, 2], good, "127.0.0.1", port, "E", expired, good, 0),          # token past its expiry
+            RecvSpec([1, 2], good, "127.0.0.1", port, "E", revoked, good, 0),          # blocks already released
             RecvSpec([1, 2], [5, 6], "127.0.0.1", port, "E", token, [5, 6], 0),        # other blocks, stolen token
             RecvSpec([1, 2], good, "127.0.0.1", port, "E", "0" * 64, good, 0),         # no valid token
             RecvSpec([1, 2], [3, 99], "127.0.0.1", port, "E", token, [3, 99], 0),      # remote id out of range
@@ -407,3 +416,82 @@ def test_host_offload_index_evicts_least_recently_used():
     c.update_state_after_alloc(req, [11, 12, 13], 8)
     m = step()
     assert [blk for _, blk in m.loads] == [11, 12] and not m.stores
+
+
+def test_host_offload_keys_blocks_by_adapter_and_salt():
+    """Equal prompts computed under different LoRA adapters, or carrying different cache salts, must not share host
+    blocks: the index hashes the adapter id and the salt with the tokens, like the device prefix cache does."""
+    from vllm_distributed_amd.parallel.kv_transfer.host_offload import HostOffloadConnector
+    cfg = SimpleNamespace(kv_transfer_config=SimpleNamespace(kv_connector_extra_config={"host_blocks": 16}),
+                          cache_config=SimpleNamespace(block_size=4, prefix_caching_hash_algo="builtin"))
+    c = HostOffloadConnector(cfg, KVConnectorRole.SCHEDULER)
+    toks = list(range(100, 109))
+
+    def req(rid, lora=None, salt=None):
+        return SimpleNamespace(request_id=rid, prompt_token_ids=toks, mm_inputs=None, cache_salt=salt,
+                               lora_request=SimpleNamespace(lora_int_id=lora) if lora else None)
+
+    def prefill(r, blocks):
+        assert c.get_num_new_matched_tokens(r, 0)[0] == 0
+        so = SimpleNamespace(
+            scheduled_new_reqs=[SimpleNamespace(req_id=r.request_id, prompt_token_ids=toks, block_ids=blocks,
+                                                num_computed_tokens=0)],
+            scheduled_cached_reqs=SimpleNamespace(req_ids=[], resumed_from_preemption=[], new_block_ids=[],
+                                                  num_computed_tokens=[]),
+            num_scheduled_tokens={r.request_id: len(toks)}, finished_req_ids=set())
+        return c.build_connector_meta(so)
+    assert len(prefill(req("plain"), [1, 2, 3]).stores) == 2
+    assert len(prefill(req("lora1", lora=1), [4, 5, 6]).stores) == 2          # not served by the plain blocks
+    assert len(prefill(req("lora2", lora=2), [7, 8, 9]).stores) == 2
+    assert len(prefill(req("salted", salt="s1"), [10, 11, 12]).stores) == 2
+    assert len(c.index) == 8
+    # the same identity does hit
+    assert c.get_num_new_matched_tokens(req("lora1-again", lora=1), 0) == (8, False)
+    assert c.get_num_new_matched_tokens(req("salted-again", salt="s1"), 0) == (8, False)
+    assert c.get_num_new_matched_tokens(req("other-salt", salt="s2"), 0) == (0, False)
+    assert c.get_num_new_matched_tokens(req("plain-again"), 0) == (8, False)
+
+
+def test_push_begin_needs_the_deployment_key_and_owns_its_transfer():
+    """PUT_BEGIN is refused without a MAC made with the deployment's auth_key; PUT_DATA / PUT_END / PUT_ABORT for a
+    transfer are honoured only on the connection that began it, and a second connection cannot take over its id."""
+    import hashlib
+    import hmac as _hmac
+
+    from vllm_distributed_amd.parallel.kv_transfer.push import XgmiPushConnector
+
+    class Conn:
+        def __init__(self, msgs):
+            self.msgs, self.sent = list(msgs), []
+
+        def recv(self):
+            if not self.msgs:
+                raise EOFError
+            return self.msgs.pop(0)
+
+        def send(self, x):
+            self.sent.append(x)
+
+    class Pool:
+        def __init__(self):
+            self.freed = []
+
+        def alloc(self, n):
+            return [("host", i) for i in range(n)]
+
+        def free(self, slots):
+            self.freed.append(slots)
+    import threading
+    c = XgmiPushConnector.__new__(XgmiPushConnector)
+    c._push_key, c._lock, c._rx, c.pool = b"secret", threading.Lock(), {}, Pool()
+    mac = _hmac.new(b"secret", b"put|t1", hashlib.sha256).hexdigest()
+    bad = Conn([("PUT_BEGIN", "t1", 2, "0" * 64), ("PUT_BEGIN", "t1", 2)])
+    c._serve_conn(bad)
+    assert bad.sent == [None, None] and not c._rx
+    owner = Conn([("PUT_BEGIN", "t1", 2, mac)])
+    c._serve_conn(owner)
+    assert owner.sent == [[("host", 0), ("host", 1)]] and "t1" in c._rx
+    thief = Conn([("PUT_BEGIN", "t1", 2, mac), ("PUT_END", "t1"), ("PUT_ABORT", "t1"), ("PUT_DATA", "t1", 0, {})])
+    c._serve_conn(thief)
+    assert thief.sent == [None, False]                    # begin refused (id in use), data refused
+    assert c._rx["t1"]["complete"] is False and not c.pool.freed

@@ -231,6 +231,29 @@ def test_streamed_safetensors_loader(tmp_path):
     assert outs[0] == outs[1] == outs[2]
 
 
+def test_streamed_safetensors_tensors_survive_later_windows(tmp_path):
+    """Tensors yielded by the streaming reader are kept by weight loaders (packed 4-bit triples wait for their
+    partners, multimodal loaders collect whole sub-models): with windows far smaller than the checkpoint, every tensor
+    held until the END of the iteration must still equal the file's contents."""
+    import torch
+    from safetensors.torch import save_file
+
+    from vllm_distributed_amd.models.loader import streamed_safetensors_iterator
+    g = torch.Generator().manual_seed(1)
+    want = {f"t{i}": torch.randn(257, 131, generator=g) for i in range(24)}        # 24 x 134 KB, windows of 256 KB
+    save_file(want, str(tmp_path / "many.safetensors"))
+    held = dict(streamed_safetensors_iterator([str(tmp_path / "many.safetensors")], concurrency=3,
+                                              window_bytes=256 << 10))
+    assert set(held) == set(want)
+    for k, v in want.items():
+        assert torch.equal(held[k], v), k
+    # views (zero_copy) are only good until the next window: the opt-in exists, and a consumer that copies at once is fine
+    got = {k: v.clone() for k, v in streamed_safetensors_iterator([str(tmp_path / "many.safetensors")], concurrency=3,
+                                                                  window_bytes=256 << 10, zero_copy=True)}
+    for k, v in want.items():
+        assert torch.equal(got[k], v), k
+
+
 def test_tensorizer_loader_round_trip(tmp_path):
     """Serialise a loaded model the way it sits in memory, start a second engine from that one file through the
     native streamed reader with hash verification: same greedy tokens; a flipped byte is caught."""

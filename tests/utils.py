@@ -18,12 +18,13 @@ EOS = 50256
 
 def make_config(max_num_seqs=16, max_num_batched_tokens=8192, max_model_len=None, block_size=16,
                 enable_prefix_caching=False, chunked=True, policy="fcfs", num_spec=0,
-                long_prefill_token_threshold=0, kv_transfer=None, pp=1, **kw) -> VllmConfig:
+                long_prefill_token_threshold=0, kv_transfer=None, pp=1, async_scheduling=False, **kw) -> VllmConfig:
     mc = ModelConfig(model="facebook/opt-125m", dtype="float16", skip_tokenizer_init=True,
                      max_model_len=max_model_len)
     sc = SchedulerConfig(max_num_seqs=max_num_seqs, max_num_batched_tokens=max_num_batched_tokens,
                          max_model_len=mc.max_model_len, enable_chunked_prefill=chunked, policy=policy,
-                         long_prefill_token_threshold=long_prefill_token_threshold)
+                         long_prefill_token_threshold=long_prefill_token_threshold,
+                         async_scheduling=async_scheduling)
     cc = CacheConfig(block_size=block_size, enable_prefix_caching=enable_prefix_caching)
     spec = SpeculativeConfig(method="ngram", num_speculative_tokens=num_spec) if num_spec else None
     return VllmConfig(model_config=mc, scheduler_config=sc, cache_config=cc,

@@ -128,11 +128,16 @@ def read_safetensors_header(path: str) -> tuple[dict, int]:
 
 
 def streamed_safetensors_iterator(files: list[str], concurrency: int = 16, window_bytes: int = 1 << 30,
-                                  pin: bool = False) -> Iterator[tuple[str, torch.Tensor]]:
+                                  pin: bool = False, zero_copy: bool = False) -> Iterator[tuple[str, torch.Tensor]]:
     """Tensors of safetensors files read by the native range reader (runtime/csrc/weight_reader.cpp): a window of
     tensors at a time, by ``concurrency`` threads, into one of two (pinned) host buffers, the next window being read
-    while the caller consumes this one.  A yielded tensor stays valid until the caller has taken every tensor of
-    the following window.  Role of the reference's fastsafetensors / Run:ai streamer loaders
+    while the caller consumes this one.
+
+    Lifetime: the read of window k + 1 is started when window k is handed out and lands in the buffer that held
+    window k - 1, so a VIEW into a buffer is only good until the first tensor of the next window is requested.  By
+    default every tensor is therefore yielded as its own copy, safe to keep for as long as the caller likes (weight loaders park tensors: packed-weight triples, per-module lists).  A caller
+    that consumes each tensor before asking for the next may pass ``zero_copy=True`` and receive views.
+    Role of the reference's fastsafetensors / Run:ai streamer loaders
     (vllm/model_executor/model_loader/weight_utils.py:480-560, runai_streamer_loader.py)."""
     import ctypes
     from concurrent.futures import ThreadPoolExecutor
@@ -183,7 +188,8 @@ def streamed_safetensors_iterator(files: list[str], concurrency: int = 16, windo
             if k + 1 < len(windows):
                 fut = pool.submit(fill, k + 1)
             for name, dtype, shape, _, nb, off in items:
-                yield name, buf[off:off + nb].view(dtype).view(shape)
+                t = buf[off:off + nb].view(dtype).view(shape)
+                yield name, (t if zero_copy else t.clone())
 
 
 def pt_iterator(files: list[str]) -> Iterator[tuple[str, torch.Tensor]]:

@@ -25,6 +25,7 @@ from __future__ import annotations
 
 from collections import OrderedDict
 from dataclasses import dataclass, field
+from typing import Optional
 
 import torch
 
@@ -58,6 +59,7 @@ class HostOffloadConnector(KVConnectorBase):
         self._pinned: set[int] = set()                              # slots read by a load not yet issued
         self._storing: dict[str, list] = {}                         # req id -> [prompt tokens, block ids]
         self._matched: dict[str, tuple[int, list[int]]] = {}        # req id -> (first block index, hashes found)
+        self._identities: dict[str, tuple] = {}                     # req id -> (lora id, cache salt) when either is set
         self.stats = {"hit_blocks": 0, "stored_blocks": 0, "evicted_blocks": 0}
         # worker side
         self.runner = None
@@ -136,10 +138,21 @@ class HostOffloadConnector(KVConnectorBase):
         self._staged = []
 
     # ---- scheduler --------------------------------------------------------------------------------------------
-    def _prompt_hashes(self, token_ids) -> list[int]:
-        """Chained hashes of the full blocks of the prompt that may be reused (the last token is always computed)."""
+    @staticmethod
+    def _identity(request) -> Optional[tuple]:
+        """What besides the tokens decides a block's contents: the LoRA adapter that computed it and the request's
+        cache salt (the same extra keys as the device prefix cache, sched/kv_cache_utils.generate_extra_keys)."""
+        lora = getattr(request, "lora_request", None)
+        salt = getattr(request, "cache_salt", None)
+        if lora is None and not salt:
+            return None
+        return (lora.lora_int_id if lora is not None else 0, salt or "")
+
+    def _prompt_hashes(self, token_ids, identity: Optional[tuple] = None) -> list[int]:
+        """Chained hashes of the full blocks of the prompt that may be reused (the last token is always computed).
+        ``identity`` seeds the chain, so equal prompts under different adapters or salts never share blocks."""
         n = (len(token_ids) - 1) // self.block_size
-        out, parent = [], None
+        out, parent = [], (self.hash_fn(("host_offload", identity)) if identity is not None else None)
         for i in range(n):
             h = hash_block_tokens(self.hash_fn, parent, token_ids[i * self.block_size:(i + 1) * self.block_size])
             out.append(h.hash_value)
@@ -150,7 +163,10 @@ class HostOffloadConnector(KVConnectorBase):
         self._ensure_slots()
         if getattr(request, "mm_inputs", None):
             return 0, False                             # placeholder tokens do not identify multimodal content
-        hashes = self._prompt_hashes(request.prompt_token_ids)
+        ident = self._identity(request)
+        if ident is not None:
+            self._identities[request.request_id] = ident     # the store side sees only NewRequestData
+        hashes = self._prompt_hashes(request.prompt_token_ids, ident)
         i0 = num_computed_tokens // self.block_size
         n = 0
         while i0 + n < len(hashes) and hashes[i0 + n] in self.index:
@@ -208,12 +224,13 @@ class HostOffloadConnector(KVConnectorBase):
         for rid in list(self._storing):
             if rid in so.finished_req_ids:
                 del self._storing[rid]
+                self._identities.pop(rid, None)
                 continue
             n = so.num_scheduled_tokens.get(rid)
             if n is None or computed.get(rid, 0) + n < len(self._storing[rid][0]):
                 continue
             toks, ids = self._storing.pop(rid)          # the step that completes the prompt: store what is new
-            for j, h in enumerate(self._prompt_hashes(toks)):
+            for j, h in enumerate(self._prompt_hashes(toks, self._identities.pop(rid, None))):
                 if h in self.index:
                     self.index.move_to_end(h)
                     continue

@@ -31,6 +31,8 @@ import os
 import queue
 import re
 import socket
+import hashlib
+import hmac
 import threading
 import time
 import uuid
@@ -126,6 +128,8 @@ class XgmiPushConnector(XgmiConnector):
         self.host_pool_bytes = int(float(xc.get("mem_pool_size_gb", 4)) * (1 << 30))
         self.landing_slots = xc.get("landing_slots")             # device slots by count instead of by bytes
         self.is_consumer = kt.kv_role in ("kv_consumer", "kv_both")
+        pk = xc.get("push_key")
+        self._push_key: Optional[bytes] = str(pk).encode() if pk else None    # shared by every instance of the deployment
         # scheduler side
         self._targets: dict[str, tuple[str, int, str]] = {}      # producer: rid -> (host, port, transfer id)
         self._blocks: dict[str, list[int]] = {}                  # producer: rid -> block ids so far
@@ -269,13 +273,34 @@ class XgmiPushConnector(XgmiConnector):
         return info
 
     # ---- consumer: receiving ------------------------------------------------------------------------------
+    def _put_mac(self, tid: str) -> str:
+        """Proof that the sender of a PUT_BEGIN knows the deployment's ``push_key`` (connector option, the same on
+        the prefill and the decode instances; the per-engine ``auth_key`` cannot serve: it is private to the
+        exporting engine).  With a key configured, a peer that merely reaches the port can neither take landing
+        slots nor name a transfer."""
+        return hmac.new(self._push_key or b"", b"put|" + tid.encode(), hashlib.sha256).hexdigest()
+
     def _serve_conn(self, c: Connection) -> None:
+        mine: set[str] = set()         # transfers begun on THIS connection: only it may feed, end or abort them
         try:
             while True:
                 msg = c.recv()
                 kind = msg[0]
                 if kind == "PUT_BEGIN":
                     tid, n = str(msg[1]), int(msg[2])
+                    mac = str(msg[3]) if len(msg) > 3 else ""
+                    with self._lock:
+                        taken = tid in self._rx and tid not in mine
+                    if self._push_key is None and not getattr(self, "_warned_open", False):
+                        self._warned_open = True
+                        logger.warning("no push_key configured: KV pushes are accepted from any peer that can reach "
+                                       "the side-channel port (set kv_connector_extra_config['push_key'] on every "
+                                       "instance)")
+                    authentic = self._push_key is None or hmac.compare_digest(self._put_mac(tid), mac)
+                    if not authentic or taken:
+                        logger.warning("refused a KV push (%s)", "transfer id in use" if taken else "bad credentials")
+                        c.send(None)
+                        continue
                     slots = self.pool.alloc(n) if self.pool is not None and 0 < n <= 1 << 20 else None
                     with self._lock:
                         old = self._rx.pop(tid, None)
@@ -283,21 +308,25 @@ class XgmiPushConnector(XgmiConnector):
                             self.pool.free(old["slots"])
                         self._rx[tid] = {"slots": slots, "complete": False, "refused": slots is None,
                                          "since": time.time()}
+                    mine.add(tid)
                     c.send(slots)
                 elif kind == "PUT_DATA":                     # (tid, first block index, {layer: [bytes per part]})
                     tid, b0, data = str(msg[1]), int(msg[2]), msg[3]
-                    st = self._rx.get(tid)
+                    with self._lock:
+                        st = self._rx.get(tid) if tid in mine else None
                     ok = st is not None and st.get("slots") is not None
                     if ok:
                         ok = self._store(st["slots"], b0, data)
                     c.send(bool(ok))
                 elif kind == "PUT_END":
                     with self._lock:
-                        st = self._rx.get(str(msg[1]))
+                        st = self._rx.get(str(msg[1])) if str(msg[1]) in mine else None
                         if st is not None:
                             st["complete"] = True
                 elif kind == "PUT_ABORT":
-                    self._drop_rx(str(msg[1]))
+                    if str(msg[1]) in mine:
+                        mine.discard(str(msg[1]))
+                        self._drop_rx(str(msg[1]))
                 else:
                     self._serve_one(c, msg)
         except (EOFError, OSError):
@@ -322,6 +351,7 @@ class XgmiPushConnector(XgmiConnector):
                     self._done_votes.pop(rid, None)
                     self._done_sending.add(rid)
                     self._expiry.pop(rid, None)
+                    self._revoke(rid)
                 else:
                     self._done_votes[rid] = got
 
@@ -372,7 +402,7 @@ class XgmiPushConnector(XgmiConnector):
         if not land or int(land["slot_bytes"]) != self.slot_bytes:
             raise ValueError("the peer has no landing pool for this cache layout")
         with peer.lock:
-            peer.conn.send(("PUT_BEGIN", spec.transfer_id, spec.num_blocks_total))
+            peer.conn.send(("PUT_BEGIN", spec.transfer_id, spec.num_blocks_total, self._put_mac(spec.transfer_id)))
             slots = peer.conn.recv()
         st = self._tx[spec.transfer_id] = {"peer": peer, "slots": slots, "rid": rid, "events": [], "failed": slots is None}
         if slots is None:

@@ -460,6 +460,9 @@ class GroupCoordinator:
         if self.ca_comm is not None:
             self.ca_comm.close()
             self.ca_comm = None
+        if self.ca_comm_async is not None:        # created lazily by the first all_reduce_async: same IPC mappings
+            self.ca_comm_async.close()
+            self.ca_comm_async = None
         if self.far_comm is not None:
             self.far_comm.close()
             self.far_comm = None
