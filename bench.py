@@ -14,13 +14,24 @@ round with the number of rounds really timed in "steps", so the last line of
 stdout is the result whenever the process ends.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 3 --warmup 1          # starts its own 8 ranks (see below)
+    python bench.py --gpus 8 --pp 2                         # PP 2 x TP 4 through the multi-process executor
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29511 bench.py --gpus 8 --steps 3 --warmup 1
+
+Started with --gpus N > 1 and no WORLD_SIZE in the environment, the process (which has not touched the GPU)
+starts ``torch.distributed.run`` with N ranks of this same file as a child, relays the child's stdout (rank 0's
+JSON lines) and exits with the child's code.  Under ``--pp P`` one engine drives all N GPUs through the
+multi-process executor (P pipeline stages of N / P tensor-parallel ranks); if that is started under
+torch.distributed.run, rank 0 runs the engine and the other ranks wait.
 """
 import argparse
 import json
 import os
+import signal
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -73,9 +84,36 @@ def run_disagg(a) -> None:
     }), flush=True)
 
 
+def launch_ranks(n: int) -> int:
+    """Run this file as ``n`` ranks under torch.distributed.run (a child process: this one has not initialised the
+    GPU and stays that way), pass the child's stdout through and return its exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"starting {n} ranks: {' '.join(cmd[1:9])} ...")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+
+    def forward(sig, _frame):                      # the driver's time limit must reach every rank
+        try:
+            os.killpg(child.pid, sig)
+        except ProcessLookupError:
+            pass
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, forward)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--pp", type=int, default=1,
+                    help="pipeline stages (tensor parallel degree = gpus / pp); runs through the multi-process "
+                         "executor of one engine")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="llama-3-70b")
@@ -108,6 +146,11 @@ def main() -> None:
     a = ap.parse_args()
     if a.disagg:
         return run_disagg(a)
+    if a.pp < 1 or a.gpus % a.pp:
+        raise SystemExit(f"--pp {a.pp} does not divide --gpus {a.gpus}")
+    launched = "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and a.pp == 1 and not launched:
+        sys.exit(launch_ranks(a.gpus))             # nothing above has touched the GPU
 
     import torch
     import torch.distributed as dist
@@ -115,24 +158,44 @@ def main() -> None:
     from vllm_distributed_amd.inputs import TokensPrompt
     from vllm_distributed_amd.sampling_params import RequestOutputKind
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    if a.pp > 1:
+        # one engine, multi-process executor: its own worker processes, one per GPU.  Under a launcher rank 0 runs
+        # it and the others only keep the launcher's rendezvous alive.
+        if world > 1:
+            import datetime
+            dist.init_process_group("gloo", timeout=datetime.timedelta(hours=3))
+            if rank != 0:
+                dist.barrier()
+                dist.destroy_process_group()
+                return
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                      "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+                os.environ.pop(k, None)            # the executor's workers make their own rendezvous
+        world_sync = world
+        world = 1
+    elif world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
+    else:
+        world_sync = 1
+    tp = a.gpus // a.pp
     kw = {}
     if a.quantization:
         kw["quantization"] = a.quantization
     if a.expert_parallel:
         kw["enable_expert_parallel"] = True
-    if world > 1:
+    if a.pp > 1:
+        kw["distributed_executor_backend"] = "mp"
+        kw["pipeline_parallel_size"] = a.pp
+    elif world > 1:
         kw["distributed_executor_backend"] = "external_launcher"
         if not a.no_async_tp:
             # prefill chunks run as two micro-batches whose TP all-reduces overlap with each other's GEMMs
             kw["compilation_config"] = {"enable_async_tp": True}
+    on_gpu_here = a.pp == 1                        # with the multi-process executor this process never uses the GPU
     llm = LLM(model=a.model, load_format="dummy", skip_tokenizer_init=True, dtype="bfloat16",
-              tensor_parallel_size=a.gpus, max_model_len=a.input_len + a.output_len + 16,
+              tensor_parallel_size=tp, max_model_len=a.input_len + a.output_len + 16,
               max_num_seqs=max(a.batch, 8), max_num_batched_tokens=a.max_num_batched_tokens,
               enable_prefix_caching=False, gpu_memory_utilization=a.gpu_memory_utilization,
               enforce_eager=a.enforce_eager, seed=0, hf_overrides=a.hf_overrides,
@@ -152,7 +215,10 @@ def main() -> None:
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu_here:
+            torch.cuda.synchronize()
+        # multi-process executor: a round ends when every request's last token has come back from the workers,
+        # which read it off the device themselves; nothing is left in flight to wait for
 
     def elapsed() -> float:
         """Seconds since process start, the same number on every rank (the slowest rank's clock)."""
@@ -202,11 +268,26 @@ def main() -> None:
     # ---- timed rounds: each bracketed by barrier + device sync; a full JSON line after every round ----
     dt, steps_done, ttfts, itls = 0.0, 0, [], []
 
+    def comm_fields() -> dict:
+        """What the collectives really ran on (rank 0's tensor-parallel group): ranks under the RCCL communicator,
+        ranks of the peer-memory arena, all-reduce calls per path."""
+        try:
+            info = llm.collective_rpc("comm_info")[0] or {}
+            tpi = info.get("tp") or {}
+            ppi = info.get("pp") or {}
+            return {"rccl_ranks": tpi.get("rccl_ranks", 0), "peer_arena_ranks": tpi.get("peer_arena_ranks", 0),
+                    "allreduce_path": tpi.get("allreduce_path", {}), "tp_world": tpi.get("world_size", 1),
+                    "pp_world": ppi.get("world_size", 1)}
+        except Exception as e:   # noqa: BLE001 - the result line must still be printed
+            return {"comm_info_error": repr(e)}
+
     def report():
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        d = dt
         if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        d = float(t.item())
+            d = float(t.item())
+        comm = comm_fields()                       # a collective_rpc: every rank makes it
         if rank != 0:
             return
         total_out = a.batch * a.output_len * steps_done
@@ -223,8 +304,10 @@ def main() -> None:
             "total_tokens_per_s": round(a.batch * (a.input_len + a.output_len) * steps_done / d, 1),
             "requested_steps": a.steps, "requested_warmup": a.warmup, "time_budget_s": budget,
             "step_definition": f"one serving round: {a.batch} requests admitted at once and run to completion",
+            **comm,
             "config": {"model": a.model, "global_batch": a.batch, "seq_len": a.input_len + a.output_len,
-                       "input_len": a.input_len, "output_len": a.output_len, "parallelism": f"tp{a.gpus}"}}),
+                       "input_len": a.input_len, "output_len": a.output_len,
+                       "parallelism": f"tp{tp}" if a.pp == 1 else f"pp{a.pp}xtp{tp}"}}),
             flush=True)
 
     for k in range(a.steps):
@@ -243,6 +326,9 @@ def main() -> None:
         itls += g
         report()
     llm.shutdown()
+    if a.pp > 1 and world_sync > 1:
+        dist.barrier()                             # releases the ranks that only waited
+        dist.destroy_process_group()
     if world > 1 and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

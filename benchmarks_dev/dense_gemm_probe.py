@@ -130,10 +130,27 @@ def prefill(model: str) -> None:
         print(f"M={M:>6}    layer: lib {tl * 1e6:8.0f} us   dense {td * 1e6:8.0f} us", flush=True)
 
 
+def _tuned_library(on: bool) -> None:
+    """Library GEMM with the committed algorithm selections (what the engine runs) or with its own heuristic."""
+    import torch.cuda.tunable as tn
+    if on:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vllm_distributed_amd", "ops",
+                            "tuned", "gfx950_gemm.csv")
+        tn.enable(True)
+        tn.tuning_enable(False)
+        tn.record_untuned_enable(False)
+        if not tn.read_file(path):
+            print("selection table rejected (library versions differ)", flush=True)
+            tn.enable(False)
+    else:
+        tn.enable(False)
+
+
 def decode(model: str) -> None:
-    print(f"\n{model} decode: us per call  lib / dense wt4 / dense wt2 / best   (weight stream of best)")
-    for M in (16, 32, 64, 128, 192, 256):
-        tot = [0.0, 0.0]
+    print(f"\n{model} decode: us per call  library (heuristic) / library (selection table) / in-tree wt4 / wt2   "
+          f"(weight stream of the in-tree best); gate_up rows: library + act_and_mul kernel against the fused epilogue")
+    for M in (1, 4, 8, 16, 32, 64, 128, 192, 256):
+        tot = [0.0, 0.0, 0.0]
         for name, N_, K in SHAPES[model]:
             nbytes = N_ * K * 2
             copies = max(2, -(-(600 << 20) // nbytes))
@@ -141,18 +158,75 @@ def decode(model: str) -> None:
             x = rnd(M, K)
             epi = "gate_up" if name == "gate_up" else "plain"
             if epi == "gate_up":
-                t0 = timeit(lambda i: ops.silu_and_mul(torch.nn.functional.linear(x, ws[i])), copies)
+                lib = lambda i: ops.silu_and_mul(torch.nn.functional.linear(x, ws[i]))   # noqa: E731
             else:
-                t0 = timeit(lambda i: torch.nn.functional.linear(x, ws[i]), copies)
+                lib = lambda i: torch.nn.functional.linear(x, ws[i])                    # noqa: E731
+            t0 = timeit(lib, copies)
+            _tuned_library(True)
+            t0t = timeit(lib, copies)
+            _tuned_library(False)
             t4 = timeit(lambda i: ops.dense_gemm(x, ws[i], epilogue=epi, wt=4), copies)
             t2 = timeit(lambda i: ops.dense_gemm(x, ws[i], epilogue=epi, wt=2), copies)
             tb = min(t4, t2)
-            print(f"M={M:>4} {name:>8}: {t0 * 1e6:>7.1f} {t4 * 1e6:>7.1f} {t2 * 1e6:>7.1f} {tb * 1e6:>7.1f}   "
+            print(f"M={M:>4} {name:>8}: {t0 * 1e6:>7.1f} {t0t * 1e6:>7.1f} {t4 * 1e6:>7.1f} {t2 * 1e6:>7.1f}   "
                   f"{nbytes / tb / 1e12:.2f} TB/s", flush=True)
             tot[0] += t0
-            tot[1] += tb
+            tot[1] += t0t
+            tot[2] += tb
             del ws
-        print(f"M={M:>4}    layer: {tot[0] * 1e6:>7.1f} {tot[1] * 1e6:>7.1f}", flush=True)
+        print(f"M={M:>4}    layer: {tot[0] * 1e6:>7.1f} {tot[1] * 1e6:>7.1f} {tot[2] * 1e6:>7.1f}", flush=True)
+
+
+def chain(model: str) -> None:
+    """One decoder layer's four GEMMs back to back with real data dependencies, over enough layers (different
+    weights each) to exceed the Infinity Cache, inside a captured graph as the engine runs them: microseconds per layer."""
+    (_, nq, k), (_, no, _), (_, ng, _), (_, nd, kd) = SHAPES[model]
+    layers = max(2, -(-(700 << 20) // ((nq + no + ng) * k * 2 + nd * kd * 2)))
+    W = [[rnd(nq, k, scale=k ** -0.5), rnd(no, k, scale=k ** -0.5), rnd(ng, k, scale=k ** -0.5),
+          rnd(nd, kd, scale=kd ** -0.5)] for _ in range(layers)]
+    print(f"\n{model} layer chain ({layers} layers of weights): us per layer  library (selection table) / in-tree / "
+          f"in-tree with the library's gate_up / in-tree without K splits")
+
+    def run(x, mode):
+        for wq, wo, wg, wd in W:
+            if mode == "lib":
+                q = torch.nn.functional.linear(x, wq)
+                o = torch.nn.functional.linear(q[:, :k], wo)
+                h = ops.silu_and_mul(torch.nn.functional.linear(o, wg))
+                x = torch.nn.functional.linear(h, wd)
+            else:
+                sp = 1 if mode == "nosplit" else 0
+                q = ops.dense_gemm(x, wq, splits=sp)
+                o = ops.dense_gemm(q[:, :k], wo, splits=sp)
+                if mode == "mixed":
+                    h = ops.silu_and_mul(torch.nn.functional.linear(o, wg))
+                else:
+                    h = ops.dense_gemm(o, wg, epilogue="gate_up", splits=sp)
+                x = ops.dense_gemm(h, wd, splits=sp)
+        return x
+    _tuned_library(True)
+    for M in (8, 64, 128, 192, 256):
+        res = []
+        for mode in ("lib", "tree", "mixed", "nosplit"):
+            x = rnd(M, k)
+            run(x, mode)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                y = run(x, mode)
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            res.append(a.elapsed_time(b) / 5 / layers * 1e3)
+            del g, y
+        print(f"M={M:>4}: " + "  ".join(f"{t:7.1f}" for t in res), flush=True)
+    _tuned_library(False)
 
 
 if __name__ == "__main__":
@@ -162,5 +236,7 @@ if __name__ == "__main__":
         sys.exit(1 if check() else 0)
     elif mode == "prefill":
         prefill(which)
+    elif mode == "chain":
+        chain(which)
     else:
         decode(which)

@@ -270,3 +270,150 @@ def test_audio_transcription_endpoint(tmp_path):
     assert b.status_code == 200 and b.text == a.json()["text"]            # same clip, greedy
     assert long.status_code == 200 and long.json()["task"] == "translate" and long.json()["duration"] == 31.0
     assert bad.status_code == 400 and "xx" in bad.json()["message"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# streamed reasoning and tool calls: a character-level tokenizer lets the grammar steer the random tiny model into
+# real JSON, so the whole path (structured output -> engine -> detokenizer -> incremental parsers -> SSE) runs
+# ---------------------------------------------------------------------------------------------------------
+def _add_char_tokenizer(path):
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    chars = [chr(c) for c in range(32, 127)]
+    vocab = {ch: i + 10 for i, ch in enumerate(chars)}       # ids 1 / 2 are the model config's bos / eos
+    vocab.update({"<unk>": 0, "<s>": 1, "</s>": 2, "<pad>": 3})
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Split("", "isolated")
+    tok.decoder = decoders.Fuse()
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>",
+                                   pad_token="<pad>")
+    fast.chat_template = ("{% for m in messages %}{{ m['role'] }}:{{ m['content'] }};{% endfor %}"
+                          "{% if add_generation_prompt %}assistant:{% endif %}")
+    fast.save_pretrained(path)
+
+
+@pytest.fixture(scope="module")
+def char_servers(tmp_path_factory):
+    """One engine, two front ends: tools through the hermes parser; reasoning through the deepseek_r1 parser."""
+    from vllm_distributed_amd.entrypoints.openai.api_server import build_app, make_arg_parser
+    from vllm_distributed_amd.engine.arg_utils import AsyncEngineArgs
+    from vllm_distributed_amd.engine.async_llm import AsyncLLM
+    tmp = str(tmp_path_factory.mktemp("srvchar"))
+    path, _ = _save_tiny(tmp, "llama")
+    _add_char_tokenizer(path)
+    base = ["--model", path, "--dtype", "float32", "--device", "cpu", "--max-model-len", "256", "--max-num-seqs", "8",
+            "--max-num-batched-tokens", "64", "--served-model-name", "tiny"]
+    args_t = make_arg_parser().parse_args(base + ["--enable-auto-tool-choice", "--tool-call-parser", "hermes"])
+    args_r = make_arg_parser().parse_args(base + ["--reasoning-parser", "deepseek_r1"])
+    engine = AsyncLLM.from_engine_args(AsyncEngineArgs.from_cli_args(args_t))
+    loop = asyncio.new_event_loop()
+    yield {"tools": (build_app(args_t, engine), loop), "reason": (build_app(args_r, engine), loop)}
+    engine.shutdown()
+    loop.close()
+
+
+async def _sse(c, body):
+    chunks = []
+    async with c.stream("POST", "/v1/chat/completions", json=dict(body, stream=True)) as s:
+        async for line in s.aiter_lines():
+            if line.startswith("data: ") and line != "data: [DONE]":
+                chunks.append(json.loads(line[6:]))
+    return chunks
+
+
+TOOLS = [{"type": "function", "function": {"name": "get_weather", "description": "weather",
+                                           "parameters": {"type": "object",
+                                                          "properties": {"city": {"type": "string", "enum": ["Paris", "Rome"]},
+                                                                         "unit": {"type": "string", "enum": ["C", "F"]}},
+                                                          "required": ["city", "unit"]}}},
+         {"type": "function", "function": {"name": "get_time", "description": "time",
+                                           "parameters": {"type": "object",
+                                                          "properties": {"zone": {"type": "string", "enum": ["UTC", "CET"]}},
+                                                          "required": ["zone"]}}}]
+
+
+def test_required_tool_choice_streams_a_valid_call(char_servers):
+    """tool_choice="required": the reply is grammar-constrained to a call of one of the tools; streamed, the call's
+    id / name arrive first and the argument fragments concatenate to exactly the non-streamed arguments."""
+    async def f(c):
+        body = {"model": "tiny", "messages": [{"role": "user", "content": "weather?"}], "tools": TOOLS,
+                "tool_choice": "required", "parallel_tool_calls": False, "max_tokens": 120, "temperature": 0}
+        whole = (await c.post("/v1/chat/completions", json=body)).json()
+        ch = whole["choices"][0]
+        assert ch["finish_reason"] == "tool_calls", whole
+        call = ch["message"]["tool_calls"][0]
+        assert call["function"]["name"] in ("get_weather", "get_time") and not ch["message"].get("content")
+        args = json.loads(call["function"]["arguments"])
+        if call["function"]["name"] == "get_weather":
+            assert args["city"] in ("Paris", "Rome") and args["unit"] in ("C", "F")
+        else:
+            assert args["zone"] in ("UTC", "CET")
+        chunks = await _sse(c, body)
+        name, frags, first_tool_chunk, ids = None, [], None, set()
+        for k, d in enumerate(chunks):
+            for tc in d["choices"][0]["delta"].get("tool_calls", []):
+                assert tc["index"] == 0
+                first_tool_chunk = k if first_tool_chunk is None else first_tool_chunk
+                if tc.get("id"):
+                    ids.add(tc["id"])
+                    assert tc["type"] == "function" and name is None
+                    name = tc["function"]["name"]
+                if tc["function"].get("arguments"):
+                    assert name is not None, "arguments before the name"
+                    frags.append(tc["function"]["arguments"])
+            assert not d["choices"][0]["delta"].get("content")
+        assert name == call["function"]["name"] and len(ids) == 1
+        assert "".join(frags) == call["function"]["arguments"]
+        assert len(frags) >= 3, "the arguments were not streamed in pieces"
+        assert first_tool_chunk < len(chunks) - 3, "the call only appeared when generation was over"
+        assert chunks[-1]["choices"][0]["finish_reason"] == "tool_calls"
+    _run(char_servers["tools"], f)
+
+
+def test_named_tool_choice_streams_arguments(char_servers):
+    async def f(c):
+        body = {"model": "tiny", "messages": [{"role": "user", "content": "time?"}], "tools": TOOLS,
+                "tool_choice": {"type": "function", "function": {"name": "get_time"}}, "max_tokens": 60,
+                "temperature": 0}
+        whole = (await c.post("/v1/chat/completions", json=body)).json()
+        call = whole["choices"][0]["message"]["tool_calls"][0]
+        assert call["function"]["name"] == "get_time" and json.loads(call["function"]["arguments"])["zone"] in ("UTC", "CET")
+        chunks = await _sse(c, body)
+        frags = [tc["function"].get("arguments") or "" for d in chunks
+                 for tc in d["choices"][0]["delta"].get("tool_calls", [])]
+        names = [tc["function"].get("name") for d in chunks for tc in d["choices"][0]["delta"].get("tool_calls", [])
+                 if tc["function"].get("name")]
+        assert names == ["get_time"] and "".join(frags) == call["function"]["arguments"] and len(frags) >= 3
+    _run(char_servers["tools"], f)
+
+
+def test_auto_tool_choice_streams_plain_content(char_servers):
+    """"auto" with a parser configured: a reply without call syntax streams as ordinary content, chunk by chunk."""
+    async def f(c):
+        body = {"model": "tiny", "messages": [{"role": "user", "content": "hi"}], "tools": TOOLS, "tool_choice": "auto",
+                "max_tokens": 12, "temperature": 0}
+        whole = (await c.post("/v1/chat/completions", json=body)).json()
+        chunks = await _sse(c, body)
+        text = "".join(d["choices"][0]["delta"].get("content") or "" for d in chunks)
+        if not whole["choices"][0]["message"].get("tool_calls"):
+            assert text == (whole["choices"][0]["message"]["content"] or "")
+            assert sum(1 for d in chunks if d["choices"][0]["delta"].get("content")) >= 3
+    _run(char_servers["tools"], f)
+
+
+def test_reasoning_is_streamed_while_the_model_generates(char_servers):
+    """With a reasoning parser the stream must not wait for the end: reasoning_content deltas arrive token by token
+    (the random model never closes its thinking, so everything is reasoning) and add up to the non-streamed field."""
+    async def f(c):
+        body = {"model": "tiny", "messages": [{"role": "user", "content": "think"}], "max_tokens": 16, "temperature": 0}
+        whole = (await c.post("/v1/chat/completions", json=body)).json()
+        msg = whole["choices"][0]["message"]
+        chunks = await _sse(c, body)
+        pieces = [(k, d["choices"][0]["delta"]["reasoning_content"]) for k, d in enumerate(chunks)
+                  if d["choices"][0]["delta"].get("reasoning_content")]
+        assert len(pieces) >= 4, "reasoning was not streamed in pieces"
+        assert pieces[0][0] < len(chunks) - 4, "the first reasoning delta came only at the end"
+        assert all(not d["choices"][0]["delta"].get("content") for d in chunks[1:])
+        assert "".join(p for _, p in pieces).strip() == (msg.get("reasoning_content") or "").strip()
+        assert not msg.get("content")
+    _run(char_servers["reason"], f)

@@ -137,23 +137,36 @@ def test_rccl_wrapper_single_rank_and_graph_capture():
     comm.close()
 
 
-def test_bench_eight_ranks_on_one_gpu(tmp_path):
-    """The driver's multi-GPU launch of bench.py (torch.distributed.run, 8 ranks, external launcher, async
-    TP, peer-memory all-reduce inside decode graphs) rehearsed on ONE device with a shrunken Llama: the run
-    must finish, every timed round must print a JSON line, and the last line must carry the 8-rank shape."""
-    port = _free_port()
+def _bench(args, timeout=420):
+    env = dict(os.environ, VDA_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     over = {"num_hidden_layers": 2, "hidden_size": 1024, "intermediate_size": 2048, "num_attention_heads": 16,
             "num_key_value_heads": 8, "vocab_size": 32000}
-    env = dict(os.environ, VDA_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "8",
-           "--steps", "2", "--warmup", "1", "--model", "llama-3-8b", "--hf-overrides", json.dumps(over), "--batch", "16",
-           "--input-len", "128", "--output-len", "16", "--max-num-batched-tokens", "1024",
-           "--gpu-memory-utilization", "0.04", "--time-budget", "0"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), *args, "--steps", "2", "--warmup", "1",
+           "--model", "llama-3-8b", "--hf-overrides", json.dumps(over), "--batch", "16", "--input-len", "128",
+           "--output-len", "16", "--max-num-batched-tokens", "1024", "--gpu-memory-utilization", "0.04",
+           "--time-budget", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) >= 2, r.stdout[-1500:]
-    last = lines[-1]
+    return lines[-1]
+
+
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
+    """``python bench.py --gpus 8`` exactly as typed, no launcher around it: the process must start its own 8 ranks
+    (external launcher, async TP, peer-memory all-reduce inside decode graphs; rehearsed on ONE device with a
+    shrunken Llama), relay a JSON line per timed round and say in the last one what the collectives ran on."""
+    last = _bench(["--gpus", "8"])
     assert last["n_gpus"] == 8 and last["steps"] == 2 and last["value"] > 0
     assert last["config"]["parallelism"] == "tp8"
+    assert last["tp_world"] == 8 and last["peer_arena_ranks"] == 8
+    assert last["allreduce_path"]["peer_memory"] + last["allreduce_path"]["fused_norm"] > 0
+
+
+def test_bench_pipeline_parallel_on_one_gpu(tmp_path):
+    """``--gpus 2 --pp 2``: two pipeline stages through the multi-process executor of one engine."""
+    last = _bench(["--gpus", "2", "--pp", "2"])
+    assert last["n_gpus"] == 2 and last["steps"] == 2 and last["value"] > 0
+    assert last["config"]["parallelism"] == "pp2xtp1" and last["pp_world"] == 2

@@ -295,7 +295,7 @@ class ChatCompletionRequest(_SamplingMixin):
     max_completion_tokens: Optional[int] = None
     tools: Optional[list[ChatCompletionToolsParam]] = None
     tool_choice: Optional[Union[Literal["none", "auto", "required"], ChatCompletionNamedToolChoiceParam]] = "none"
-    parallel_tool_calls: Optional[bool] = False
+    parallel_tool_calls: Optional[bool] = None
     echo: bool = False
     add_generation_prompt: bool = True
     continue_final_message: bool = False
@@ -314,7 +314,31 @@ class ChatCompletionRequest(_SamplingMixin):
             for t in self.tools:
                 if t.function.name == name and t.function.parameters:
                     sp.guided_decoding = GuidedDecodingParams(json=t.function.parameters)
+        elif self.tool_choice == "required" and self.tools and sp.guided_decoding is None:
+            sp.guided_decoding = GuidedDecodingParams(json=self.required_tools_schema())
         return sp
+
+    def required_tools_schema(self) -> dict:
+        """``tool_choice="required"``: the reply must BE one or more calls of the given tools, so generation is
+        constrained to a non-empty JSON array whose items are {"name": <a tool>, "parameters": <its schema>}
+        (reference: vllm/entrypoints/openai/protocol.py:676-692)."""
+        items, defs = [], {}
+        for t in self.tools or []:
+            params = dict(t.function.parameters or {"type": "object", "properties": {}})
+            for key in ("$defs", "definitions"):
+                for k, v in (params.pop(key, None) or {}).items():
+                    if k in defs and defs[k] != v:
+                        raise ValueError(f"tools define {k!r} in different ways")
+                    defs[k] = v
+            items.append({"type": "object",
+                          "properties": {"name": {"type": "string", "enum": [t.function.name]}, "parameters": params},
+                          "required": ["name", "parameters"]})
+        schema: dict = {"type": "array", "minItems": 1, "items": {"anyOf": items} if len(items) != 1 else items[0]}
+        if self.parallel_tool_calls is False:
+            schema["maxItems"] = 1
+        if defs:
+            schema["$defs"] = defs
+        return schema
 
     @model_validator(mode="after")
     def _check_chat(self):

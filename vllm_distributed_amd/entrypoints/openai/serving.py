@@ -22,6 +22,8 @@ from ...tracing import extract_trace_headers
 from ...utils import random_uuid
 from ..chat_utils import apply_chat_template
 from .parsers import get_reasoning_parser, get_tool_parser
+from .stream_parsers import (ChatDeltaStream, JsonCallStream, make_reasoning_stream, make_tool_stream,
+                             run_tool_stream)
 from .protocol import *  # noqa: F401,F403
 from .protocol import (ChatCompletionLogProb, ChatCompletionLogProbs, ChatCompletionLogProbsContent,
                        ChatCompletionRequest, ChatCompletionResponse, ChatCompletionResponseChoice,
@@ -339,6 +341,8 @@ class OpenAIServingChat(OpenAIServing):
         self.chat_template = chat_template
         self.tool_parser = get_tool_parser(tool_parser) if (tool_parser and enable_auto_tools) else None
         self.reasoning_parser = get_reasoning_parser(reasoning_parser) if reasoning_parser else None
+        make_tool_stream(self.tool_parser.name) if self.tool_parser is not None else None        # fail at start-up
+        make_reasoning_stream(self.reasoning_parser.name) if self.reasoning_parser is not None else None
         self.default_sampling = default_sampling or {}
         self.response_role = response_role
 
@@ -433,20 +437,41 @@ class OpenAIServingChat(OpenAIServing):
                                                          bytes=list(s.encode("utf-8", "replace")), top_logprobs=tops))
         return ChatCompletionLogProbs(content=content)
 
+    def _tool_mode(self, request) -> Optional[str]:
+        """How the reply of this request turns into tool calls: "named" (the whole content is the arguments of the
+        chosen function), "required" (a JSON array of {name, parameters}, enforced by the grammar), "auto" (the
+        model's own call syntax, read by the configured parser) or None."""
+        if not request.tools or request.tool_choice in (None, "none"):
+            return None
+        if isinstance(request.tool_choice, ChatCompletionNamedToolChoiceParam):
+            return "named"
+        if request.tool_choice == "required":
+            return "required"
+        return "auto" if self.tool_parser is not None else None
+
     def _post(self, text: str, request):
+        """Whole-text form of the streaming machines: the same calls and argument strings as a streamed reply."""
+        from .protocol import FunctionCall, ToolCall
         reasoning = None
         content: Optional[str] = text
         if self.reasoning_parser is not None:
-            reasoning, content = self.reasoning_parser.extract(text)
+            r, c = make_reasoning_stream(self.reasoning_parser.name).feed(text, final=True)
+            reasoning, content = r.strip() or None, c.strip() or None
         calls = []
-        if request.tools and request.tool_choice not in (None, "none"):
-            if isinstance(request.tool_choice, ChatCompletionNamedToolChoiceParam):
-                from .protocol import FunctionCall, ToolCall
-                calls = [ToolCall(function=FunctionCall(name=request.tool_choice.function.get("name", ""),
-                                                        arguments=content or ""))]
-                content = None
-            elif self.tool_parser is not None and content:
-                content, calls = self.tool_parser.extract(content)
+        mode = self._tool_mode(request)
+        if mode == "named":
+            calls = [ToolCall(function=FunctionCall(name=request.tool_choice.function.get("name", ""),
+                                                    arguments=content or ""))]
+            content = None
+        elif mode == "required" and content:
+            _, found = _run_stream(JsonCallStream(bare=True), content)
+            calls = [ToolCall(function=FunctionCall(name=n, arguments=a)) for n, a in found]
+            content = None if calls else content
+        elif mode == "auto" and content:
+            rest, found = run_tool_stream(self.tool_parser.name, content)
+            if found:
+                calls = [ToolCall(function=FunctionCall(name=n, arguments=a)) for n, a in found]
+                content = rest.strip() or None
         return reasoning, content, calls
 
     def _final(self, request, res: RequestOutput, rid, created, model_name, tok, as_ids) -> ChatCompletionResponse:
@@ -473,16 +498,33 @@ class OpenAIServingChat(OpenAIServing):
                                       prompt_logprobs=_clean_prompt_logprobs(res.prompt_logprobs),
                                       kv_transfer_params=res.kv_transfer_params)
 
+    def _delta_stream(self, request) -> Optional[ChatDeltaStream]:
+        """The incremental parser chain of one streamed choice, or None when the text goes out as it is."""
+        mode = self._tool_mode(request)
+        rname = self.reasoning_parser.name if self.reasoning_parser is not None else None
+        if mode is None and rname is None:
+            return None
+        st = ChatDeltaStream(rname, self.tool_parser.name if mode == "auto" else None)
+        if mode == "required":
+            st.tool = JsonCallStream(bare=True)
+        elif mode == "named":
+            st.tool = _NamedCallStream(request.tool_choice.function.get("name", ""))
+        return st
+
     async def _stream(self, request, gen, rid, created, model_name, tok, as_ids):
         n = request.n
         first = [True] * n
-        acc_text = [""] * n
-        sent_content = [0] * n
         ct = [0] * n
         pt = 0
         include_usage = bool(request.stream_options and request.stream_options.include_usage)
-        use_parsers = self.reasoning_parser is not None or (self.tool_parser is not None and request.tools
-                                                            and request.tool_choice == "auto")
+        streams = [self._delta_stream(request) for _ in range(n)]
+        tool_ids: list[dict[int, str]] = [{} for _ in range(n)]
+
+        def chunk(i, delta, lp=None, finish=None, stop_reason=None) -> str:
+            c = ChatCompletionStreamResponse(id=rid, created=created, model=model_name, choices=[
+                ChatCompletionResponseStreamChoice(index=i, delta=delta, logprobs=lp, finish_reason=finish,
+                                                   stop_reason=stop_reason)])
+            return f"data: {c.model_dump_json(exclude_unset=True)}\n\n"
         try:
             async for res in gen:
                 pt = len(res.prompt_token_ids or ())
@@ -490,35 +532,42 @@ class OpenAIServingChat(OpenAIServing):
                     i = out.index
                     if first[i]:
                         first[i] = False
-                        c = ChatCompletionStreamResponse(id=rid, created=created, model=model_name, choices=[
-                            ChatCompletionResponseStreamChoice(index=i, delta=DeltaMessage(role=self.response_role,
-                                                                                           content=""))])
-                        yield f"data: {c.model_dump_json(exclude_unset=True)}\n\n"
+                        yield chunk(i, DeltaMessage(role=self.response_role, content=""))
                     ct[i] += len(out.token_ids)
-                    acc_text[i] += out.text
                     lp = self._chat_logprobs(list(out.token_ids), out.logprobs, request.top_logprobs, tok, as_ids) \
                         if request.logprobs and out.logprobs is not None else None
                     finish = out.finish_reason
-                    if use_parsers:
-                        # parsers need complete constructs: stream plain content as it becomes final,
-                        # emit reasoning / tool calls when the request finishes
-                        if finish is None:
-                            continue
-                        reasoning, content, calls = self._post(acc_text[i], request)
-                        delta = DeltaMessage(content=content, reasoning_content=reasoning,
-                                             tool_calls=[DeltaToolCall(index=k, id=tc.id, type="function",
-                                                                       function=DeltaFunctionCall(
-                                                                           name=tc.function.name,
-                                                                           arguments=tc.function.arguments))
-                                                         for k, tc in enumerate(calls)])
-                        if calls and finish == "stop":
-                            finish = "tool_calls"
-                    else:
+                    st = streams[i]
+                    if st is None:
                         delta = DeltaMessage(content=out.text)
-                    c = ChatCompletionStreamResponse(id=rid, created=created, model=model_name, choices=[
-                        ChatCompletionResponseStreamChoice(index=i, delta=delta, logprobs=lp, finish_reason=finish,
-                                                           stop_reason=out.stop_reason)])
-                    yield f"data: {c.model_dump_json(exclude_unset=True)}\n\n"
+                    else:
+                        # reasoning text, the name of a tool call and the fragments of its arguments go out as the
+                        # tokens arrive; only what may still be the beginning of a marker is held back
+                        d = st.feed(out.text, final=finish is not None)
+                        kw = {}
+                        if d.content:
+                            kw["content"] = d.content
+                        if d.reasoning:
+                            kw["reasoning_content"] = d.reasoning
+                        if d.tools:
+                            tcs = []
+                            for t in d.tools:
+                                fn = DeltaFunctionCall(arguments=t.arguments)
+                                if t.name is not None:        # first delta of this call: id, type and name
+                                    tool_ids[i][t.index] = ToolCall(function=FunctionCall(name=t.name,
+                                                                                          arguments="")).id
+                                    fn = DeltaFunctionCall(name=t.name, arguments=t.arguments)
+                                    tcs.append(DeltaToolCall(index=t.index, id=tool_ids[i][t.index], type="function",
+                                                             function=fn))
+                                else:
+                                    tcs.append(DeltaToolCall(index=t.index, function=fn))
+                            kw["tool_calls"] = tcs
+                        if not kw and finish is None and lp is None:
+                            continue                         # nothing to tell the client yet
+                        delta = DeltaMessage(**kw)
+                        if finish == "stop" and st.num_tool_calls:
+                            finish = "tool_calls"
+                    yield chunk(i, delta, lp, finish, out.stop_reason)
             if include_usage:
                 tot = sum(ct)
                 c = ChatCompletionStreamResponse(id=rid, created=created, model=model_name, choices=[],
@@ -528,6 +577,35 @@ class OpenAIServingChat(OpenAIServing):
         except (ValueError, EngineDeadError) as e:
             yield f"data: {json.dumps({'error': self.error(str(e)).model_dump()})}\n\n"
         yield "data: [DONE]\n\n"
+
+
+def _run_stream(st, text: str):
+    """One tool-call machine run over a finished text: (content, [(name, arguments)])."""
+    content, deltas = st.feed(text, final=True)
+    calls: dict[int, list] = {}
+    for d in deltas:
+        c = calls.setdefault(d.index, ["", ""])
+        if d.name is not None:
+            c[0] = d.name
+        c[1] += d.arguments
+    return content, [(c[0], c[1]) for _, c in sorted(calls.items())]
+
+
+class _NamedCallStream:
+    """``tool_choice`` names one function: the generated text (grammar-constrained to its schema) IS the argument
+    string of call 0, streamed as it comes."""
+
+    def __init__(self, name: str):
+        self.name, self.sent = name, [{"name": False, "args": 0}]
+
+    def feed(self, text: str, final: bool = False):
+        from .stream_parsers import ToolDelta
+        st = self.sent[0]
+        d = ToolDelta(index=0, arguments=text[st["args"]:])
+        st["args"] = len(text)
+        if not st["name"]:
+            st["name"], d.name = True, self.name
+        return "", ([d] if (d.name is not None or d.arguments) else [])
 
 
 class OpenAIServingEmbedding(OpenAIServing):

@@ -79,6 +79,12 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_DECODE_GEMM_MIN_M": (int, 33),
     "VDA_DECODE_GEMM_MAX_M": (int, 0),           # 0 = never (default: the tuned library GEMMs are faster, see docs/kernels.md)
     "VDA_DECODE_GEMM_WS_MB": (int, 128),         # fp32 split-K workspace per device
+    "VDA_DENSE_GEMM_MAX_M": (int, 192),          # rows up to which 16-bit linears run the in-tree ping-pong MFMA GEMM (0 = never;
+                                                 # at 256 rows the library's selected algorithms win inside the engine)
+    "VDA_DENSE_GEMM_MIN_M": (int, 33),           # below: the library GEMM is as fast or faster (measured, graph-captured layer chains)
+    "VDA_DENSE_GEMM_MAX_N": (int, 16384),        # wider weight matrices (gate/up) fill the chip without a K split: library
+    "VDA_DENSE_GATE_UP_MAX_M": (int, 0),         # rows up to which a gated MLP runs SiLU * up inside the GEMM epilogue (0 = never:
+                                                 # library GEMM + activation kernel measured faster on the wide gate/up matrix)
     "VDA_ASYNC_SCHEDULING": (int, 1),            # default of --async-scheduling when the flag is not given (the
                                                  # config turns it off again where it cannot apply)
     "VDA_REHEARSE_ON_ONE_GPU": (_bool, False),   # all ranks share cuda:0: gloo groups + peer-memory all-reduce (tests)
@@ -147,7 +153,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
 # Knobs that change numerics or graph shape: part of the config fingerprint.
 _HASHED = (
     "VDA_FORCE_TORCH_OPS", "VDA_SKINNY_GEMM_MAX_M", "VDA_DISABLE_SKINNY_GEMM", "VDA_INT4_WEIGHTS", "VDA_MLA",
-    "VDA_DECODE_GEMM_MIN_M", "VDA_DECODE_GEMM_MAX_M",
+    "VDA_DECODE_GEMM_MIN_M", "VDA_DECODE_GEMM_MAX_M", "VDA_DENSE_GEMM_MAX_M", "VDA_DENSE_GEMM_MIN_M", "VDA_DENSE_GEMM_MAX_N", "VDA_DENSE_GATE_UP_MAX_M",
     "VLLM_ROCM_QUICK_REDUCE_QUANTIZATION", "VLLM_DISABLE_CUSTOM_ALL_REDUCE",
     "VLLM_FUSED_MOE_CHUNK_SIZE",
 )

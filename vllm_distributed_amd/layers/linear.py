@@ -137,6 +137,18 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
     """Several column-parallel projections of the same input fused into one GEMM
     (gate_proj + up_proj).  ``shard_id`` selects the logical projection."""
 
+    def forward_silu_mul(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """SiLU(gate) * up of a gated MLP with the activation fused into the GEMM epilogue, or None when this
+        layer / batch does not qualify (quantised or LoRA-wrapped layer, bias, gathered output, large batch): the
+        caller then runs the projection and the activation kernel separately."""
+        if (type(self) is not MergedColumnParallelLinear or type(self.quant_method) is not UnquantizedLinearMethod
+                or self.bias is not None or self.gather_output or len(self.output_sizes) != 2
+                or self.output_sizes[0] != self.output_sizes[1] or not x.is_cuda):
+            return None
+        shape = x.shape
+        y = ops.gate_up_silu_mul(x.reshape(-1, shape[-1]), self.weight)
+        return None if y is None else y.view(*shape[:-1], -1)
+
     def __init__(self, input_size, output_sizes: Sequence[int], bias=True, gather_output=False,
                  params_dtype=None, quant_config=None, prefix=""):
         tp = get_tensor_model_parallel_world_size()

@@ -39,8 +39,13 @@ class LlamaMLP(nn.Module):
         self.down_proj = RowParallelLinear(intermediate_size, hidden_size, bias=bias, quant_config=quant_config,
                                            reduce_results=reduce_results, prefix=f"{prefix}.down_proj")
         self.act_fn = SiluAndMul() if act == "silu" else get_act_and_mul_fn(act)
+        self._silu = act == "silu"
 
     def forward(self, x):
+        if self._silu:
+            h = self.gate_up_proj.forward_silu_mul(x)      # decode batches: activation inside the GEMM epilogue
+            if h is not None:
+                return self.down_proj(h)
         return self.down_proj(self.act_fn(self.gate_up_proj(x)))
 
 

@@ -555,9 +555,21 @@ def dense_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out
 
 
+def dense_gemm_wanted(x: torch.Tensor, w: torch.Tensor, max_n: Optional[int] = None) -> bool:
+    """True when a 16-bit linear of this size takes the in-tree GEMM by default: decode batches of
+    ``VDA_DENSE_GEMM_MIN_M`` .. ``VDA_DENSE_GEMM_MAX_M`` rows against weight matrices of up to ``VDA_DENSE_GEMM_MAX_N``
+    rows (qkv / o / down projections, which need a K split to fill the chip).  There the in-tree kernel is 5 - 13 %
+    faster per Llama-3-70B layer than the library with its offline selection table and up to 25 % at batch sizes the
+    table does not list (profiles/dense_gemm_chain_r3.log); smaller batches, the wide gate/up matrix and prefill
+    batches stay on the library GEMM."""
+    return (x.is_cuda and envs.VDA_DENSE_GEMM_MIN_M <= x.shape[0] <= envs.VDA_DENSE_GEMM_MAX_M
+            and 64 <= w.shape[0] <= (envs.VDA_DENSE_GEMM_MAX_N if max_n is None else max_n)
+            and dense_gemm_ok(x, w) and w.shape[1] == x.shape[1])
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Unquantised linear: skinny MFMA kernel for the smallest M, the weight-streaming split-K kernel for
-    decode batches, hipBLASLt otherwise."""
+    """Unquantised linear: the in-tree ping-pong MFMA GEMM for decode-sized batches (skinny / split-K kernels when
+    their switches are set), hipBLASLt otherwise."""
     if x.is_cuda and x.dim() == 2 and x.stride(-1) == 1 and w.stride(-1) == 1:
         M, K = x.shape
         if skinny_gemm_ok(M, w.shape[0], K, x.dtype):
@@ -565,7 +577,18 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         if decode_gemm_ok(M, w.shape[0], K, x.dtype) and w.dtype == x.dtype and w.is_contiguous() \
                 and x.stride(0) % 8 == 0 and (bias is None or bias.dtype == x.dtype):
             return decode_gemm(x, w, bias)
+        if dense_gemm_wanted(x, w) and (bias is None or (bias.dtype == x.dtype and w.shape[0] % 4 == 0)):
+            return dense_gemm(x, w, bias)
     return torch.nn.functional.linear(x, w, bias)
+
+
+def gate_up_silu_mul(x: torch.Tensor, w: torch.Tensor) -> Optional[torch.Tensor]:
+    """silu(x @ gate.T) * (x @ up.T) for w = [gate rows; up rows] in ONE kernel (the activation runs in the GEMM
+    epilogue, the [M, 2 I] intermediate never exists), or None when this batch does not take the in-tree GEMM."""
+    if x.dim() != 2 or x.shape[0] > envs.VDA_DENSE_GATE_UP_MAX_M or w.shape[0] % 8 \
+            or not dense_gemm_wanted(x, w, max_n=1 << 30):
+        return None
+    return dense_gemm(x, w, epilogue="gate_up")
 
 
 # ---- 4-bit weight-only linear (GPTQ / AWQ) ------------------------------------------------------

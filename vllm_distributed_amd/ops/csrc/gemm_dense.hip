@@ -586,23 +586,44 @@ VDA_EXPORT int vda_dense_gemm(void* out, const void* x, const void* w, const voi
   const long w_rows = epi == DG_GATE_UP ? 2L * N : N;
   if (w_rows * K * 2 >= (1LL << 32) || (long)M * x_stride * 2 >= (1LL << 32)) return -2;
   int xt = M > 128 ? 8 : M > 64 ? 4 : M > 32 ? 2 : 1;
-  if (wt != 2 && wt != 4) wt = 4;
+  const int nu = K >> 5;
+  const int m_tiles = (M + 32 * xt - 1) / (32 * xt);
+  const bool can_split = !(N % 4 || out_stride % 4 || !ws);
+  // Tile height and K split, when the caller leaves them open: the pair with the smaller estimated time.  A
+  // workgroup streams (64 wt weight rows + 32 xt activation rows) x 64 bytes per unit; weight rows come from HBM at
+  // about 24 GB/s per CU, activation rows from L2 (a sixteenth of that per row); a split adds the reduction
+  // launch and its round trip over the fp32 partial sums.  Splits never create a second round of workgroups.
+  auto plan = [&](int t, int forced_splits, double* cost) {
+    const int ncol = epi == DG_GATE_UP ? 32 * t : 64 * t;
+    const long tiles = (long)m_tiles * ((N + ncol - 1) / ncol);
+    int sp = forced_splits;
+    if (sp < 1) {
+      sp = 1;
+      if (tiles * 4 < 256 * 3) sp = (int)(256 / tiles);
+      sp = min(sp, max(nu / 16, 1));
+      sp = min(sp, 16);
+    }
+    if (!can_split) sp = 1;
+    while (sp > 1 && (size_t)sp * M * w_rows * sizeof(float) > ws_bytes) --sp;
+    const long rounds = (tiles * sp + 255) / 256;
+    const double unit_us = 0.17 * t + 0.011 * xt;
+    *cost = rounds * ((nu + sp - 1) / sp) * unit_us + (sp > 1 ? 4.0 + (double)M * w_rows * sp * 8 / 3e6 : 0.0);
+    return sp;
+  };
+  if (wt != 2 && wt != 4) {
+    double c4, c2;
+    plan(4, splits, &c4);
+    plan(2, splits, &c2);
+    wt = (m_tiles > 1 || c4 <= c2) ? 4 : 2;
+  }
+  double unused;
+  splits = plan(wt, splits, &unused);
   const int ncol = epi == DG_GATE_UP ? 32 * wt : 64 * wt;
   DenseGemmArgs a;
   a.out = out; a.x = x; a.w = w; a.bias = bias; a.residual = residual; a.ws = ws;
   a.M = M; a.N = N; a.K = K; a.x_stride = x_stride; a.out_stride = out_stride; a.res_stride = res_stride;
-  a.m_tiles = (M + 32 * xt - 1) / (32 * xt);
+  a.m_tiles = m_tiles;
   a.n_tiles = (N + ncol - 1) / ncol;
-  const int nu = K >> 5;
-  if (splits < 1) {                                // fill the CUs; at least 16 units per split
-    splits = 1;
-    const long tiles = (long)a.m_tiles * a.n_tiles;
-    if (tiles * 4 < 256 * 3) splits = (int)(256 / tiles);            // one workgroup per CU, never a second round
-    splits = min(splits, max(nu / 16, 1));
-    splits = min(splits, 16);
-  }
-  if (N % 4 || out_stride % 4 || !ws) splits = 1;
-  while (splits > 1 && (size_t)splits * M * w_rows * sizeof(float) > ws_bytes) --splits;
   // variant: 0 = chosen here, 1 = ring of 32-element units, 2 = 64-element units (256 x 256 tiles, K % 64 == 0)
   const bool k64 = variant == 2 || (variant == 0 && a.m_tiles > 1);
   const bool use_k64 = k64 && xt == 8 && wt == 4 && K % 64 == 0;

@@ -74,6 +74,8 @@ class GroupCoordinator:
         self.far_comm = None      # peer-memory all-reduce fused with residual add + RMSNorm
         self.ca_comm_async = None # second context (own arena, own call counters) for the communication stream
         self.qr_comm = None       # quantised peer-memory all-reduce (opt-in)
+        # all-reduce calls issued from the host by path (a call captured into a graph counts once, at capture)
+        self.path_counts = {"quick": 0, "peer_memory": 0, "fused_norm": 0, "rccl": 0, "torch": 0}
         self.rccl_comm = None     # stream-explicit RCCL (graph capturable)
         self.mq_broadcaster = None
         self.all2all = None
@@ -166,6 +168,7 @@ class GroupCoordinator:
             if self.qr_comm is not None and not _side_stream:          # opt-in, lossy, large messages only
                 out = self.qr_comm.all_reduce(x)
                 if out is not None:
+                    self.path_counts["quick"] += 1
                     return out
             if ca is not None and (self.rccl_comm is None or envs.VDA_CUSTOM_AR_CHUNKED
                                    or x.numel() * x.element_size() <= ca.max_bytes):
@@ -173,9 +176,12 @@ class GroupCoordinator:
                 # (prefill chunks, 100+ MiB) are bandwidth bound and go to RCCL
                 out = ca.all_reduce(x)
                 if out is not None:
+                    self.path_counts["peer_memory"] += 1
                     return out
             if self.rccl_comm is not None:
+                self.path_counts["rccl"] += 1
                 return self.rccl_comm.all_reduce(x)
+        self.path_counts["torch"] += 1
         h = self._down(x)
         dist.all_reduce(h, group=self._pg(x))
         if h is not x:
@@ -194,6 +200,7 @@ class GroupCoordinator:
         if self.can_fuse_reduce_norm(x):
             out = self.far_comm.run(x, residual, weight, eps, weight_bias)
             if out is not None:
+                self.path_counts["fused_norm"] += 1
                 return out, residual
         from .. import ops
         x = self.all_reduce(x)
@@ -224,6 +231,17 @@ class GroupCoordinator:
             done = torch.cuda.Event()
             done.record(comm)
         return AsyncWork(out, done)
+
+    def comm_info(self) -> dict:
+        """What this group's collectives really ran on: the ranks the RCCL communicator and the peer-memory arena
+        were built over (0 = that layer is absent) and the all-reduce calls per path so far."""
+        def ranks(c):
+            if c is None or getattr(c, "disabled", False):
+                return 0
+            return int(getattr(c, "world_size", None) or getattr(c, "world", None) or self.world_size)
+        return {"group": self.name, "world_size": self.world_size,
+                "rccl_ranks": ranks(self.rccl_comm), "peer_arena_ranks": ranks(self.ca_comm),
+                "fused_norm_ranks": ranks(self.far_comm), "allreduce_path": dict(self.path_counts)}
 
     def check_comm_errors(self) -> None:
         """Raise if a peer-memory collective of this group timed out since the last check.  A kernel

@@ -206,6 +206,18 @@ class Worker:
         else:
             self.profiler.stop()
 
+    def comm_info(self) -> dict:
+        """Per parallel group of this rank: the ranks its RCCL communicator and its peer-memory arena span and the
+        all-reduce calls per path (GroupCoordinator.comm_info); read by bench.py for its result line."""
+        from ..parallel import state as ps
+        out = {}
+        for key, getter in (("tp", ps.get_tp_group), ("pp", ps.get_pp_group)):
+            try:
+                out[key] = getter().comm_info()
+            except Exception:   # noqa: BLE001 - group not initialised (single process)
+                out[key] = None
+        return out
+
     def check_health(self) -> bool:
         return True
 
