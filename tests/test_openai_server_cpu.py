@@ -141,6 +141,14 @@ def test_metrics_endpoint(server):
         await c.post("/v1/completions", json={"prompt": "w1", "max_tokens": 2})
         txt = (await c.get("/metrics")).text
         assert "vllm:generation_tokens_total" in txt and "vllm:time_to_first_token_seconds" in txt
+        await c.post("/v1/completions", json={"prompt": "w1", "max_tokens": 3, "n": 2, "temperature": 1.0})
+        txt = (await c.get("/metrics")).text
+        assert "vllm:cache_config_info{" in txt and 'block_size="16"' in txt
+        assert "vllm:request_max_num_generation_tokens_count" in txt
+        import re
+        n_sum = re.search(r"vllm:request_params_n_sum\{[^}]*\} ([0-9.]+)", txt)
+        assert n_sum and float(n_sum.group(1)) >= 3.0          # one request with n = 1 and one with n = 2
+        assert (await c.get("/ping")).status_code == 200 and (await c.post("/ping")).status_code == 200
     _run(server, f)
 
 

@@ -338,6 +338,17 @@ class OutputProcessor:
                     iteration_stats.update_from_finished_request(finish, len(st.prompt_ids), st.max_tokens_param,
                                                                  st.stats)
                     self.lora_states.running_requests.discard(eco.request_id)
+                    # per USER request: the longest of its n samples, and n (reference: ParentRequest.
+                    # observe_finished_request, vllm/v1/engine/parallel_sampling.py:110-133)
+                    gen = st.stats.num_generation_tokens
+                    if st.parent is None:
+                        iteration_stats.max_num_generation_tokens_iter.append(gen)
+                        iteration_stats.n_params_iter.append(1)
+                    else:
+                        st.parent.max_num_generation_tokens = max(st.parent.max_num_generation_tokens, gen)
+                        if not st.parent.child_ids:
+                            iteration_stats.max_num_generation_tokens_iter.append(st.parent.max_num_generation_tokens)
+                            iteration_stats.n_params_iter.append(st.parent.params.n)
         return result
 
     def _pooling_output(self, st: RequestState, eco: EngineCoreOutput):

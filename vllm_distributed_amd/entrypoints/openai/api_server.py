@@ -381,6 +381,13 @@ def build_app(args: argparse.Namespace, engine: AsyncLLM) -> FastAPI:
         return JSONResponse({"is_sleeping": await engine.is_sleeping()})
 
     if envs.VLLM_SERVER_DEV_MODE:
+        @app.get("/server_info")
+        async def server_info():
+            """The engine configuration as the server sees it (development mode only: it names paths and options).
+            Reference: vllm/entrypoints/openai/api_server.py:961."""
+            cfg = await engine.get_vllm_config() if hasattr(engine, "get_vllm_config") else getattr(engine, "vllm_config", None)
+            return JSONResponse({"vllm_config": str(cfg), "version": __version__})
+
         @app.post("/collective_rpc")
         async def collective_rpc(raw: Request):
             body = await raw.json()

@@ -128,6 +128,29 @@ class PrometheusStatLogger(StatLoggerBase):
         self.c_spec_drafts = _mk(C, "vllm:spec_decode_num_drafts", "Speculative drafts.")
         self.c_spec_draft_tokens = _mk(C, "vllm:spec_decode_num_draft_tokens", "Draft tokens.")
         self.c_spec_accepted = _mk(C, "vllm:spec_decode_num_accepted_tokens", "Accepted draft tokens.")
+        self.h_max_gen = _mk(H, "vllm:request_max_num_generation_tokens",
+                             "Histogram of maximum number of requested generation tokens.", buckets=tok_buckets)
+        # info metrics: a gauge permanently at 1 whose labels carry the values (multiprocess collectors have no Info)
+        cc = vllm_config.cache_config
+        info = {k: str(v) for k, v in sorted(vars(cc).items()) if not k.startswith("_")
+                and isinstance(v, (int, float, str, bool, type(None)))}
+        info["engine"] = str(engine_index)
+        try:
+            g = G("vllm:cache_config_info", "Information of the LLMEngine CacheConfig", labelnames=list(info))
+        except ValueError:
+            g = pc.REGISTRY._names_to_collectors["vllm:cache_config_info"]
+        try:
+            g.labels(**info).set(1)
+        except ValueError:          # registered earlier with another label set (a second engine in one process)
+            pass
+        self.g_lora = None
+        if getattr(vllm_config, "lora_config", None) is not None:
+            self.max_lora = str(vllm_config.lora_config.max_loras)
+            try:
+                self.g_lora = G("vllm:lora_requests_info", "Running stats on lora requests.",
+                                labelnames=["max_lora", "waiting_lora_adapters", "running_lora_adapters"])
+            except ValueError:
+                self.g_lora = pc.REGISTRY._names_to_collectors["vllm:lora_requests_info"]
 
     def record(self, scheduler_stats, iteration_stats) -> None:
         s = scheduler_stats
@@ -146,6 +169,16 @@ class PrometheusStatLogger(StatLoggerBase):
         it = iteration_stats
         if it is None:
             return
+        if self.g_lora is not None:
+            # the value is the time of the sample; the adapter names ride in the labels
+            self.g_lora.labels(max_lora=self.max_lora,
+                               waiting_lora_adapters=",".join(sorted(getattr(it, "waiting_lora_adapters", {}) or {})),
+                               running_lora_adapters=",".join(sorted(getattr(it, "running_lora_adapters", {}) or {}))
+                               ).set_to_current_time()
+        for v in getattr(it, "max_num_generation_tokens_iter", ()) or ():
+            self.h_max_gen.observe(v)
+        for v in getattr(it, "n_params_iter", ()) or ():
+            self.h_n.observe(v)
         self.c_preempt.inc(it.num_preempted_reqs)
         self.c_prompt.inc(it.num_prompt_tokens)
         self.c_gen.inc(it.num_generation_tokens)

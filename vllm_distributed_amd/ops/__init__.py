@@ -13,8 +13,39 @@ from typing import Optional
 import torch
 
 from .. import envs
+from ..logger import init_logger
 from . import native as N
-from . import reference as R
+from . import reference as _reference
+
+logger = init_logger(__name__)
+
+
+class _ReferenceOps:
+    """``ops/reference.py`` behind a tripwire: the PyTorch forms are the CPU backend and the oracle of the tests, but
+    a GPU tensor landing in one of them means a shape or dtype the HIP kernel does not take, silently orders of
+    magnitude slower.  The first such call of every op is logged (once per op and process)."""
+
+    def __init__(self, mod):
+        self._mod, self._seen = mod, set()
+
+    def __getattr__(self, name):
+        fn = getattr(self._mod, name)
+        if not callable(fn):
+            return fn
+
+        def call(*a, **k):
+            if name not in self._seen and not envs.VDA_FORCE_TORCH_OPS:
+                t = next((v for v in list(a) + list(k.values()) if isinstance(v, torch.Tensor)), None)
+                if t is not None and t.is_cuda:
+                    self._seen.add(name)
+                    shapes = [tuple(v.shape) for v in a if isinstance(v, torch.Tensor)][:4]
+                    logger.warning("ops.%s: no HIP kernel takes this call (tensor shapes %s, %s): it runs as plain "
+                                   "PyTorch ops on the GPU, far below the kernel's speed", name, shapes, t.dtype)
+            return fn(*a, **k)
+        return call
+
+
+R = _ReferenceOps(_reference)
 
 
 def _dev(x: torch.Tensor) -> bool:
