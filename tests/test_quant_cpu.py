@@ -118,20 +118,21 @@ def _pack_cols(v, bits, order=None):
     return (out & 0xFFFFFFFF).to(torch.uint32).view(torch.int32)
 
 
-def _int4_quantise(w, group):
-    """w [N, K] -> q [K, N] in 0..15, zeros [G, N], scales [G, N] and the dequantised [N, K]."""
+def _int4_quantise(w, group, bits=4):
+    """w [N, K] -> q [K, N] in 0..2^bits-1, zeros [G, N], scales [G, N] and the dequantised [N, K]."""
     N, K = w.shape
+    top = (1 << bits) - 1
     wt = w.t().reshape(K // group, group, N)
     lo, hi = wt.amin(1), wt.amax(1)
-    scales = ((hi - lo) / 15).clamp(min=1e-6).half()
-    zeros = (-lo / scales.float()).round().clamp(0, 15)
-    q = (wt / scales.float().unsqueeze(1) + zeros.unsqueeze(1)).round().clamp(0, 15)
+    scales = ((hi - lo) / top).clamp(min=1e-6).half()
+    zeros = (-lo / scales.float()).round().clamp(1, top)
+    q = (wt / scales.float().unsqueeze(1) + zeros.unsqueeze(1)).round().clamp(0, top)
     deq = ((q - zeros.unsqueeze(1)) * scales.float().unsqueeze(1)).reshape(K, N).t().contiguous()
     return q.reshape(K, N).to(torch.int32), zeros.to(torch.int32), scales, deq
 
 
 @pytest.mark.parametrize("fmt,packed", [("gptq", True), ("gptq", False), ("awq", True), ("awq", False),
-                                        ("fp8_block", False)])
+                                        ("fp8_block", False), ("gptq8", True), ("gptq_act", True)])
 def test_weight_only_checkpoints_are_dequantised_while_loading(tmp_path, fmt, packed, monkeypatch):
     """A GPTQ / AWQ / block-fp8 checkpoint of the tiny Llama generates the tokens of the HF model
     that holds the dequantised weights, with the 4-bit weights kept packed (W4A16 layers) or expanded
@@ -147,7 +148,7 @@ def test_weight_only_checkpoints_are_dequantised_while_loading(tmp_path, fmt, pa
     from vllm_distributed_amd.models.dequant import _AWQ_ORDER
     path, hf = _save_tiny(str(tmp_path), "llama")
     sd = load_file(os.path.join(path, "model.safetensors"))
-    out, group = {}, 32
+    out, group, orders = {}, 32, {}
     for name, t in sd.items():
         if not (name.endswith("_proj.weight") and t.dim() == 2):
             out[name] = t
@@ -161,6 +162,21 @@ def test_weight_only_checkpoints_are_dequantised_while_loading(tmp_path, fmt, pa
             q = (blocks / s[:, None, :, None]).view(N, K).to(torch.float8_e4m3fn)
             out[name], out[prefix + ".weight_scale_inv"] = q, s.float()
             deq = (q.float().view(N // bn, bn, K // bk, bk) * s[:, None, :, None]).view(N, K)
+        elif fmt in ("gptq8", "gptq_act"):
+            # 8-bit weights, or 4-bit weights quantised in a shuffled column order (desc_act): the projections
+            # that share an input share the order, as they do in real files
+            bits = 8 if fmt == "gptq8" else 4
+            K = t.shape[1]
+            order = orders.setdefault(K, torch.randperm(K, generator=torch.Generator().manual_seed(K)))
+            if fmt == "gptq8":
+                order = torch.arange(K)
+            q, zeros, scales, deq = _int4_quantise(t.float()[:, order], group, bits)
+            inv = torch.argsort(order)
+            q, deq = q[inv], deq[:, inv].contiguous()
+            out[prefix + ".qweight"] = _pack_rows(q, bits)
+            out[prefix + ".qzeros"] = _pack_cols(zeros - 1, bits)
+            out[prefix + ".g_idx"] = (inv // group).to(torch.int32)
+            out[prefix + ".scales"] = scales
         else:
             q, zeros, scales, deq = _int4_quantise(t.float(), group)
             if fmt == "gptq":
@@ -177,6 +193,8 @@ def test_weight_only_checkpoints_are_dequantised_while_loading(tmp_path, fmt, pa
     save_file(out, os.path.join(path, "model.safetensors"))
     cfg = json.load(open(os.path.join(path, "config.json")))
     cfg["quantization_config"] = {"gptq": {"quant_method": "gptq", "bits": 4, "group_size": group, "desc_act": False},
+                                  "gptq8": {"quant_method": "gptq", "bits": 8, "group_size": group, "desc_act": False},
+                                  "gptq_act": {"quant_method": "gptq", "bits": 4, "group_size": group, "desc_act": True},
                                   "awq": {"quant_method": "awq", "bits": 4, "group_size": group, "zero_point": True,
                                           "version": "gemm"},
                                   "fp8_block": {"quant_method": "fp8", "weight_block_size": [32, 32],

@@ -1,0 +1,132 @@
+"""Weight-only quantised GEMM (ops/csrc/gemm_wq.hip) against a plain fp32 product with the dequantised weights:
+4- and 8-bit weights, every row-count class, group sizes, K splits, edges, bias, strides, graph capture, and the
+linear method of GPTQ / AWQ layers (packed memory, activation reordering)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _quantised(N, K, G, bits, dtype):
+    from vllm_distributed_amd import ops
+    top = (1 << bits) - 1
+    q = torch.randint(0, top + 1, (N, K), device="cuda")
+    scales = ((torch.rand(N, K // G, device="cuda") + 0.5) * (K ** -0.5) * (16.0 / (top + 1))).to(dtype)
+    zeros = torch.randint(0, top + 1, (N, K // G), device="cuda").to(dtype)
+    g = torch.arange(K, device="cuda") // G
+    deq = (q.float() - zeros.float()[:, g]) * scales.float()[:, g]
+    qw = ops.w4_pack(q) if bits == 4 else q.to(torch.uint8)
+    sz = torch.stack([scales.t(), zeros.t()], dim=-1).contiguous()
+    return qw, scales, zeros, sz, deq
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("bits", [4, 8])
+@pytest.mark.parametrize("M", [1, 7, 32, 33, 64, 100, 128, 129, 256, 300, 1024, 4096])
+@pytest.mark.parametrize("N,K,G", [(256, 256, 32), (1000, 512, 128), (264, 96, 32), (512, 1024, 1024), (4096, 4096, 128)])
+def test_wq_gemm_matches_fp32(dtype, bits, M, N, K, G):
+    from vllm_distributed_amd import ops
+    torch.manual_seed(M * 7 + N + bits)
+    x = ((torch.rand(M, K, device="cuda") * 2 - 1)).to(dtype)
+    qw, scales, zeros, sz, deq = _quantised(N, K, G, bits, dtype)
+    ref = x.float() @ deq.t()
+    # the kernel rounds each widened weight to the activation type, as a dequantise-then-GEMM path does
+    ref16 = x.float() @ deq.to(dtype).float().t()
+    tol = 2e-2 * ref.abs().max().item() + 2e-2
+    variants = (1, 2, 3) if M <= 128 and K % 128 == 0 else (1,)         # tiled everywhere, both streaming forms where they apply
+    for variant in (0,) + variants:
+        for splits in (0, 1, 3):
+            got = ops.wq_gemm(x, qw, sz, G, bits, splits=splits, variant=variant).float()
+            assert (got - ref).abs().max().item() < tol, (variant, splits, (got - ref).abs().max().item())
+            assert (got - ref16).abs().max().item() < 0.5 * tol, (variant, splits)
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+def test_wq_gemm_exact_layout(bits):
+    """Identity activations return the dequantised rows exactly: a misplaced nibble, byte, scale or zero cannot pass."""
+    from vllm_distributed_amd import ops
+    N, K, G = 320, 128, 32
+    top = (1 << bits) - 1
+    q = (torch.arange(N * K, device="cuda").reshape(N, K) * 7 % (top + 1))
+    scales = (2.0 ** torch.randint(-3, 2, (N, K // G), device="cuda")).to(torch.bfloat16)
+    zeros = torch.randint(0, min(top, 63) + 1, (N, K // G), device="cuda").to(torch.bfloat16)
+    g = torch.arange(K, device="cuda") // G
+    deq = (q.float() - zeros.float()[:, g]) * scales.float()[:, g]
+    qw = ops.w4_pack(q) if bits == 4 else q.to(torch.uint8)
+    sz = torch.stack([scales.t(), zeros.t()], dim=-1).contiguous()
+    for M, variant in ((16, 1), (16, 2), (16, 3), (40, 2), (40, 3), (128, 1), (128, 2), (512, 1), (1100, 1)):
+        idx = torch.arange(M, device="cuda")
+        x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+        x[idx, idx % K] = 1
+        got = ops.wq_gemm(x, qw, sz, G, bits, splits=1, variant=variant).float()
+        assert torch.equal(got, deq.t()[idx % K]), (bits, M, variant)
+
+
+def test_wq_gemm_bias_strides_and_graph():
+    from vllm_distributed_amd import ops
+    N, K, G = 1032, 768, 128
+    qw, scales, zeros, sz, deq = _quantised(N, K, G, 4, torch.bfloat16)
+    b = torch.randn(N, device="cuda", dtype=torch.bfloat16)
+    full = torch.randn(200, K + 64, device="cuda", dtype=torch.bfloat16)
+    x = full[:, 64:]
+    ref = x.float() @ deq.t() + b.float()
+    for splits in (1, 2):
+        got = ops.wq_gemm(x, qw, sz, G, 4, bias=b, splits=splits).float()
+        assert (got - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2
+    xs = torch.randn(48, K, device="cuda", dtype=torch.bfloat16)
+    out = ops.wq_gemm(xs, qw, sz, G, 4)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.wq_gemm(xs, qw, sz, G, 4)
+    xs.copy_(torch.randn(48, K, device="cuda", dtype=torch.bfloat16))
+    g.replay()
+    torch.cuda.synchronize()
+    ref = xs.float() @ deq.t()
+    assert (out.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2
+
+
+@pytest.mark.parametrize("bits,act_order", [(4, False), (8, False), (4, True), (8, True)])
+def test_gptq_layers_keep_their_weights_packed(bits, act_order):
+    """GPTQ tensors -> the packed linear method: the layer's memory is the checkpoint's, decode and mid-sized
+    batches run a packed-weight kernel (no expanded copy), large prefill batches a transient expansion plus the library
+    GEMM, and every result equals the dequantised product."""
+    from tests.test_quant_cpu import _pack_cols, _pack_rows
+    from vllm_distributed_amd import ops
+    from vllm_distributed_amd.models.dequant import PackedIntLinearMethod, dequantize_gptq, gptq_to_packed
+    N, K, G = 768, 1024, 128
+    top = (1 << bits) - 1
+    q = torch.randint(0, top + 1, (K, N))
+    zeros = torch.randint(1, top + 1, (K // G, N))
+    scales = ((torch.rand(K // G, N) + 0.5) / (top + 1) / 8).half()
+    g_idx = (torch.randperm(K) // G if act_order else torch.arange(K) // G).to(torch.int32)
+    ck = {"qweight": _pack_rows(q, bits), "qzeros": _pack_cols(zeros - 1, bits), "scales": scales, "g_idx": g_idx}
+    deq = dequantize_gptq(ck["qweight"], ck["qzeros"], scales, g_idx, bits, 1, torch.float32)        # [N, K]
+    assert torch.equal(deq, ((q.float() - zeros.float()[g_idx.long()]) * scales.float()[g_idx.long()]).t())
+    t = gptq_to_packed(ck["qweight"], ck["qzeros"], scales, g_idx, bits, 1, torch.float16)
+    assert ("perm" in t) == act_order
+
+    class Layer(torch.nn.Module):
+        input_size = K
+    layer = Layer()
+    method = PackedIntLinearMethod(G, bits, act_order)
+    with torch.device("cuda"):
+        method.create_weights(layer, K, N, torch.float16)
+    for name, v in t.items():
+        getattr(layer, name).data.copy_(v)
+    method.process_weights_after_loading(layer)
+    assert sum(p.numel() * p.element_size() for p in layer.parameters()) <= N * K * bits // 8 + 4 * N * (K // G) + 4 * K
+    seen = []
+    real_gemm, real_deq = ops.wq_gemm, ops.wq_dequant
+    ops.wq_gemm = lambda *a, **k: (seen.append("gemm"), real_gemm(*a, **k))[1]
+    ops.wq_dequant = lambda *a, **k: (seen.append("dequant"), real_deq(*a, **k))[1]
+    try:
+        for M in (1, 16, 48, 200, 512, 2048):
+            x = torch.randn(3, M, K, device="cuda", dtype=torch.float16)[1]
+            y = method.apply(layer, x)
+            ref = x.float() @ deq.cuda().t()
+            assert y.shape == (M, N)
+            assert (y.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2, M
+    finally:
+        ops.wq_gemm, ops.wq_dequant = real_gemm, real_deq
+    assert seen == ["gemm"] * 5 + ["dequant"]

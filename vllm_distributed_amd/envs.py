@@ -93,6 +93,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_LORA_KERNEL_MAX_TOKENS": (int, 1024),   # multi-LoRA: batches up to this many rows use the fused shrink/expand kernels
     "VDA_SCAN_CHUNK_MIN_TOKENS": (int, 256),     # state-space scan: sequences of at least this many new tokens run chunk-parallel
     "VDA_W4_SKINNY_MAX_M": (int, 32),            # W4A16: rows served by the packed-weight skinny kernel
+    "VDA_WQ_GEMM_MAX_M": (int, 512),             # W4A16 / W8A16: rows served by the packed-weight GEMM kernels
     "VDA_MLA": (_bool, True),                    # DeepSeek: latent KV cache + absorbed projections; 0 = expanded heads
     "VDA_INT4_WEIGHTS": (_bool, True),           # keep 4-bit GPTQ/AWQ linear weights packed (W4A16 kernel); 0 = expand at load
     "VDA_FP8_BLOCK_NATIVE": (_bool, True),       # 128x128 block-scaled fp8 checkpoints: keep weights in fp8 (0: expand to 16 bit at load)
@@ -153,7 +154,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
 # Knobs that change numerics or graph shape: part of the config fingerprint.
 _HASHED = (
     "VDA_FORCE_TORCH_OPS", "VDA_SKINNY_GEMM_MAX_M", "VDA_DISABLE_SKINNY_GEMM", "VDA_INT4_WEIGHTS", "VDA_MLA",
-    "VDA_DECODE_GEMM_MIN_M", "VDA_DECODE_GEMM_MAX_M", "VDA_DENSE_GEMM_MAX_M", "VDA_DENSE_GEMM_MIN_M", "VDA_DENSE_GEMM_MAX_N", "VDA_DENSE_GATE_UP_MAX_M",
+    "VDA_DECODE_GEMM_MIN_M", "VDA_DECODE_GEMM_MAX_M", "VDA_DENSE_GEMM_MAX_M", "VDA_DENSE_GEMM_MIN_M", "VDA_DENSE_GEMM_MAX_N", "VDA_DENSE_GATE_UP_MAX_M", "VDA_WQ_GEMM_MAX_M",
     "VLLM_ROCM_QUICK_REDUCE_QUANTIZATION", "VLLM_DISABLE_CUSTOM_ALL_REDUCE",
     "VLLM_FUSED_MOE_CHUNK_SIZE",
 )

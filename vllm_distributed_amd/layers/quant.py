@@ -308,7 +308,7 @@ def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
     if q in ("awq", "gptq", "bitsandbytes") or (q == "fp8" and hf_q and hf_q.get("weight_block_size")):
         # weight-only formats without a kernel of their own: dequantised while the checkpoint loads
         from ..models.dequant import LoadTimeDequant
-        return LoadTimeDequant(q, dict(hf_q or {}))
+        return LoadTimeDequant(q, dict(hf_q or {}), tp_size=vllm_config.parallel_config.tensor_parallel_size)
     if q == "fp8" and hf_q and str(hf_q.get("quant_method", "")).lower() == "modelopt":
         # ModelOpt FP8 export: fp8 weights with per-tensor weight_scale and a calibrated input_scale
         return Fp8Config(True, "static", list(hf_q.get("exclude_modules") or []))

@@ -71,6 +71,31 @@ def gptq_to_packed4(qweight, qzeros, scales, zero_offset: int, dtype: torch.dtyp
     return w4_pack(q), scales.t().contiguous().to(dtype), z.to(dtype)
 
 
+def gptq_to_packed(qweight, qzeros, scales, g_idx, bits: int, zero_offset: int, dtype: torch.dtype) -> dict:
+    """GPTQ 4- or 8-bit tensors -> the tensors of ``PackedIntLinearMethod``: qweight (4 bit: int32 [N, K/8] in the
+    nibble order of ops.w4_pack; 8 bit: uint8 [N, K]), scales [N, G], zero points [N, G] and, for activation
+    reordering (``g_idx`` not in natural order), ``perm`` int32 [K]: the weights' K columns are stored in the order
+    that makes every group contiguous, and the activations' columns are gathered in that order before the GEMM."""
+    from ..ops import w4_pack
+    q = _unpack_rows(qweight, bits).t().contiguous()                   # [N, K]
+    z = (_unpack_cols(qzeros, bits) + zero_offset).t().contiguous()    # [N, G]
+    out = {}
+    K, G = q.shape[1], scales.shape[0]
+    if g_idx is not None:
+        g = g_idx.to(torch.int64).reshape(-1)
+        natural = torch.arange(K, dtype=torch.int64) // (K // G)
+        if not torch.equal(g, natural):
+            perm = torch.argsort(g, stable=True)
+            if not torch.equal(g[perm], natural):
+                raise ValueError("gptq act-order: groups of unequal size are not supported")
+            q = q[:, perm].contiguous()
+            out["perm"] = perm.to(torch.int32)
+    out["qweight"] = w4_pack(q) if bits == 4 else q.to(torch.uint8)
+    out["scales"] = scales.t().contiguous().to(dtype)
+    out["qzeros"] = z.to(dtype)
+    return out
+
+
 def awq_to_packed4(qweight, qzeros, scales, dtype: torch.dtype):
     from ..ops import w4_pack
 
@@ -169,13 +194,17 @@ def dequantize_bnb8(weight: torch.Tensor, scb: torch.Tensor, dtype: torch.dtype)
     return (weight.float() * (scb.float().view(-1, 1) / 127.0)).to(dtype)
 
 
-class Int4LinearMethod:
-    """Linear layer over packed 4-bit weights with group scales and zero points (W4A16): decode-sized
-    batches stream a quarter of the bytes through the MFMA skinny kernel (ops/csrc/w4.hip).
-    Reference: vllm/model_executor/layers/quantization/gptq.py:GPTQLinearMethod, awq.py:AWQLinearMethod."""
+class PackedIntLinearMethod:
+    """Linear layer over packed 4- or 8-bit weights with group scales and zero points (W4A16 / W8A16).  The weights
+    stay packed in device memory (model memory = checkpoint size): decode-sized batches of 4-bit layers stream them
+    through the MFMA skinny kernel (ops/csrc/w4.hip), everything else through the ping-pong GEMM that widens the
+    weights on their way into the MFMA operands (ops/csrc/gemm_wq.hip), for any number of rows.  Activation
+    reordering (GPTQ ``desc_act``) is a column gather of the activations in front of the GEMM.
+    Reference: vllm/model_executor/layers/quantization/gptq.py:GPTQLinearMethod, awq.py:AWQLinearMethod,
+    gptq_marlin.py."""
 
-    def __init__(self, group_size: int):
-        self.group_size = group_size
+    def __init__(self, group_size: int, bits: int = 4, act_order: bool = False):
+        self.group_size, self.bits, self.act_order = group_size, bits, act_order
 
     def create_weights(self, layer, in_per_rank: int, out_per_rank: int, dtype: torch.dtype) -> None:
         import torch.nn as nn
@@ -187,23 +216,49 @@ class Int4LinearMethod:
         if in_per_rank % 8 or (not whole and in_per_rank % G):
             raise ValueError(f"{getattr(layer, 'prefix', '')}: {in_per_rank} input features per rank do not "
                              f"divide into groups of {G}")
+        if self.act_order and in_per_rank != total_in:
+            raise ValueError(f"{getattr(layer, 'prefix', '')}: activation reordering with a row-parallel shard")
         layer.w4_group = in_per_rank if whole else G
-        qw = nn.Parameter(torch.zeros(out_per_rank, in_per_rank // 8, dtype=torch.int32), requires_grad=False)
+        layer.wq_bits = self.bits
+        if self.bits == 4:
+            qw = nn.Parameter(torch.zeros(out_per_rank, in_per_rank // 8, dtype=torch.int32), requires_grad=False)
+        else:
+            qw = nn.Parameter(torch.zeros(out_per_rank, in_per_rank, dtype=torch.uint8), requires_grad=False)
         set_weight_attrs(qw, {"input_dim": 1, "output_dim": 0})
         layer.register_parameter("qweight", qw)
         for name in ("scales", "qzeros"):
             p = nn.Parameter(torch.zeros(out_per_rank, g_per_rank, dtype=dtype), requires_grad=False)
             set_weight_attrs(p, {"output_dim": 0} if whole else {"input_dim": 1, "output_dim": 0})
             layer.register_parameter(name, p)
+        if self.act_order:
+            # identity until a checkpoint tensor arrives (a layer of the file may be in natural order)
+            p = nn.Parameter(torch.arange(in_per_rank, dtype=torch.int32), requires_grad=False)
+            set_weight_attrs(p, {})
+            layer.register_parameter("perm", p)
 
     def process_weights_after_loading(self, layer) -> None:
-        pass
+        # (scale, zero) pairs per group and row, the layout the tiled kernel copies into LDS
+        layer.wq_sz = torch.stack([layer.scales.data.t(), layer.qzeros.data.t()], dim=-1).contiguous()
+        perm = getattr(layer, "perm", None)
+        if perm is not None and bool((perm.data.cpu() == torch.arange(perm.numel(), dtype=torch.int32)).all()):
+            layer.perm = None                    # natural order after all: no gather
 
     def apply(self, layer, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         from .. import ops
         shape = x.shape
-        y = ops.w4_linear(x.reshape(-1, shape[-1]), layer.qweight, layer.scales, layer.qzeros, layer.w4_group, bias)
+        x2 = x.reshape(-1, shape[-1])
+        perm = getattr(layer, "perm", None)
+        if perm is not None:
+            x2 = ops.permute_cols(x2, perm)
+        sz = getattr(layer, "wq_sz", None)
+        if sz is None:
+            self.process_weights_after_loading(layer)
+            sz = layer.wq_sz
+        y = ops.wq_linear(x2, layer.qweight, layer.scales, layer.qzeros, sz, layer.w4_group, layer.wq_bits, bias)
         return y.view(*shape[:-1], -1)
+
+
+Int4LinearMethod = PackedIntLinearMethod
 
 
 class LoadTimeDequant:
@@ -213,8 +268,9 @@ class LoadTimeDequant:
     while loading, so those layers are ordinary ones.  Microscaling fp4 checkpoints calibrated for 4-bit
     activations run with 16-bit activations here (``quant_dequant_mxfp4`` is the rounding they assume)."""
 
-    def __init__(self, method: str, cfg: dict):
+    def __init__(self, method: str, cfg: dict, tp_size: int = 1):
         self.method = method
+        self.tp_size = tp_size
         self.bits = int(cfg.get("bits", cfg.get("w_bit", 4)) or 4)
         self.block = tuple(cfg.get("weight_block_size") or (128, 128))
         # AutoGPTQ v1 files store zero - 1
@@ -224,7 +280,11 @@ class LoadTimeDequant:
         from .. import envs
         self.group_size = int(cfg.get("group_size", cfg.get("q_group_size", 128)) or 128)
         self.skip = list(cfg.get("modules_to_not_convert") or [])
-        self.pack4 = (method in ("gptq", "awq") and self.bits == 4 and not cfg.get("desc_act", False)
+        # activation reordering gathers whole-K activations: kept packed only without tensor parallelism (a
+        # row-parallel shard would need every group's scales); 8-bit GPTQ stays 8 bit
+        self.act_order = bool(cfg.get("desc_act", False)) and method == "gptq"
+        self.pack4 = (method in ("gptq", "awq") and (self.bits == 4 or (self.bits == 8 and method == "gptq"))
+                      and (not self.act_order or tp_size == 1)
                       and envs.VDA_INT4_WEIGHTS and (self.group_size == -1 or self.group_size % 32 == 0))
 
     def _packed(self, prefix: str) -> bool:
@@ -234,7 +294,7 @@ class LoadTimeDequant:
     def get_quant_method(self, layer, prefix):
         from ..layers.linear import LinearBase
         if isinstance(layer, LinearBase) and self._packed(prefix):
-            return Int4LinearMethod(self.group_size)
+            return PackedIntLinearMethod(self.group_size, self.bits, self.act_order)
         return None
 
     def _wrap_bnb(self, weights, dtype: torch.dtype) -> Iterator[tuple[str, torch.Tensor]]:
@@ -309,9 +369,11 @@ class LoadTimeDequant:
             if not all(k in d for k in ("qweight", "qzeros", "scales")):
                 return None
             if self._packed(prefix):
-                qw, sc, z = (awq_to_packed4(d["qweight"], d["qzeros"], d["scales"], dtype) if self.method == "awq"
-                             else gptq_to_packed4(d["qweight"], d["qzeros"], d["scales"], self.zero_offset, dtype))
-                return {"qweight": qw, "scales": sc, "qzeros": z}
+                if self.method == "awq":
+                    qw, sc, z = awq_to_packed4(d["qweight"], d["qzeros"], d["scales"], dtype)
+                    return {"qweight": qw, "scales": sc, "qzeros": z}
+                return gptq_to_packed(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx") if self.act_order else None,
+                                      self.bits, self.zero_offset, dtype)
             if self.method == "awq":
                 return dequantize_awq(d["qweight"], d["qzeros"], d["scales"], self.bits, dtype)
             return dequantize_gptq(d["qweight"], d["qzeros"], d["scales"], d.get("g_idx"), self.bits,

@@ -625,12 +625,13 @@ def gate_up_silu_mul(x: torch.Tensor, w: torch.Tensor) -> Optional[torch.Tensor]
 # ---- 4-bit weight-only linear (GPTQ / AWQ) ------------------------------------------------------
 def w4_pack(q: torch.Tensor) -> torch.Tensor:
     """Integer weights [N, K] with values 0..15 -> the kernel's packed form, int32 [N, K/8]: element e
-    of every 8 sits in nibble 2*(e%4) + e//4 (see ops/csrc/w4.hip)."""
+    of every 8 sits in nibble e//2 + 4*(e%2), so ``(w >> 4 i) & 0x000F000F`` is the pair (2 i, 2 i + 1) as two
+    16-bit fields, the layout of an MFMA operand register (see ops/csrc/w4.hip)."""
     N_, K = q.shape
     v = q.to(torch.int64).view(N_, K // 8, 8)
     word = torch.zeros((N_, K // 8), dtype=torch.int64, device=q.device)
     for e in range(8):
-        word |= (v[:, :, e] & 0xF) << (4 * (2 * (e % 4) + e // 4))
+        word |= (v[:, :, e] & 0xF) << (4 * (e // 2 + 4 * (e % 2)))
     return word.to(torch.uint32).view(torch.int32) if hasattr(torch, "uint32") else word.to(torch.int32)
 
 
@@ -661,6 +662,62 @@ def w4_linear(x: torch.Tensor, qw: torch.Tensor, scales: torch.Tensor, zeros: to
                N.ptr(bias), M, N_, K, group, x.stride(0), y.stride(0), N.dt(x.dtype), N.stream())
         return y
     return torch.nn.functional.linear(x, w4_dequant(qw, scales, zeros, group, x.dtype), bias)
+
+
+def wq_dequant(qw: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, group: int, bits: int,
+               dtype: torch.dtype) -> torch.Tensor:
+    """Packed 4- / 8-bit weights -> [N, K] in ``dtype``: (q - zero) * scale per group of ``group`` K elements."""
+    if bits == 4:
+        return w4_dequant(qw, scales, zeros, group, dtype)
+    N_, K = qw.shape
+    if _dev(qw) and dtype in (torch.bfloat16, torch.float16) and scales.dtype == dtype and K % 8 == 0 and group % 8 == 0:
+        out = torch.empty((N_, K), dtype=dtype, device=qw.device)
+        N.call("vda_w8_dequant", out.data_ptr(), qw.data_ptr(), scales.data_ptr(), zeros.data_ptr(), N_, K, group,
+               N.dt(dtype), N.stream())
+        return out
+    g = torch.arange(K, device=qw.device) // group
+    return ((qw.float() - zeros.float()[:, g]) * scales.float()[:, g]).to(dtype)
+
+
+def wq_gemm_ok(x: torch.Tensor, qw: torch.Tensor, group: int, bits: int) -> bool:
+    K = x.shape[1]
+    return (_dev(x) and x.dtype in (torch.bfloat16, torch.float16) and x.stride(1) == 1 and x.stride(0) % 8 == 0
+            and K % 32 == 0 and group % 32 == 0 and K % group == 0 and qw.is_contiguous()
+            and qw.numel() * qw.element_size() < (1 << 32) and x.shape[0] * x.stride(0) * 2 < (1 << 32))
+
+
+def wq_gemm(x: torch.Tensor, qw: torch.Tensor, sz: torch.Tensor, group: int, bits: int,
+            bias: Optional[torch.Tensor] = None, splits: int = 0, variant: int = 0) -> torch.Tensor:
+    """y = x @ dequant(qw).T (+ bias) for any number of rows with the weights kept packed: they are widened inside
+    the kernel (ops/csrc/gemm_wq.hip): up to 128 rows a weight-streaming kernel (packed words global -> registers),
+    more rows a tiled ping-pong kernel.  ``qw``: int32 [N, K/8] (4 bit, nibble order of ``w4_pack``) or uint8 [N, K];
+    ``sz``: [K/group, N, 2] (scale, zero) pairs in x's dtype.  ``variant`` 1 / 2 force the tiled / streaming kernel."""
+    M, K = x.shape
+    N_ = qw.shape[0]
+    if sz.shape != (K // group, N_, 2) or sz.dtype != x.dtype or not sz.is_contiguous():
+        raise ValueError(f"wq_gemm: sz must be contiguous [K/group, N, 2] of {x.dtype}, got {tuple(sz.shape)} {sz.dtype}")
+    y = torch.empty((M, N_), dtype=x.dtype, device=x.device)
+    ws = _DECODE_WS.get(x.device)
+    if ws is None:
+        ws = _DECODE_WS[x.device] = torch.empty(envs.VDA_DECODE_GEMM_WS_MB << 18, dtype=torch.float32, device=x.device)
+    N.call("vda_wq_gemm", y.data_ptr(), x.data_ptr(), qw.data_ptr(), sz.data_ptr(), N.ptr(bias), ws.data_ptr(),
+           ws.numel() * 4, M, N_, K, group, bits, x.stride(0), y.stride(0), N.dt(x.dtype), splits, variant, N.stream())
+    return y
+
+
+def wq_linear(x: torch.Tensor, qw: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, sz: torch.Tensor,
+              group: int, bits: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight-only quantised linear over weights that stay packed in device memory.  Up to ``VDA_WQ_GEMM_MAX_M``
+    rows the packed-weight kernels run (weight-streaming up to 128 rows, tiled ping-pong above: both read a quarter /
+    half of the bytes of 16-bit weights).  Larger prefill batches are compute bound: a transient 16-bit copy made by
+    the dequantisation kernel plus the library GEMM is faster there and is freed right after.  CPU: PyTorch."""
+    M = x.shape[0]
+    if M <= envs.VDA_WQ_GEMM_MAX_M and wq_gemm_ok(x, qw, group, bits) \
+            and (bias is None or (bias.dtype == x.dtype and qw.shape[0] % 4 == 0)):
+        return wq_gemm(x, qw, sz, group, bits, bias)
+    if bits == 4 and M <= envs.VDA_W4_SKINNY_MAX_M:
+        return w4_linear(x, qw, scales, zeros, group, bias)
+    return torch.nn.functional.linear(x, wq_dequant(qw, scales, zeros, group, bits, x.dtype), bias)
 
 
 # ---- multi-LoRA ----------------------------------------------------------------------------------

@@ -2,9 +2,10 @@
 //
 // Weights are repacked at load time into a layout chosen for this kernel, not for the file format:
 //   qweight uint32 [N, K/8]   word j of row n holds K elements 8j..8j+7; element e (0..7) sits in
-//                             nibble 2*(e%4) + e/4, so `w & 0x0F0F0F0F` yields elements 0..3 as
-//                             bytes and `(w >> 4) & 0x0F0F0F0F` elements 4..7 (byte -> float is one
-//                             v_cvt_f32_ubyteN each)
+//                             nibble e/2 + 4*(e%2): `(w >> 4 i) & 0x000F000F` is the pair (2i, 2i+1) as two
+//                             16-bit fields (an MFMA operand register once a float's exponent is or-ed in,
+//                             see gemm_wq.hip), and `w & 0x0F0F0F0F` / `(w >> 4) & 0x0F0F0F0F` yield elements
+//                             0, 4, 1, 5 / 2, 6, 3, 7 as bytes (byte -> float is one v_cvt_f32_ubyteN each)
 //   scales  T [N, K/G], zeros T [N, K/G]   value = (q - zero) * scale, G a multiple of 32
 // Decode (M <= 64): the skinny-GEMM scheme of gemv.hip, with a quarter of its HBM traffic: 16 weight
 // rows per workgroup, each lane streams 32 consecutive K elements (one 16-byte load) per 128-wide
@@ -19,12 +20,12 @@ __device__ __forceinline__ typename Vec<T>::v8 w4_expand(uint32_t w, float s, fl
   const uint32_t lo = w & 0x0F0F0F0Fu, hi = (w >> 4) & 0x0F0F0F0Fu;
   typename Vec<T>::v8 o;
   o[0] = (T)fmaf((float)(lo & 0xff), s, nzs);
-  o[1] = (T)fmaf((float)((lo >> 8) & 0xff), s, nzs);
-  o[2] = (T)fmaf((float)((lo >> 16) & 0xff), s, nzs);
-  o[3] = (T)fmaf((float)(lo >> 24), s, nzs);
-  o[4] = (T)fmaf((float)(hi & 0xff), s, nzs);
-  o[5] = (T)fmaf((float)((hi >> 8) & 0xff), s, nzs);
-  o[6] = (T)fmaf((float)((hi >> 16) & 0xff), s, nzs);
+  o[4] = (T)fmaf((float)((lo >> 8) & 0xff), s, nzs);
+  o[1] = (T)fmaf((float)((lo >> 16) & 0xff), s, nzs);
+  o[5] = (T)fmaf((float)(lo >> 24), s, nzs);
+  o[2] = (T)fmaf((float)(hi & 0xff), s, nzs);
+  o[6] = (T)fmaf((float)((hi >> 8) & 0xff), s, nzs);
+  o[3] = (T)fmaf((float)((hi >> 16) & 0xff), s, nzs);
   o[7] = (T)fmaf((float)(hi >> 24), s, nzs);
   return o;
 }
@@ -159,6 +160,48 @@ __global__ __launch_bounds__(256) void w4_dequant_kernel(T* __restrict__ out, co
   const float s = (float)scales[n * (K / G) + grp];
   const float nzs = -(float)zeros[n * (K / G) + grp] * s;
   st16<V8>(out + i * 8, w4_expand<T>(qw[i], s, nzs));
+}
+
+// 8-bit weights (unsigned bytes [N, K]): out[n, 8j .. 8j+7] = (q - zero) * scale; one thread per 8 bytes
+template <typename T>
+__global__ __launch_bounds__(256) void w8_dequant_kernel(T* __restrict__ out, const uint8_t* __restrict__ qw,
+                                                         const T* __restrict__ scales, const T* __restrict__ zeros,
+                                                         long nchunks, int K, int G) {
+  using V8 = typename Vec<T>::v8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int cpr = K / 8;
+  const long n = i / cpr;
+  const int j = (int)(i - n * cpr);
+  const int grp = (j * 8) / G;
+  const float s = (float)scales[n * (K / G) + grp];
+  const float nzs = -(float)zeros[n * (K / G) + grp] * s;
+  const u32x2 raw = *reinterpret_cast<const u32x2*>(qw + i * 8);
+  V8 o;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    o[4 * h + 0] = (T)fmaf((float)(raw[h] & 0xff), s, nzs);
+    o[4 * h + 1] = (T)fmaf((float)((raw[h] >> 8) & 0xff), s, nzs);
+    o[4 * h + 2] = (T)fmaf((float)((raw[h] >> 16) & 0xff), s, nzs);
+    o[4 * h + 3] = (T)fmaf((float)(raw[h] >> 24), s, nzs);
+  }
+  st16<V8>(out + i * 8, o);
+}
+
+VDA_EXPORT int vda_w8_dequant(void* out, const void* qw, const void* scales, const void* zeros, int N, int K, int G,
+                              int dtype, hipStream_t st) {
+  if (K % 8 || G % 8 || G <= 0 || K % G) return -1;
+  const long nchunks = (long)N * (K / 8);
+  dim3 grid((unsigned)((nchunks + 255) / 256)), block(256);
+  if (dtype == VDA_BF16)
+    hipLaunchKernelGGL(w8_dequant_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)out, (const uint8_t*)qw,
+                       (const bf16_t*)scales, (const bf16_t*)zeros, nchunks, K, G);
+  else if (dtype == VDA_F16)
+    hipLaunchKernelGGL(w8_dequant_kernel<f16_t>, grid, block, 0, st, (f16_t*)out, (const uint8_t*)qw,
+                       (const f16_t*)scales, (const f16_t*)zeros, nchunks, K, G);
+  else return -3;
+  VDA_CHECK_LAUNCH();
+  return 0;
 }
 
 VDA_EXPORT int vda_w4_dequant(void* out, const void* qw, const void* scales, const void* zeros, int N, int K, int G,

@@ -64,11 +64,13 @@ _SIGS = {
     "vda_moe_align_large": [P, P, P, P, P, I, I, P],
     "vda_tile_gemm": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, I, I, I, I, I, P],
     "vda_decode_gemm": [P, P, P, P, P, L, I, I, I, L, L, I, P],
+    "vda_wq_gemm": [P, P, P, P, P, P, L, I, I, I, I, I, L, L, I, I, I, P],
     "vda_dense_gemm_stamp": [P, P, P, I, I, I, I, P],
     "vda_dense_gemm": [P, P, P, P, P, P, L, I, I, I, L, L, L, I, I, I, I, I, P],
     "vda_per_group_fp8_quant": [P, P, P, I, I, I, L, L, I, P],
     "vda_w4_skinny_gemm": [P, P, P, P, P, P, I, I, I, I, L, L, I, P],
     "vda_w4_dequant": [P, P, P, P, I, I, I, I, P],
+    "vda_w8_dequant": [P, P, P, P, I, I, I, I, P],
     "vda_mla_cache_write": [P, P, P, P, P, I, I, I, I, L, L, I, P],
     "vda_mla_attention": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, I, P],
     "vda_mla_supported": [I, I],

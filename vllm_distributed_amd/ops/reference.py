@@ -437,7 +437,7 @@ def selective_scan(u, delta, A, B, C, D, z, delta_bias, ssm_state, qsl, seq_lens
 def w4_unpack(qw: torch.Tensor) -> torch.Tensor:
     """int32 [N, K/8] in the kernel's nibble order -> int64 [N, K] of values 0..15."""
     w = qw.to(torch.int64) & 0xFFFFFFFF
-    cols = [(w >> (4 * (2 * (e % 4) + e // 4))) & 0xF for e in range(8)]
+    cols = [(w >> (4 * (e // 2 + 4 * (e % 2)))) & 0xF for e in range(8)]
     return torch.stack(cols, dim=-1).reshape(qw.shape[0], -1)
 
 
