@@ -56,6 +56,25 @@ def quant_q8_0(w: np.ndarray) -> bytes:
     return b"".join(d[i].astype(np.float16).tobytes() + q[i].tobytes() for i in range(b.shape[0]))
 
 
+def quant_q4_0(w: np.ndarray) -> bytes:
+    b = w.reshape(-1, 32).astype(np.float32)
+    idx = np.abs(b).argmax(1)
+    d = b[np.arange(b.shape[0]), idx] / -8.0
+    q = np.clip(np.round(b / np.where(d != 0, d, 1)[:, None]) + 8, 0, 15).astype(np.uint8)
+    qs = q[:, :16] | (q[:, 16:] << 4)
+    return b"".join(d[i].astype(np.float16).tobytes() + qs[i].tobytes() for i in range(b.shape[0]))
+
+
+def quant_q4_1(w: np.ndarray) -> bytes:
+    b = w.reshape(-1, 32).astype(np.float32)
+    lo, hi = b.min(1), b.max(1)
+    d = (hi - lo) / 15.0
+    q = np.clip(np.round((b - lo[:, None]) / np.where(d != 0, d, 1)[:, None]), 0, 15).astype(np.uint8)
+    qs = q[:, :16] | (q[:, 16:] << 4)
+    return b"".join(d[i].astype(np.float16).tobytes() + lo[i].astype(np.float16).tobytes() + qs[i].tobytes()
+                    for i in range(b.shape[0]))
+
+
 # ---- scalar references (ggml-quants.c, one block at a time) ------------------------------------------------
 def _h(b, o):
     return float(np.frombuffer(bytes(b[o:o + 2]), dtype=np.float16)[0])
@@ -151,7 +170,51 @@ def test_q5_0_and_q8_0_roundtrip():
     np.testing.assert_allclose(got, 0.5 * (codes.astype(np.float32) - 16))
 
 
-def _export(hf, path, quant: bool):
+@pytest.mark.parametrize("tid", [2, 3, 6, 7, 8, 12, 13])
+def test_packed_codes_reproduce_the_block_dequantisers(tid):
+    """Codes, scales and zero points kept for the packed-weight kernels expand to the values of the float
+    dequantiser of the same type, blocks with a zero scale included."""
+    from vllm_distributed_amd import ops
+    name, per, nbytes = G.GGML_TYPES[tid]
+    rng = np.random.default_rng(tid)
+    N, K = 6, 512
+    blocks = rng.integers(0, 256, size=(N * K // per, nbytes), dtype=np.uint8)
+    fields = {"Q4_0": (0,), "Q5_0": (0,), "Q8_0": (0,)}.get(name, (0, 2))
+    for o in fields:
+        vals = rng.uniform(0.01, 0.5, blocks.shape[0]).astype(np.float16)
+        vals[0] = 0                                   # a block whose scale (or minimum) is exactly zero
+        blocks[:, o:o + 2] = np.frombuffer(vals.tobytes(), dtype=np.uint8).reshape(-1, 2)
+    want = G.dequantize(blocks.reshape(-1), tid, (N, K))
+    for bits in ((4, 8) if G._BLOCKS[tid][0] == 4 else (8,)):
+        t = G.packed_tensors(blocks.reshape(-1), tid, (N, K), bits, torch.float32)
+        assert t["qweight"].shape == ((N, K // 8) if bits == 4 else (N, K)) and t["scales"].shape == (N, K // 32)
+        got = ops.wq_dequant(t["qweight"], t["scales"], t["qzeros"], 32, bits, torch.float32)
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+def test_packed_config_follows_the_fused_layers(tmp_path):
+    """A fused layer is packed only when every projection in it is: q and k in Q4_0 with v in Q6_K stay 16 bit,
+    gate in Q4_0 with up in Q8_0 becomes an 8-bit layer."""
+    path = str(tmp_path / "mix.gguf")
+    w = np.ones((64, 256), np.float32)
+    q6 = bytes(210 * (64 * 256 // 256))
+    tensors = [("blk.0.attn_q.weight", w.shape, 2, quant_q4_0(w)), ("blk.0.attn_k.weight", w.shape, 2, quant_q4_0(w)),
+               ("blk.0.attn_v.weight", w.shape, 14, q6), ("blk.0.attn_output.weight", w.shape, 3, quant_q4_1(w)),
+               ("blk.0.ffn_gate.weight", w.shape, 2, quant_q4_0(w)), ("blk.0.ffn_up.weight", w.shape, 8, quant_q8_0(w)),
+               ("blk.0.ffn_down.weight", w.shape, 14, q6), ("token_embd.weight", w.shape, 8, quant_q8_0(w))]
+    write_gguf(path, {"general.architecture": "llama", "llama.attention.head_count": 2}, tensors)
+    cfg = G.GGUFPackedConfig(path)
+    L = "model.layers.0."
+    assert cfg.bits_for(L + "self_attn.qkv_proj") is None and cfg.bits_for(L + "self_attn.q_proj") is None
+    assert cfg.bits_for(L + "self_attn.o_proj") == 4
+    assert cfg.bits_for(L + "mlp.gate_up_proj") == 8 and cfg.bits_for(L + "mlp.gate_proj") == 8
+    assert cfg.bits_for(L + "mlp.down_proj") is None and cfg.bits_for("model.embed_tokens") is None
+    names = [n for n, _ in G.gguf_weights_iterator(path, torch.float16, cfg)]
+    assert L + "self_attn.q_proj.weight" in names and L + "self_attn.o_proj.qweight" in names
+    assert L + "mlp.up_proj.qzeros" in names and L + "mlp.down_proj.weight" in names
+
+
+def _export(hf, path, quant):
     c = hf.config
     H, KV = c.num_attention_heads, c.num_key_value_heads
     md = {"general.architecture": "llama", "general.alignment": 32, "llama.block_count": c.num_hidden_layers,
@@ -187,15 +250,24 @@ def _export(hf, path, quant: bool):
         if w.ndim == 1:
             tensors.append((n, w.shape, 0, w.astype(np.float32).tobytes()))
         elif quant:
-            tensors.append((n, w.shape, 8, quant_q8_0(w)))
+            # "mixed": 4-bit attention and down projections, the 8-bit type elsewhere (a fused 8-bit gate / up layer)
+            kind = quant if quant != "mixed" else ("q4_1" if "attn" in n else "q4_0" if "ffn_down" in n else "q8_0")
+            if not n.startswith("blk."):
+                kind = "q8_0"
+            tid, fn = {"q8_0": (8, quant_q8_0), "q4_0": (2, quant_q4_0), "q4_1": (3, quant_q4_1)}[kind]
+            tensors.append((n, w.shape, tid, fn(w)))
         else:
             tensors.append((n, w.shape, 1, w.astype(np.float16).tobytes()))
     tensors.append(("rope_freqs.weight", (c.head_dim // 2,), 0, np.ones(c.head_dim // 2, np.float32).tobytes()))
     write_gguf(path, md, tensors)
 
 
-@pytest.mark.parametrize("quant", [False, True])
-def test_gguf_llama_end_to_end(tmp_path, quant):
+@pytest.mark.parametrize("quant", [False, "q8_0", "mixed", "expanded"])
+def test_gguf_llama_end_to_end(tmp_path, quant, monkeypatch):
+    packed = quant not in (False, "expanded")
+    if quant == "expanded":
+        monkeypatch.setenv("VDA_GGUF_PACKED", "0")
+        quant = "q8_0"
     from tests.test_e2e_cpu import _save_tiny
     _, hf = _save_tiny(str(tmp_path), "llama")
     hf = hf.half().float()             # the F16 export is then exact
@@ -208,6 +280,22 @@ def test_gguf_llama_end_to_end(tmp_path, quant):
               max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False)
     outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=10,
                                                                                    ignore_eos=True, logprobs=0))
+    names = {n for n, _ in llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+             .named_parameters()}
+    assert any(n.endswith("qkv_proj.qweight") for n in names) == packed       # the block codes stay packed
+    if quant:
+        # compare against the model that holds the dequantised weights: the packed layers must match it closely
+        r = G.GGUFReader(path)
+        sd = hf.state_dict()
+        for name, info in r.tensors.items():
+            target = G.hf_name(name)
+            if target is None or len(info.shape) != 2:
+                continue
+            w = r.load(name, torch.float32)
+            if name.endswith((".attn_q.weight", ".attn_k.weight")):
+                w = G._unpermute(w, hf.config.num_attention_heads if ".attn_q." in name else hf.config.num_key_value_heads)
+            sd[target].copy_(w)
+        r.close()
     for p, o in zip(prompts, outs):
         gen = list(o.outputs[0].token_ids)
         with torch.no_grad():
@@ -219,7 +307,7 @@ def test_gguf_llama_end_to_end(tmp_path, quant):
         # teacher-forced: the reported log-probabilities follow the unquantised model's
         worst = max(abs(float(lp[len(p) + k - 1, t]) - o.outputs[0].logprobs[k][t].logprob)
                     for k, t in enumerate(gen))
-        assert worst < (0.05 if quant else 1e-3), worst
+        assert worst < 1e-3, worst
     llm.shutdown()
 
 

@@ -130,3 +130,29 @@ def test_gptq_layers_keep_their_weights_packed(bits, act_order):
     finally:
         ops.wq_gemm, ops.wq_dequant = real_gemm, real_deq
     assert seen == ["gemm"] * 5 + ["dequant"]
+
+
+@pytest.mark.parametrize("tid", [2, 12, 13, 8])
+def test_gguf_blocks_run_packed(tid):
+    """ggml blocks (Q4_0, Q4_K, Q5_K, Q8_0) -> packed codes with one (scale, zero) pair per 32 weights -> the
+    packed-weight kernels, against the float dequantiser of the block type."""
+    import numpy as np
+
+    from vllm_distributed_amd import ops
+    from vllm_distributed_amd.models import gguf as G
+    name, per, nbytes = G.GGML_TYPES[tid]
+    rng = np.random.default_rng(tid)
+    N, K = 512, 1024
+    blocks = rng.integers(0, 256, size=(N * K // per, nbytes), dtype=np.uint8)
+    for o in ((0,) if name in ("Q4_0", "Q8_0") else (0, 2)):
+        vals = rng.uniform(0.001, 0.01, blocks.shape[0]).astype(np.float16)
+        blocks[:, o:o + 2] = np.frombuffer(vals.tobytes(), dtype=np.uint8).reshape(-1, 2)
+    deq = G.dequantize(blocks.reshape(-1), tid, (N, K)).cuda()
+    bits = 4 if G._BLOCKS[tid][0] == 4 else 8
+    t = {k: v.cuda() for k, v in G.packed_tensors(blocks.reshape(-1), tid, (N, K), bits, torch.float16).items()}
+    sz = torch.stack([t["scales"].t(), t["qzeros"].t()], dim=-1).contiguous()
+    for M in (1, 24, 100, 300, 1024):
+        x = torch.randn(M, K, device="cuda", dtype=torch.float16)
+        ref = x.float() @ deq.t()
+        y = ops.wq_linear(x, t["qweight"], t["scales"], t["qzeros"], sz, 32, bits)
+        assert (y.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2, (name, M)

@@ -14,6 +14,8 @@ kv_cache.py (BaseKVCacheMethod).
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Optional
 
 import torch
@@ -290,7 +292,10 @@ class Bnb4LinearMethod:
 def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:
     mc = vllm_config.model_config
     q = mc.quantization
-    if q is None:
+    if q in (None, "gguf") and str(mc.model).endswith(".gguf") and os.path.isfile(mc.model) and envs.VDA_GGUF_PACKED:
+        from ..models.gguf import GGUFPackedConfig
+        return GGUFPackedConfig(mc.model)
+    if q in (None, "gguf"):
         return None
     hf_q = mc.hf_config.get("quantization_config") if hasattr(mc.hf_config, "get") else \
         getattr(mc.hf_config, "quantization_config", None)

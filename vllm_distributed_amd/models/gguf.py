@@ -1,7 +1,10 @@
 """GGUF checkpoints: a reader for the container (v2 / v3), block dequantisers for the common ggml
 types, and the mapping from llama.cpp tensor / metadata names to the Hugging Face ones the model
-classes load.  Weights are expanded to 16 bit while loading (like GPTQ / AWQ checkpoints with
-act-order); the file is memory-mapped and decoded tensor by tensor.
+classes load.  Linear layers whose tensors are all of a 4-, 5- or 8-bit block type with 32-element sub-blocks
+(Q4_0, Q4_1, Q4_K / Q5_0, Q5_1, Q5_K, Q8_0) keep their codes packed in device memory (4 or 8 bits per weight, one
+(scale, zero) pair per 32 weights) and run the packed-weight GEMM kernels (ops/csrc/gemm_wq.hip); every other tensor
+(Q6_K with its 16-element sub-blocks, embeddings, norms) is expanded to 16 bit while loading.  The file is
+memory-mapped and decoded tensor by tensor.
 
 Only what is read from the file's own tables is trusted: sizes are checked against the file length
 before any slice is taken.
@@ -225,6 +228,80 @@ def dequantize(raw: np.ndarray, ggml_type: int, shape: tuple[int, ...]) -> torch
     return torch.from_numpy(np.ascontiguousarray(out, dtype=np.float32)).reshape(shape)
 
 
+# ---- codes for the packed-weight kernels: value = code * scale + offset per 32 elements -------------------------
+def _blocks_q4_0(b):
+    q = b[:, 2:]
+    return np.concatenate([q & 15, q >> 4], axis=1), _f16(b[:, :2]), -8.0 * _f16(b[:, :2])
+
+
+def _blocks_q4_1(b):
+    q = b[:, 4:]
+    return np.concatenate([q & 15, q >> 4], axis=1), _f16(b[:, :2]), _f16(b[:, 2:4])
+
+
+def _blocks_q5_0(b):
+    h, q = _high_bits(b[:, 2:6]), b[:, 6:]
+    return (np.concatenate([(q & 15) | (h[:, :16] << 4), (q >> 4) | (h[:, 16:] << 4)], axis=1), _f16(b[:, :2]),
+            -16.0 * _f16(b[:, :2]))
+
+
+def _blocks_q5_1(b):
+    h, q = _high_bits(b[:, 4:8]), b[:, 8:]
+    return (np.concatenate([(q & 15) | (h[:, :16] << 4), (q >> 4) | (h[:, 16:] << 4)], axis=1), _f16(b[:, :2]),
+            _f16(b[:, 2:4]))
+
+
+def _blocks_q8_0(b):
+    d = _f16(b[:, :2])
+    return (b[:, 2:].copy().view(np.int8).astype(np.int16) + 128).astype(np.uint8), d, -128.0 * d
+
+
+def _blocks_q4_k(b):
+    d, dmin = _f16(b[:, 0:2]), _f16(b[:, 2:4])
+    sc, mn = _k_scales(b[:, 4:16])
+    q = b[:, 16:].reshape(-1, 4, 32)
+    v = np.stack([q & 15, q >> 4], axis=2).reshape(-1, 256)
+    return v, d * sc, -(dmin * mn)
+
+
+def _blocks_q5_k(b):
+    d, dmin = _f16(b[:, 0:2]), _f16(b[:, 2:4])
+    sc, mn = _k_scales(b[:, 4:16])
+    qh = b[:, 16:48]
+    q = b[:, 48:].reshape(-1, 4, 32)
+    lo = np.stack([q & 15, q >> 4], axis=2).reshape(-1, 8, 32)
+    hb = ((qh[:, None, :] >> np.arange(8, dtype=np.uint8)[None, :, None]) & 1).astype(np.uint8)
+    return (lo | (hb << 4)).reshape(-1, 256), d * sc, -(dmin * mn)
+
+
+# ggml type id -> (bits of a code, codes / scales / offsets of the blocks)
+_BLOCKS = {2: (4, _blocks_q4_0), 3: (4, _blocks_q4_1), 12: (4, _blocks_q4_k), 6: (5, _blocks_q5_0),
+           7: (5, _blocks_q5_1), 13: (5, _blocks_q5_k), 8: (8, _blocks_q8_0)}
+
+
+def packed_tensors(raw: np.ndarray, ggml_type: int, shape: tuple[int, ...], bits: int,
+                   dtype: torch.dtype) -> dict[str, torch.Tensor]:
+    """Bytes of one [N, K] tensor -> the tensors of a packed linear layer (models/dequant.py
+    PackedIntLinearMethod, groups of 32): qweight (4 bit: int32 [N, K/8]; 8 bit: uint8 [N, K]), scales and zero
+    points [N, K/32] with value = (code - zero) * scale.  A sub-block whose scale is 0 (every element equals the
+    offset) gets a scale small enough for the codes not to matter."""
+    from ..ops import w4_pack
+    _, per, nbytes = GGML_TYPES[ggml_type]
+    code_bits, fn = _BLOCKS[ggml_type]
+    if code_bits > bits or len(shape) != 2:
+        raise ValueError(f"ggml type {GGML_TYPES[ggml_type][0]} does not fit {bits}-bit codes")
+    q, s, off = fn(raw.reshape(-1, nbytes))
+    N, K = shape
+    q = torch.from_numpy(np.ascontiguousarray(q)).reshape(N, K)
+    s = np.ascontiguousarray(s, dtype=np.float32).reshape(N, K // 32)
+    off = np.ascontiguousarray(off, dtype=np.float32).reshape(N, K // 32)
+    flat = s == 0
+    s = np.where(flat, np.abs(off) / (32768.0 if dtype == torch.float16 else 1048576.0), s)     # zero stays finite
+    z = np.where(s != 0, -off / np.where(s != 0, s, 1.0), 0.0)
+    return {"qweight": w4_pack(q) if bits == 4 else q.to(torch.uint8),
+            "scales": torch.from_numpy(s).to(dtype), "qzeros": torch.from_numpy(z.astype(np.float32)).to(dtype)}
+
+
 # ---- llama.cpp names -> Hugging Face names ---------------------------------------------------------------
 _LAYER_NAMES = {
     "attn_norm": "input_layernorm", "attn_q": "self_attn.q_proj", "attn_k": "self_attn.k_proj",
@@ -287,8 +364,60 @@ def config_from_gguf(path: str) -> dict:
         r.close()
 
 
-def gguf_weights_iterator(path: str, dtype: torch.dtype) -> Iterator[tuple[str, torch.Tensor]]:
-    """(Hugging Face name, 16-bit tensor) for every tensor of the file the model classes know."""
+# projections the model classes fuse into one layer: all of them must be packable for the layer to be packed
+_FUSED = (("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), ("mlp.gate_proj", "mlp.up_proj"))
+_FUSED_NAME = {"self_attn.qkv_proj": _FUSED[0], "mlp.gate_up_proj": _FUSED[1]}
+
+
+class GGUFPackedConfig:
+    """Quantisation config of a GGUF file: which linear layers keep their block codes packed, and at how many
+    bits.  Decided from the file's tensor table alone, so the layer constructors and the weight iterator agree.
+    Reference: vllm/model_executor/layers/quantization/gguf.py:GGUFConfig / GGUFLinearMethod."""
+
+    def __init__(self, path: str):
+        r = GGUFReader(path)
+        try:
+            self.types: dict[str, int] = {}            # HF module path -> ggml type of its weight
+            for name, info in r.tensors.items():
+                target = hf_name(name)
+                if target is not None and target.endswith(".weight") and len(info.shape) == 2:
+                    self.types[target[: -len(".weight")]] = info.ggml_type
+        finally:
+            r.close()
+
+    def _members(self, prefix: str) -> list[str]:
+        head, _, leaf2 = prefix.rpartition(".")
+        head, _, leaf1 = head.rpartition(".")
+        leaf = f"{leaf1}.{leaf2}"
+        if leaf in _FUSED_NAME:
+            return [f"{head}.{m}" for m in _FUSED_NAME[leaf]]
+        for group in _FUSED:
+            if leaf in group:
+                return [f"{head}.{m}" for m in group]
+        return [prefix]
+
+    def bits_for(self, prefix: str) -> Optional[int]:
+        """4 / 8 when the layer at ``prefix`` (a fused layer or one of its projections) stays packed, else None."""
+        if ".layers." not in prefix:
+            return None                                  # embeddings and the output head stay 16 bit
+        kinds = [self.types.get(m) for m in self._members(prefix)]
+        if any(k not in _BLOCKS for k in kinds):
+            return None
+        return 4 if all(_BLOCKS[k][0] == 4 for k in kinds) else 8
+
+    def get_quant_method(self, layer, prefix: str):
+        from ..layers.linear import LinearBase
+        from .dequant import PackedIntLinearMethod
+        if not isinstance(layer, LinearBase):
+            return None
+        bits = self.bits_for(prefix)
+        return PackedIntLinearMethod(32, bits) if bits else None
+
+
+def gguf_weights_iterator(path: str, dtype: torch.dtype,
+                          packed: Optional[GGUFPackedConfig] = None) -> Iterator[tuple[str, torch.Tensor]]:
+    """(Hugging Face name, tensor) for every tensor of the file the model classes know: 16-bit weights, or the
+    packed codes, scales and zero points of the layers ``packed`` keeps quantised."""
     r = GGUFReader(path)
     try:
         arch = r.metadata.get("general.architecture", "llama")
@@ -298,8 +427,17 @@ def gguf_weights_iterator(path: str, dtype: torch.dtype) -> Iterator[tuple[str, 
             target = hf_name(name)
             if target is None:
                 continue                    # rope_freqs and other derived tensors
+            permuted = arch in _PERMUTED_QK and name.endswith((".attn_q.weight", ".attn_k.weight"))
+            bits = packed.bits_for(target[: -len(".weight")]) if packed is not None and target.endswith(".weight") \
+                and len(info.shape) == 2 else None
+            if bits:
+                for suffix, t in packed_tensors(r.raw(info), info.ggml_type, info.shape, bits, dtype).items():
+                    if permuted:
+                        t = _unpermute(t, heads if ".attn_q." in name else kv)
+                    yield f"{target[: -len('.weight')]}.{suffix}", t
+                continue
             w = dequantize(r.raw(info), info.ggml_type, info.shape).to(dtype)
-            if arch in _PERMUTED_QK and name.endswith((".attn_q.weight", ".attn_k.weight")):
+            if permuted:
                 w = _unpermute(w, heads if ".attn_q." in name else kv)
             yield target, w
     finally:

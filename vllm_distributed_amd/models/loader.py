@@ -38,7 +38,7 @@ def set_default_torch_dtype(dtype: torch.dtype):
 
 def _quant_config(vllm_config: VllmConfig):
     q = vllm_config.model_config.quantization
-    if q is None:
+    if q is None and not str(vllm_config.model_config.model).endswith(".gguf"):
         return None
     from ..layers.quant import get_quant_config
     return get_quant_config(vllm_config)
@@ -250,8 +250,11 @@ class DefaultModelLoader(BaseModelLoader):
     def get_all_weights(self, vllm_config: VllmConfig) -> Iterable[tuple[str, torch.Tensor]]:
         folder = vllm_config.model_config.model
         if folder.endswith(".gguf") and os.path.isfile(folder):
-            from .gguf import gguf_weights_iterator
-            return gguf_weights_iterator(folder, vllm_config.model_config.dtype)
+            from ..layers.quant import get_quant_config
+            from .gguf import GGUFPackedConfig, gguf_weights_iterator
+            qc = get_quant_config(vllm_config)
+            return gguf_weights_iterator(folder, vllm_config.model_config.dtype,
+                                         qc if isinstance(qc, GGUFPackedConfig) else None)
         fmt = self.load_config.load_format
         streamed = fmt in ("fastsafetensors", "runai_streamer")
         files, is_st = find_weight_files(folder, "safetensors" if streamed else fmt, self.load_config.ignore_patterns)
