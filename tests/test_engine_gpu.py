@@ -58,9 +58,9 @@ def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     assert worst < 0.08, worst
 
 
-@pytest.mark.parametrize("head_dim", [80, 192])
+@pytest.mark.parametrize("head_dim", [80, 96, 112, 192])
 def test_gpu_padded_head_sizes_match_hf(tmp_path, head_dim):
-    """Head sizes the MFMA kernels are not built for run zero-padded (80 -> 128, 192 -> 256), graphs on."""
+    """Head sizes 96 and 192 run natively; 80 and 112 run zero-padded to 96 and 128.  Graphs on."""
     import transformers as tf
     from vllm_distributed_amd import SamplingParams
     torch.manual_seed(0)
@@ -73,7 +73,10 @@ def test_gpu_padded_head_sizes_match_hf(tmp_path, head_dim):
     llm = _llm(path)
     outs = llm.generate(prompt_token_ids=PROMPTS,
                         sampling_params=SamplingParams(temperature=0, max_tokens=10, ignore_eos=True, logprobs=0))
+    runner = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+    rows = {m.k_cache.shape[-1] for m in runner.attn_layers.values()}
     llm.shutdown()
+    assert rows == {{80: 96, 96: 96, 112: 128, 192: 192}[head_dim]}        # width of a cache row
     worst = 0.0
     for p, o in zip(PROMPTS, outs):
         gen = list(o.outputs[0].token_ids)

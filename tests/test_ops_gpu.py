@@ -166,7 +166,8 @@ def _paged_problem(seq_lens, q_lens, Hq, Hkv, D, bs, dt, scale_in=1.0):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (12, 12, 64), (28, 4, 128), (16, 2, 256)])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (12, 12, 64), (28, 4, 128), (16, 2, 256), (32, 32, 96),
+                                       (12, 4, 96), (16, 2, 192)])
 @pytest.mark.parametrize("bs", [16, 32, 64])
 @pytest.mark.parametrize("nsplit", [1, 4])
 def test_paged_attention_decode(dt, Hq, Hkv, D, bs, nsplit):
@@ -194,7 +195,8 @@ def test_paged_attention_decode_window_softcap_alibi_multiq(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (12, 12, 64), (28, 4, 128)])
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (8, 1, 128), (12, 12, 64), (28, 4, 128), (32, 32, 96), (12, 4, 96),
+                                       (16, 2, 192)])
 @pytest.mark.parametrize("bs", [16, 32])
 def test_paged_attention_prefill(dt, Hq, Hkv, D, bs):
     # mix of full prefills, chunked prefills with cached context, and single-token rows
@@ -218,7 +220,7 @@ def test_paged_attention_prefill_window():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (12, 12, 64), (4, 1, 256)])
+@pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (12, 12, 64), (4, 1, 256), (8, 2, 96), (4, 1, 192)])
 def test_paged_attention_prefill_bidirectional_and_lse(dt, Hq, Hkv, D):
     seq_lens = [5, 130, 300, 33]
     q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, seq_lens, Hq, Hkv, D, 16, dt)

@@ -18,6 +18,9 @@ from ..forward_context import AttentionMetadata, get_forward_context
 from ..sched.kv_cache_interface import FullAttentionSpec, KVCacheSpec, MLASpec, SlidingWindowSpec
 
 
+NATIVE_HEAD_SIZES = (64, 96, 128, 192, 256)
+
+
 class Attention(nn.Module):
     def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
                  alibi_slopes: Optional[list[float]] = None, sliding_window: Optional[int] = None,
@@ -28,14 +31,21 @@ class Attention(nn.Module):
         # [p - p % local_chunk, p] only; the runner supplies the per-chunk virtual batch
         # (reference: vllm/v1/attention/backends/utils.py:242 make_local_attention_virtual_batches)
         self.local_chunk = int(local_chunk or 0)
-        # The MFMA kernels are built for heads of 64, 128 and 256 values.  Other sizes (80, 96, 112, 192, ...)
-        # run zero-padded to the next of these: padding adds nothing to q.k, and the padded output values
-        # are zero and cut off again (reference head sizes: csrc/attention/paged_attention_v1.cu:150-188).
+        # The MFMA kernels are built for heads of 64, 96, 128, 192 and 256 values (96 and 192 with 16-bit caches).
+        # Other sizes (80, 112, 160, ...) run zero-padded to the next of these: padding adds nothing to q.k, and
+        # the padded output values are zero and cut off again (reference head sizes:
+        # csrc/attention/paged_attention_v1.cu:150-188).
         self.true_head_size = int(head_size)
-        if head_size not in (64, 128, 256):
-            if head_size > 256:
-                raise ValueError(f"head size {head_size} is beyond the MFMA attention kernels (at most 256)")
-            head_size = 64 if head_size < 64 else 128 if head_size < 128 else 256
+        from ..config import get_current_vllm_config_or_none
+        cfg = get_current_vllm_config_or_none()
+        if cache_dtype == "auto" and cfg is not None and getattr(cfg, "cache_config", None) is not None:
+            cache_dtype = cfg.cache_config.cache_dtype        # models that do not pass it on
+        sizes = (64, 128) if str(cache_dtype).startswith("fp8") else NATIVE_HEAD_SIZES
+        if head_size not in sizes:
+            if head_size > sizes[-1]:
+                raise ValueError(f"head size {head_size} is beyond the MFMA attention kernels (at most {sizes[-1]}"
+                                 f"{' with an fp8 cache' if len(sizes) == 2 else ''})")
+            head_size = next(d for d in sizes if d >= head_size)
         self.num_heads, self.head_size, self.scale = num_heads, head_size, float(scale)
         self.causal = causal          # False: encoder models, every token sees its whole sequence
         self.num_kv_heads = num_kv_heads or num_heads
@@ -45,8 +55,6 @@ class Attention(nn.Module):
         self.cache_dtype = cache_dtype
         # fp8 KV cache scales: stored value = x / scale (1.0 unless the checkpoint carries calibrated scales)
         self._k_scale_float = self._v_scale_float = 1.0
-        from ..config import get_current_vllm_config_or_none
-        cfg = get_current_vllm_config_or_none()
         qc = getattr(cfg, "quant_config", None) if cfg is not None else None
         self.quant_method = qc.get_quant_method(self, prefix) if qc is not None else None
         if self.quant_method is not None:

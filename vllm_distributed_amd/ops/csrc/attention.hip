@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64) void attn_reduce_kernel(T* out, const float* pa
   float W = w_mine;
 #pragma unroll
   for (int o_ = 32; o_ > 0; o_ >>= 1) W += __shfl_xor(W, o_, 64);
-  constexpr int PER = D / 64 > 0 ? D / 64 : 1;
+  constexpr int PER = (D + 63) / 64;
   float o[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) o[i] = 0.f;
@@ -671,7 +671,7 @@ static int launch_attn(const AttnParams& p, int form, int grid_x, hipStream_t st
     hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, true, F8>), grid, block, 0, st, p);
   } else if (form == 3) {
     dim3 grid(grid_x, p.Hkv, 1);
-    if constexpr (D <= 128) {
+    if constexpr (D == 64 || D == 128) {          // the LDS tile layout is built for rows of 8 or 16 pieces
       hipLaunchKernelGGL((paged_prefill_lds_kernel<T, D, BS, F8>), grid, block, 0, st, p);
     } else {
       hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, false, F8>), grid, block, 0, st, p);
@@ -694,12 +694,21 @@ static int dispatch_bs(const AttnParams& p, int bs, int form, int grid_x, hipStr
   return -2;
 }
 
+// Head sizes: any multiple of 32 fits the kernels (a lane group owns D / 4 values in MFMA steps of 8); built are
+// 64, 96, 128, 192 and 256, so heads of 80 / 96 run in 96-value rows and 160 / 192 in 192-value rows instead of
+// the next power of two (reference head sizes: csrc/attention/paged_attention_v1.cu:150-188).
 template <typename T, bool F8>
 static int dispatch_d8(const AttnParams& p, int d, int bs, int form, int grid_x, hipStream_t st) {
   switch (d) {
     case 64: return dispatch_bs<T, 64, F8>(p, bs, form, grid_x, st);
     case 128: return dispatch_bs<T, 128, F8>(p, bs, form, grid_x, st);
-    case 256: return dispatch_bs<T, 256, F8>(p, bs, form, grid_x, st);
+  }
+  if constexpr (!F8) {
+    switch (d) {
+      case 96: return dispatch_bs<T, 96, F8>(p, bs, form, grid_x, st);
+      case 192: return dispatch_bs<T, 192, F8>(p, bs, form, grid_x, st);
+      case 256: return dispatch_bs<T, 256, F8>(p, bs, form, grid_x, st);
+    }
   }
   return -3;
 }
@@ -707,7 +716,7 @@ static int dispatch_d8(const AttnParams& p, int d, int bs, int form, int grid_x,
 template <typename T>
 static int dispatch_d(const AttnParams& p, int d, int bs, int form, int grid_x, hipStream_t st, int kv_fp8) {
   // fp8 caches: head sizes 64 / 128 (the common ones) to bound the number of kernel variants
-  if (kv_fp8) return d == 256 ? -3 : dispatch_d8<T, true>(p, d, bs, form, grid_x, st);
+  if (kv_fp8) return dispatch_d8<T, true>(p, d, bs, form, grid_x, st);
   return dispatch_d8<T, false>(p, d, bs, form, grid_x, st);
 }
 
@@ -736,9 +745,11 @@ VDA_EXPORT int vda_paged_attention_decode(
 #define RED(TT, DD) hipLaunchKernelGGL((attn_reduce_kernel<TT, DD>), dim3(n), dim3(64), 0, st, (TT*)out, \
                                        part_out, part_lse, Hq, nsplit, out_stride)
     if (dtype == VDA_BF16) {
-      if (D == 64) RED(bf16_t, 64); else if (D == 128) RED(bf16_t, 128); else RED(bf16_t, 256);
+      if (D == 64) RED(bf16_t, 64); else if (D == 96) RED(bf16_t, 96); else if (D == 128) RED(bf16_t, 128);
+      else if (D == 192) RED(bf16_t, 192); else RED(bf16_t, 256);
     } else {
-      if (D == 64) RED(f16_t, 64); else if (D == 128) RED(f16_t, 128); else RED(f16_t, 256);
+      if (D == 64) RED(f16_t, 64); else if (D == 96) RED(f16_t, 96); else if (D == 128) RED(f16_t, 128);
+      else if (D == 192) RED(f16_t, 192); else RED(f16_t, 256);
     }
 #undef RED
     VDA_CHECK_LAUNCH();
