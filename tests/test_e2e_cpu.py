@@ -432,6 +432,26 @@ def test_llama4_chunked_attention_with_chunked_prefill(tmp_path):
     llm.shutdown()
 
 
+def test_deepseek_fp8_latent_cache(tmp_path):
+    """kv_cache_dtype=fp8 with MLA: the latent cache holds e4m3 rows and generation follows the 16-bit-cache run
+    (teacher-forced log-probabilities within fp8 tolerance)."""
+    path, hf = _save_tiny(str(tmp_path), "deepseek_v2")
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 40]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,
+              max_num_seqs=8, max_num_batched_tokens=64, enable_prefix_caching=False, kv_cache_dtype="fp8")
+    mr = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+    assert all(getattr(m, "is_mla", False) and m.k_cache.dtype == torch.float8_e4m3fn for m in mr.attn_layers.values())
+    outs = llm.generate(prompt_token_ids=prompts,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True, logprobs=0))
+    llm.shutdown()
+    for p, o in zip(prompts, outs):
+        gen = list(o.outputs[0].token_ids)
+        with torch.no_grad():
+            lp = torch.log_softmax(hf(torch.tensor([p + gen])).logits[0].float(), -1)
+        worst = max(abs(float(lp[len(p) + k - 1, t]) - o.outputs[0].logprobs[k][t].logprob) for k, t in enumerate(gen))
+        assert worst < 0.2, worst
+
+
 def test_deepseek_expanded_heads_path_still_matches_hf(tmp_path, monkeypatch):
     """VDA_MLA=0 keeps the per-head K/V cache (padded heads) instead of the latent cache."""
     monkeypatch.setenv("VDA_MLA", "0")

@@ -58,6 +58,29 @@ def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     assert worst < 0.08, worst
 
 
+def test_gpu_fp8_latent_cache_follows_hf(tmp_path):
+    """DeepSeek-V2 with an fp8 latent cache: e4m3 rows in the MLA cache, log-probabilities of the generated tokens
+    within fp8 tolerance of transformers' (teacher-forced)."""
+    import transformers as tf
+    from vllm_distributed_amd import SamplingParams
+    path, _ = _save_tiny(str(tmp_path), "deepseek_v2_mla")
+    llm = _llm(path, kv_cache_dtype="fp8")
+    mr = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+    assert all(getattr(m, "is_mla", False) and m.k_cache.dtype == torch.float8_e4m3fn for m in mr.attn_layers.values())
+    outs = llm.generate(prompt_token_ids=PROMPTS,
+                        sampling_params=SamplingParams(temperature=0, max_tokens=12, ignore_eos=True, logprobs=0))
+    llm.shutdown()
+    hf = tf.AutoModelForCausalLM.from_pretrained(path, torch_dtype=torch.float32).eval()
+    worst = 0.0
+    for p, o in zip(PROMPTS, outs):
+        gen = list(o.outputs[0].token_ids)
+        with torch.no_grad():
+            lp = torch.log_softmax(hf(torch.tensor([p + gen])).logits[0].float(), -1)
+        for k, t in enumerate(gen):
+            worst = max(worst, abs(float(lp[len(p) + k - 1, t]) - o.outputs[0].logprobs[k][t].logprob))
+    assert worst < 0.25, worst
+
+
 @pytest.mark.parametrize("head_dim", [80, 96, 112, 192])
 def test_gpu_padded_head_sizes_match_hf(tmp_path, head_dim):
     """Head sizes 96 and 192 run natively; 80 and 112 run zero-padded to 96 and 128.  Graphs on."""

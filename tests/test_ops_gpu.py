@@ -775,13 +775,15 @@ def test_lora_update(dt, T, K, N, Rk):
 @pytest.mark.parametrize("H,lens,computed,nsplit", [(16, [1, 1, 1], [37, 700, 5], 1), (16, [1, 1], [1500, 90], 4),
                                                     (4, [9, 40, 1], [0, 13, 100], 1), (128, [2, 1], [300, 64], 2),
                                                     (8, [130], [0], 1)])
-def test_mla_attention(dt, DK, DV, H, lens, computed, nsplit):
+@pytest.mark.parametrize("fp8", [False, True])
+def test_mla_attention(dt, DK, DV, H, lens, computed, nsplit, fp8):
     BS, S = 16, len(lens)
+    cdt, kv_scale = (torch.float8_e4m3fn, 0.5) if fp8 else (dt, 1.0)
     T = sum(lens)
     total = [l + c for l, c in zip(lens, computed)]
     nblocks = sum((t + BS - 1) // BS for t in total) + 4
-    kc = torch.zeros(nblocks, BS, DK, device=DEV, dtype=dt)
-    vt = torch.zeros(nblocks, DV, BS, device=DEV, dtype=dt)
+    kc = torch.zeros(nblocks, BS, DK, device=DEV, dtype=cdt)
+    vt = torch.zeros(nblocks, DV, BS, device=DEV, dtype=cdt)
     kc_ref, vt_ref = kc.clone(), vt.clone()
     perm = torch.randperm(nblocks - 1, device=DEV) + 1
     maxb = max((t + BS - 1) // BS for t in total)
@@ -800,15 +802,20 @@ def test_mla_attention(dt, DK, DV, H, lens, computed, nsplit):
         slots.append(bt[s, pos // BS].long() * BS + pos % BS)
     slots = torch.cat(slots)
     slots[3] = -1                                   # skipped token
-    ops.mla_cache_write(all_c, all_pe, kc, vt, slots)
-    R.mla_cache_write(all_c, all_pe, kc_ref, vt_ref, slots)
-    assert torch.equal(kc, kc_ref) and torch.equal(vt, vt_ref)
+    ops.mla_cache_write(all_c, all_pe, kc, vt, slots, kv_scale)
+    R.mla_cache_write(all_c, all_pe, kc_ref, vt_ref, slots, kv_scale)
+    if fp8:          # the same e4m3 bytes up to the rounding of a tie
+        assert (kc.float() - kc_ref.float()).abs().max().item() <= 0.13 * kc_ref.float().abs().max().item()
+        assert (kc.view(torch.uint8) != kc_ref.view(torch.uint8)).float().mean().item() < 0.01
+        kc_ref, vt_ref = kc, vt
+    else:
+        assert torch.equal(kc, kc_ref) and torch.equal(vt, vt_ref)
     qsl = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
     seq = torch.tensor(total, dtype=torch.int32, device=DEV)
     q = torch.randn(T, H, DK, device=DEV, dtype=dt) * 0.5
     out = torch.empty(T, H, DV, device=DEV, dtype=dt)
-    ops.mla_attention(out, q, kc, vt, bt, seq, qsl, DK ** -0.5, max(lens), nsplit)
-    ref = R.mla_attention(q, kc, vt, bt, seq, qsl, DK ** -0.5)
+    ops.mla_attention(out, q, kc, vt, bt, seq, qsl, DK ** -0.5, max(lens), nsplit, kv_scale)
+    ref = R.mla_attention(q, kc_ref, vt_ref, bt, seq, qsl, DK ** -0.5, kv_scale)
     torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
 
 

@@ -290,10 +290,10 @@ class MLAAttention(nn.Module):
         self.max_model_len = cfg.model_config.max_model_len if cfg is not None else 4096
         self.k_cache: Optional[torch.Tensor] = None       # [blocks, BS, dk]
         self.v_cache: Optional[torch.Tensor] = None       # [blocks, dv, BS]
+        self._kv_scale_float = 1.0                        # fp8 cache: stored value = x / scale
 
     def get_kv_cache_spec(self, block_size: int, dtype: torch.dtype) -> KVCacheSpec:
-        if dtype == torch.float8_e4m3fn:
-            raise ValueError("the latent KV cache is 16-bit (fp8 is not supported for MLA)")
+        # fp8: e4m3 bytes of value / _kv_scale_float (normalised latents and rotated keys sit well inside its range)
         return MLASpec(block_size=block_size, num_kv_heads=1, head_size=self.dk, dtype=dtype, use_mla=True,
                        v_size=self.dv)
 
@@ -309,7 +309,7 @@ class MLAAttention(nn.Module):
         if md is None or self.k_cache is None:
             return out.zero_()
         n = md.num_actual_tokens
-        ops.mla_cache_write(kv_c[:n], k_pe[:n], self.k_cache, self.v_cache, md.slot_mapping[:n])
+        ops.mla_cache_write(kv_c[:n], k_pe[:n], self.k_cache, self.v_cache, md.slot_mapping[:n], self._kv_scale_float)
         if n < T:
             out[n:].zero_()
         S = md.num_decode_seqs + md.num_prefill_seqs
@@ -320,5 +320,5 @@ class MLAAttention(nn.Module):
         if md.max_query_len <= 4:
             nsplit = ops.decode_num_splits(S * max(self.num_heads // 16, 1), 1, self.max_model_len)
         ops.mla_attention(out[:n], q[:n], self.k_cache, self.v_cache, md.block_table[:S], md.seq_lens[:S],
-                          md.query_start_loc[:S + 1], self.scale, md.max_query_len, nsplit)
+                          md.query_start_loc[:S + 1], self.scale, md.max_query_len, nsplit, self._kv_scale_float)
         return out

@@ -86,7 +86,7 @@ class DeepseekAttention(nn.Module):
         # 16-bit weights (its two halves become W_UK and W_UV); expanded, padded heads otherwise.
         on_dev = vllm_config.device_config.device != "cpu"
         self.use_mla = bool(envs.VDA_MLA and (quant_config is None or getattr(quant_config, "mla_compatible", False))
-                            and vllm_config.cache_config.cache_dtype == "auto"
+                            and vllm_config.cache_config.cache_dtype in ("auto", "fp8")
                             and vllm_config.kv_transfer_config is None
                             and ops.mla_supported(self.kv_lora_rank + self.rope_dim, self.kv_lora_rank,
                                                   vllm_config.model_config.dtype, on_dev))

@@ -313,27 +313,28 @@ def mla_supported(dk: int, dv: int, dtype: torch.dtype, on_device: bool) -> bool
 
 
 def mla_cache_write(kv_c: torch.Tensor, k_pe: torch.Tensor, kc: torch.Tensor, vt: torch.Tensor,
-                    slot_mapping: torch.Tensor) -> None:
+                    slot_mapping: torch.Tensor, kv_scale: float = 1.0) -> None:
     """Write the normalised latent kv_c [T, R] and the rotated shared key k_pe [T, rope] of every token
-    into the latent cache: kc [blocks, BS, R + rope] and the transposed copy vt [blocks, R, BS]."""
+    into the latent cache: kc [blocks, BS, R + rope] and the transposed copy vt [blocks, R, BS].  An e4m3 cache
+    stores value / kv_scale."""
     if not _dev(kv_c):
-        return R.mla_cache_write(kv_c, k_pe, kc, vt, slot_mapping)
+        return R.mla_cache_write(kv_c, k_pe, kc, vt, slot_mapping, kv_scale)
     T, Rk = kv_c.shape
     assert kv_c.stride(1) == 1 and k_pe.stride(1) == 1 and kc.is_contiguous() and vt.is_contiguous()
     N.call("vda_mla_cache_write", kv_c.data_ptr(), k_pe.data_ptr(), kc.data_ptr(), vt.data_ptr(),
            slot_mapping.data_ptr(), T, Rk, k_pe.shape[1], kc.shape[1], kv_c.stride(0), k_pe.stride(0),
-           N.dt(kv_c.dtype), N.stream())
+           N.dt(kv_c.dtype), int(kc.dtype == torch.float8_e4m3fn), float(kv_scale), N.stream())
 
 
 def mla_attention(out: torch.Tensor, q: torch.Tensor, kc: torch.Tensor, vt: torch.Tensor, block_table: torch.Tensor,
                   seq_lens: torch.Tensor, q_start_loc: torch.Tensor, scale: float, max_query_len: int,
-                  num_splits: int = 1) -> torch.Tensor:
+                  num_splits: int = 1, kv_scale: float = 1.0) -> torch.Tensor:
     """Causal multi-query attention of q [T, H, DK] over the latent cache; out [T, H, DV] stays in latent
     space (the caller applies the value up-projection).  Decode and (chunked) prefill are one path."""
     T, H, DK = q.shape
     DV = vt.shape[1]
     if not _dev(q):
-        out.copy_(R.mla_attention(q, kc, vt, block_table, seq_lens, q_start_loc, scale))
+        out.copy_(R.mla_attention(q, kc, vt, block_table, seq_lens, q_start_loc, scale, kv_scale))
         return out
     part_out = part_lse = None
     if num_splits > 1:
@@ -343,7 +344,7 @@ def mla_attention(out: torch.Tensor, q: torch.Tensor, kc: torch.Tensor, vt: torc
     N.call("vda_mla_attention", out.data_ptr(), q.data_ptr(), kc.data_ptr(), vt.data_ptr(), block_table.data_ptr(),
            seq_lens.data_ptr(), q_start_loc.data_ptr(), N.ptr(part_out), N.ptr(part_lse), seq_lens.shape[0], T, H, DK,
            DV, kc.shape[1], block_table.stride(0), num_splits, max(int(max_query_len), 1), q.stride(0),
-           out.stride(0), scale, N.dt(q.dtype), N.stream())
+           out.stride(0), scale, N.dt(q.dtype), int(kc.dtype == torch.float8_e4m3fn), float(kv_scale), N.stream())
     return out
 
 

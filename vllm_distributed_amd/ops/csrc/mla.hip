@@ -8,7 +8,10 @@
 // With the key up-projection absorbed into the query (q_abs = q_nope . W_UK) and the value
 // up-projection applied after attention (o = o_lat . W_UV), every head attends over the same latent
 // rows: multi-query attention with head sizes DK / DV.  The cache is (DK + DV) elements per token,
-// against 2 * heads * head_dim for expanded heads (57x smaller for DeepSeek-V3).
+// against 2 * heads * head_dim for expanded heads (57x smaller for DeepSeek-V3).  With an fp8 cache both copies
+// hold e4m3 bytes of value / kv_scale (one scale for the latent and the rotated key): half the bytes again; the
+// kernel widens them on the way into the MFMA operands and folds the scale into the logits and the output
+// (reference: csrc/cache_kernels.cu:309-343 concat_and_cache_mla with kv_cache_dtype fp8).
 //
 // Kernel: the MFMA scheme of attention.hip (S^T = K.Q^T with keys on the MFMA row, O^T += V^T.P^T),
 // 16 (token, head) query columns per workgroup, the 4 waves split the keys and merge through LDS;
@@ -22,41 +25,46 @@
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ---- cache write -----------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool F8>
 __global__ __launch_bounds__(256) void mla_cache_write_kernel(const T* __restrict__ kv_c, const T* __restrict__ k_pe,
-                                                              T* __restrict__ kc, T* __restrict__ vt,
+                                                              typename KVElem<T, F8>::type* __restrict__ kc,
+                                                              typename KVElem<T, F8>::type* __restrict__ vt,
                                                               const long* __restrict__ slot_mapping, int R, int ROPE,
-                                                              int BS, long c_stride, long pe_stride) {
+                                                              int BS, long c_stride, long pe_stride, float inv_scale) {
+  using CT = typename KVElem<T, F8>::type;
   const int t = blockIdx.x;
   const long slot = slot_mapping[t];
   if (slot < 0) return;
   const long blk = slot / BS;
   const int off = (int)(slot % BS);
   const int DK = R + ROPE;
-  T* krow = kc + (blk * BS + off) * (long)DK;
+  CT* krow = kc + (blk * BS + off) * (long)DK;
   for (int d = threadIdx.x; d < DK; d += 256) {
     if (d < R) {
       const T v = kv_c[(long)t * c_stride + d];
-      krow[d] = v;
-      vt[(blk * R + d) * (long)BS + off] = v;
+      KVStore<T, F8>::st1(krow + d, v, inv_scale);
+      KVStore<T, F8>::st1(vt + (blk * R + d) * (long)BS + off, v, inv_scale);
     } else {
-      krow[d] = k_pe[(long)t * pe_stride + (d - R)];
+      KVStore<T, F8>::st1(krow + d, k_pe[(long)t * pe_stride + (d - R)], inv_scale);
     }
   }
 }
 
+// kv_fp8: the cache holds e4m3 bytes of value / kv_scale
 VDA_EXPORT int vda_mla_cache_write(const void* kv_c, const void* k_pe, void* kc, void* vt, const long* slot_mapping,
                                    int T, int R, int ROPE, int BS, long c_stride, long pe_stride, int dtype,
-                                   hipStream_t st) {
+                                   int kv_fp8, float kv_scale, hipStream_t st) {
   if (T <= 0) return 0;
   dim3 grid(T), block(256);
-  if (dtype == VDA_BF16)
-    hipLaunchKernelGGL(mla_cache_write_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)kv_c, (const bf16_t*)k_pe,
-                       (bf16_t*)kc, (bf16_t*)vt, slot_mapping, R, ROPE, BS, c_stride, pe_stride);
-  else if (dtype == VDA_F16)
-    hipLaunchKernelGGL(mla_cache_write_kernel<f16_t>, grid, block, 0, st, (const f16_t*)kv_c, (const f16_t*)k_pe,
-                       (f16_t*)kc, (f16_t*)vt, slot_mapping, R, ROPE, BS, c_stride, pe_stride);
+  const float inv = kv_fp8 ? 1.f / kv_scale : 1.f;
+#define W(TT, F8)                                                                                                   \
+  hipLaunchKernelGGL((mla_cache_write_kernel<TT, F8>), grid, block, 0, st, (const TT*)kv_c, (const TT*)k_pe,          \
+                     (typename KVElem<TT, F8>::type*)kc, (typename KVElem<TT, F8>::type*)vt, slot_mapping, R, ROPE, BS, \
+                     c_stride, pe_stride, inv)
+  if (dtype == VDA_BF16) { if (kv_fp8) W(bf16_t, true); else W(bf16_t, false); }
+  else if (dtype == VDA_F16) { if (kv_fp8) W(f16_t, true); else W(f16_t, false); }
   else return -3;
+#undef W
   VDA_CHECK_LAUNCH();
   return 0;
 }
@@ -74,13 +82,15 @@ struct MlaParams {
   const int* q_start_loc;
   int H, BS, max_blocks, nsplit;
   long q_stride, out_stride;
-  float scale;
+  float scale;              // softmax scale, times the cache scale for an fp8 cache
+  float v_scale;            // 1, or the cache scale for an fp8 cache
 };
 
-template <typename T, int DK, int DV>
+template <typename T, int DK, int DV, bool F8>
 __global__ __launch_bounds__(256) void mla_attention_kernel(MlaParams p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
+  using CT = typename KVElem<T, F8>::type;
   constexpr int KS = DK / 32;        // MFMA k-steps over the query/key width
   constexpr int NT = DV / 16;        // 16-row tiles of the latent output
   constexpr int DQ = DK / 4;         // key dims owned by one lane group
@@ -123,8 +133,8 @@ __global__ __launch_bounds__(256) void mla_attention_kernel(MlaParams p) {
   f32x4 acc[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) acc[n] = f32x4{0, 0, 0, 0};
-  const T* kc = (const T*)p.kc;
-  const T* vt = (const T*)p.vt;
+  const CT* kc = (const CT*)p.kc;
+  const CT* vt = (const CT*)p.vt;
   const int krow0 = 8 * (r >> 2) + (r & 3);     // tile u, row r <-> key 8*(r>>2) + 4u + (r&3) of the step
   const float sc = p.scale * 1.4426950408889634f;
 
@@ -135,10 +145,10 @@ __global__ __launch_bounds__(256) void mla_attention_kernel(MlaParams p) {
     for (int u = 0; u < 2; ++u) {
       const int tok = step * 32 + krow0 + 4 * u;
       const int bi = max(min(tok / BS, nblk_valid - 1), 0);
-      const T* kp = kc + ((long)bt[bi] * BS + (tok % BS)) * DK + g * DQ;
+      const CT* kp = kc + ((long)bt[bi] * BS + (tok % BS)) * DK + g * DQ;
       f32x4 s = {0, 0, 0, 0};
 #pragma unroll
-      for (int k = 0; k < KS; ++k) s = mfma16(ld16<V8>(kp + 8 * k), qf[k], s);
+      for (int k = 0; k < KS; ++k) s = mfma16(KVLoad<T, F8>::ld(kp + 8 * k), qf[k], s);
       s2[u] = s;
     }
     float sv[8] = {s2[0][0], s2[0][1], s2[0][2], s2[0][3], s2[1][0], s2[1][1], s2[1][2], s2[1][3]};
@@ -164,12 +174,12 @@ __global__ __launch_bounds__(256) void mla_attention_kernel(MlaParams p) {
     }
     l = l * alpha + ps;
     const int bi = max(min(tb / BS, nblk_valid - 1), 0);
-    const T* vp = vt + ((long)bt[bi] * DV + r) * BS + (tb % BS);
+    const CT* vp = vt + ((long)bt[bi] * DV + r) * BS + (tb % BS);
 #pragma unroll
     for (int n0 = 0; n0 < NT; n0 += VCH) {
       V8 vf[VCH];
 #pragma unroll
-      for (int n = 0; n < VCH; ++n) vf[n] = ld16<V8>(vp + (long)(n0 + n) * 16 * BS);
+      for (int n = 0; n < VCH; ++n) vf[n] = KVLoad<T, F8>::ld(vp + (long)(n0 + n) * 16 * BS);
 #pragma unroll
       for (int n = 0; n < VCH; ++n) {
         acc[n0 + n] *= alpha;
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256) void mla_attention_kernel(MlaParams p) {
     __syncthreads();
   }
   if (wave != 0 || !valid) return;
-  const float inv = l > 0.f ? 1.f / l : 0.f;
+  const float inv = l > 0.f ? p.v_scale / l : 0.f;
   const long tok = qs + ti;
   if (p.nsplit == 1) {
     T* op = (T*)p.out + tok * p.out_stride + (long)head * DV + 4 * g;
@@ -269,9 +279,10 @@ __global__ __launch_bounds__(64) void mla_reduce_kernel(T* out, const float* par
 }
 
 template <typename T, int DK, int DV>
-static int launch_mla(const MlaParams& p, int S, int T_tokens, int max_q, hipStream_t st) {
+static int launch_mla(const MlaParams& p, int S, int T_tokens, int max_q, bool f8, hipStream_t st) {
   dim3 block(256), grid(S, (max_q * p.H + 15) / 16, p.nsplit);
-  hipLaunchKernelGGL((mla_attention_kernel<T, DK, DV>), grid, block, 0, st, p);
+  if (f8) hipLaunchKernelGGL((mla_attention_kernel<T, DK, DV, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((mla_attention_kernel<T, DK, DV, false>), grid, block, 0, st, p);
   if (p.nsplit > 1)
     hipLaunchKernelGGL((mla_reduce_kernel<T, DV>), dim3((unsigned)((long)T_tokens * p.H)), dim3(64), 0, st,
                        (T*)p.out, p.part_out, p.part_lse, p.H, p.nsplit, p.out_stride);
@@ -285,7 +296,8 @@ VDA_EXPORT int vda_mla_supported(int DK, int DV) {
 VDA_EXPORT int vda_mla_attention(void* out, const void* q, const void* kc, const void* vt, const int* block_table,
                                  const int* seq_lens, const int* q_start_loc, float* part_out, float* part_lse,
                                  int S, int T_tokens, int H, int DK, int DV, int BS, int max_blocks, int nsplit,
-                                 int max_q, long q_stride, long out_stride, float scale, int dtype, hipStream_t st) {
+                                 int max_q, long q_stride, long out_stride, float scale, int dtype, int kv_fp8,
+                                 float kv_scale, hipStream_t st) {
   if (S <= 0 || T_tokens <= 0) return 0;
   if (!vda_mla_supported(DK, DV) || BS % 8 || nsplit < 1 || nsplit > 64 || (nsplit > 1 && (!part_out || !part_lse)))
     return -1;      // (the reduce kernel keeps one partition per lane)
@@ -293,10 +305,12 @@ VDA_EXPORT int vda_mla_attention(void* out, const void* q, const void* kc, const
   p.q = q; p.kc = kc; p.vt = vt; p.out = out; p.part_out = part_out; p.part_lse = part_lse;
   p.block_table = block_table; p.seq_lens = seq_lens; p.q_start_loc = q_start_loc;
   p.H = H; p.BS = BS; p.max_blocks = max_blocks; p.nsplit = nsplit;
-  p.q_stride = q_stride; p.out_stride = out_stride; p.scale = scale;
-#define BYD(TT) do { if (DK == 576) launch_mla<TT, 576, 512>(p, S, T_tokens, max_q, st);      \
-                     else if (DK == 96) launch_mla<TT, 96, 64>(p, S, T_tokens, max_q, st);    \
-                     else launch_mla<TT, 160, 128>(p, S, T_tokens, max_q, st); } while (0)
+  p.q_stride = q_stride; p.out_stride = out_stride;
+  p.scale = scale * (kv_fp8 ? kv_scale : 1.f); p.v_scale = kv_fp8 ? kv_scale : 1.f;
+  const bool f8 = kv_fp8 != 0;
+#define BYD(TT) do { if (DK == 576) launch_mla<TT, 576, 512>(p, S, T_tokens, max_q, f8, st);      \
+                     else if (DK == 96) launch_mla<TT, 96, 64>(p, S, T_tokens, max_q, f8, st);    \
+                     else launch_mla<TT, 160, 128>(p, S, T_tokens, max_q, f8, st); } while (0)
   if (dtype == VDA_BF16) BYD(bf16_t);
   else if (dtype == VDA_F16) BYD(f16_t);
   else return -3;

@@ -71,8 +71,8 @@ _SIGS = {
     "vda_w4_skinny_gemm": [P, P, P, P, P, P, I, I, I, I, L, L, I, P],
     "vda_w4_dequant": [P, P, P, P, I, I, I, I, P],
     "vda_w8_dequant": [P, P, P, P, I, I, I, I, P],
-    "vda_mla_cache_write": [P, P, P, P, P, I, I, I, I, L, L, I, P],
-    "vda_mla_attention": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, I, P],
+    "vda_mla_cache_write": [P, P, P, P, P, I, I, I, I, L, L, I, I, F, P],
+    "vda_mla_attention": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, I, I, F, P],
     "vda_mla_supported": [I, I],
     "vda_lora_shrink": [P, P, P, P, I, I, I, L, I, P],
     "vda_lora_expand": [P, P, P, P, I, I, I, L, I, P],

@@ -459,9 +459,11 @@ def lora_update(y, x, A, B, tok_slot):
 
 
 # ---- multi-head latent attention -----------------------------------------------------------------------
-def mla_cache_write(kv_c, k_pe, kc, vt, slot_mapping):
+def mla_cache_write(kv_c, k_pe, kc, vt, slot_mapping, kv_scale=1.0):
     BS = kc.shape[1]
     Rk = kv_c.shape[1]
+    if kc.dtype == torch.float8_e4m3fn:
+        kv_c, k_pe = kv_c.float() / kv_scale, k_pe.float() / kv_scale
     for t in range(kv_c.shape[0]):
         slot = int(slot_mapping[t])
         if slot < 0:
@@ -472,9 +474,11 @@ def mla_cache_write(kv_c, k_pe, kc, vt, slot_mapping):
         vt[b, :, o] = kv_c[t].to(vt.dtype)
 
 
-def mla_attention(q, kc, vt, block_table, seq_lens, q_start_loc, scale):
+def mla_attention(q, kc, vt, block_table, seq_lens, q_start_loc, scale, kv_scale=1.0):
     T, H, DK = q.shape
     DV, BS = vt.shape[1], kc.shape[1]
+    if kc.dtype != torch.float8_e4m3fn:
+        kv_scale = 1.0
     out = torch.zeros((T, H, DV), dtype=q.dtype, device=q.device)
     for s in range(seq_lens.shape[0]):
         L = int(seq_lens[s])
@@ -483,8 +487,8 @@ def mla_attention(q, kc, vt, block_table, seq_lens, q_start_loc, scale):
             continue
         nblk = (L + BS - 1) // BS
         blocks = block_table[s, :nblk].long()
-        K = kc[blocks].reshape(-1, DK)[:L].float()                         # [L, DK]
-        V = vt[blocks].permute(0, 2, 1).reshape(-1, DV)[:L].float()        # [L, DV]
+        K = kc[blocks].reshape(-1, DK)[:L].float() * kv_scale              # [L, DK]
+        V = vt[blocks].permute(0, 2, 1).reshape(-1, DV)[:L].float() * kv_scale   # [L, DV]
         qs = q[a:b].float()                                                # [n, H, DK]
         n = b - a
         sc = torch.einsum("nhd,ld->nhl", qs, K) * scale

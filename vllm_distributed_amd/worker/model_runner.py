@@ -457,8 +457,9 @@ class ModelRunner:
     def get_kv_cache_spec(self) -> dict[str, KVCacheSpec]:
         dt = self.dtype if self.cache_config.cache_dtype == "auto" else \
             {"fp8": torch.float8_e4m3fn, "bfloat16": torch.bfloat16, "float16": torch.float16}[self.cache_config.cache_dtype]
-        if dt == torch.float8_e4m3fn and self.head_size not in (64, 128):
-            raise ValueError("the fp8 KV cache supports head sizes 64 and 128")
+        if dt == torch.float8_e4m3fn and any(isinstance(m, Attention) and m.head_size not in (64, 128)
+                                             for m in self.attn_layers.values()):
+            raise ValueError("the fp8 KV cache supports head sizes up to 128 (and latent caches)")
         return {n: m.get_kv_cache_spec(self.block_size, dt) for n, m in self.attn_layers.items()}
 
     def initialize_kv_cache(self, cfg: KVCacheConfig) -> None:
