@@ -1,5 +1,7 @@
-"""Rank program for the multi-process CPU tests: runs LLM.generate with the
-external-launcher executor and prints the generated token ids as JSON."""
+"""Rank program for the multi-process tests: runs LLM.generate with the external-launcher executor and writes the
+generated token ids (``<out>.<rank>``) and their log-probabilities (``<out>.<rank>.lp``) as JSON.  With a fourth
+argument (JSON list of continuations, one per prompt) the continuations are teacher-forced instead: the engine
+scores prompt + continuation and the log-probability of every forced token is written."""
 import json
 import os
 import sys
@@ -18,12 +20,24 @@ def main():
     base = dict(skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
                 max_num_batched_tokens=64, distributed_executor_backend="external_launcher")
     base.update(kw)          # GPU rehearsals override device / dtype / memory settings
+    forced = json.loads(sys.argv[4]) if len(sys.argv) > 4 else None
     llm = LLM(model=model, **base)
-    outs = llm.generate(prompt_token_ids=prompts,
-                        sampling_params=SamplingParams(temperature=0, max_tokens=10, ignore_eos=True))
-    toks = [list(o.outputs[0].token_ids) for o in outs]
+    if forced is not None:
+        outs = llm.generate(prompt_token_ids=[p + c for p, c in zip(prompts, forced)],
+                            sampling_params=SamplingParams(temperature=0, max_tokens=1, ignore_eos=True,
+                                                           prompt_logprobs=0))
+        toks = forced
+        lps = [[o.prompt_logprobs[len(p) + k][t].logprob for k, t in enumerate(c)]
+               for o, p, c in zip(outs, prompts, forced)]
+    else:
+        outs = llm.generate(prompt_token_ids=prompts,
+                            sampling_params=SamplingParams(temperature=0, max_tokens=10, ignore_eos=True, logprobs=0))
+        toks = [list(o.outputs[0].token_ids) for o in outs]
+        lps = [[o.outputs[0].logprobs[k][t].logprob for k, t in enumerate(ts)] for o, ts in zip(outs, toks)]
     with open(f"{out_path}.{os.environ['RANK']}", "w") as f:
         json.dump(toks, f)
+    with open(f"{out_path}.{os.environ['RANK']}.lp", "w") as f:
+        json.dump(lps, f)
     llm.shutdown()          # closes communicators and process groups in order (Worker.shutdown)
 
 

@@ -65,8 +65,12 @@ __device__ __forceinline__ bool cross_barrier(const CarArgs& a, uint32_t target)
   return peer_barrier(a.sig, a.rank, a.world, a.spin_limit, target, a.host_err);
 }
 
-// Element ownership is FIXED: 16-byte element i belongs to thread (i mod GRID_THREADS) of the
-// grid, for every call and every message size (the grid is always MAX_BLOCKS x 512).  Each
+// Element ownership is FIXED: 16-byte element i belongs to thread (i mod GRID_THREADS) of a
+// MAX_BLOCKS x 512 grid, for every call and every message size.  A call launches only the blocks
+// that own elements of its message (two for a 16 KiB decode message, all 64 from 512 KiB up): the
+// barrier arrival words, pass counters and call parities are per block, and the number of blocks is
+// a function of the message size alone, so every rank leaves the same blocks out and a block that
+// sits out a call simply keeps its counters.  Each
 // block only synchronises with the same block of the peers, and it only ever touches
 // elements it owns, so "my block passed barrier k+1" implies "the peer block finished
 // reading my call-k data": that is what makes the two staging halves (call parity) safe
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(512) void car_kernel(CarArgs a, const u32x4* __rest
   const uint32_t cnt = s_cnt;                       // barriers this block has passed so far
   const size_t half_off = (size_t)(s_call & 1) * a.half_bytes;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t stride = (size_t)MAX_BLOCKS * blockDim.x;      // of the full grid, whatever was launched
   constexpr int N = 16 / sizeof(T);
 
   // 0) my input -> my staging half (peers read it from there)
@@ -138,6 +142,63 @@ __global__ __launch_bounds__(512) void car_kernel(CarArgs a, const u32x4* __rest
     }
   }
   if (threadIdx.x == 0) { me->counter[blockIdx.x] = cnt + 2; me->calls[blockIdx.x] = s_call + 1; }
+}
+
+// Reduce-scatter and all-gather over dimension 0 with the same arena, counters and ownership rule as car_kernel
+// (element = its index in the FULL message, so a block meets the same elements in every kind of call and the
+// parity-selected halves stay safe when the three kinds alternate):
+//   GATHER = false: in is the full message [n16]; rank r gets out = sum over ranks of elements
+//                   [r * n16 / world, (r + 1) * n16 / world) -- the first half of a two-shot all-reduce with
+//                   contiguous slices (what sequence parallelism needs: whole token rows per rank);
+//   GATHER = true:  in is this rank's slice; out is the full message -- the second half.
+// Role of the reference's reduce_scatter / all_gather in vllm/distributed/device_communicators/base_device_communicator.py
+// as used by vllm/compilation/sequence_parallelism.py:103-115.
+template <typename T, bool GATHER>
+__global__ __launch_bounds__(512) void car_slice_kernel(CarArgs a, const u32x4* __restrict__ in, u32x4* __restrict__ out,
+                                                        size_t n16) {
+  Signal* me = a.sig[a.rank];
+  __shared__ uint32_t s_cnt, s_call;
+  if (threadIdx.x == 0) { s_cnt = me->counter[blockIdx.x]; s_call = me->calls[blockIdx.x]; }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;
+  const size_t half_off = (size_t)(s_call & 1) * a.half_bytes;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)MAX_BLOCKS * blockDim.x;
+  const size_t slice = n16 / a.world, lo = slice * a.rank, hi = lo + slice;
+  constexpr int N = 16 / sizeof(T);
+  u32x4* my_in = reinterpret_cast<u32x4*>(a.data[a.rank] + half_off);
+  if (GATHER) {
+    for (size_t i = tid; i < n16; i += stride)
+      if (i >= lo && i < hi) my_in[i] = in[i - lo];
+  } else {
+    for (size_t i = tid; i < n16; i += stride)
+      if (i < lo || i >= hi) my_in[i] = in[i];              // what the peers read; my own slice stays in `in`
+  }
+  const bool ok = cross_barrier(a, cnt + 1);
+  if (ok) {
+    if (GATHER) {
+      for (size_t i = tid; i < n16; i += stride) {
+        const int src = (int)(i / slice);
+        out[i] = src == a.rank ? in[i - lo] : reinterpret_cast<const u32x4*>(a.data[src] + half_off)[i];
+      }
+    } else {
+      for (size_t i = tid; i < n16; i += stride) {
+        if (i < lo || i >= hi) continue;
+        u32x4 v[MAX_RANKS];
+#pragma unroll
+        for (int r = 0; r < MAX_RANKS; ++r)
+          if (r < a.world) v[r] = r == a.rank ? in[i] : reinterpret_cast<const u32x4*>(a.data[r] + half_off)[i];
+        float acc[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r < MAX_RANKS; ++r)
+          if (r < a.world) acc_add<T>(acc, v[r]);
+        out[i - lo] = acc_pack<T>(acc);
+      }
+    }
+  }
+  if (threadIdx.x == 0) { me->counter[blockIdx.x] = cnt + 1; me->calls[blockIdx.x] = s_call + 1; }
 }
 
 // ---------------------------------------------------------------------------
@@ -221,13 +282,38 @@ VDA_EXPORT int vda_car_allreduce(void* ctx, const void* in, void* out, size_t nb
   a.rank = c->rank; a.world = c->world; a.half_bytes = c->half_bytes; a.in_bytes = c->in_bytes;
   a.spin_limit = c->spin_limit; a.host_err = c->host_err;
   const int threads = 512;
-  const int blocks = MAX_BLOCKS;   // fixed grid: see the ownership rule above the kernel
+  const int blocks = (int)(n16 >= (size_t)MAX_BLOCKS * threads ? MAX_BLOCKS : (n16 + threads - 1) / threads);
 #define L(T, TS) hipLaunchKernelGGL((car_kernel<T, TS>), dim3(blocks), dim3(threads), 0, st, a, (const u32x4*)in, \
                                     (u32x4*)out, n16)
   if (algo == 1) {
     if (dtype == 0) L(bf16_t, false); else if (dtype == 1) L(f16_t, false); else L(float, false);
   } else {
     if (dtype == 0) L(bf16_t, true); else if (dtype == 1) L(f16_t, true); else L(float, true);
+  }
+#undef L
+  return (int)hipGetLastError();
+}
+
+// Reduce-scatter (gather = 0: in full [nbytes], out [nbytes / world]) or all-gather (gather = 1: in
+// [nbytes / world], out full [nbytes]) over dimension 0.  nbytes: the FULL message, a multiple of 16 * world and
+// <= vda_car_max_bytes.  Shares counters with vda_car_allreduce: the same sequence of calls on every rank.
+VDA_EXPORT int vda_car_slice(void* ctx, const void* in, void* out, size_t nbytes, int dtype, int gather,
+                             hipStream_t st) {
+  CarCtx* c = (CarCtx*)ctx;
+  if (nbytes == 0 || nbytes % ((size_t)16 * c->world) || nbytes > c->in_bytes) return -1;
+  const size_t n16 = nbytes / 16;
+  CarArgs a;
+  for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
+  a.rank = c->rank; a.world = c->world; a.half_bytes = c->half_bytes; a.in_bytes = c->in_bytes;
+  a.spin_limit = c->spin_limit; a.host_err = c->host_err;
+  const int threads = 512;
+  const int blocks = (int)(n16 >= (size_t)MAX_BLOCKS * threads ? MAX_BLOCKS : (n16 + threads - 1) / threads);
+#define L(T, G) hipLaunchKernelGGL((car_slice_kernel<T, G>), dim3(blocks), dim3(threads), 0, st, a, (const u32x4*)in, \
+                                   (u32x4*)out, n16)
+  if (gather) {
+    L(float, true);            // a copy: the element type does not matter
+  } else {
+    if (dtype == 0) L(bf16_t, false); else if (dtype == 1) L(f16_t, false); else L(float, false);
   }
 #undef L
   return (int)hipGetLastError();
@@ -360,7 +446,9 @@ VDA_EXPORT int vda_far_run(void* ctx, const void* in, void* residual, const void
   for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
   a.rank = c->rank; a.world = c->world; a.half_bytes = c->half_bytes; a.in_bytes = c->in_bytes;
   a.spin_limit = c->spin_limit; a.host_err = c->host_err;
-#define L(T, E) hipLaunchKernelGGL((far_kernel<T, E>), dim3(MAX_BLOCKS), dim3(512), 0, st, a, (const u32x4*)in, \
+  // rows r = b, b + MAX_BLOCKS, ... belong to workgroup b: with fewer rows than workgroups the rest own nothing
+  const int blocks = M < MAX_BLOCKS ? M : MAX_BLOCKS;
+#define L(T, E) hipLaunchKernelGGL((far_kernel<T, E>), dim3(blocks), dim3(512), 0, st, a, (const u32x4*)in, \
                                    (u32x4*)residual, (const u32x4*)weight, (u32x4*)out, M, row16, H, eps, wbias, c->in_bytes)
   const int emax = (row16 + 511) / 512;
   if (dtype == 0) { if (emax <= 1) L(bf16_t, 1); else if (emax <= 2) L(bf16_t, 2); else L(bf16_t, 4); }

@@ -47,6 +47,7 @@ def comm_library() -> ctypes.CDLL:
         lib.vda_car_max_bytes.restype = sz
         lib.vda_car_error.argtypes = [vp]
         lib.vda_car_allreduce.argtypes = [vp, vp, vp, sz, i32, i32, sz, vp]
+        lib.vda_car_slice.argtypes = [vp, vp, vp, sz, i32, i32, vp]
         lib.vda_qr_half_bytes.argtypes = [sz, i32]
         lib.vda_qr_half_bytes.restype = sz
         lib.vda_qr_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), sz, i32, u64]
@@ -160,6 +161,13 @@ class CustomAllReduce:
                 torch.cuda.synchronize(self.device)
                 if self.lib.vda_car_error(self.ctx) != 0 or not torch.equal(out, exp):
                     return False
+            # the sliced forms between all-reduces: same counters, same halves
+            m = n - n % (self.world * 64)
+            part = self.reduce_scatter(x[:m].view(self.world * 8, -1))
+            back = None if part is None else self.all_gather(part)
+            torch.cuda.synchronize(self.device)
+            if back is None or self.lib.vda_car_error(self.ctx) != 0 or not torch.equal(back.view(-1), exp[:m]):
+                return False
         return True
 
     def should_use(self, x: torch.Tensor) -> bool:
@@ -188,6 +196,40 @@ class CustomAllReduce:
         if not self.should_use(x):
             return None
         return self._launch(x)
+
+    def _slice_ok(self, x: torch.Tensor, full_bytes: int) -> bool:
+        return (not self.disabled and x.dtype in _DT and x.is_contiguous() and full_bytes > 0
+                and full_bytes % (16 * self.world) == 0 and full_bytes <= self.max_bytes)
+
+    def reduce_scatter(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """Sum over the group of x [R, ...], this rank keeping rows [rank R / world, (rank + 1) R / world): one
+        kernel, one barrier (the first half of a two-shot all-reduce with contiguous slices).  None when the
+        tensor should take the RCCL path."""
+        nb = x.numel() * x.element_size()
+        if x.dim() == 0 or x.shape[0] % self.world or not self._slice_ok(x, nb):
+            return None
+        if not getattr(self, "_slice_logged", False):
+            self._slice_logged = True
+            logger.info("peer-memory reduce-scatter / all-gather in use (%d ranks)", self.world)
+        out = torch.empty((x.shape[0] // self.world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        rc = self.lib.vda_car_slice(self.ctx, x.data_ptr(), out.data_ptr(), nb, _DT[x.dtype], 0,
+                                    torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(f"peer-memory reduce-scatter launch failed with {rc}")
+        return out
+
+    def all_gather(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """Concatenation over the group along dimension 0 of x [r, ...] (the same shape on every rank), or None
+        when the tensor should take the RCCL path."""
+        nb = x.numel() * x.element_size() * self.world
+        if x.dim() == 0 or not self._slice_ok(x, nb):
+            return None
+        out = torch.empty((x.shape[0] * self.world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        rc = self.lib.vda_car_slice(self.ctx, x.data_ptr(), out.data_ptr(), nb, _DT[x.dtype], 1,
+                                    torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(f"peer-memory all-gather launch failed with {rc}")
+        return out
 
     def check_error(self) -> int:
         return int(self.lib.vda_car_error(self.ctx))

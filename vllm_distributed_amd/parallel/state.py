@@ -264,10 +264,18 @@ class GroupCoordinator:
         x = x.contiguous()
         if x.dim() == 0:
             x = x.reshape(1)
-        flat = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        if x.is_cuda and self.rccl_comm is not None:
+        flat = None
+        if x.is_cuda and self.ca_comm is not None and not self.ca_comm.disabled:
+            flat = self.ca_comm.all_gather(x)              # peer-memory kernel for on-node groups
+            if flat is not None:
+                self.path_counts["peer_memory"] += 1
+        if flat is not None:
+            pass
+        elif x.is_cuda and self.rccl_comm is not None:
+            flat = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             self.rccl_comm.all_gather(flat, x)
         else:
+            flat = torch.empty((self.world_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             hf, hx = self._down(flat), self._down(x)
             dist.all_gather_into_tensor(hf, hx, group=self._pg(x))
             if hf is not flat:
@@ -285,6 +293,11 @@ class GroupCoordinator:
             dim += x.dim()
         xt = x.movedim(dim, 0).contiguous()
         assert xt.shape[0] % self.world_size == 0
+        if x.is_cuda and self.ca_comm is not None and not self.ca_comm.disabled:
+            got = self.ca_comm.reduce_scatter(xt)           # peer-memory kernel for on-node groups
+            if got is not None:
+                self.path_counts["peer_memory"] += 1
+                return got if dim == 0 else got.movedim(0, dim)
         out = torch.empty((xt.shape[0] // self.world_size,) + tuple(xt.shape[1:]), dtype=x.dtype, device=x.device)
         if x.is_cuda and self.rccl_comm is not None:
             self.rccl_comm.reduce_scatter(out, xt)
