@@ -38,6 +38,12 @@ def main():
         json.dump(toks, f)
     with open(f"{out_path}.{os.environ['RANK']}.lp", "w") as f:
         json.dump(lps, f)
+    try:
+        info = llm.llm_engine.engine_core.engine_core.model_executor.worker.comm_info()
+        with open(f"{out_path}.{os.environ['RANK']}.comm", "w") as f:
+            json.dump(info, f)
+    except Exception:   # noqa: BLE001 - executors without an in-process worker
+        pass
     llm.shutdown()          # closes communicators and process groups in order (Worker.shutdown)
 
 

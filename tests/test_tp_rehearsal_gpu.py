@@ -84,6 +84,31 @@ def test_tp2_on_one_gpu(tmp_path, eager, async_tp):
     assert gap < 0.1, gap
 
 
+@pytest.mark.parametrize("kw2,eager", [({"pipeline_parallel_size": 2}, True), ({"pipeline_parallel_size": 2}, False),
+                                       ({"pipeline_parallel_size": 2, "tensor_parallel_size": 2}, False)])
+def test_pipeline_parallel_on_one_gpu(tmp_path, kw2, eager):
+    """Two pipeline stages on one device: after the first hop (which fixes the layout) the activations travel through
+    the peer-memory pipe with no metadata message, also when the second stage replays decode graphs; the result
+    equals the single-rank run."""
+    from tests.test_e2e_cpu import _save_tiny
+    model, _ = _save_tiny(str(tmp_path), "llama")
+    kw = dict(device="cuda", dtype="bfloat16", gpu_memory_utilization=0.03, enforce_eager=eager, max_num_seqs=8)
+    single, _ = _launch(1, model, str(tmp_path / "one"), kw, {})
+    env = {"VDA_REHEARSE_ON_ONE_GPU": "1", "VLLM_LOGGING_LEVEL": "INFO"}
+    world = 2 * kw2.get("tensor_parallel_size", 1)
+    got, logs = _launch(world, model, str(tmp_path / "pp"), dict(kw, **kw2), env)
+    assert all(g == got[0] for g in got)
+    assert any("peer-memory pipeline hand-off enabled" in l for l in logs), logs[0][-2000:]
+    for r in range(world):
+        hops = json.load(open(f"{tmp_path / 'pp'}.{r}.comm"))["pp"]["hops"]
+        assert hops["metadata"] == 1 and hops["pipe"] >= 9, hops            # one layout hop, then the pipe only
+    if world == 2:
+        # the same kernels on the same rows, only on another rank: tokens equal the single-rank run
+        assert got[0] == single[0]
+    gap = _teacher_forced_gap(world, model, str(tmp_path / "tf"), dict(kw, **kw2), env, str(tmp_path / "one"))
+    assert gap < (0.05 if world == 2 else 0.1), gap
+
+
 @pytest.mark.parametrize("eager", [True, False])
 def test_sequence_parallel_on_one_gpu(tmp_path, eager):
     """Sequence parallelism over two ranks: the row-parallel layers end in the peer-memory reduce-scatter and the

@@ -48,6 +48,12 @@ def comm_library() -> ctypes.CDLL:
         lib.vda_car_error.argtypes = [vp]
         lib.vda_car_allreduce.argtypes = [vp, vp, vp, sz, i32, i32, sz, vp]
         lib.vda_car_slice.argtypes = [vp, vp, vp, sz, i32, i32, vp]
+        lib.vda_pipe_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), sz, u64]
+        lib.vda_pipe_create.restype = vp
+        lib.vda_pipe_destroy.argtypes = [vp]
+        lib.vda_pipe_error.argtypes = [vp]
+        lib.vda_pipe_send.argtypes = [vp, vp, sz, vp]
+        lib.vda_pipe_recv.argtypes = [vp, vp, sz, vp]
         lib.vda_qr_half_bytes.argtypes = [sz, i32]
         lib.vda_qr_half_bytes.restype = sz
         lib.vda_qr_create.argtypes = [i32, i32, ctypes.POINTER(vp), ctypes.POINTER(vp), sz, i32, u64]
@@ -562,6 +568,103 @@ class PeerAllToAll(CustomAllReduce):
     def close(self) -> None:
         if getattr(self, "ctx", None):
             self.lib.vda_a2a_destroy(self.ctx)
+            self.ctx = None
+            for p in self._opened:
+                self.lib.vda_car_close(p)
+            self.lib.vda_car_free(*self._own)
+        self.disabled = True
+
+
+class PeerPipe(CustomAllReduce):
+    """Activations between neighbouring pipeline stages through peer memory (parallel/csrc/peer_pipe.hip): the sender's
+    kernel writes into a two-slot ring in the receiver's arena and raises a flag, the receiver's kernel waits for
+    it, copies the slot out and acknowledges.  Counters live on the device: a hop involves no host round trip, no
+    pickled metadata and no RCCL call.  ``slot_bytes`` bounds one message.
+    Reference role: vllm/distributed/parallel_state.py:629-749 (send_tensor_dict / recv_tensor_dict)."""
+
+    def __init__(self, cpu_group, device: torch.device, slot_bytes: int):
+        self.lib = comm_library()
+        self.group = cpu_group
+        self.device = device
+        self.rank = dist.get_rank(cpu_group)
+        self.world = dist.get_world_size(cpu_group)
+        self.slot_bytes = max(-(-int(slot_bytes) // 4096) * 4096, 1 << 16)
+        self.disabled = True
+        pd, ps = self._exchange_arena(2 * self.slot_bytes)
+        spins = int(envs.VDA_COMM_SPIN_TIMEOUT_MS * 1e4)
+        self.ctx = self.lib.vda_pipe_create(self.rank, self.world, pd, ps, self.slot_bytes, spins)
+        if not self.ctx:
+            raise RuntimeError("could not create the pipe context")
+        dist.barrier(group=cpu_group)
+        self.disabled = False
+
+    @classmethod
+    def maybe_create(cls, cpu_group, device: torch.device, slot_bytes: int) -> Optional["PeerPipe"]:
+        world = dist.get_world_size(cpu_group)
+        if world not in cls.SUPPORTED_WORLD:
+            return None
+        ok, obj, err = 1, None, ""
+        try:
+            obj = cls(cpu_group, device, slot_bytes)
+            ok = int(obj._self_test())
+        except Exception as e:  # noqa: BLE001 - any failure just disables the fast path
+            ok, err = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=cpu_group)
+        if int(flag.item()) == 0:
+            if dist.get_rank(cpu_group) == 0:
+                logger.warning("peer-memory pipeline hand-off disabled (%s); using RCCL send / recv",
+                               err or "self-test failed on a peer")
+            if obj is not None:
+                obj.disabled = True
+            return None
+        if dist.get_rank(cpu_group) == 0:
+            logger.info("peer-memory pipeline hand-off enabled: %d stages, %.1f MiB per message", world,
+                        obj.slot_bytes / 2**20)
+        return obj
+
+    def fits(self, x: torch.Tensor) -> bool:
+        nb = x.numel() * x.element_size()
+        return not self.disabled and x.is_contiguous() and nb % 16 == 0 and 0 < nb <= self.slot_bytes
+
+    def send(self, x: torch.Tensor) -> None:
+        """To the next rank of the ring."""
+        rc = self.lib.vda_pipe_send(self.ctx, x.data_ptr(), x.numel() * x.element_size(),
+                                    torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(f"pipe send launch failed with {rc}")
+
+    def recv(self, shape, dtype: torch.dtype) -> torch.Tensor:
+        """From the previous rank of the ring."""
+        out = torch.empty(shape, dtype=dtype, device=self.device)
+        rc = self.lib.vda_pipe_recv(self.ctx, out.data_ptr(), out.numel() * out.element_size(),
+                                    torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(f"pipe receive launch failed with {rc}")
+        return out
+
+    def _self_test(self) -> bool:
+        # a ring of messages of three sizes, five rounds: both slots, every workgroup count, slot reuse
+        for it in range(5):
+            for n in (512, 40_000, 600_000):
+                n = min(n, self.slot_bytes // 2)            # elements of two bytes: at most the slot
+                n -= n % 8
+                x = ((torch.arange(n, device=self.device) % 13) + self.rank + it).to(torch.bfloat16)
+                self.send(x)
+                got = self.recv((n,), torch.bfloat16)
+                torch.cuda.synchronize(self.device)
+                prev = (self.rank - 1) % self.world
+                exp = ((torch.arange(n, device=self.device) % 13) + prev + it).to(torch.bfloat16)
+                if self.check_error() or not torch.equal(got, exp):
+                    return False
+        return True
+
+    def check_error(self) -> int:
+        return int(self.lib.vda_pipe_error(self.ctx))
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None):
+            self.lib.vda_pipe_destroy(self.ctx)
             self.ctx = None
             for p in self._opened:
                 self.lib.vda_car_close(p)

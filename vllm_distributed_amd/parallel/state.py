@@ -74,6 +74,9 @@ class GroupCoordinator:
         self.far_comm = None      # peer-memory all-reduce fused with residual add + RMSNorm
         self.ca_comm_async = None # second context (own arena, own call counters) for the communication stream
         self.qr_comm = None       # quantised peer-memory all-reduce (opt-in)
+        self.pipe = None          # peer-memory hand-off between neighbouring pipeline stages (enable_pipe)
+        self._pipe_layout = None  # tensor dictionary layout agreed on the first hop: later hops carry no metadata
+        self.hop_counts = {"pipe": 0, "metadata": 0}
         # all-reduce calls issued from the host by path (a call captured into a graph counts once, at capture)
         self.path_counts = {"quick": 0, "peer_memory": 0, "fused_norm": 0, "rccl": 0, "torch": 0}
         self.rccl_comm = None     # stream-explicit RCCL (graph capturable)
@@ -122,6 +125,22 @@ class GroupCoordinator:
                 except Exception as e:
                     logger.warning("quantised all-reduce disabled for group %s: %s", self.name, e)
                     self.qr_comm = None
+
+    def enable_pipe(self, slot_bytes: int) -> bool:
+        """Collective over the group: build the peer-memory pipe for messages of up to ``slot_bytes`` between
+        neighbouring ranks (on-node GPU groups; every rank answers alike)."""
+        if self.world_size < 2 or not self._use_device_comm or not envs.VDA_PP_PEER_PIPE or self.pipe is not None:
+            return self.pipe is not None
+        from ..platforms import current_platform
+        if not current_platform.use_custom_allreduce():
+            return False
+        try:
+            from .custom_allreduce import PeerPipe
+            self.pipe = PeerPipe.maybe_create(self.cpu_group, self.device, slot_bytes)
+        except Exception as e:   # noqa: BLE001
+            logger.warning("peer-memory pipeline hand-off disabled for group %s: %s", self.name, e)
+            self.pipe = None
+        return self.pipe is not None
 
     # ---- properties --------------------------------------------------------
     @property
@@ -241,14 +260,15 @@ class GroupCoordinator:
             return int(getattr(c, "world_size", None) or getattr(c, "world", None) or self.world_size)
         return {"group": self.name, "world_size": self.world_size,
                 "rccl_ranks": ranks(self.rccl_comm), "peer_arena_ranks": ranks(self.ca_comm),
-                "fused_norm_ranks": ranks(self.far_comm), "allreduce_path": dict(self.path_counts)}
+                "fused_norm_ranks": ranks(self.far_comm), "allreduce_path": dict(self.path_counts),
+                "pipe_ranks": ranks(self.pipe), "hops": dict(self.hop_counts)}
 
     def check_comm_errors(self) -> None:
         """Raise if a peer-memory collective of this group timed out since the last check.  A kernel
         whose barrier timed out skipped its reads, so the step that contained it produced garbage: the
         worker must die (the engine then reports ENGINE_CORE_DEAD) rather than serve it.  Reads pinned
         host words only; call after the stream has been synchronised (the sampled-token read-back)."""
-        for name in ("ca_comm", "ca_comm_async", "qr_comm", "far_comm"):
+        for name in ("ca_comm", "ca_comm_async", "qr_comm", "far_comm", "pipe"):
             c = getattr(self, name, None)
             if c is not None and not c.disabled:
                 e = c.check_error()
@@ -427,15 +447,66 @@ class GroupCoordinator:
                 out[k] = m[1]
         return out
 
-    def send_tensor_dict(self, d: dict, dst: Optional[int] = None, all_gather_group: "GroupCoordinator" = None) -> None:
+    # Pipe form of a hop (``rows`` given, pipe enabled, next / previous rank): the first hop of a group travels with
+    # its metadata as before and fixes the LAYOUT of the dictionary: per key the dtype and trailing shape of a tensor
+    # whose leading dimension is the step's row count, an empty tensor, or a constant.  Every later hop sends the
+    # first ``rows`` rows of each tensor through the peer-memory pipe and nothing else: both sides know ``rows``
+    # from the scheduler output they share, so no host message accompanies the activations.
+    @staticmethod
+    def _layout_of(d: dict, rows: int) -> list:
+        out = []
+        for k, v in d.items():
+            if isinstance(v, torch.Tensor) and v.numel() == 0:
+                out.append((k, "empty", v.dtype, tuple(v.shape)))
+            elif isinstance(v, torch.Tensor) and v.is_cuda and v.dim() >= 1 and v.shape[0] >= rows:
+                out.append((k, "rows", v.dtype, tuple(v.shape[1:])))
+            else:
+                return []                         # something the pipe does not carry: keep the metadata form
+        return out
+
+    def _pipe_fits(self, layout: list, rows: int, n: int) -> bool:
+        for _, kind, dtype, trail in layout:
+            if kind != "rows":
+                continue
+            numel = rows
+            for s_ in trail:
+                numel *= s_
+            if numel == 0 or numel % n:
+                return False
+            nb = numel // n * torch.empty((), dtype=dtype).element_size()
+            if nb % 16 or nb > self.pipe.slot_bytes:
+                return False
+        return True
+
+    def send_tensor_dict(self, d: dict, dst: Optional[int] = None, all_gather_group: "GroupCoordinator" = None,
+                         rows: Optional[int] = None) -> None:
         """Metadata over Gloo, payload over the device link.  With ``all_gather_group``
         (the TP group) each rank ships only its 1/TP slice and the receiver
-        all-gathers, so a PP hop costs M/TP per xGMI link instead of M."""
+        all-gathers, so a PP hop costs M/TP per xGMI link instead of M.  With ``rows`` (the number of leading rows
+        that matter, known to both sides) and an enabled pipe, hops after the first carry no metadata at all."""
         if self.world_size == 1:
             return
         dst = (self.rank_in_group + 1) % self.world_size if dst is None else dst
         ag = all_gather_group
         n, r = (ag.world_size, ag.rank_in_group) if ag is not None else (1, 0)
+        piped = rows is not None and self.pipe is not None and not self.pipe.disabled \
+            and dst == (self.rank_in_group + 1) % self.world_size
+        if piped and self._pipe_layout is None:
+            # first hop: the ordinary form, preceded by the layout the later hops will follow
+            self._pipe_layout = self._layout_of(d, rows)
+            self.send_object(("layout", self._pipe_layout), dst)
+        elif piped and self._pipe_layout and self._pipe_fits(self._pipe_layout, rows, n):
+            if self._layout_of(d, rows) != self._pipe_layout:
+                raise RuntimeError(f"group {self.name}: the tensors handed to the next stage changed their layout")
+            for k, kind, _, _ in self._pipe_layout:
+                if kind != "rows":
+                    continue
+                t = d[k][:rows]
+                t = t.reshape(n, -1)[r] if n > 1 else t
+                self.pipe.send(t.contiguous())
+            self.hop_counts["pipe"] += 1
+            return
+        self.hop_counts["metadata"] += 1
         meta, tensors = self._split_dict(d)
         self.send_object(meta, dst)
         for t in tensors:
@@ -445,12 +516,33 @@ class GroupCoordinator:
                 t = t.reshape(n, -1)[r]
             self.send(t.contiguous(), dst)
 
-    def recv_tensor_dict(self, src: Optional[int] = None, all_gather_group: "GroupCoordinator" = None) -> Optional[dict]:
+    def recv_tensor_dict(self, src: Optional[int] = None, all_gather_group: "GroupCoordinator" = None,
+                         rows: Optional[int] = None) -> Optional[dict]:
         if self.world_size == 1:
             return None
         src = (self.rank_in_group - 1) % self.world_size if src is None else src
         ag = all_gather_group
         n = ag.world_size if ag is not None else 1
+        piped = rows is not None and self.pipe is not None and not self.pipe.disabled \
+            and src == (self.rank_in_group - 1) % self.world_size
+        if piped and self._pipe_layout is None:
+            tag, layout = self.recv_object(src)
+            assert tag == "layout"
+            self._pipe_layout = [tuple(e) for e in layout]
+        elif piped and self._pipe_layout and self._pipe_fits(self._pipe_layout, rows, n):
+            out = {}
+            for k, kind, dtype, trail in self._pipe_layout:
+                if kind == "empty":
+                    out[k] = torch.empty(trail, dtype=dtype, device=self.device)
+                    continue
+                numel = rows
+                for s_ in trail:
+                    numel *= s_
+                part = self.pipe.recv((numel // n,), dtype)
+                out[k] = (ag.all_gather(part, dim=0) if n > 1 else part).reshape((rows,) + tuple(trail))
+            self.hop_counts["pipe"] += 1
+            return out
+        self.hop_counts["metadata"] += 1
         meta = self.recv_object(src)
         out = {}
         for k, m in meta:
@@ -497,6 +589,9 @@ class GroupCoordinator:
         if self.far_comm is not None:
             self.far_comm.close()
             self.far_comm = None
+        if self.pipe is not None:
+            self.pipe.close()
+            self.pipe = None
         if self.rccl_comm is not None:
             self.rccl_comm.close()
             self.rccl_comm = None

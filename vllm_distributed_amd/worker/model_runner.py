@@ -991,6 +991,13 @@ class ModelRunner:
                         self.d_succ_lens[Sg:graph_bs].zero_()
                         self.d_inter_lens[Sg:graph_bs].zero_()
             g, hidden_buf, md = self.graphs[graph_bs]
+            if not pp.is_first_rank and intermediate_tensors is not None:
+                # the graph reads the previous stage's activations from the buffers it was captured with
+                for k, buf in self._capture_inter(graph_bs).tensors.items():
+                    src = intermediate_tensors.tensors.get(k)
+                    if src is not None and src.numel():
+                        n_rows = min(src.shape[0], graph_bs)
+                        buf[:n_rows].copy_(src[:n_rows])
             with set_forward_context(md, kv_connector=conn, num_tokens=T):
                 if conn is not None:
                     conn.start_load_kv()

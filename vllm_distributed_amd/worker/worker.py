@@ -115,6 +115,13 @@ class Worker:
 
     def load_model(self) -> None:
         self.model_runner.load_model()
+        pp = pstate.get_pp_group()
+        if pp.world_size > 1 and self.device.type == "cuda":
+            # activations of the largest step, one tensor-parallel slice of them per pipe
+            mr = self.model_runner
+            tp = pstate.get_tp_group().world_size
+            per_row = mr.hidden_size * torch.empty((), dtype=mr.dtype).element_size()
+            pp.enable_pipe(-(-mr.max_num_tokens * per_row // tp))
 
     def get_model(self):
         return self.model_runner.get_model()
@@ -183,8 +190,11 @@ class Worker:
         inter = None
         # non-root token-parallel ranks run attention only: no activations travel between their stages
         attn_only = getattr(self.model_runner.model, "is_tknp_worker", False)
-        if not pp.is_first_rank and scheduler_output.total_num_scheduled_tokens and not attn_only:
-            d = pp.recv_tensor_dict(all_gather_group=tp)
+        # rows of the activations that matter: known to both stages from the scheduler output they share, which is
+        # what lets the peer-memory pipe do without per-hop metadata
+        rows = scheduler_output.total_num_scheduled_tokens
+        if not pp.is_first_rank and rows and not attn_only:
+            d = pp.recv_tensor_dict(all_gather_group=tp, rows=rows)
             inter = IntermediateTensors(d)
         out = self.model_runner.execute_model(scheduler_output, inter)
         # torchrun mode: every rank runs its own scheduler and needs the sampled tokens, so the
@@ -192,7 +202,7 @@ class Worker:
         share = pp.world_size > 1 and scheduler_output.total_num_scheduled_tokens > 0 and \
             self.parallel_config.distributed_executor_backend == "external_launcher"
         if isinstance(out, IntermediateTensors):
-            pp.send_tensor_dict(out.tensors, all_gather_group=tp)
+            pp.send_tensor_dict(out.tensors, all_gather_group=tp, rows=rows)
             return pp.broadcast_object(None, src=pp.world_size - 1) if share else None
         if share:
             out = pp.broadcast_object(out if pp.is_last_rank else None, src=pp.world_size - 1)
