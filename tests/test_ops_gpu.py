@@ -453,6 +453,27 @@ def test_fused_moe_every_kernel_form(monkeypatch, form, fp8, T, E, k, H, I):
     torch.testing.assert_close(out.float(), ref.float(), atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("activation", ["gelu", "gelu_tanh", "relu", "relu2", "silu"])
+@pytest.mark.parametrize("T,tiled", [(6, False), (150, False), (700, True)])
+def test_fused_moe_gate_activations(monkeypatch, activation, T, tiled):
+    """The gate activation is applied inside the first expert GEMM's epilogue in every kernel form: the small-batch
+    grouped kernels (K split and row split) and the LDS-tiled GEMM."""
+    if tiled:
+        monkeypatch.setenv("VDA_MOE_GROUPED_MAX_PAIRS", "64")
+    E, k, H, I = 8, 2, 512, 256
+    dt = torch.bfloat16
+    x = torch.randn(T, H, device=DEV, dtype=dt) * 0.5
+    w13 = torch.randn(E, 2 * I, H, device=DEV, dtype=dt) * (H ** -0.5) * 3
+    w2 = torch.randn(E, H, I, device=DEV, dtype=dt) * (I ** -0.5)
+    tw, ids = R.moe_topk_softmax(torch.randn(T, E, device=DEV), k, True)
+    out = ops.fused_moe(x, w13, w2, tw, ids, activation=activation)
+    ref = R.fused_moe(x, w13, w2, tw, ids, activation=activation)
+    torch.testing.assert_close(out.float(), ref.float(), atol=3e-2, rtol=3e-2)
+    if activation != "silu":          # and it is not silently the default
+        silu = R.fused_moe(x, w13, w2, tw, ids)
+        assert (ref.float() - silu.float()).abs().max().item() > 0.05
+
+
 def test_fused_moe_expert_parallel_mask_and_large_path(monkeypatch):
     dt = torch.bfloat16
     T, E, k, H, I = 96, 8, 2, 512, 256

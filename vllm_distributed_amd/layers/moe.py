@@ -71,7 +71,8 @@ class UnquantizedMoEMethod:
         pass
 
     def apply(self, layer: "FusedMoE", x: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
-        return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids)
+        return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids,
+                             activation=getattr(layer, "activation", "silu"))
 
 
 class FusedMoE(nn.Module):
@@ -80,8 +81,13 @@ class FusedMoE(nn.Module):
                  use_grouped_topk: bool = False, num_expert_group: Optional[int] = None,
                  topk_group: Optional[int] = None, quant_config=None, prefix: str = "",
                  custom_routing_function: Optional[Callable] = None, scoring_func: str = "softmax",
-                 e_score_correction_bias: Optional[torch.Tensor] = None, routed_scaling_factor: float = 1.0):
+                 e_score_correction_bias: Optional[torch.Tensor] = None, routed_scaling_factor: float = 1.0,
+                 activation: str = "silu"):
         super().__init__()
+        if activation not in ops.MOE_ACTIVATIONS:
+            raise ValueError(f"{prefix}: expert activation {activation!r} is not supported "
+                             f"(supported: {', '.join(ops.MOE_ACTIVATIONS)})")
+        self.activation = activation            # of the gate half, fused into the first expert GEMM
         self.params_dtype = params_dtype or torch.get_default_dtype()
         self.global_num_experts, self.top_k = num_experts, top_k
         self.hidden_size = hidden_size

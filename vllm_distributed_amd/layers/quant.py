@@ -536,9 +536,10 @@ class Fp8MoEMethod:
     def apply(self, layer, x: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
         if self.cfg.weight_block_size is not None:
             return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids, layer.w13_weight_scale_inv,
-                                 layer.w2_weight_scale_inv, block_scales=True)
+                                 layer.w2_weight_scale_inv, block_scales=True,
+                                 activation=getattr(layer, "activation", "silu"))
         return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids, layer.w13_weight_scale,
-                             layer.w2_weight_scale)
+                             layer.w2_weight_scale, activation=getattr(layer, "activation", "silu"))
 
 
 class Fp8KVCacheMethod:

@@ -33,7 +33,7 @@ def _num_experts(config) -> int:
 class SparseMoeBlock(nn.Module):
     def __init__(self, hidden_size: int, intermediate_size: int, num_experts: int, top_k: int, renormalize: bool,
                  quant_config=None, prefix: str = "", shared_intermediate: int = 0, shared_gate: bool = False,
-                 routing=None):
+                 routing=None, activation: str = "silu"):
         super().__init__()
         self.gate = ReplicatedLinear(hidden_size, num_experts, bias=False, quant_config=None, prefix=f"{prefix}.gate")
         self.tp = get_tensor_model_parallel_world_size()
@@ -41,7 +41,7 @@ class SparseMoeBlock(nn.Module):
         # with a shared expert both partial results are summed once, after adding them
         self.experts = FusedMoE(num_experts, top_k, hidden_size, intermediate_size, reduce_results=not self.has_shared,
                                 renormalize=renormalize, quant_config=quant_config, prefix=f"{prefix}.experts",
-                                custom_routing_function=routing)
+                                custom_routing_function=routing, activation=activation)
         if self.has_shared:
             self.shared_expert = LlamaMLP(hidden_size, shared_intermediate, quant_config=quant_config,
                                           prefix=f"{prefix}.shared_expert", reduce_results=False)
@@ -456,3 +456,71 @@ class ArcticForCausalLM(MixtralForCausalLM):
                 yield n, t
         return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie,
                                          expert_mapping=experts)
+
+
+# ---- Grok-1 ------------------------------------------------------------------------------------------
+class Grok1DecoderLayer(LlamaDecoderLayer):
+    """Grok-1 block: soft-capped attention whose output is scaled by ``attn_output_multiplier``, a routed expert MLP
+    with a GELU gate (fused into the first expert GEMM), and a norm on BOTH sides of each of the two sub-blocks.
+    Reference: vllm/model_executor/models/grok1.py (Grok1MoE :62-111, Grok1Attention :114-200,
+    Grok1DecoderLayer :203-284)."""
+    supports_sequence_parallel = False
+
+    def _attention_extras(self, config, layer_idx: int) -> dict:
+        cap = getattr(config, "attn_logit_softcapping", 30.0)
+        return {"logits_soft_cap": max(float(30.0 if cap is None else cap), 0.0) or None}
+
+    def _make_mlp(self, config, vllm_config, quant_config, prefix):
+        return SparseMoeBlock(config.hidden_size, config.intermediate_size, _num_experts(config) or 8,
+                              config.num_experts_per_tok, True, quant_config, prefix.replace(".mlp", ".moe_block"),
+                              activation="gelu")
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = ""):
+        super().__init__(config, vllm_config, quant_config, prefix)
+        self.moe_block = self.mlp                  # parameter names follow the checkpoint
+        del self.mlp
+        self.pre_moe_norm = self.make_norm(config)
+        self.post_moe_norm = self.make_norm(config)
+        self.attn_multiplier = float(getattr(config, "attn_output_multiplier", 0.08838834764831845))
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.post_attention_layernorm(self.self_attn(positions, hidden_states) * self.attn_multiplier)
+        hidden_states, residual = self.pre_moe_norm(hidden_states, residual)
+        return self.post_moe_norm(self.moe_block(hidden_states)), residual
+
+
+class Grok1Model(LlamaModel):
+    layer_cls = Grok1DecoderLayer
+    embed_scale_of = staticmethod(lambda config: float(getattr(config, "embedding_multiplier_scale", 78.38367176906169)))
+
+
+class Grok1ModelForCausalLM(MixtralForCausalLM):
+    """Checkpoint names: ``attn`` / ``pre_attn_norm`` / ``post_attn_norm`` / ``moe_block`` with experts
+    ``linear`` (gate), ``linear_v`` (up), ``linear_1`` (down), and norm weights called ``scale``.  Logits are
+    multiplied by ``output_multiplier_scale``."""
+    model_cls = Grok1Model
+    expert_names = ("linear", "linear_1", "linear_v")
+    _RENAMES = ((".attn.", ".self_attn."), (".pre_attn_norm.", ".input_layernorm."),
+                (".post_attn_norm.", ".post_attention_layernorm."))
+
+    @staticmethod
+    def _logit_scale(config) -> float:
+        return float(getattr(config, "output_multiplier_scale", 0.5773502691896257))
+
+    def num_experts(self) -> int:
+        return _num_experts(self.config) or 8
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]) -> set[str]:
+        def renamed():
+            for name, t in weights:
+                if name.endswith("norm.scale"):
+                    name = name[: -len("scale")] + "weight"
+                for a, b in self._RENAMES:
+                    name = name.replace(a, b)
+                yield name, t
+        return super().load_weights(renamed())

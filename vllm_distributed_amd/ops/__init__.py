@@ -808,7 +808,7 @@ def fp8_gemm(xq: torch.Tensor, w: torch.Tensor, x_scale: torch.Tensor, w_scale: 
     out = torch.empty((M, N_), dtype=out_dtype, device=xq.device)
     N.call("vda_tile_gemm", out.data_ptr(), xq.data_ptr(), w.data_ptr(), xs.data_ptr(), ws.data_ptr(), None,
            N.ptr(bias), None, None, None, None, None, M, N_, K, 1, 0, xq.stride(0), out.stride(0), 0, EPI_PLAIN,
-           SC_BLOCK if block else SC_TOKEN, _tile_rows(M), N.dt(xq.dtype), N.dt(out_dtype), N.stream())
+           SC_BLOCK if block else SC_TOKEN, _tile_rows(M), N.dt(xq.dtype), N.dt(out_dtype), 0, N.stream())
     return out
 
 
@@ -844,7 +844,7 @@ def tile_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     out = torch.empty((M, N_), dtype=x.dtype, device=x.device)
     N.call("vda_tile_gemm", out.data_ptr(), x.data_ptr(), w.data_ptr(), None, None, None, N.ptr(bias), None, None,
            None, None, None, M, N_, K, 1, 0, x.stride(0), out.stride(0), 0, EPI_PLAIN, SC_NONE,
-           rows_per_tile or _tile_rows(M), N.dt(x.dtype), N.dt(x.dtype), N.stream())
+           rows_per_tile or _tile_rows(M), N.dt(x.dtype), N.dt(x.dtype), 0, N.stream())
     return out
 
 
@@ -872,7 +872,8 @@ def moe_align_tiles(topk_ids: torch.Tensor, E: int, rows_per_tile: int):
     return sorted_ids, offsets, tiles, max_tiles
 
 
-def _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales: bool = False):
+def _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales: bool = False,
+               activation: str = "silu"):
     """Compute-bound batches: both expert GEMMs run as LDS-tiled MFMA GEMMs over the expert-sorted pairs
     (ops/csrc/gemm_tile.hip).  e4m3 weights: activations are quantised per token (or per group of 128
     with block-scaled weights) and the fp8 matrix cores do the products; 16-bit weights: 16-bit MFMA."""
@@ -900,7 +901,7 @@ def _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales: 
         mode, xq, xs = SC_NONE, _contig_last(x), None
     N.call("vda_tile_gemm", inter.data_ptr(), xq.data_ptr(), w13.data_ptr(), N.ptr(xs), N.ptr(w13_scale), None, None,
            sorted_ids.data_ptr(), te.data_ptr(), tb.data_ptr(), tend.data_ptr(), ntl.data_ptr(), 0, I, H, k,
-           max_tiles, xq.stride(0), I, I2 * H, EPI_GATE_UP, mode, rows, N.dt(xq.dtype), N.dt(x.dtype), st)
+           max_tiles, xq.stride(0), I, I2 * H, EPI_GATE_UP, mode, rows, N.dt(xq.dtype), N.dt(x.dtype), N.ACT[activation], st)
     if fp8:
         hq, hs = per_group_fp8_quant(inter) if block_scales else per_token_fp8_quant(inter)
         hs = hs.contiguous()
@@ -909,7 +910,7 @@ def _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales: 
     N.call("vda_tile_gemm", out2.data_ptr(), hq.data_ptr(), w2.data_ptr(), N.ptr(hs), N.ptr(w2_scale),
            tw.data_ptr(), None, sorted_ids.data_ptr(), te.data_ptr(), tb.data_ptr(), tend.data_ptr(),
            ntl.data_ptr(), 0, H, I, 1, max_tiles, hq.stride(0), H, H * I, EPI_DOWN, mode, rows, N.dt(hq.dtype),
-           N.dt(x.dtype), st)
+           N.dt(x.dtype), 0, st)
     N.call("vda_moe_sum", out.data_ptr(), out2.data_ptr(), topk_ids.contiguous().data_ptr(), T, H, k,
            out.stride(0), N.dt(x.dtype), st)
     return out
@@ -945,13 +946,20 @@ def moe_rows_form(num_pairs: int, num_experts: int, rows: int, weight_bytes: int
     return wide if avg >= 8 and (fills or avg >= 64) else 0
 
 
+MOE_ACTIVATIONS = ("silu", "gelu", "gelu_tanh", "gelu_pytorch_tanh", "relu", "relu2")
+
+
 def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,
               w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None,
-              block_scales: bool = False) -> torch.Tensor:
-    """Routed SwiGLU expert MLPs.  x [T,H]; w13 [E,2I,H] (gate rows then up rows); w2 [E,H,I];
+              block_scales: bool = False, activation: str = "silu") -> torch.Tensor:
+    """Routed gated expert MLPs, out[t] = sum_j w[t, j] * W2_e(act(Wg_e x_t) * (Wu_e x_t)) with ``activation`` one of
+    MOE_ACTIVATIONS (reference: vllm/model_executor/layers/fused_moe/fused_moe.py:1003,1034 ``activation``), fused
+    into the first GEMM's epilogue in every kernel form.  x [T,H]; w13 [E,2I,H] (gate rows then up rows); w2 [E,H,I];
     topk_w f32 [T,k]; topk_ids i32 [T,k] with local expert ids, negative = not on this rank.
     e4m3 weights carry one scale per expert, or with ``block_scales`` one per 128 x 128 block
     (w13_scale [E, 2I/128, H/128], w2_scale [E, H/128, I/128])."""
+    if activation not in MOE_ACTIVATIONS:
+        raise ValueError(f"expert activation {activation!r} is not supported (supported: {', '.join(MOE_ACTIVATIONS)})")
     if _dev(x) and block_scales and not moe_tiled_ok(x, w13, w2):
         raise RuntimeError(f"block-scaled expert shapes {tuple(w13.shape)} / {tuple(w2.shape)} are outside the tiled "
                            "fp8 GEMM (hidden and expert width must be multiples of 128)")
@@ -961,9 +969,9 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
                 f"expert shapes {tuple(w13.shape)} / {tuple(w2.shape)} are outside the grouped MoE kernel (hidden and "
                 "expert width must be multiples of 128); the PyTorch fallback synchronises and cannot be captured "
                 "into a hipGraph: run with enforce_eager=True")
-        return R.fused_moe(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales)
+        return R.fused_moe(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales, activation)
     if not moe_grouped_ok(x, w13, w2):
-        return _moe_tiled(_contig_last(x), w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales)
+        return _moe_tiled(_contig_last(x), w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales, activation)
     T, H = x.shape
     k = topk_ids.shape[1]
     E, I2, _ = w13.shape
@@ -974,7 +982,7 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
     if w13.dtype == torch.float8_e4m3fn:
         limit = min(limit, envs.VDA_MOE_GROUPED_MAX_PAIRS_FP8)
     if T * k > limit or block_scales:
-        return _moe_tiled(_contig_last(x), w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales)
+        return _moe_tiled(_contig_last(x), w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales, activation)
     x = _contig_last(x)
     dev = x.device
     ids = topk_ids.contiguous()
@@ -991,7 +999,7 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
     max_pairs = T
     N.call("vda_moe_gate_up", inter.data_ptr(), x.data_ptr(), w13.data_ptr(), N.ptr(w13_scale), sorted_ids.data_ptr(),
            offsets.data_ptr(), E, I, H, k, max_pairs, x.stride(0), N.dt(x.dtype), wd,
-           int(moe_rows_form(T * k, E, I, w13.element_size())), st)
+           int(moe_rows_form(T * k, E, I, w13.element_size())), N.ACT[activation], st)
     N.call("vda_moe_down", out2.data_ptr(), inter.data_ptr(), w2.data_ptr(), N.ptr(w2_scale), tw.data_ptr(),
            sorted_ids.data_ptr(), offsets.data_ptr(), E, H, I, max_pairs, N.dt(x.dtype), wd,
            int(moe_rows_form(T * k, E, H, w2.element_size())), st)

@@ -155,5 +155,17 @@ template <typename T> struct KVStore<T, true> {
   static __device__ __forceinline__ void st1(uint8_t* p, T v, float inv) { *p = f32_to_fp8((float)v * inv); }
 };
 
+// Activation of the gate half of a gated MLP inside a GEMM epilogue, chosen at run time (wave-uniform branch).
+// Codes follow ops/native.py ACT: 0 silu, 1 gelu (erf), 2 gelu (tanh), 3 relu, 8 relu squared.
+__device__ __forceinline__ float gate_act(float x, int kind) {
+  switch (kind) {
+    case 1: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
+    case 2: return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    case 3: return fmaxf(x, 0.f);
+    case 8: { const float r = fmaxf(x, 0.f); return r * r; }
+    default: return x / (1.f + __expf(-x));
+  }
+}
+
 #define VDA_CHECK_LAUNCH() \
   do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

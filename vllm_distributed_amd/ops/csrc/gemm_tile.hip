@@ -61,6 +61,7 @@ struct TileGemmArgs {
   int N;                     // output columns (EPI_GATE_UP: I, the weight has 2 I rows)
   int K;                     // elements
   int top_k;
+  int act;                   // EPI_GATE_UP: activation of the gate half (codes of gate_act)
   int m_tiles;               // grid bound on m-tiles
   int n_tiles;
   long x_stride;             // elements
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(512, 1) void tile_gemm_kernel(const TileGemmArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float gte = acc[mt][nt][i] * s, up = acc[mt + 2][nt][i] * s;
-          o[i] = (TO)(gte / (1.f + __expf(-gte)) * up);
+          o[i] = (TO)(gate_act(gte, a.act) * up);
         }
         if (n + 3 < a.N) *reinterpret_cast<V4*>(op + n) = o;
         else
@@ -423,7 +424,7 @@ VDA_EXPORT int vda_tile_gemm(void* out, const void* x, const void* w, const floa
                              const float* topk_w, const void* bias, const int* sorted, const int* tile_expert,
                              const int* tile_beg, const int* tile_end, const int* num_tiles, int M, int N, int K,
                              int top_k, int max_m_tiles, long x_stride, long out_stride, long w_expert_stride,
-                             int epi, int scale_mode, int rows_per_tile, int in_dtype, int out_dtype,
+                             int epi, int scale_mode, int rows_per_tile, int in_dtype, int out_dtype, int act,
                              hipStream_t st) {
   const bool grouped = sorted != nullptr;
   const int eb = in_dtype == VDA_FP8 ? 1 : 2;
@@ -440,7 +441,7 @@ VDA_EXPORT int vda_tile_gemm(void* out, const void* x, const void* w, const floa
   TileGemmArgs a;
   a.out = out; a.x = x; a.w = w; a.x_scale = x_scale; a.w_scale = w_scale; a.topk_w = topk_w; a.bias = bias;
   a.sorted = sorted; a.tile_expert = tile_expert; a.tile_beg = tile_beg; a.tile_end = tile_end; a.num_tiles = num_tiles;
-  a.M = M; a.N = N; a.K = K; a.top_k = top_k > 0 ? top_k : 1;
+  a.M = M; a.N = N; a.K = K; a.top_k = top_k > 0 ? top_k : 1; a.act = act;
   a.m_tiles = grouped ? max_m_tiles : (M + rows_per_tile - 1) / rows_per_tile;
   a.n_tiles = epi == EPI_GATE_UP ? (N + 127) / 128 : (N + 255) / 256;
   a.x_stride = x_stride; a.out_stride = out_stride; a.w_expert_stride = w_expert_stride;

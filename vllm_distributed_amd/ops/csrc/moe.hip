@@ -2,7 +2,7 @@
 //
 //   vda_moe_topk_softmax   router: softmax over experts + top-k (+ renormalise), one wave per token
 //   vda_moe_align          counting sort of the (token, slot) pairs by expert -> sorted ids + offsets
-//   vda_moe_gate_up        grouped skinny GEMM  inter[p, :] = silu(x[t] . Wg_e^T) * (x[t] . Wu_e^T)
+//   vda_moe_gate_up        grouped skinny GEMM  inter[p, :] = act(x[t] . Wg_e^T) * (x[t] . Wu_e^T)  (act: gate_act codes)
 //   vda_moe_down           grouped skinny GEMM  out2[p, :] = w[p] * (inter[p] . Wd_e^T)
 //   vda_moe_sum            out[t] = sum_j out2[t*k + j]   (entries routed to non-local experts skipped)
 //
@@ -131,7 +131,7 @@ template <typename T, typename WL, bool GATE_UP>
 __global__ __launch_bounds__(256) void moe_grouped_kernel(
     T* __restrict__ out, const T* __restrict__ act, const void* __restrict__ w, const float* __restrict__ w_scale,
     const float* __restrict__ topk_w, const int* __restrict__ sorted, const int* __restrict__ offsets,
-    int N, int K, int top_k, long act_stride, long out_stride, long w_expert_stride) {
+    int N, int K, int top_k, long act_stride, long out_stride, long w_expert_stride, int act_kind) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   const int e = blockIdx.y;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void moe_grouped_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float gte = a[i] * ws, up = b[i] * ws;
-          o[i] = (T)(gte / (1.f + __expf(-gte)) * up);
+          o[i] = (T)(gate_act(gte, act_kind) * up);
         }
       } else {
         const float tw = topk_w[pid[mt]] * ws;
@@ -232,7 +232,7 @@ template <typename T, typename WL, bool GATE_UP, int MT>
 __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
     T* __restrict__ out, const T* __restrict__ act, const void* __restrict__ w, const float* __restrict__ w_scale,
     const float* __restrict__ topk_w, const int* __restrict__ sorted, const int* __restrict__ offsets,
-    int N, int K, int top_k, long act_stride, long out_stride, long w_expert_stride) {
+    int N, int K, int top_k, long act_stride, long out_stride, long w_expert_stride, int act_kind) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   // 256-byte rows of sixteen 16-byte pieces, piece p of row t stored at p ^ (t & 15): the lane groups that
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float gte = acc0[mt][i] * ws, up = acc1[mt][i] * ws;
-          o[i] = (T)(gte / (1.f + __expf(-gte)) * up);
+          o[i] = (T)(gate_act(gte, act_kind) * up);
         }
       } else {
         const float tw = topk_w[pid[mt]] * ws;
@@ -352,18 +352,18 @@ __global__ __launch_bounds__(256) void moe_grouped_rows_kernel(
 // is a multiple of 64); the caller decides from the batch shape (see ops.fused_moe).
 VDA_EXPORT int vda_moe_gate_up(void* inter, const void* x, const void* w13, const float* w_scale, const int* sorted,
                                const int* offsets, int E, int I, int K, int top_k, int max_pairs, long x_stride,
-                               int dtype, int wdtype, int rows_form, hipStream_t st) {
+                               int dtype, int wdtype, int rows_form, int act_kind, hipStream_t st) {
   if (I % 16 || K % 128 || E < 1 || max_pairs < 1) return -1;
   const bool rows = rows_form && I % 64 == 0;
   const int per = rows && rows_form == 2 ? 128 : 64;
   dim3 grid(rows ? I / 64 : I / 16, E, (max_pairs + per - 1) / per), block(256);
   const long es = (long)2 * I * K;
 #define L(TT, WL) do { if (rows && per == 128) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, true, 8>), grid, block, 0, st, \
-        (TT*)inter, (const TT*)x, w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es); \
+        (TT*)inter, (const TT*)x, w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es, act_kind); \
     else if (rows) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, true, 4>), grid, block, 0, st, (TT*)inter, \
-        (const TT*)x, w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es); \
+        (const TT*)x, w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es, act_kind); \
     else hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, true>), grid, block, 0, st, (TT*)inter, (const TT*)x, \
-        w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es); } while (0)
+        w13, w_scale, (const float*)nullptr, sorted, offsets, I, K, top_k, x_stride, (long)I, es, act_kind); } while (0)
   if (dtype == VDA_BF16) { if (wdtype == VDA_FP8) L(bf16_t, WLoadFp8<bf16_t>); else L(bf16_t, WLoad<bf16_t>); }
   else if (dtype == VDA_F16) { if (wdtype == VDA_FP8) L(f16_t, WLoadFp8<f16_t>); else L(f16_t, WLoad<f16_t>); }
   else return -3;
@@ -381,11 +381,11 @@ VDA_EXPORT int vda_moe_down(void* out2, const void* inter, const void* w2, const
   dim3 grid(rows ? H / 64 : H / 16, E, (max_pairs + per - 1) / per), block(256);
   const long es = (long)H * I;
 #define L(TT, WL) do { if (rows && per == 128) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, false, 8>), grid, block, 0, st, \
-        (TT*)out2, (const TT*)inter, w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es); \
+        (TT*)out2, (const TT*)inter, w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es, 0); \
     else if (rows) hipLaunchKernelGGL((moe_grouped_rows_kernel<TT, WL, false, 4>), grid, block, 0, st, (TT*)out2, \
-        (const TT*)inter, w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es); \
+        (const TT*)inter, w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es, 0); \
     else hipLaunchKernelGGL((moe_grouped_kernel<TT, WL, false>), grid, block, 0, st, (TT*)out2, (const TT*)inter, \
-        w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es); } while (0)
+        w2, w_scale, topk_w, sorted, offsets, H, I, 1, (long)I, (long)H, es, 0); } while (0)
   if (dtype == VDA_BF16) { if (wdtype == VDA_FP8) L(bf16_t, WLoadFp8<bf16_t>); else L(bf16_t, WLoad<bf16_t>); }
   else if (dtype == VDA_F16) { if (wdtype == VDA_FP8) L(f16_t, WLoadFp8<f16_t>); else L(f16_t, WLoad<f16_t>); }
   else return -3;

@@ -57,12 +57,12 @@ _SIGS = {
     "vda_skinny_gemm": [P, P, P, P, P, I, I, I, L, L, L, I, I, P],
     "vda_moe_topk_softmax": [P, P, P, I, I, I, I, L, I, P],
     "vda_moe_align": [P, P, P, I, I, P],
-    "vda_moe_gate_up": [P, P, P, P, P, P, I, I, I, I, I, L, I, I, I, P],
+    "vda_moe_gate_up": [P, P, P, P, P, P, I, I, I, I, I, L, I, I, I, I, P],
     "vda_moe_down": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "vda_moe_sum": [P, P, P, I, I, I, L, I, P],
     "vda_moe_tile_map": [P, P, P, P, P, I, I, I, P],
     "vda_moe_align_large": [P, P, P, P, P, I, I, P],
-    "vda_tile_gemm": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, I, I, I, I, I, P],
+    "vda_tile_gemm": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, I, I, I, I, I, I, P],
     "vda_decode_gemm": [P, P, P, P, P, L, I, I, I, L, L, I, P],
     "vda_wq_gemm": [P, P, P, P, P, P, L, I, I, I, I, I, L, L, I, I, I, P],
     "vda_dense_gemm_stamp": [P, P, P, I, I, I, I, P],

@@ -313,8 +313,8 @@ def moe_topk_softmax(logits: torch.Tensor, k: int, renormalize: bool):
 
 def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,
               w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None,
-              block_scales: bool = False) -> torch.Tensor:
-    """out[t] = sum_j topk_w[t, j] * W2_e( silu(Wg_e x_t) * (Wu_e x_t) ), e = topk_ids[t, j];
+              block_scales: bool = False, activation: str = "silu") -> torch.Tensor:
+    """out[t] = sum_j topk_w[t, j] * W2_e( act(Wg_e x_t) * (Wu_e x_t) ), e = topk_ids[t, j];
     negative ids (expert on another rank) contribute nothing.  fp32 accumulation.  ``block_scales``:
     the weight scales are per 128 x 128 block instead of per expert."""
     T, H = x.shape
@@ -337,7 +337,7 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
             q, s_ = per_group_fp8_quant(xe.to(x.dtype))
             xe = (q.float().view(*s_.shape, -1) * s_.unsqueeze(-1)).view(xe.shape)
         h = xe @ a.t()
-        act = (torch.nn.functional.silu(h[:, :I]) * h[:, I:]).to(x.dtype).float()
+        act = (_act(activation, h[:, :I]) * h[:, I:]).to(x.dtype).float()
         if block_scales:
             q, s_ = per_group_fp8_quant(act.to(x.dtype))
             act = (q.float().view(*s_.shape, -1) * s_.unsqueeze(-1)).view(act.shape)
