@@ -112,12 +112,45 @@ def main():
     for T in (1, 37, 80):
         xt = torch.randn((T, H), generator=gen).to(torch.bfloat16).to(dev)
         tw, ids = ops.moe_topk_softmax(torch.randn((T, E), generator=gen).to(dev), k, True)
+        if T == 37:
+            ids[3, 1] = -1                      # a padded pair and an id outside the table go nowhere
+            ids[5, 0] = E + 7
+        # the bookkeeping kernel against its PyTorch form
+        got = ops.ep_prep(ids.reshape(-1), world, epr)
+        want = ops.ep_prep(ids.reshape(-1).cpu(), world, epr)
+        n_live = int(want[3][world])
+        for name, a, b_ in zip(("ids", "dest", "sorted", "offsets", "slot"), got, want):
+            a, b_ = a.cpu(), b_.cpu()
+            if name == "sorted":
+                a, b_ = a[:n_live], b_[:n_live]
+            assert torch.equal(a, b_), (T, name, a, b_)
         recv, local, st = disp.dispatch(xt, ids)
+        # local expert ids arrive ready-made: -1 past every source's count
+        rc_ = st.recv_counts.cpu().tolist()
+        lv = local.view(world, st.cap).cpu()
+        for s_ in range(world):
+            assert bool((lv[s_, rc_[s_]:] == -1).all()) and bool(((lv[s_, :rc_[s_]] >= 0) & (lv[s_, :rc_[s_]] < epr)).all())
         ones = torch.ones((recv.shape[0], 1), dtype=torch.float32, device=dev)
         y = ops.fused_moe(recv, w13[rank * epr:(rank + 1) * epr].contiguous(), w2[rank * epr:(rank + 1) * epr].contiguous(),
                           ones, local)
         out = disp.combine(y, tw, st)
+        # the fused return + weighted sum against the separate exchange + PyTorch gather: the same fp32 sum up to the
+        # fused multiply-add (one rounding instead of two), i.e. at most one step of the 16-bit result
+        peer, disp.rx.peer = disp.rx.peer, None
+        try:
+            ret, _ = peer.exchange_regions(y, st.recv_counts, st.cap)
+            d = st.dest.long()
+            pos = (d.clamp(min=0) * st.cap + st.slot.long().clamp(min=0))
+            rows = torch.where((d >= 0).view(T, k, 1), ret[pos].view(T, k, -1).float(), torch.zeros((), device=dev))
+            plain = (rows * torch.where((d >= 0).view(T, k), tw.float(), torch.zeros((), device=dev)).unsqueeze(-1)).sum(1)
+        finally:
+            disp.rx.peer = peer
         torch.cuda.synchronize()
+        plain = plain.to(out.dtype).float()
+        gap = (out.float() - plain).abs()
+        assert bool((gap <= plain.abs() * 2 ** -7 + 1e-6).all()), (T, gap.max())
+        assert float((gap > 0).float().mean()) < 0.02, T
+        ids = torch.where((ids >= 0) & (ids < E), ids, torch.full_like(ids, -1))
         ref = ops.reference.fused_moe(xt, w13, w2, tw, ids)
         err = float((out.float() - ref.float()).norm() / ref.float().norm())
         assert err < 2e-2, (T, err)

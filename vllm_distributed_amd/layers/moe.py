@@ -213,19 +213,32 @@ class FusedMoE(nn.Module):
         return ops.moe_topk_softmax(router_logits, k, self.renormalize)
 
     def _forward_ep_dispatch(self, x: torch.Tensor, lg: torch.Tensor, routed=None) -> torch.Tensor:
-        """Expert parallel over ranks that all hold the same tokens (TP attention in front): rank r routes
-        its 1/ep slice of the tokens to the expert owners through the all-to-all-v, the owners compute,
-        the results return and are weighted at the source, and an all-gather replicates the rows again.
-        Per xGMI link: T k H / ep^2 bytes each way plus the all-gather, against the T H of an all-reduce."""
+        """Expert parallel with token routing.  The ranks that hold the same rows (all of them after tensor-parallel
+        attention; the tensor-parallel ranks of one replica after data-parallel attention) each take a slice of
+        those rows, route it to the expert owners through the all-to-all-v, the owners compute, the results return
+        and are weighted at the source, and an all-gather among the same ranks replicates the rows again.
+        Per xGMI link: T k H / ep^2 bytes each way plus the all-gather, against the T H of an all-reduce -- or, with
+        data-parallel attention, against an all-gather of EVERY replica's tokens to every rank.
+        Reference: vllm/model_executor/layers/fused_moe/layer.py:1439-1484,
+        vllm/distributed/device_communicators/all2all.py:77-264."""
         from ..parallel.all2all import get_expert_dispatcher
         ep = get_ep_group()
         T, H = x.shape
-        Tp = -(-T // self.ep_size)
+        dp_meta = None
+        if self.dp_size > 1:
+            from ..forward_context import get_forward_context
+            dp_meta = get_forward_context().dp
+            if dp_meta is None:
+                raise RuntimeError("data-parallel expert dispatch needs DPMetadata in the forward context")
+        parts, part_rank = (self.tp_size, self.tp_rank) if self.dp_size > 1 else (self.ep_size, self.ep_rank)
+        Tp = -(-T // parts)
+        # rows per (source, destination) pair of this call: the same on every rank of the expert-parallel group
+        cap_tokens = -(-int(dp_meta.max_tokens) // parts) if dp_meta is not None else Tp
         if self._ep_disp is None:
             self._ep_disp = get_expert_dispatcher(ep, self.local_num_experts, self.top_k, H * x.element_size(),
-                                                  -(-self._max_tokens // self.ep_size))
-        lo = self.ep_rank * Tp
-        pad = self.ep_size * Tp - T
+                                                  -(-self._max_tokens // parts))
+        lo = part_rank * Tp
+        pad = parts * Tp - T
         if pad:
             x = torch.nn.functional.pad(x, (0, 0, 0, pad))
             if routed is None:
@@ -246,10 +259,17 @@ class FusedMoE(nn.Module):
             self.eplb_state.record(self.eplb_layer, topk_ids)
         if self.routed_scaling_factor != 1.0:
             topk_w = topk_w * self.routed_scaling_factor
-        recv, local_ids, st = self._ep_disp.dispatch(xs.contiguous(), topk_ids.to(torch.int32))
+        recv, local_ids, st = self._ep_disp.dispatch(xs.contiguous(), topk_ids.to(torch.int32), cap_tokens)
         ones = torch.ones((recv.shape[0], 1), dtype=torch.float32, device=x.device)
         y = self.quant_method.apply(self, recv, ones, local_ids)
-        out = self._ep_disp.rx.all_gather_rows(self._ep_disp.combine(y, topk_w, st))[:T]
+        part = self._ep_disp.combine(y, topk_w, st)
+        if self.dp_size == 1:
+            out = self._ep_disp.rx.all_gather_rows(part)[:T]
+        elif self.tp_size > 1:
+            from ..parallel.state import tensor_model_parallel_all_gather
+            out = tensor_model_parallel_all_gather(part, 0)[:T]
+        else:
+            out = part[:T]
         if not self.reduce_results:
             # the caller adds a tensor-parallel partial sum (shared experts) and all-reduces the total:
             # hand it the complete routed output in 1 / tp parts
@@ -261,7 +281,9 @@ class FusedMoE(nn.Module):
         itself (models that scale the experts' INPUT by the router score pass weights of one)."""
         x, lg = hidden_states, router_logits
         dispatch = self.dp_size > 1
-        if self.use_ep and not dispatch and self._ep_route:
+        if self.use_ep and self._ep_route and (not dispatch or routed is None):
+            # expert parallel: tokens travel to the expert owners through the all-to-all-v, also when attention
+            # ran data-parallel (each replica routes its own tokens; nothing is all-gathered)
             return self._forward_ep_dispatch(x, lg, routed)
         if dispatch:
             if routed is not None:

@@ -836,6 +836,32 @@ def sort_by_key(keys: torch.Tensor, num_keys: int):
     return sorted_ids, offsets
 
 
+def ep_prep(topk_ids: torch.Tensor, world: int, experts_per_rank: int):
+    """Expert-parallel dispatch bookkeeping for the flattened (token, slot) pairs with global expert ids
+    ``topk_ids`` int32 [P]: returns (ids with invalid entries set to -1, destination rank per pair or -1, pair
+    positions sorted by destination (stable), offsets int32 [world + 1], position of every pair inside its
+    destination's region or -1).  One kernel on the GPU (ops/csrc/moe.hip ep_prep_kernel)."""
+    ids = topk_ids.contiguous().view(-1).to(torch.int32)
+    P_ = ids.numel()
+    if not _dev(ids) or world > 8:
+        valid = (ids >= 0) & (ids < world * experts_per_rank)
+        clean = torch.where(valid, ids, torch.full_like(ids, -1))
+        dest = torch.where(valid, ids // experts_per_rank, torch.full_like(ids, -1))
+        sorted_ids, offsets = sort_by_key(dest, world)
+        inv = torch.zeros(P_ + 1, dtype=torch.int64, device=ids.device)
+        seq = torch.arange(P_, device=ids.device, dtype=torch.int64)
+        inv[torch.where(seq < offsets[world].long(), sorted_ids.long(), torch.full_like(seq, P_))] = seq
+        slot = torch.where(valid, (inv[:P_] - offsets.long()[dest.clamp(min=0).long()]).to(torch.int32),
+                           torch.full_like(ids, -1))
+        return clean, dest, sorted_ids, offsets, slot
+    out = torch.empty(4 * P_ + world + 1, dtype=torch.int32, device=ids.device)
+    clean, dest, sorted_ids, slot = (out[i * P_:(i + 1) * P_] for i in range(4))
+    offsets = out[4 * P_:]
+    N.call("vda_ep_prep", ids.data_ptr(), P_, world, experts_per_rank, clean.data_ptr(), dest.data_ptr(),
+           sorted_ids.data_ptr(), offsets.data_ptr(), slot.data_ptr(), N.stream())
+    return clean, dest, sorted_ids, offsets, slot
+
+
 def tile_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, rows_per_tile: int = 0
                 ) -> torch.Tensor:
     """y = x @ w.T (+ bias) through the LDS-tiled 16-bit MFMA GEMM (x [M, K], w [N, K], same 16-bit dtype)."""

@@ -429,3 +429,100 @@ VDA_EXPORT int vda_moe_sum(void* out, const void* out2, const int* ids, int num_
   VDA_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Expert-parallel dispatch bookkeeping in ONE launch.  For every (token, slot) pair p with global expert id
+// ids[p]: the rank that owns the expert (dest = id / experts_per_rank, -1 for ids outside the table: padding, a
+// router fed NaNs), a stable counting sort of the pairs by destination (sorted / offsets, the form the row
+// exchange packs from), and the pair's position inside its destination's region (slot: where its result comes back
+// to).  One workgroup: the sort key has at most 8 values, so a pass is one ballot per value and wave; 64 K pairs
+// take 64 trips.  Role of the reference's prepare step in vllm/model_executor/layers/fused_moe/layer.py:1439-1484
+// and of the index math of its all2all managers (vllm/distributed/device_communicators/all2all.py:77-264).
+__global__ __launch_bounds__(1024) void ep_prep_kernel(const int* __restrict__ ids, int P, int world, int epr,
+                                                       int* __restrict__ ids_out, int* __restrict__ dest_out,
+                                                       int* __restrict__ sorted, int* __restrict__ offsets,
+                                                       int* __restrict__ slot_out) {
+  constexpr int NT = 1024, NW = NT / 64, MAXR = 8;
+  __shared__ int wave_cnt[NW][MAXR];
+  __shared__ int base[MAXR + 1], running[MAXR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto dest_of = [&](int p) {
+    if (p >= P) return -1;
+    const int e = ids[p];
+    return (e >= 0 && e < world * epr) ? e / epr : -1;
+  };
+  // pass 1: how many pairs go to each rank
+  int cnt[MAXR];
+#pragma unroll
+  for (int d = 0; d < MAXR; ++d) cnt[d] = 0;
+  for (int p = tid; p < P; p += NT) {
+    const int d = dest_of(p);
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) cnt[q] += (d == q);
+  }
+#pragma unroll
+  for (int d = 0; d < MAXR; ++d) {
+    int v = cnt[d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) wave_cnt[wave][d] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int d = 0; d < MAXR; ++d) {
+      base[d] = acc;
+      if (d < world) offsets[d] = acc;
+      int t = 0;
+      for (int w = 0; w < NW; ++w) t += wave_cnt[w][d];
+      acc += d < world ? t : 0;
+      running[d] = 0;
+    }
+    base[MAXR] = acc;
+    offsets[world] = acc;
+  }
+  __syncthreads();
+  // pass 2: positions, chunk by chunk in pair order (stable)
+  for (int c0 = 0; c0 < P; c0 += NT) {
+    const int p = c0 + tid;
+    const int d = dest_of(p);
+    int before = 0;
+#pragma unroll
+    for (int q = 0; q < MAXR; ++q) {
+      const unsigned long long m = __ballot(d == q);
+      if (lane == 0) wave_cnt[wave][q] = __popcll(m);
+      if (d == q) before = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (p < P) {
+      int pos = -1;
+      if (d >= 0) {
+        int wb = 0;
+        for (int w = 0; w < wave; ++w) wb += wave_cnt[w][d];
+        const int sl = running[d] + wb + before;
+        pos = sl;
+        sorted[base[d] + sl] = p;
+      }
+      slot_out[p] = pos;
+      dest_out[p] = d;
+      ids_out[p] = d >= 0 ? ids[p] : -1;
+    }
+    __syncthreads();
+    if (tid < MAXR) {
+      int t = 0;
+      for (int w = 0; w < NW; ++w) t += wave_cnt[w][tid];
+      running[tid] += t;
+    }
+    __syncthreads();
+  }
+}
+
+VDA_EXPORT int vda_ep_prep(const int* ids, int P, int world, int epr, int* ids_out, int* dest_out, int* sorted,
+                           int* offsets, int* slot_out, hipStream_t st) {
+  if (P < 0 || world < 1 || world > 8 || epr < 1) return -1;
+  hipLaunchKernelGGL(ep_prep_kernel, dim3(1), dim3(1024), 0, st, ids, P, world, epr, ids_out, dest_out, sorted, offsets,
+                     slot_out);
+  VDA_CHECK_LAUNCH();
+  return 0;
+}

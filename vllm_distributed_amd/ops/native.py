@@ -60,6 +60,7 @@ _SIGS = {
     "vda_moe_gate_up": [P, P, P, P, P, P, I, I, I, I, I, L, I, I, I, I, P],
     "vda_moe_down": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "vda_moe_sum": [P, P, P, I, I, I, L, I, P],
+    "vda_ep_prep": [P, I, I, I, P, P, P, P, P, P],
     "vda_moe_tile_map": [P, P, P, P, P, I, I, I, P],
     "vda_moe_align_large": [P, P, P, P, P, I, I, P],
     "vda_tile_gemm": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, I, I, I, I, I, I, P],

@@ -162,7 +162,7 @@ class RowExchange:
 @dataclass
 class EpState:
     dest: torch.Tensor          # [P] destination rank of every (token, slot) pair, -1 = padding
-    inv: torch.Tensor           # [P] position of pair p in the destination-sorted order
+    slot: torch.Tensor          # [P] position of pair p inside its destination's region (-1 = padding)
     offsets: torch.Tensor       # [world + 1]
     recv_counts: torch.Tensor   # [world]
     cap: int
@@ -183,39 +183,37 @@ class ExpertDispatcher:
         cap = -(-max(max_tokens, 1) * top_k // 16) * 16
         self.rx = RowExchange(group, cap, row_bytes)
 
-    def dispatch(self, x: torch.Tensor, topk_ids: torch.Tensor):
-        """x [T, H]; topk_ids int32 [T, k] global (physical) expert ids, negative = padding.  Returns
-        (rows received [world * cap, H], their local expert ids int32 [world * cap, 1] with -1 on empty
-        slots, state for ``combine``)."""
+    def dispatch(self, x: torch.Tensor, topk_ids: torch.Tensor, cap_tokens: int = 0):
+        """x [T, H]; topk_ids int32 [T, k] global (physical) expert ids, negative = padding.  ``cap_tokens``: the
+        largest T of any rank in this call when the ranks hold different numbers of tokens (data-parallel
+        attention); every rank must pass the same value.  Returns (rows received [world * cap, H], their local
+        expert ids int32 [world * cap, 1] with -1 on empty slots, state for ``combine``).
+        On the GPU: one bookkeeping kernel (ops.ep_prep) and the exchange, which hands out local expert ids itself."""
         from .. import ops
         T, k = topk_ids.shape
-        cap = min(self.rx.cap, -(-max(T, 1) * k // 16) * 16)
-        ids = topk_ids.reshape(-1)
-        # ids outside [0, world * experts_per_rank) (padding; a router fed NaNs) go nowhere
-        ids = torch.where((ids >= 0) & (ids < self.world * self.epr), ids, torch.full_like(ids, -1))
-        dest = torch.where(ids >= 0, ids // self.epr, ids)
-        sorted_ids, offsets = ops.sort_by_key(dest, self.world)
+        cap = min(self.rx.cap, -(-max(int(cap_tokens) or T, 1) * k // 16) * 16)
+        ids, dest, sorted_ids, offsets, slot = ops.ep_prep(topk_ids.reshape(-1), self.world, self.epr)
+        if self.rx.peer is not None and x.is_cuda:
+            recv, local, rc = self.rx.peer.exchange(x, sorted_ids, offsets, k, ids, cap, meta_sub=self.rank * self.epr,
+                                                    fill_meta=True)
+            return recv, local.view(-1, 1), EpState(dest, slot, offsets, rc, cap)
         recv, rmeta, rc = self.rx.exchange(x, sorted_ids, offsets, k, ids.contiguous(), cap)
-        slot = torch.arange(cap, device=x.device, dtype=torch.int32).unsqueeze(0)
-        local = torch.where(slot < rc.unsqueeze(1), rmeta.view(self.world, cap) - self.rank * self.epr,
+        pos = torch.arange(cap, device=x.device, dtype=torch.int32).unsqueeze(0)
+        local = torch.where(pos < rc.unsqueeze(1), rmeta.view(self.world, cap) - self.rank * self.epr,
                             torch.full((), -1, dtype=torch.int32, device=x.device))
-        # inverse permutation of the live part of the sort (entries past offsets[world] are not pairs)
-        P_ = sorted_ids.numel()
-        seq = torch.arange(P_, device=x.device, dtype=torch.int64)
-        inv = torch.zeros(P_ + 1, dtype=torch.int64, device=x.device)
-        inv[torch.where(seq < offsets[self.world].long(), sorted_ids.long(), torch.full_like(seq, P_))] = seq
-        inv = inv[:P_]
-        return recv, local.reshape(-1, 1).contiguous(), EpState(dest, inv, offsets, rc, cap)
+        return recv, local.reshape(-1, 1).contiguous(), EpState(dest, slot, offsets, rc, cap)
 
     def combine(self, y: torch.Tensor, topk_w: torch.Tensor, st: EpState) -> torch.Tensor:
         """y [world * cap, H]: outputs of the rows received by ``dispatch`` (same slots).  Returns
-        out [T, H] = sum_j topk_w[t, j] * y(pair t, j)."""
+        out [T, H] = sum_j topk_w[t, j] * y(pair t, j), fp32 sums.  On the GPU one kernel: the rows return through
+        peer memory and are weighted and summed where they land."""
         T, k = topk_w.shape
+        if self.rx.peer is not None and y.is_cuda and y.dtype in (torch.bfloat16, torch.float16):
+            return self.rx.peer.combine(y, st.recv_counts, st.dest, st.slot, topk_w, st.cap)
         ret, _ = self.rx.exchange_regions(y, st.recv_counts, st.cap)
         d = st.dest.long()
         valid = d >= 0
-        dc = d.clamp(min=0)
-        pos = (dc * st.cap + (st.inv.long() - st.offsets.long()[dc])).clamp(min=0, max=ret.shape[0] - 1)
+        pos = (d.clamp(min=0) * st.cap + st.slot.long().clamp(min=0)).clamp(max=ret.shape[0] - 1)
         w = torch.where(valid.view(T, k), topk_w.float(), torch.zeros((), device=y.device))
         rows = ret[pos].view(T, k, -1).float()
         rows = torch.where(valid.view(T, k, 1), rows, torch.zeros((), device=y.device))   # unwritten slots may hold NaN

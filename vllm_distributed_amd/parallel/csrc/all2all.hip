@@ -27,6 +27,7 @@
 #include "peer_sync.h"
 
 struct A2aCtx {
+  uint32_t* gsync;          // local grid barrier of the combine kernel: [0] arrivals, [1 + b] barriers workgroup b passed
   int rank, world, cap, row_bytes;
   size_t half_bytes, meta_off, rows_off;
   char* data[MAX_RANKS];
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(A2A_THREADS) void a2a_kernel(A2aArgs a, const char*
                                                            const int* __restrict__ offsets_or_counts, int k_div,
                                                            const int* __restrict__ meta_in, char* __restrict__ recv,
                                                            long recv_row_stride, int copy_bytes,
-                                                           int* __restrict__ recv_meta, int* __restrict__ recv_counts) {
+                                                           int* __restrict__ recv_meta, int* __restrict__ recv_counts,
+                                                           int meta_sub, int fill_meta) {
   Signal* me = a.sig[a.rank];
   __shared__ uint32_t s_cnt, s_call;
   __shared__ int s_n[MAX_RANKS];
@@ -109,11 +111,108 @@ __global__ __launch_bounds__(A2A_THREADS) void a2a_kernel(A2aArgs a, const char*
         copy_row(reinterpret_cast<u32x4*>(recv + ((size_t)s * a.cap + j) * recv_row_stride),
                  reinterpret_cast<const u32x4*>(peer + a.rows_off + ((size_t)a.rank * a.cap + j) * a.row_bytes), units);
         if (recv_meta && threadIdx.x == 0)
-          recv_meta[(size_t)s * a.cap + j] = reinterpret_cast<const int*>(peer + a.meta_off)[(size_t)a.rank * a.cap + j];
+          recv_meta[(size_t)s * a.cap + j] =
+              reinterpret_cast<const int*>(peer + a.meta_off)[(size_t)a.rank * a.cap + j] - meta_sub;
       }
+    }
+    if (recv_meta && fill_meta) {             // slots past a source's count: -1 ("no row here")
+      const int total = a.world * a.cap;
+      for (int idx = b * A2A_THREADS + threadIdx.x; idx < total; idx += B * A2A_THREADS)
+        if (idx % a.cap >= s_n[idx / a.cap]) recv_meta[idx] = -1;
     }
   }
   if (threadIdx.x == 0) { me->counter[blockIdx.x] = cnt + 1; me->calls[blockIdx.x] = s_call + 1; }
+}
+
+// The way back of an expert-parallel dispatch with the weighting fused in: y [world][cap] rows (results of the rows
+// received, grouped by the rank they came from) return to their senders exactly like a regions-form exchange, and
+// then -- after a barrier among this GPU's own workgroups, all of which are resident -- every token's k rows are
+// read back from the scratch they landed in (still in L2 for decode sizes), weighted and summed in fp32:
+//     out[t] = sum_j w[t, j] * ret[dest[t k + j] * cap + slot[t k + j]]
+// One launch instead of an exchange, a gather, a broadcast multiply and a reduction.
+template <typename T>
+__global__ __launch_bounds__(A2A_THREADS) void a2a_combine_kernel(A2aArgs a, uint32_t* __restrict__ gsync,
+                                                                   const char* __restrict__ y, long y_row_stride,
+                                                                   const int* __restrict__ counts,
+                                                                   char* __restrict__ ret, long ret_row_stride,
+                                                                   int copy_bytes, const int* __restrict__ dest,
+                                                                   const int* __restrict__ slot,
+                                                                   const float* __restrict__ topk_w, T* __restrict__ out,
+                                                                   long out_row_stride, int Tn, int k) {
+  Signal* me = a.sig[a.rank];
+  __shared__ uint32_t s_cnt, s_call, s_seen;
+  __shared__ int s_n[MAX_RANKS];
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) { s_cnt = me->counter[blockIdx.x]; s_call = me->calls[blockIdx.x]; s_seen = gsync[1 + blockIdx.x]; }
+  __syncthreads();
+  const uint32_t cnt = s_cnt;
+  const size_t half_off = (size_t)(s_call & 1) * a.half_bytes;
+  const int b = blockIdx.x, B = gridDim.x;
+  const int units = copy_bytes >> 4;
+  char* mine = a.data[a.rank] + half_off;
+  for (int d = 0; d < a.world; ++d) {
+    const int n = min(max(counts[d], 0), a.cap);
+    if (threadIdx.x == 0) reinterpret_cast<int*>(mine)[b * MAX_RANKS + d] = n;
+    for (int j = b; j < n; j += B)
+      copy_row(reinterpret_cast<u32x4*>(mine + a.rows_off + ((size_t)d * a.cap + j) * a.row_bytes),
+               reinterpret_cast<const u32x4*>(y + ((long)d * a.cap + j) * y_row_stride), units);
+  }
+  bool ok = peer_barrier(a.sig, a.rank, a.world, a.spin_limit, cnt + 1, a.host_err);
+  if (ok) {
+    if (threadIdx.x < a.world)
+      s_n[threadIdx.x] = reinterpret_cast<const int*>(a.data[threadIdx.x] + half_off)[b * MAX_RANKS + a.rank];
+    __syncthreads();
+    for (int i = 0; i < a.world; ++i) {
+      const int s = (a.rank + i) % a.world;
+      const char* peer = a.data[s] + half_off;
+      const int n = s_n[s];
+      for (int j = b; j < n; j += B)
+        copy_row(reinterpret_cast<u32x4*>(ret + ((size_t)s * a.cap + j) * ret_row_stride),
+                 reinterpret_cast<const u32x4*>(peer + a.rows_off + ((size_t)a.rank * a.cap + j) * a.row_bytes), units);
+    }
+  }
+  if (threadIdx.x == 0) { me->counter[blockIdx.x] = cnt + 1; me->calls[blockIdx.x] = s_call + 1; }
+  // ---- every workgroup of THIS GPU has its rows in ret ----------------------------------------------
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t target = (s_seen + 1) * (uint32_t)B;
+    __hip_atomic_fetch_add(&gsync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long spins = 0;
+    int good = 1;
+    while ((int32_t)(__hip_atomic_load(&gsync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > a.spin_limit) { good = 0; break; }
+    }
+    gsync[1 + b] = s_seen + 1;
+    s_ok = good;
+  }
+  __syncthreads();
+  __threadfence();
+  if (!ok || !s_ok) return;
+  constexpr int N = 16 / sizeof(T);
+  for (int t = b; t < Tn; t += B) {
+    for (int e = threadIdx.x; e < units; e += A2A_THREADS) {
+      float acc[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc[i] = 0.f;
+      for (int j = 0; j < k; ++j) {
+        const int p = t * k + j;
+        const int d = dest[p];
+        if (d < 0) continue;
+        const float w = topk_w[p];
+        const u32x4 raw = reinterpret_cast<const u32x4*>(ret + ((size_t)d * a.cap + slot[p]) * ret_row_stride)[e];
+        const T* v = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] += w * (float)v[i];
+      }
+      u32x4 o;
+      T* op = reinterpret_cast<T*>(&o);
+#pragma unroll
+      for (int i = 0; i < N; ++i) op[i] = (T)acc[i];
+      reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (long)t * out_row_stride)[e] = o;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -141,12 +240,19 @@ VDA_EXPORT void* vda_a2a_create(int rank, int world, void** peer_data, void** pe
   for (int i = 0; i < world; ++i) { c->data[i] = (char*)peer_data[i]; c->sig[i] = (Signal*)peer_sig[i]; }
   c->spin_limit = spin_limit;
   c->host_err = alloc_host_err();
+  c->gsync = nullptr;
+  if (hipMalloc((void**)&c->gsync, (1 + MAX_BLOCKS) * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(c->gsync, 0, (1 + MAX_BLOCKS) * sizeof(uint32_t)) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
   return c;
 }
 
 VDA_EXPORT void vda_a2a_destroy(void* ctx) {
   A2aCtx* c = (A2aCtx*)ctx;
   if (c->host_err) hipHostFree(c->host_err);
+  if (c->gsync) hipFree(c->gsync);
   delete c;
 }
 
@@ -168,7 +274,7 @@ VDA_EXPORT int vda_a2a_error(void* ctx) {
 VDA_EXPORT int vda_a2a_exchange(void* ctx, const void* x, long x_row_stride, const int* sorted,
                                 const int* offsets_or_counts, int k_div, const int* meta_in, void* recv,
                                 long recv_row_stride, int copy_bytes, int* recv_meta, int* recv_counts, int gather,
-                                int cap, hipStream_t st) {
+                                int cap, int meta_sub, int fill_meta, hipStream_t st) {
   A2aCtx* c = (A2aCtx*)ctx;
   if (cap <= 0) cap = c->cap;
   if (cap > c->cap) return -2;
@@ -184,10 +290,40 @@ VDA_EXPORT int vda_a2a_exchange(void* ctx, const void* x, long x_row_stride, con
   if (gather)
     hipLaunchKernelGGL(a2a_kernel<true>, dim3(MAX_BLOCKS), dim3(A2A_THREADS), 0, st, a, (const char*)x, x_row_stride,
                        sorted, offsets_or_counts, k_div, meta_in, (char*)recv, recv_row_stride, copy_bytes, recv_meta,
-                       recv_counts);
+                       recv_counts, meta_sub, fill_meta);
   else
     hipLaunchKernelGGL(a2a_kernel<false>, dim3(MAX_BLOCKS), dim3(A2A_THREADS), 0, st, a, (const char*)x, x_row_stride,
                        sorted, offsets_or_counts, k_div, meta_in, (char*)recv, recv_row_stride, copy_bytes, recv_meta,
-                       recv_counts);
+                       recv_counts, meta_sub, fill_meta);
+  return (int)hipGetLastError();
+}
+
+// y: [world][cap] rows grouped by the rank they go back to, counts[world] valid rows each (the recv_counts of the
+// dispatch); ret: scratch of world * cap rows; dest / slot: per (token, slot) pair of THIS rank the owner rank (-1:
+// none) and the position inside that owner's region; topk_w fp32 [T * k]; out [T] rows of dtype (0 bf16, 1 f16).
+VDA_EXPORT int vda_a2a_combine(void* ctx, const void* y, long y_row_stride, const int* counts, void* ret,
+                               long ret_row_stride, int copy_bytes, const int* dest, const int* slot,
+                               const float* topk_w, void* out, long out_row_stride, int T, int k, int dtype, int cap,
+                               hipStream_t st) {
+  A2aCtx* c = (A2aCtx*)ctx;
+  if (cap <= 0) cap = c->cap;
+  if (cap > c->cap) return -2;
+  if (!y || !counts || !ret || !dest || !slot || !topk_w || !out || y_row_stride % 16 || ret_row_stride % 16 ||
+      out_row_stride % 16 || copy_bytes < 16 || copy_bytes % 16 || copy_bytes > c->row_bytes ||
+      ret_row_stride < copy_bytes || T < 0 || k < 1 || (dtype != 0 && dtype != 1))
+    return -1;
+  A2aArgs a;
+  for (int i = 0; i < MAX_RANKS; ++i) { a.data[i] = c->data[i < c->world ? i : 0]; a.sig[i] = c->sig[i < c->world ? i : 0]; }
+  a.rank = c->rank; a.world = c->world; a.cap = cap; a.row_bytes = c->row_bytes;
+  a.half_bytes = c->half_bytes; a.meta_off = c->meta_off; a.rows_off = c->rows_off; a.spin_limit = c->spin_limit;
+  a.host_err = c->host_err;
+  if (dtype == 0)
+    hipLaunchKernelGGL(a2a_combine_kernel<__bf16>, dim3(MAX_BLOCKS), dim3(A2A_THREADS), 0, st, a, c->gsync, (const char*)y,
+                       y_row_stride, counts, (char*)ret, ret_row_stride, copy_bytes, dest, slot, topk_w, (__bf16*)out,
+                       out_row_stride, T, k);
+  else
+    hipLaunchKernelGGL(a2a_combine_kernel<_Float16>, dim3(MAX_BLOCKS), dim3(A2A_THREADS), 0, st, a, c->gsync,
+                       (const char*)y, y_row_stride, counts, (char*)ret, ret_row_stride, copy_bytes, dest, slot, topk_w,
+                       (_Float16*)out, out_row_stride, T, k);
   return (int)hipGetLastError();
 }

@@ -68,7 +68,10 @@ def comm_library() -> ctypes.CDLL:
         lib.vda_a2a_create.restype = vp
         lib.vda_a2a_destroy.argtypes = [vp]
         lib.vda_a2a_error.argtypes = [vp]
-        lib.vda_a2a_exchange.argtypes = [vp, vp, ctypes.c_long, vp, vp, i32, vp, vp, ctypes.c_long, i32, vp, vp, i32, i32, vp]
+        lib.vda_a2a_exchange.argtypes = [vp, vp, ctypes.c_long, vp, vp, i32, vp, vp, ctypes.c_long, i32, vp, vp, i32, i32,
+                                         i32, i32, vp]
+        lib.vda_a2a_combine.argtypes = [vp, vp, ctypes.c_long, vp, vp, ctypes.c_long, i32, vp, vp, vp, vp, ctypes.c_long,
+                                        i32, i32, i32, i32, vp]
         _LIB = lib
     return _LIB
 
@@ -528,12 +531,36 @@ class PeerAllToAll(CustomAllReduce):
         return True
 
     def exchange(self, x: torch.Tensor, sorted_ids: torch.Tensor, offsets: torch.Tensor, k_div: int = 1,
-                 meta: Optional[torch.Tensor] = None, cap: int = 0):
+                 meta: Optional[torch.Tensor] = None, cap: int = 0, meta_sub: int = 0, fill_meta: bool = False):
         """Send row ``sorted_ids[i] // k_div`` of ``x`` to rank d for offsets[d] <= i < offsets[d + 1].
         ``cap``: rows per (source, destination) pair of this call (default: the arena's capacity; the same
-        on every rank).  Returns (recv [world * cap, W], recv_meta int32 [world * cap] or None,
+        on every rank).  The received meta values have ``meta_sub`` subtracted; with ``fill_meta`` the slots past
+        a source's count read -1.  Returns (recv [world * cap, W], recv_meta int32 [world * cap] or None,
         recv_counts int32 [world])."""
-        return self._run(x, sorted_ids, offsets, k_div, meta, 1, cap)
+        return self._run(x, sorted_ids, offsets, k_div, meta, 1, cap, meta_sub, fill_meta)
+
+    def combine(self, y: torch.Tensor, counts: torch.Tensor, dest: torch.Tensor, slot: torch.Tensor,
+                topk_w: torch.Tensor, cap: int = 0) -> torch.Tensor:
+        """The way back of a dispatch with the weighting fused in (one launch): ``y`` [world * cap, W] returns to the
+        senders like ``exchange_regions`` and out[t] = sum_j topk_w[t, j] * returned row of pair (t, j), where
+        ``dest`` / ``slot`` int32 [T * k] name the owner rank (-1: none) and the pair's position in its region."""
+        cap = int(cap) or self.cap
+        T, k = topk_w.shape
+        wb = y.shape[1] * y.element_size()
+        if y.dtype not in (torch.bfloat16, torch.float16) or wb % 16 or wb > self.row_bytes or cap > self.cap \
+                or y.shape[0] < self.world * cap or y.stride(1) != 1:
+            raise ValueError("combine: rows do not fit the all-to-all arena")
+        ret = torch.empty((self.world * cap, y.shape[1]), dtype=y.dtype, device=y.device)
+        out = torch.empty((T, y.shape[1]), dtype=y.dtype, device=y.device)
+        w = topk_w.contiguous().float()
+        rcode = self.lib.vda_a2a_combine(
+            self.ctx, y.data_ptr(), y.stride(0) * y.element_size(), counts.data_ptr(), ret.data_ptr(),
+            ret.stride(0) * ret.element_size(), wb, dest.data_ptr(), slot.data_ptr(), w.data_ptr(), out.data_ptr(),
+            out.stride(0) * out.element_size(), T, k, 0 if y.dtype == torch.bfloat16 else 1, cap,
+            torch.cuda.current_stream().cuda_stream)
+        if rcode:
+            raise RuntimeError(f"peer-memory combine launch failed with {rcode}")
+        return out
 
     def exchange_regions(self, y: torch.Tensor, counts: torch.Tensor, cap: int = 0):
         """``y`` [world * cap, W]: rows [d * cap, d * cap + counts[d]) go to rank d (the way back of an
@@ -541,7 +568,7 @@ class PeerAllToAll(CustomAllReduce):
         recv, _, rc = self._run(y, None, counts, 1, None, 0, cap)
         return recv, rc
 
-    def _run(self, x, sorted_ids, offs, k_div, meta, gather, cap=0):
+    def _run(self, x, sorted_ids, offs, k_div, meta, gather, cap=0, meta_sub=0, fill_meta=False):
         assert x.dim() == 2 and x.stride(1) == 1
         cap = int(cap) or self.cap
         wb = x.shape[1] * x.element_size()
@@ -557,7 +584,7 @@ class PeerAllToAll(CustomAllReduce):
             self.ctx, x.data_ptr(), x.stride(0) * x.element_size(), sorted_ids.data_ptr() if sorted_ids is not None else None,
             offs.data_ptr(), int(k_div), meta.data_ptr() if meta is not None else None, recv.data_ptr(),
             recv.stride(0) * recv.element_size(), wb, rmeta.data_ptr() if rmeta is not None else None, rc.data_ptr(),
-            gather, cap, torch.cuda.current_stream().cuda_stream)
+            gather, cap, int(meta_sub), int(bool(fill_meta)), torch.cuda.current_stream().cuda_stream)
         if rcode:
             raise RuntimeError(f"peer-memory all-to-all launch failed with {rcode}")
         return recv, rmeta, rc
