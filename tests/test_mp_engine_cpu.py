@@ -102,6 +102,40 @@ def test_data_parallel_two_engines(tmp_path, monkeypatch):
     assert all(tuple(c) == (0, 0) for c in counts), counts
 
 
+def test_data_parallel_attention_with_expert_parallel(tmp_path, monkeypatch):
+    """DP=2 with the experts split over the two engine cores: every replica routes its own tokens to the expert
+    owners through the all-to-all-v (torch.distributed form on the CPU) instead of all-gathering everybody's tokens;
+    replicas step in lock step (an idle one runs dummy batches).  Tokens equal the single-engine run."""
+    import asyncio
+    from vllm_distributed_amd.engine.arg_utils import AsyncEngineArgs
+    from vllm_distributed_amd.engine.async_llm import AsyncLLM
+    path, _ = _save_tiny(str(tmp_path), "mixtral")
+    prompts = [[(3 * i + j) % 300 for j in range(6 + 3 * i)] for i in range(7)]
+    sp = SamplingParams(temperature=0, max_tokens=6, ignore_eos=True)
+    a = _llm(path, monkeypatch, False)
+    ref = [list(o.outputs[0].token_ids) for o in a.generate(prompt_token_ids=prompts, sampling_params=sp)]
+    a.shutdown()
+    monkeypatch.setenv("VLLM_ENABLE_V1_MULTIPROCESSING", "1")
+    eng = AsyncLLM.from_engine_args(AsyncEngineArgs(
+        model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+        max_num_batched_tokens=64, data_parallel_size=2, enable_expert_parallel=True))
+
+    async def one(i):
+        toks = []
+        async for out in eng.generate({"prompt_token_ids": prompts[i]}, sp, f"r{i}"):
+            toks = list(out.outputs[0].token_ids)
+        return toks
+
+    async def go():
+        return await asyncio.gather(*(one(i) for i in range(len(prompts))))
+
+    try:
+        got = asyncio.run(asyncio.wait_for(go(), 240))
+    finally:
+        eng.shutdown()
+    assert got == ref
+
+
 def _async_args(path, **kw):
     from vllm_distributed_amd.engine.arg_utils import AsyncEngineArgs
     return AsyncEngineArgs(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256,

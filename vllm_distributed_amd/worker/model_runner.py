@@ -165,6 +165,7 @@ class ModelRunner:
         # one step uploads ~24 bytes per token plus one block-table row per sequence
         self._stage_bytes = int(Tpad * 40 + Spad * (self.max_blocks * 4 + 64) + (1 << 20))
         self.intermediate: Optional[IntermediateTensors] = None
+        self._dp_moe = False
         # run-ahead scheduling: sampled ids of the step in flight, still on the device, and which request
         # takes which of them as its next input token
         self._pend_ids: Optional[torch.Tensor] = None
@@ -223,6 +224,14 @@ class ModelRunner:
         if self.is_gpu:
             self.model_memory = torch.cuda.memory_allocated(self.device) - before
             logger.info("weights take %.2f GiB, loaded in %.1f s", self.model_memory / 2**30, time.time() - t0)
+        # expert layers behind data-parallel attention trade tokens between replicas: every step then starts with the
+        # replicas' row counts, and decode graphs are off (a captured exchange would freeze another replica's size)
+        from ..layers.moe import FusedMoE
+        from ..parallel.state import get_dp_group
+        self._dp_moe = get_dp_group().world_size > 1 and any(isinstance(m, FusedMoE) for m in self.model.modules())
+        if self._dp_moe and self.use_graphs:
+            logger.info("data-parallel attention with expert layers: decode graphs off")
+            self.use_graphs, self.capture_sizes = False, []
         # every layer that owns per-request cache memory: attention layers and state-space mixers
         self.attn_layers = {n: m for n, m in self.model.named_modules()
                             if isinstance(m, Attention) or getattr(m, "is_state_space_layer", False)
@@ -1030,7 +1039,8 @@ class ModelRunner:
             if self.async_tp and T >= envs.VDA_ASYNC_TP_MIN_TOKENS and conn is None and self.lora_manager is None \
                     and inputs_embeds is None and T_in == T and not P and not self.local_chunk:
                 mbs = self._make_micro_batches(rows, n_sched, cu, S, T, nd)
-            with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T, micro_batches=mbs) as fctx:
+            with set_forward_context(md, tknp=tmd, kv_connector=conn, num_tokens=T, micro_batches=mbs,
+                                     dp=self._dp_metadata(T_in)) as fctx:
                 if encoder_outputs:
                     fctx.extra["encoder_outputs"] = encoder_outputs
                 if conn is not None:
@@ -1391,9 +1401,25 @@ class ModelRunner:
                     self.d_succ_lens[:S].zero_()
                     self.d_inter_lens[:S].zero_()
             md = self._build_attn_metadata(S, num_tokens, S, num_tokens, 0, 1, nsplit, decode_only=True)
-        with set_forward_context(md, num_tokens=0):
+        with set_forward_context(md, num_tokens=0, dp=self._dp_metadata(num_tokens)):
             out = self.model(self.input_ids[:num_tokens], self.positions[:num_tokens], inter, None)
         return out
+
+    def _dp_metadata(self, rows: int):
+        """Row counts of every data-parallel replica for this step (one small host all-reduce), for expert layers
+        that exchange tokens between replicas; None when nothing needs it.  Every replica makes the same sequence
+        of calls: steps run in lock step and idle replicas run dummy batches.
+        Reference: vllm/forward_context.py:57-70 (DPMetadata.num_tokens_across_dp)."""
+        if not self._dp_moe:
+            return None
+        import torch.distributed as dist
+        from ..forward_context import DPMetadata
+        from ..parallel.state import get_dp_group
+        g = get_dp_group()
+        t = torch.zeros(g.world_size, dtype=torch.int32)
+        t[g.rank_in_group] = int(rows)
+        dist.all_reduce(t, group=g.cpu_group)
+        return DPMetadata([int(v) for v in t.tolist()])
 
     @torch.inference_mode()
     def profile_run(self) -> None:
