@@ -117,6 +117,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_CASCADE_MIN_PREFIX": (int, 256),        # cascade attention: shortest common prefix (tokens) worth a shared pass
     "VDA_CASCADE_MIN_SEQS": (int, 8),            # ... and fewest sequences in the step
     "VDA_ASYNC_TP_MIN_TOKENS": (int, 2048),      # async TP: batches of at least this many tokens run as 2 micro-batches
+    "VDA_NATIVE_BLOCK_POOL": (_bool, True),      # scheduler free list in the host runtime library (0: numpy arrays)
     "VDA_PP_PEER_PIPE": (_bool, True),           # pipeline hops through the peer-memory pipe on one node (0: RCCL + metadata)
     "VDA_COMM_SPIN_TIMEOUT_MS": (int, 20000),
     "VLLM_ROCM_QUICK_REDUCE_QUANTIZATION": (str.upper, "NONE"),

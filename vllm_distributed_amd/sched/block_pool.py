@@ -127,6 +127,91 @@ class FreeBlockQueue:
         return out
 
 
+class NativeFreeBlockQueue:
+    """The same queue kept by the host runtime library (runtime/csrc/block_pool.cpp): one call pops or appends a
+    request's whole list of blocks.  Used when the library is built and ``VDA_NATIVE_BLOCK_POOL`` is on."""
+
+    def __init__(self, num_blocks: int, skip: Iterable[int] = ()):
+        import ctypes
+        from ..runtime.shm_ring import host_library
+        lib = host_library()
+        c64, vp = ctypes.c_int64, ctypes.c_void_p
+        lib.vda_fbq_create.restype = vp
+        lib.vda_fbq_create.argtypes = [c64, vp, c64]
+        lib.vda_fbq_destroy.argtypes = [vp]
+        lib.vda_fbq_count.restype = c64
+        lib.vda_fbq_count.argtypes = [vp]
+        lib.vda_fbq_contains.argtypes = [vp, c64]
+        lib.vda_fbq_popleft_n.restype = c64
+        lib.vda_fbq_popleft_n.argtypes = [vp, c64, vp]
+        lib.vda_fbq_remove.argtypes = [vp, c64]
+        lib.vda_fbq_append_n.restype = c64
+        lib.vda_fbq_append_n.argtypes = [vp, vp, c64]
+        lib.vda_fbq_list.restype = c64
+        lib.vda_fbq_list.argtypes = [vp, vp]
+        self._lib = lib
+        sk = np.asarray(sorted(set(skip)), dtype=np.int64)
+        self._h = lib.vda_fbq_create(num_blocks, sk.ctypes.data, len(sk))
+        if not self._h:
+            raise RuntimeError("could not create the native free list")
+        self._one = np.zeros(1, dtype=np.int64)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.vda_fbq_destroy(h)
+
+    @property
+    def num_free_blocks(self) -> int:
+        return int(self._lib.vda_fbq_count(self._h))
+
+    def popleft(self) -> int:
+        if self._lib.vda_fbq_popleft_n(self._h, 1, self._one.ctypes.data) != 1:
+            raise ValueError("no free KV blocks")
+        return int(self._one[0])
+
+    def popleft_n(self, n: int) -> list[int]:
+        out = np.empty(max(n, 1), dtype=np.int64)
+        if self._lib.vda_fbq_popleft_n(self._h, n, out.ctypes.data) != n:
+            raise ValueError(f"asked for {n} blocks, {self.num_free_blocks} free")
+        return out[:n].tolist()
+
+    def remove(self, b: int) -> None:
+        if self._lib.vda_fbq_remove(self._h, b):
+            raise RuntimeError(f"block {b} is not in the free list")
+
+    def append(self, b: int) -> None:
+        self._one[0] = b
+        if self._lib.vda_fbq_append_n(self._h, self._one.ctypes.data, 1) != 1:
+            raise RuntimeError(f"block {b} is already free")
+
+    def append_n(self, ids: list[int]) -> None:
+        if not ids:
+            return
+        a = np.asarray(ids, dtype=np.int64)
+        rc = self._lib.vda_fbq_append_n(self._h, a.ctypes.data, len(a))
+        if rc != len(a):
+            raise RuntimeError(f"block {ids[-1 - rc]} is already free")
+
+    def __contains__(self, b: int) -> bool:
+        return bool(self._lib.vda_fbq_contains(self._h, b))
+
+    def get_all_free_blocks(self) -> list[int]:
+        out = np.empty(max(self.num_free_blocks, 1), dtype=np.int64)
+        n = self._lib.vda_fbq_list(self._h, out.ctypes.data)
+        return out[:n].tolist()
+
+
+def make_free_queue(num_blocks: int, skip: Iterable[int] = ()):
+    from .. import envs
+    if envs.VDA_NATIVE_BLOCK_POOL:
+        try:
+            return NativeFreeBlockQueue(num_blocks, skip)
+        except Exception:   # noqa: BLE001 - library not built: the numpy form serves the same contract
+            pass
+    return FreeBlockQueue(num_blocks, skip)
+
+
 class BlockPool:
     def __init__(self, num_gpu_blocks: int, enable_caching: bool, enable_kv_cache_events: bool = False):
         if num_gpu_blocks < 2:
@@ -136,7 +221,7 @@ class BlockPool:
         self.blocks = [KVCacheBlock(i) for i in range(num_gpu_blocks)]
         self.null_block = self.blocks[0]
         self.null_block.is_null = True
-        self.free_queue = FreeBlockQueue(num_gpu_blocks, skip=(0,))
+        self.free_queue = make_free_queue(num_gpu_blocks, skip=(0,))
         # hash -> {block_id: block}; several blocks may hold identical content
         self.cached: dict = defaultdict(dict)
         self.enable_kv_cache_events = enable_kv_cache_events
@@ -222,13 +307,16 @@ class BlockPool:
     def free_blocks(self, ordered: Iterable[KVCacheBlock]) -> None:
         """Drop one reference from each block; blocks that reach zero are appended
         to the free list in the given order (callers pass tail blocks first)."""
+        freed = []
         for blk in ordered:
             if blk.is_null:
                 continue
             blk.ref_cnt -= 1
             assert blk.ref_cnt >= 0, f"double free of {blk}"
             if blk.ref_cnt == 0:
-                self.free_queue.append(blk.block_id)
+                freed.append(blk.block_id)
+        if freed:
+            self.free_queue.append_n(freed)
 
     def reset_prefix_cache(self) -> bool:
         used = self.num_gpu_blocks - self.get_num_free_blocks()

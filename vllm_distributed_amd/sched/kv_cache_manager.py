@@ -325,6 +325,13 @@ class KVCacheManager:
         self.req_to_block_hashes: dict[str, list[BlockHash]] = defaultdict(list)
         # requests whose blocks live on another token-parallel rank
         self._foreign: set[str] = set()
+        # Decode steps mostly need nothing from the pool: a request's blocks already cover the next token and no
+        # block fills up.  Per request: (token slots its blocks cover, first token count at which another block
+        # becomes full and must be hashed).  While a step stays below both marks allocate_slots returns at once.
+        # Only for layouts whose every group is plain full attention (windows release blocks as they go).
+        self._covered: dict[str, tuple[int, int]] = {}
+        self._fast_ok = all(type(m) is FullAttentionManager for m in self.coordinator.managers)
+        self._no_blocks = self._empty()
 
     @property
     def usage(self) -> float:
@@ -380,6 +387,12 @@ class KVCacheManager:
         if not owned:
             self._foreign.add(rid)
             return self._empty()
+        if new_computed_blocks is None and not num_new_computed_tokens:
+            mark = self._covered.get(rid)
+            if mark is not None:
+                total = request.num_computed_tokens + num_new_tokens
+                if min(total + num_lookahead_tokens, self.max_model_len) <= mark[0] and total < mark[1]:
+                    return self._no_blocks
         new_computed = new_computed_blocks.blocks if new_computed_blocks is not None \
             else tuple([] for _ in range(self.num_groups))
         # blocks that fell out of every window can be released before counting
@@ -401,6 +414,14 @@ class KVCacheManager:
                           if request.spec_token_ids else computed + num_new_tokens,
                           request.num_tokens)
             self.coordinator.cache_blocks(request, self.req_to_block_hashes[rid], certain)
+        if self._fast_ok:
+            bs = self.block_size
+            covered = min(len(m.req_to_blocks[rid]) for m in self.coordinator.managers) * bs
+            # with caching off nothing is ever hashed; with delayed caching the caller hashes on its own
+            hashed = min(m.num_cached_block.get(rid, 0) for m in self.coordinator.managers) \
+                if self.enable_caching and not delay_cache_blocks else None
+            self._covered[rid] = (covered, (hashed + 1) * bs if hashed is not None else (1 << 62)
+                                  if not self.enable_caching else 0)
         return KVCacheBlocks(new_blocks)
 
     def cache_blocks(self, request, num_computed_tokens: int) -> None:
@@ -411,6 +432,7 @@ class KVCacheManager:
 
     def free(self, request) -> None:
         self._foreign.discard(request.request_id)
+        self._covered.pop(request.request_id, None)
         self.coordinator.free(request.request_id)
 
     def free_block_hashes(self, request) -> None:

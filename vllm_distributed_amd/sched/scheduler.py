@@ -440,19 +440,23 @@ class Scheduler(SchedulerInterface):
                                   req_to_new_blocks) -> CachedRequestData:
         d = CachedRequestData()
         use_pp = self.vllm_config.parallel_config.pipeline_parallel_size > 1
+        # decode steps mostly allocate nothing: those requests share one (never mutated) empty id tuple
+        nothing = self.kv_cache_manager._no_blocks
+        no_ids = nothing.get_block_ids()
         for req, resumed in itertools.chain(zip(running_reqs, itertools.repeat(False)),
                                             zip(resumed_reqs, itertools.repeat(True))):
             rid = req.request_id
             d.req_ids.append(rid)
             d.resumed_from_preemption.append(resumed)
-            n_tok = num_scheduled[rid] - len(spec_tokens.get(rid, ()))
             if use_pp or resumed:
                 # first-stage workers never see sampled tokens: ship the ones this step consumes
+                n_tok = num_scheduled[rid] - len(spec_tokens.get(rid, ()))
                 s = req.num_computed_tokens
                 d.new_token_ids.append(list(req.all_token_ids[s:s + n_tok]))
             else:
                 d.new_token_ids.append([])
-            d.new_block_ids.append(req_to_new_blocks[rid].get_block_ids())
+            blocks = req_to_new_blocks[rid]
+            d.new_block_ids.append(no_ids if blocks is nothing else blocks.get_block_ids())
             d.num_computed_tokens.append(req.num_computed_tokens)
         return d
 
