@@ -474,3 +474,72 @@ class Fairseq2LlamaForCausalLM(LlamaForCausalLM):
                     t = t.view(heads, hd // 2, 2, *t.shape[1:]).transpose(1, 2).reshape(t.shape)
                 yield n, t
         return super().load_weights(convert())
+
+
+# ---- DeciLM / Nemotron-NAS -------------------------------------------------------------------------
+def _find_multiple(n: int, k: int) -> int:
+    return n if n % k == 0 else n + k - n % k
+
+
+def deci_intermediate_size(ffn_mult: float, hidden: int) -> int:
+    """Width of a block's gated MLP from its ``ffn_mult``: 2/3 of mult x hidden, rounded up to 256."""
+    return _find_multiple(int(2 * ffn_mult * hidden / 3), 256)
+
+
+def _field(obj, name, default=None):
+    return obj.get(name, default) if isinstance(obj, dict) else getattr(obj, name, default)
+
+
+class DeciLMDecoderLayer(LlamaDecoderLayer):
+    """Llama block whose shape comes from a per-layer entry of ``block_configs`` (a neural-architecture search
+    picked them): the attention keeps ``num_attention_heads / n_heads_in_group`` KV heads or is skipped altogether
+    (``no_op``), the MLP is ``ffn_mult`` wide or skipped.  Skipped halves have no weights and no norm.
+    Reference: vllm/model_executor/models/nemotron_nas.py (DeciLMDecoderLayer :110-208)."""
+    supports_sequence_parallel = False
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = ""):
+        import copy
+        from ..config import HFConfig
+        bc = config.block_configs[int(prefix.split(".")[-1])]
+        attn, ffn = _field(bc, "attention", {}), _field(bc, "ffn", {})
+        no_attn, no_ffn = bool(_field(attn, "no_op", False)), bool(_field(ffn, "no_op", False))
+        if _field(attn, "replace_with_linear", False) or _field(ffn, "replace_with_linear", False):
+            raise NotImplementedError("DeciLM blocks replaced by a linear layer")
+        own = HFConfig(config.to_dict()) if isinstance(config, HFConfig) else copy.copy(config)
+        group = _field(attn, "n_heads_in_group", None)
+        if not no_attn and group:
+            own.num_key_value_heads = config.num_attention_heads // int(group)
+        mult = _field(ffn, "ffn_mult", None)
+        if not no_ffn and mult:
+            own.intermediate_size = deci_intermediate_size(float(mult), config.hidden_size)
+        super().__init__(own, vllm_config, quant_config, prefix)
+        self.no_attn, self.no_ffn = no_attn, no_ffn
+        if no_attn:
+            del self.self_attn, self.input_layernorm
+        if no_ffn:
+            del self.mlp, self.post_attention_layernorm
+
+    def forward(self, positions, hidden_states, residual):
+        if not self.no_attn:
+            if residual is None:
+                residual = hidden_states
+                hidden_states = self.input_layernorm(hidden_states)
+            else:
+                hidden_states, residual = self.input_layernorm(hidden_states, residual)
+            hidden_states = self.self_attn(positions, hidden_states)
+        if not self.no_ffn:
+            if residual is None:                        # a first block without attention
+                residual = hidden_states
+                hidden_states = self.post_attention_layernorm(hidden_states)
+            else:
+                hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+            hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class DeciLMModel(LlamaModel):
+    layer_cls = DeciLMDecoderLayer
+
+
+class DeciLMForCausalLM(LlamaForCausalLM):
+    model_cls = DeciLMModel

@@ -12,6 +12,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Qwen2ForCausalLM": ("llama", "Qwen2ForCausalLM"),
     "Qwen3ForCausalLM": ("llama", "Qwen3ForCausalLM"),
     "MixtralForCausalLM": ("mixtral", "MixtralForCausalLM"),
+    "DeciLMForCausalLM": ("llama_variants", "DeciLMForCausalLM"),
     "Grok1ModelForCausalLM": ("mixtral", "Grok1ModelForCausalLM"),
     "Grok1ForCausalLM": ("mixtral", "Grok1ModelForCausalLM"),
     "Llama4ForCausalLM": ("llama4", "Llama4ForCausalLM"),

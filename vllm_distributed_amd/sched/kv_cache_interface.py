@@ -132,6 +132,8 @@ class KVCacheTensor:
 class KVCacheGroupSpec:
     layer_names: list[str]
     kv_cache_spec: KVCacheSpec
+    # layers of one group that keep different numbers of KV heads: their own spec (the group's spec is the largest)
+    per_layer: Optional[dict] = None
 
 
 @dataclass

@@ -173,6 +173,15 @@ def get_kv_cache_config(vllm_config, spec: dict[str, KVCacheSpec], available: in
         nb = _num_blocks(vllm_config, available, page, len(names))
         tensors = [KVCacheTensor(size=page * nb, shared_by=[n]) for n in names]
         groups = [KVCacheGroupSpec(names, spec[names[0]])]
+    elif all(type(s_) is FullAttentionSpec and not s_.use_mla for s_ in spec.values()) \
+            and len({s_.block_size for s_ in spec.values()}) == 1:
+        # full attention everywhere, but layers keep different numbers of KV heads (DeciLM / Nemotron-NAS): one
+        # group and one block table, every layer's tensor sized by its own page
+        total = sum(spec[n].page_size_bytes for n in names)
+        nb = _num_blocks(vllm_config, available, total, 1)
+        tensors = [KVCacheTensor(size=spec[n].page_size_bytes * nb, shared_by=[n]) for n in names]
+        groups = [KVCacheGroupSpec(names, max(spec.values(), key=lambda s_: s_.page_size_bytes),
+                                   per_layer={n: spec[n] for n in names})]
     elif _uniform_page(spec):
         # hybrid model: group layers by type, pad groups to equal length, and let
         # the i-th layer of every group share one allocation

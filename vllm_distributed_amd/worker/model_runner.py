@@ -509,7 +509,7 @@ class ModelRunner:
         spec_of = {}
         for g in cfg.kv_cache_groups:
             for n in g.layer_names:
-                spec_of[n] = g.kv_cache_spec
+                spec_of[n] = (g.per_layer or {}).get(n, g.kv_cache_spec)
         self.kv_caches = []
         # layer name -> (chunk index, byte offset of K inside the chunk, bytes of K == bytes of V)
         self.kv_layer_loc: dict[str, tuple[int, int, int]] = {}
