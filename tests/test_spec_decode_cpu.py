@@ -63,6 +63,18 @@ def _save_draft(tmp, kind, target_path):
              "layers.0.self_attn.v_proj.weight": r(nkv * hd, H), "layers.0.self_attn.o_proj.weight": r(H, nh * hd),
              "layers.0.mlp.gate_proj.weight": r(I, H), "layers.0.mlp.up_proj.weight": r(I, H),
              "layers.0.mlp.down_proj.weight": r(H, I), "layers.0.post_attention_layernorm.weight": torch.ones(H)}
+    elif kind == "eagle_minicpm":
+        cfg.update(architectures=["EagleMiniCPMForCausalLM"], num_hidden_layers=1, scale_emb=4.0, scale_depth=1.4,
+                   mup_denominator=8, dim_model_base=H // 2, tie_word_embeddings=False)
+        hd, nh, nkv = cfg["head_dim"], cfg["num_attention_heads"], cfg["num_key_value_heads"]
+        p_ = "model.eagle_layers.0."
+        w = {"model.fc.weight": r(H, 2 * H), "model.input_norm1.weight": torch.ones(H),
+             "model.input_norm2.weight": torch.ones(H), "model.embed_tokens.weight": r(V, H), "lm_head.weight": r(V, H),
+             p_ + "self_attn.q_proj.weight": r(nh * hd, H), p_ + "self_attn.k_proj.weight": r(nkv * hd, H),
+             p_ + "self_attn.v_proj.weight": r(nkv * hd, H), p_ + "self_attn.o_proj.weight": r(H, nh * hd),
+             p_ + "mlp.gate_proj.weight": r(I, H), p_ + "mlp.up_proj.weight": r(I, H),
+             p_ + "mlp.down_proj.weight": r(H, I), p_ + "input_layernorm.weight": torch.ones(H),
+             p_ + "post_attention_layernorm.weight": torch.ones(H)}
     else:
         cfg = {"architectures": ["MedusaModel"], "hidden_size": H, "vocab_size": V, "num_heads": 3,
                "num_hidden_layers": 1, "model_type": "medusa"}
@@ -78,10 +90,11 @@ def _save_draft(tmp, kind, target_path):
 def test_eagle_and_medusa_same_tokens(tmp_path):
     path, _ = _save_tiny(str(tmp_path), "llama")
     ref, _ = _gen(path)
-    for kind in ("eagle", "medusa"):
+    for kind in ("eagle", "medusa", "eagle_minicpm"):
         draft = _save_draft(str(tmp_path), kind, path)
-        got, _ = _gen(path, speculative_config={"method": kind, "model": draft, "num_speculative_tokens": 3})
-        assert got == ref, kind
+        got, n = _proposals(path, speculative_config={"method": kind.split("_")[0], "model": draft,
+                                                      "num_speculative_tokens": 3})
+        assert got == ref and n > 0, kind        # the target's own tokens, and drafts were verified
 
 
 def test_rejection_sampler_greedy_and_distribution():

@@ -86,6 +86,71 @@ class EagleLlamaForCausalLM(nn.Module):
         return None      # embedding / head may legitimately be absent (shared with the target)
 
 
+class _EagleMiniCPMLayer(LlamaDecoderLayer):
+    """MiniCPM draft block: both branches enter the residual stream scaled by scale_depth / sqrt(mup_denominator)."""
+
+    def __init__(self, config, vllm_config, prefix: str):
+        super().__init__(config, vllm_config, None, prefix)
+        self.branch_scale = float(getattr(config, "scale_depth", 1.0)) / \
+            float(getattr(config, "mup_denominator", None) or config.num_hidden_layers) ** 0.5
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states) * self.branch_scale
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.mlp(hidden_states) * self.branch_scale, residual
+
+
+class EagleMiniCPMForCausalLM(EagleLlamaForCausalLM):
+    """EAGLE draft of the MiniCPM family: the token embedding (times ``scale_emb``) and the target's hidden state
+    are each RMS-normalised before the fusing projection, the blocks scale their branches like MiniCPM's, and the
+    output is divided by hidden_size / dim_model_base before the head.  Checkpoint names: ``eagle_layers.N``,
+    ``input_norm1`` / ``input_norm2``.
+    Reference: vllm/model_executor/models/minicpm_eagle.py (EagleMiniCPMModel :136-230, EagleMiniCPMForCausalLM
+    :288-388)."""
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        nn.Module.__init__(self)
+        from ..layers.basic import RMSNorm
+        config = vllm_config.model_config.hf_config
+        self.config = config
+        H = config.hidden_size
+        n = int(getattr(config, "num_hidden_layers", 1) or 1)
+        eps = float(getattr(config, "rms_norm_eps", 1e-5))
+        self.embed_tokens = VocabParallelEmbedding(config.vocab_size, H, prefix="draft.embed_tokens")
+        self.fc = ReplicatedLinear(2 * H, H, bias=False, prefix="draft.fc")
+        self.input_norm1, self.input_norm2 = RMSNorm(H, eps), RMSNorm(H, eps)
+        self.layers = nn.ModuleList([_EagleMiniCPMLayer(config, vllm_config, f"draft.layers.{i}") for i in range(n)])
+        self.lm_head = ParallelLMHead(config.vocab_size, H, prefix="draft.lm_head")
+        self.logits_processor = LogitsProcessor(config.vocab_size, config.vocab_size)
+        self.scale_emb = float(getattr(config, "scale_emb", 1.0) or 1.0)
+        base = float(getattr(config, "dim_model_base", 0) or 0)
+        self.scale_width = H / base if base else 1.0
+        self._own_embed = self._own_head = False
+
+    def forward(self, input_ids, positions, hidden_states):
+        e = self.input_norm1(self.embed_tokens(input_ids) * self.scale_emb)
+        x = self.fc(torch.cat((e, self.input_norm2(hidden_states)), dim=-1))
+        residual = None
+        for layer in self.layers:
+            x, residual = layer(positions, x, residual)
+        return (x + residual) / self.scale_width
+
+    def load_weights(self, weights: Iterable[tuple[str, torch.Tensor]]):
+        def renamed():
+            for name, t in weights:
+                yield name.replace("eagle_layers.", "layers."), t
+        out = super().load_weights(renamed())
+        if getattr(self.config, "tie_word_embeddings", False) and self._own_embed:
+            self.lm_head.tie_weights(self.embed_tokens)
+            self._own_head = True
+        return out
+
+
 class _Eagle3Attention(LlamaAttention):
     """Queries, keys and values are projected from [normed token embedding | normed hidden state] (2 H wide)."""
 

@@ -121,6 +121,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Gemma2Model": ("pooling", "Gemma2EmbeddingModel"),
     "InternLM2ForRewardModel": ("pooling", "InternLM2ForRewardModel"),
     "EagleLlamaForCausalLM": ("eagle", "EagleLlamaForCausalLM"),
+    "EagleMiniCPMForCausalLM": ("eagle", "EagleMiniCPMForCausalLM"),
     "LlamaForCausalLMEagle": ("eagle", "EagleLlamaForCausalLM"),
     "LlavaNextForConditionalGeneration": ("llava_next", "LlavaNextForConditionalGeneration"),
     "LlavaOnevisionForConditionalGeneration": ("llava_next", "LlavaOnevisionForConditionalGeneration"),
