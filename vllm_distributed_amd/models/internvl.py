@@ -158,6 +158,8 @@ class InternVLChatModel(nn.Module):
         x = self.language_model.get_input_embeddings(input_ids)
         if mm_embeds is not None and mm_embeds.numel():
             x[mm_mask] = mm_embeds.to(x.dtype)
+            if hasattr(self.language_model, "set_visual_rows"):      # decoders with visual experts
+                self.language_model.set_visual_rows(mm_mask)
         return x
 
     def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None):

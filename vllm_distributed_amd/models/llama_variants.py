@@ -365,7 +365,8 @@ class InternLM2ForCausalLM(LlamaForCausalLM):
         table = (("tok_embeddings", "embed_tokens"), (".attention.wo.", ".self_attn.o_proj."),
                  (".attention_norm.", ".input_layernorm."), (".ffn_norm.", ".post_attention_layernorm."),
                  (".feed_forward.w1.", ".mlp.gate_proj."), (".feed_forward.w3.", ".mlp.up_proj."),
-                 (".feed_forward.w2.", ".mlp.down_proj."))
+                 (".feed_forward.w2.", ".mlp.down_proj."), (".feed_forward_ve.w1.", ".mlp_ve.gate_proj."),
+                 (".feed_forward_ve.w3.", ".mlp_ve.up_proj."), (".feed_forward_ve.w2.", ".mlp_ve.down_proj."))
 
         def fix(items):
             for name, t in items:
@@ -383,6 +384,64 @@ class InternLM2ForCausalLM(LlamaForCausalLM):
                 yield name, t
 
         return load_weights_with_mapping(self, fix(weights), self.stacked_params_mapping, tie_lm_head=self.tie)
+
+
+class _VisualMask:
+    """Which rows of the step are image positions (set by the multimodal wrapper when it merges the image
+    embeddings, consumed by the next forward of the visual-expert decoder)."""
+    rows: Optional[torch.Tensor] = None
+
+
+class InternLM2VEDecoderLayer(LlamaDecoderLayer):
+    """InternLM2 block with a second MLP for image positions ("visual expert"): rows flagged as image tokens run
+    ``feed_forward_ve``, all others ``feed_forward``.
+    Reference: vllm/model_executor/models/internlm2_ve.py (InternLM2VEDecoderLayer :26-103)."""
+    supports_sequence_parallel = False
+
+    def __init__(self, config, vllm_config, quant_config=None, prefix: str = "", attention_only: bool = False):
+        super().__init__(config, vllm_config, quant_config, prefix, attention_only)
+        if not attention_only:
+            self.mlp_ve = self._make_mlp(config, vllm_config, quant_config, f"{prefix}.mlp_ve")
+
+    def forward(self, positions, hidden_states, residual):
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        rows = _VisualMask.rows
+        if rows is None:
+            return self.mlp(hidden_states), residual
+        # both experts over the step's rows, picked per row: no host synchronisation, and steps with image
+        # positions are prefill steps anyway
+        return torch.where(rows.unsqueeze(1), self.mlp_ve(hidden_states), self.mlp(hidden_states)), residual
+
+
+class InternLM2VEModel(LlamaModel):
+    layer_cls = InternLM2VEDecoderLayer
+
+    def forward(self, input_ids, positions, intermediate_tensors=None, inputs_embeds=None):
+        rows = _VisualMask.rows
+        T = positions.shape[0] if inputs_embeds is None else inputs_embeds.shape[0]
+        if rows is not None and rows.shape[0] != T:       # the step was padded behind the last real row
+            rows = torch.nn.functional.pad(rows[:T], (0, max(T - rows.shape[0], 0)))
+            _VisualMask.rows = rows
+        try:
+            return super().forward(input_ids, positions, intermediate_tensors, inputs_embeds)
+        finally:
+            _VisualMask.rows = None
+
+
+class InternLM2VEForCausalLM(InternLM2ForCausalLM):
+    """The decoder of InternVL checkpoints with visual experts.  ``set_visual_rows`` tells the next forward which
+    rows are image positions (the wrapper calls it while it merges the image embeddings)."""
+    model_cls = InternLM2VEModel
+
+    @staticmethod
+    def set_visual_rows(rows: Optional[torch.Tensor]) -> None:
+        _VisualMask.rows = rows if rows is not None and bool(rows.numel()) else None
 
 
 # ---- Baichuan ----------------------------------------------------------------------------------------

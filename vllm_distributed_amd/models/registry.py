@@ -61,6 +61,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "Gemma3ForCausalLM": ("llama_variants", "Gemma3ForCausalLM"),
     "Gemma3ForConditionalGeneration": ("llama_variants", "Gemma3TextOnlyFromMultimodal"),
     "InternLM2ForCausalLM": ("llama_variants", "InternLM2ForCausalLM"),
+    "InternLM2VEForCausalLM": ("llama_variants", "InternLM2VEForCausalLM"),
     "InternLM3ForCausalLM": ("llama", "LlamaForCausalLM"),
     "BaichuanForCausalLM": ("llama_variants", "BaichuanForCausalLM"),
     "BaiChuanForCausalLM": ("llama_variants", "BaichuanForCausalLM"),
