@@ -459,8 +459,9 @@ VDA_EXPORT int vda_far_run(void* ctx, const void* in, void* residual, const void
 
 
 // ---------------------------------------------------------------------------
-// Quantised two-shot all-reduce ("quick reduce"): the bytes that cross xGMI are int8 or int4
-// with one fp32 scale per 32 values, so a bandwidth-bound all-reduce moves 1.8x / 3.2x less.
+// Quantised two-shot all-reduce ("quick reduce"): the bytes that cross xGMI are int8, int6 or int4
+// with one fp32 scale per 32 values, so a bandwidth-bound all-reduce moves 1.8x / 2.3x / 3.2x less; the
+// fourth codec ("FP") sends the 16-bit values themselves through the same two-shot schedule.
 // Both shots carry quantised data: inputs are quantised into the staging half, the reducer
 // dequantises all peers' slices, sums in fp32 and re-quantises its result, the gather phase
 // dequantises into the output.  The error is two rounding steps of absmax/127 (or /7) per group.
@@ -548,6 +549,82 @@ template <> struct QCodec<4> {
   }
 };
 
+// 6 bits per value: 32 values are a 192-bit stream (value i at bit 6 i), six 32-bit words, moved as three 8-byte
+// pieces (a unit's 24 bytes are 8-byte aligned).
+template <> struct QCodec<6> {
+  static constexpr int DATA_BYTES = 24;
+  static constexpr float QMAX = 31.f;
+  struct Packed { uint32_t w[6]; };
+  __device__ static __forceinline__ Packed encode(const float* v, float inv) {
+    Packed p;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p.w[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      int q = __float2int_rn(v[i] * inv);
+      q = q < -31 ? -31 : (q > 31 ? 31 : q);
+      const uint32_t u = (uint32_t)q & 63u;
+      const int bit = 6 * i, word = bit >> 5, off = bit & 31;
+      p.w[word] |= u << off;
+      if (off > 26) p.w[word + 1] |= u >> (32 - off);
+    }
+    return p;
+  }
+  __device__ static __forceinline__ void accumulate(float* acc, const Packed& p, float scale) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int bit = 6 * i, word = bit >> 5, off = bit & 31;
+      uint32_t u = p.w[word] >> off;
+      if (off > 26) u |= p.w[word + 1] << (32 - off);
+      const int q = (int)((u & 63u) ^ 32u) - 32;             // sign-extend six bits
+      acc[i] += (float)q * scale;
+    }
+  }
+  __device__ static __forceinline__ Packed load(const char* base, size_t unit) {
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t* s = reinterpret_cast<const u32x2_t*>(base + unit * DATA_BYTES);
+    Packed r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const u32x2_t t = s[i]; r.w[2 * i] = t[0]; r.w[2 * i + 1] = t[1]; }
+    return r;
+  }
+  __device__ static __forceinline__ void store(char* base, size_t unit, const Packed& v) {
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t* d = reinterpret_cast<u32x2_t*>(base + unit * DATA_BYTES);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = u32x2_t{v.w[2 * i], v.w[2 * i + 1]};
+  }
+};
+// "FP": no quantisation, bf16 on the wire (exact for bf16 inputs; fp16 inputs round to bf16's 8 bits once per
+// shot).  The scale plane carries ones.
+template <> struct QCodec<16> {
+  static constexpr int DATA_BYTES = 64;
+  static constexpr float QMAX = 1.f;
+  struct Packed { u32x4 d[4]; };
+  __device__ static __forceinline__ Packed encode(const float* v, float) {
+    Packed p;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p.d[q] = acc_pack<bf16_t>(v + q * 8);
+    return p;
+  }
+  __device__ static __forceinline__ void accumulate(float* acc, const Packed& p, float) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc_add<bf16_t>(acc + q * 8, p.d[q]);
+  }
+  __device__ static __forceinline__ Packed load(const char* base, size_t unit) {
+    const u32x4* s = reinterpret_cast<const u32x4*>(base + unit * DATA_BYTES);
+    Packed r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r.d[q] = s[q];
+    return r;
+  }
+  __device__ static __forceinline__ void store(char* base, size_t unit, const Packed& v) {
+    u32x4* d = reinterpret_cast<u32x4*>(base + unit * DATA_BYTES);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = v.d[q];
+  }
+};
+
 // One staging half of the quantised path: [in data][in scales][result data][result scales], each
 // sized for `cap` units (CarArgs::in_bytes carries cap).
 template <int BITS> struct QLayout {
@@ -576,6 +653,7 @@ template <int BITS> __device__ __forceinline__ float group_scale(const float* v,
   float m = 0.f;
 #pragma unroll
   for (int i = 0; i < 32; ++i) m = fmaxf(m, fabsf(v[i]));
+  if (BITS == 16) { inv = 1.f; return 1.f; }
   const float scale = m > 0.f ? m / QCodec<BITS>::QMAX : 1.f;
   inv = 1.f / scale;
   return scale;
@@ -660,14 +738,15 @@ static size_t qr_capacity(size_t max_bytes) {
 
 VDA_EXPORT size_t vda_qr_half_bytes(size_t max_bytes, int bits) {
   const size_t cap = qr_capacity(max_bytes);
-  return bits == 8 ? QLayout<8>::half_bytes(cap) : QLayout<4>::half_bytes(cap);
+  return bits == 16 ? QLayout<16>::half_bytes(cap) : bits == 8 ? QLayout<8>::half_bytes(cap)
+       : bits == 6 ? QLayout<6>::half_bytes(cap) : QLayout<4>::half_bytes(cap);
 }
 
 // The context is a CarCtx whose in_bytes field holds the capacity in units; arenas and signal
 // blocks come from vda_car_alloc (a separate pair from the unquantised path).
 VDA_EXPORT void* vda_qr_create(int rank, int world, void** peer_data, void** peer_sig, size_t max_bytes, int bits,
                                unsigned long long spin_limit) {
-  if (world < 2 || world > MAX_RANKS || (bits != 8 && bits != 4)) return nullptr;
+  if (world < 2 || world > MAX_RANKS || (bits != 16 && bits != 8 && bits != 6 && bits != 4)) return nullptr;
   CarCtx* c = new CarCtx();
   c->rank = rank; c->world = world;
   c->in_bytes = qr_capacity(max_bytes);
@@ -690,8 +769,10 @@ VDA_EXPORT int vda_qr_allreduce(void* ctx, const void* in, void* out, size_t nby
   a.spin_limit = c->spin_limit; a.host_err = c->host_err;
 #define L(T, B) hipLaunchKernelGGL((qr_kernel<T, B>), dim3(MAX_BLOCKS), dim3(512), 0, st, a, (const u32x4*)in, \
                                    (u32x4*)out, nunits)
-  if (bits == 8) { if (dtype == 0) L(bf16_t, 8); else L(f16_t, 8); }
-  else           { if (dtype == 0) L(bf16_t, 4); else L(f16_t, 4); }
+  if (bits == 16)     { if (dtype == 0) L(bf16_t, 16); else L(f16_t, 16); }
+  else if (bits == 8) { if (dtype == 0) L(bf16_t, 8); else L(f16_t, 8); }
+  else if (bits == 6) { if (dtype == 0) L(bf16_t, 6); else L(f16_t, 6); }
+  else                { if (dtype == 0) L(bf16_t, 4); else L(f16_t, 4); }
 #undef L
   return (int)hipGetLastError();
 }

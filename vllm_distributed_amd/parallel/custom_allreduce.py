@@ -358,10 +358,10 @@ class FusedAllReduceNorm(CustomAllReduce):
 
 
 class QuickAllReduce(CustomAllReduce):
-    """Quantised two-shot all-reduce for bandwidth-bound messages: int8 or int4 values with one fp32
-    scale per 32 values cross xGMI (1.8x / 3.2x fewer bytes than bf16), sums are formed in fp32.
-    Lossy by design; off unless ``VLLM_ROCM_QUICK_REDUCE_QUANTIZATION`` is INT8 or INT4 (INT6 is served
-    by INT8, FP by the unquantised peer-memory kernel).  Used for messages of at least
+    """Quantised two-shot all-reduce for bandwidth-bound messages: int8, int6 or int4 values with one fp32
+    scale per 32 values cross xGMI (1.8x / 2.3x / 3.2x fewer bytes than bf16), sums are formed in fp32; the FP
+    codec sends bf16 values through the same schedule.  Lossy by design; off unless
+    ``VLLM_ROCM_QUICK_REDUCE_QUANTIZATION`` is INT8, INT6, INT4 or FP.  Used for messages of at least
     ``min_bytes`` (the reference's table, quick_all_reduce.py:50-59, has 1-4 MiB for fp16).
     Reference: vllm/distributed/device_communicators/quick_all_reduce.py:46-278."""
     SUPPORTED_WORLD = (2, 4, 8)
@@ -391,7 +391,7 @@ class QuickAllReduce(CustomAllReduce):
     @classmethod
     def maybe_create(cls, cpu_group, device: torch.device) -> Optional["QuickAllReduce"]:
         mode = envs.VLLM_ROCM_QUICK_REDUCE_QUANTIZATION
-        bits = {"INT8": 8, "INT6": 8, "INT4": 4}.get(mode)
+        bits = {"INT8": 8, "INT6": 6, "INT4": 4, "FP": 16}.get(mode)
         world = dist.get_world_size(cpu_group)
         if bits is None or world not in cls.SUPPORTED_WORLD:
             return None
@@ -410,7 +410,7 @@ class QuickAllReduce(CustomAllReduce):
                 obj.disabled = True
             return None
         if dist.get_rank(cpu_group) == 0:
-            logger.info("quantised all-reduce enabled: int%d, %d ranks, messages of %d KiB .. %d MiB", bits, world,
+            logger.info("quantised all-reduce enabled: %d bits, %d ranks, messages of %d KiB .. %d MiB", bits, world,
                         obj.min_bytes // 1024, obj.max_bytes >> 20)
         return obj
 
@@ -426,7 +426,7 @@ class QuickAllReduce(CustomAllReduce):
                 if self.lib.vda_car_error(self.ctx) != 0:
                     return False
                 # two rounding steps, each at most half a quantisation step of the group maximum
-                tol = exp.abs().max().item() * (2.2 / (127 if self.bits == 8 else 7))
+                tol = exp.abs().max().item() * (2.2 / {16: 100, 8: 127, 6: 31, 4: 7}[self.bits])
                 if not bool(((out - exp).abs() <= tol).all()):
                     return False
         return True

@@ -118,7 +118,7 @@ class GroupCoordinator:
                 except Exception as e:
                     logger.warning("fused all-reduce + norm disabled for group %s: %s", self.name, e)
                     self.far_comm = None
-            if envs.VLLM_ROCM_QUICK_REDUCE_QUANTIZATION not in ("NONE", "FP"):
+            if envs.VLLM_ROCM_QUICK_REDUCE_QUANTIZATION != "NONE":
                 try:
                     from .custom_allreduce import QuickAllReduce
                     self.qr_comm = QuickAllReduce.maybe_create(self.cpu_group, self.device)
