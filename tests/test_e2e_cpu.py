@@ -271,11 +271,16 @@ def _save_tiny(tmp, kind):
         cfg = tf.Olmo2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
                              num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256)
         m = tf.Olmo2ForCausalLM(cfg)
-    elif kind == "cohere":
+    elif kind in ("cohere", "cohere_qknorm"):
         cfg = tf.CohereConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
                               num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
-                              logit_scale=0.25)
+                              logit_scale=0.25, use_qk_norm=kind == "cohere_qknorm")
         m = tf.CohereForCausalLM(cfg)
+        if kind == "cohere_qknorm":
+            with torch.no_grad():
+                for n, p in m.named_parameters():
+                    if "q_norm" in n or "k_norm" in n:
+                        p.uniform_(0.5, 1.5)
     elif kind == "cohere2":
         cfg = tf.Cohere2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=4,
                                num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
@@ -353,7 +358,7 @@ def _save_tiny(tmp, kind):
 @pytest.mark.parametrize("kind", ["llama", "opt", "qwen2", "gpt2", "mixtral", "qwen2_moe", "qwen3_moe",
                                   "deepseek_v2", "deepseek_v2_yarn", "deepseek_v2_mla", "deepseek_v3", "gemma", "gemma2", "phi3",
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
-                                  "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "nemotron",
+                                  "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "cohere_qknorm", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
                                   "mpt", "phi", "olmoe", "granitemoe", "jamba", "minimax", "falcon_h1", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
                                   "dots1", "hunyuan_dense", "hunyuan_moe", "persimmon"])

@@ -1022,3 +1022,43 @@ def test_minimax_vl_01_runs_llava_next_path_over_minimax_decoder(tmp_path):
             ref.append(int(lg.argmax()))
             cur.append(ref[-1])
     assert list(out.outputs[0].token_ids) == ref
+
+
+@pytest.mark.parametrize("swin", [False, True])
+def test_chameleon_greedy_matches_hf(tmp_path, swin):
+    """Chameleon: VQ-VAE image codes -> vocabulary ids -> the decoder's own embedding table; per-head LayerNorm on
+    q / k; both norm placements.  Against transformers' greedy generation on the expanded prompt."""
+    import transformers as tf
+    torch.manual_seed(0)
+    vocab = {"<image>": 300, "<racm3:break>": 301, "<eoss>": 302}
+    for i in range(64):                                   # 64 codes, spelled with A..J digits
+        vocab["IMGIMG" + "".join(chr(ord("A") + int(c)) for c in str(i)) + "Z"] = 200 + (i * 37) % 64
+    vq = dict(embed_dim=16, num_embeddings=64, latent_channels=16, resolution=32, in_channels=3, base_channels=32,
+              channel_multiplier=[1, 2, 2], num_res_blocks=1, attn_resolutions=[16], attn_type="vanilla")
+    cfg = tf.ChameleonConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                             num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512,
+                             swin_norm=swin, vq_config=vq, vocabulary_map=vocab, image_token_id=300)
+    hf = tf.ChameleonForConditionalGeneration(cfg).float().eval()
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if "q_norm" in n or "k_norm" in n:
+                p.uniform_(0.5, 1.5) if n.endswith("weight") else p.normal_(0, 0.2)
+    path = os.path.join(tmp_path, "cham")
+    hf.save_pretrained(path, safe_serialization=True)
+    px = torch.randn(3, 32, 32, generator=torch.Generator().manual_seed(2))
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4)
+    out = llm.generate([{"prompt_token_ids": [5, 300, 17, 45], "multi_modal_data": {"image": px}}],
+                       SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+    ids = out.prompt_token_ids
+    assert ids[:2] == [5, 301] and ids.count(300) == 64 and ids[66] == 302
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    with torch.no_grad():
+        codes = model.image_tokens(px[None])
+        ref_codes = hf.model.get_image_tokens(px[None])
+        assert torch.equal(codes, ref_codes.to(codes.dtype))
+        ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=px[None], max_new_tokens=8, do_sample=False,
+                          eos_token_id=None, pad_token_id=0)[0, len(ids):].tolist()
+    got = list(out.outputs[0].token_ids)
+    llm.shutdown()
+    assert got == ref
+    assert not any(200 <= t < 264 for t in got)           # image codes are masked out of the logits

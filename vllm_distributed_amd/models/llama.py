@@ -49,6 +49,39 @@ class LlamaMLP(nn.Module):
         return self.down_proj(self.act_fn(self.gate_up_proj(x)))
 
 
+class PerHeadLayerNorm(nn.Module):
+    """LayerNorm over the head dimension with a scale (and optional shift) of its own per head: weight
+    ``[heads, head_dim]``, this rank's heads only (Chameleon, Cohere / StableLM q-k norms).  KV heads replicated
+    over ranks take the shard of the head they hold."""
+
+    def __init__(self, total_heads: int, head_dim: int, eps: float = 1e-5, bias: bool = True):
+        super().__init__()
+        tp, r = get_tensor_model_parallel_world_size(), get_tensor_model_parallel_rank()
+        self.heads = max(1, total_heads // tp)
+        self.first = (r * total_heads // tp) if total_heads >= tp else r // (tp // total_heads)
+        self.head_dim, self.eps = head_dim, eps
+        self.weight = nn.Parameter(torch.ones(self.heads, head_dim))
+        self.weight.weight_loader = self._load
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(self.heads, head_dim))
+            self.bias.weight_loader = self._load
+        else:
+            self.bias = None
+
+    def _load(self, param, tensor):
+        param.data.copy_(tensor.reshape(-1, self.head_dim)[self.first:self.first + self.heads])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [T, heads * head_dim] (a view is fine) -> same shape."""
+        T = x.shape[0]
+        y = nn.functional.layer_norm(x.reshape(T, self.heads, self.head_dim).float(), (self.head_dim,), None, None,
+                                     self.eps)
+        y = y * self.weight.float()
+        if self.bias is not None:
+            y = y + self.bias.float()
+        return y.to(x.dtype).view(T, self.heads * self.head_dim)
+
+
 class LlamaAttention(nn.Module):
     def __init__(self, config, hidden_size: int, num_heads: int, num_kv_heads: int, rope_theta: float,
                  rope_scaling: Optional[dict], max_position: int, bias: bool = False, o_bias: bool = False,
@@ -91,11 +124,16 @@ class LlamaAttention(nn.Module):
                                   self.num_kv_heads, alibi_slopes=alibi_slopes, sliding_window=sliding_window,
                                   logits_soft_cap=logits_soft_cap, prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
         # True: RMSNorm per head (Qwen3); "gemma": the (1 + w) form per head; "full": one RMSNorm over the
-        # whole q / k projection (OLMo-2)
+        # whole q / k projection (OLMo-2); "layernorm" / "layernorm_nobias": LayerNorm over the head dimension
+        # with per-head scale (and shift)
         self.qk_norm = qk_norm if not attention_only else False
         if self.qk_norm:
             eps = getattr(config, "rms_norm_eps", 1e-6)
-            if self.qk_norm == "full":
+            if self.qk_norm in ("layernorm", "layernorm_nobias"):
+                ln_eps = float(getattr(config, "qk_layernorm_eps", None) or getattr(config, "layer_norm_eps", 1e-5))
+                self.q_norm = PerHeadLayerNorm(num_heads, self.head_dim, ln_eps, self.qk_norm == "layernorm")
+                self.k_norm = PerHeadLayerNorm(num_kv_heads, self.head_dim, ln_eps, self.qk_norm == "layernorm")
+            elif self.qk_norm == "full":
                 self.q_norm = RMSNorm(num_heads * self.head_dim, eps)
                 self.k_norm = RMSNorm(num_kv_heads * self.head_dim, eps)
             else:
@@ -139,6 +177,9 @@ class LlamaAttention(nn.Module):
             qkv.clamp_(-self.qkv_clip, self.qkv_clip)
         if self.qk_norm == "full":
             self._full_width_qk_norm(qkv)
+        elif self.qk_norm in ("layernorm", "layernorm_nobias"):
+            qkv[:, : self.q_size] = self.q_norm(qkv[:, : self.q_size])
+            qkv[:, self.q_size: self.q_size + self.kv_size] = self.k_norm(qkv[:, self.q_size: self.q_size + self.kv_size])
         elif self.qk_norm:
             T = qkv.shape[0]
             q = qkv[:, : self.q_size].reshape(T * self.num_heads, self.head_dim)

@@ -168,8 +168,8 @@ class CohereDecoderLayer(LlamaDecoderLayer):
         return LayerNorm(config.hidden_size, getattr(config, "layer_norm_eps", 1e-5), bias=False)
 
     def _attention_extras(self, config, layer_idx: int) -> dict:
-        if getattr(config, "use_qk_norm", False):
-            raise ValueError("Cohere checkpoints with per-head q/k LayerNorm are not supported")
+        if getattr(config, "use_qk_norm", False):      # per-head LayerNorm (scale only) on q and k before the rotation
+            return {"neox_style": False, "qk_norm": "layernorm_nobias"}
         return {"neox_style": False}
 
     def __init__(self, config, vllm_config, quant_config=None, prefix: str = "", attention_only: bool = False):

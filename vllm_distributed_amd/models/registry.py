@@ -136,6 +136,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "ModernBertForSequenceClassification": ("bert", "ModernBertForSequenceClassification"),
     "TarsierForConditionalGeneration": ("llava", "TarsierForConditionalGeneration"),
     "PaliGemmaForConditionalGeneration": ("paligemma", "PaliGemmaForConditionalGeneration"),
+    "ChameleonForConditionalGeneration": ("chameleon", "ChameleonForConditionalGeneration"),
     "Tarsier2ForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "BartForConditionalGeneration": ("bart", "BartForConditionalGeneration"),
     "BartModel": ("bart", "BartModel"),

@@ -485,3 +485,11 @@ def _ultravox(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("UltravoxModel", _ultravox)
+
+
+def _chameleon(vllm_config):
+    from ..models.chameleon import chameleon_processor
+    return chameleon_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("ChameleonForConditionalGeneration", _chameleon)
