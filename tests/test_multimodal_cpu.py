@@ -1062,3 +1062,39 @@ def test_chameleon_greedy_matches_hf(tmp_path, swin):
     llm.shutdown()
     assert got == ref
     assert not any(200 <= t < 264 for t in got)           # image codes are masked out of the logits
+
+
+def test_blip2_greedy_matches_hf(tmp_path):
+    """BLIP-2 (ViT + Q-Former + projection over OPT) against transformers' greedy generation."""
+    import transformers as tf
+    torch.manual_seed(0)
+    vc = tf.Blip2VisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                              image_size=28, patch_size=7)
+    qc = tf.Blip2QFormerConfig(vocab_size=100, hidden_size=48, num_hidden_layers=3, num_attention_heads=2,
+                               intermediate_size=96, encoder_hidden_size=64, cross_attention_frequency=2)
+    tc = tf.OPTConfig(vocab_size=320, hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=2,
+                      max_position_embeddings=256, word_embed_proj_dim=128)
+    cfg = tf.Blip2Config(vision_config=vc.to_dict(), qformer_config=qc.to_dict(), text_config=tc.to_dict(),
+                         num_query_tokens=8, image_token_index=300)
+    hf = tf.Blip2ForConditionalGeneration(cfg).float().eval()
+    with torch.no_grad():
+        hf.query_tokens.normal_(0, 1.0)
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2 and "language_model" not in n:
+                p.mul_(2.0)
+    path = os.path.join(tmp_path, "blip2")
+    hf.save_pretrained(path, safe_serialization=True)
+    img = (np.random.default_rng(3).random((33, 47, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4)
+    out = llm.generate([{"prompt_token_ids": [2, 300, 17, 45, 108], "multi_modal_data": {"image": img}}],
+                       SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+    ids = out.prompt_token_ids
+    assert ids.count(300) == 8
+    from vllm_distributed_amd.multimodal import process_multimodal
+    _, inputs, _, _ = process_multimodal(llm.llm_engine.vllm_config, [2, 300, 17, 45, 108], {"image": img})
+    with torch.no_grad():
+        ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=inputs[0][None].float(), max_new_tokens=8,
+                          do_sample=False, eos_token_id=None, pad_token_id=1)[0].tolist()
+    ref = ref[-8:]
+    llm.shutdown()
+    assert list(out.outputs[0].token_ids) == ref

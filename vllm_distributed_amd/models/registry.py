@@ -137,6 +137,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "TarsierForConditionalGeneration": ("llava", "TarsierForConditionalGeneration"),
     "PaliGemmaForConditionalGeneration": ("paligemma", "PaliGemmaForConditionalGeneration"),
     "ChameleonForConditionalGeneration": ("chameleon", "ChameleonForConditionalGeneration"),
+    "Blip2ForConditionalGeneration": ("blip2", "Blip2ForConditionalGeneration"),
     "Tarsier2ForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "BartForConditionalGeneration": ("bart", "BartForConditionalGeneration"),
     "BartModel": ("bart", "BartModel"),

@@ -493,3 +493,11 @@ def _chameleon(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("ChameleonForConditionalGeneration", _chameleon)
+
+
+def _blip2(vllm_config):
+    from ..models.blip2 import blip2_processor
+    return blip2_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("Blip2ForConditionalGeneration", _blip2)
