@@ -225,6 +225,20 @@ def _save_tiny(tmp, kind):
                                 ssm_multipliers=[0.9, 1.1, 1.2, 0.8, 1.3], ssm_in_multiplier=1.1,
                                 ssm_out_multiplier=0.85)
         m = tf.FalconH1ForCausalLM(cfg)
+    elif kind == "zamba2":
+        # hybrid layer ids chosen so that transformers' block id (layer index mod num_mem_blocks) agrees with the
+        # order in which the shared blocks are taken in turn
+        cfg = tf.Zamba2Config(vocab_size=320, hidden_size=64, num_hidden_layers=5,
+                              layers_block_type=["hybrid", "mamba", "mamba", "hybrid", "hybrid"], mamba_d_state=16,
+                              mamba_d_conv=4, mamba_expand=2, mamba_ngroups=2, n_mamba_heads=4, num_attention_heads=2,
+                              num_key_value_heads=2, intermediate_size=128, num_mem_blocks=2, adapter_rank=8,
+                              use_shared_attention_adapter=True, use_mem_rope=True, max_position_embeddings=256,
+                              chunk_size=8, pad_token_id=0, use_mamba_kernels=False)
+        m = tf.Zamba2ForCausalLM(cfg)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() >= 2 and "A_log" not in n:
+                    p.mul_(2.0)
     elif kind == "bamba":
         cfg = tf.BambaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=4,
                              num_attention_heads=2, num_key_value_heads=1, attn_layer_indices=[1, 3], mamba_n_heads=8,
@@ -360,7 +374,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "cohere_qknorm", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "minimax", "falcon_h1", "cohere2", "granitemoeshared", "bamba", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "minimax", "falcon_h1", "cohere2", "granitemoeshared", "bamba", "zamba2", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
                                   "dots1", "hunyuan_dense", "hunyuan_moe", "persimmon"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)

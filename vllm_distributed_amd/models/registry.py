@@ -90,6 +90,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "WhisperForConditionalGeneration": ("whisper", "WhisperForConditionalGeneration"),
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "BambaForCausalLM": ("jamba", "BambaForCausalLM"),
+    "Zamba2ForCausalLM": ("zamba2", "Zamba2ForCausalLM"),
     "NemotronHForCausalLM": ("jamba", "NemotronHForCausalLM"),
     "GraniteMoeHybridForCausalLM": ("jamba", "GraniteMoeHybridForCausalLM"),
     "MambaForCausalLM": ("mamba", "MambaForCausalLM"),
