@@ -1098,3 +1098,44 @@ def test_blip2_greedy_matches_hf(tmp_path):
     ref = ref[-8:]
     llm.shutdown()
     assert list(out.outputs[0].token_ids) == ref
+
+
+def test_glm4v_matches_hf(tmp_path):
+    """GLM-4.1V: resampled position table, full-frame vision attention, convolutional 2 x 2 merge, gated merger,
+    GLM-4 decoder with interleaved partial multimodal rotary positions; two images with different grids."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.Glm4vConfig(
+        text_config=dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512,
+                         rope_parameters={"rope_type": "default", "mrope_section": [4, 6, 6], "rope_theta": 10000.0,
+                                          "partial_rotary_factor": 0.5}, pad_token_id=0),
+        vision_config=dict(depth=2, hidden_size=64, intermediate_size=96, num_heads=2, out_hidden_size=128,
+                           patch_size=14, spatial_merge_size=2, temporal_patch_size=2, image_size=112, in_channels=3),
+        image_token_id=300, video_token_id=301, image_start_token_id=302, image_end_token_id=303)
+    hf = tf.Glm4vForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+    hf = hf.float().eval()
+    path = os.path.join(str(tmp_path), "glm4v")
+    hf.save_pretrained(path, safe_serialization=True)
+    g = torch.Generator().manual_seed(5)
+    imgs = [{"pixel_values": torch.randn(6 * 10, 1176, generator=g), "image_grid_thw": torch.tensor([1, 6, 10])},
+            {"pixel_values": torch.randn(4 * 4, 1176, generator=g), "image_grid_thw": torch.tensor([1, 4, 4])}]
+    p = [5, 17, 302, 300, 303, 9, 302, 300, 303, 11, 250]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16)
+    o = llm.generate([{"prompt_token_ids": p, "multi_modal_data": {"image": imgs}}],
+                     SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+    ids = [5, 17, 302] + [300] * 15 + [303, 9, 302] + [300] * 4 + [303, 11, 250]
+    assert list(o.prompt_token_ids) == ids
+    with torch.no_grad():
+        ref = hf.generate(input_ids=torch.tensor([ids]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                          eos_token_id=None, pixel_values=torch.cat([i["pixel_values"] for i in imgs]),
+                          image_grid_thw=torch.stack([i["image_grid_thw"] for i in imgs]),
+                          mm_token_type_ids=torch.tensor([[1 if t == 300 else 0 for t in ids]], dtype=torch.int32)
+                          )[0, len(ids):].tolist()
+    assert list(o.outputs[0].token_ids) == ref
+    llm.shutdown()

@@ -501,3 +501,11 @@ def _blip2(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("Blip2ForConditionalGeneration", _blip2)
+
+
+def _glm4v(vllm_config):
+    from ..models.glm4v import glm4v_processor
+    return glm4v_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("Glm4vForConditionalGeneration", _glm4v)
