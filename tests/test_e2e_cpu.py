@@ -239,6 +239,22 @@ def _save_tiny(tmp, kind):
             for n, p in m.named_parameters():
                 if p.dim() >= 2 and "A_log" not in n:
                     p.mul_(2.0)
+    elif kind == "gemma3n":
+        cfg = tf.Gemma3nTextConfig(vocab_size=320, vocab_size_per_layer_input=320, hidden_size=128,
+                                   hidden_size_per_layer_input=16, intermediate_size=[192] * 6, num_hidden_layers=6,
+                                   num_attention_heads=2, num_key_value_heads=1, head_dim=64,
+                                   max_position_embeddings=256, sliding_window=16,
+                                   layer_types=["sliding_attention", "sliding_attention", "full_attention"] * 2,
+                                   altup_num_inputs=3, altup_active_idx=0, laurel_rank=8, num_kv_shared_layers=2,
+                                   activation_sparsity_pattern=[0.9, 0.9, 0.0, 0.0, 0.0, 0.0], pad_token_id=0,
+                                   final_logit_softcapping=30.0)
+        m = tf.Gemma3nForCausalLM(cfg)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.dim() >= 2:
+                    p.mul_(3.0)
+                elif "correct_output_scale" in n:
+                    p.normal_(0, 0.5)
     elif kind == "bamba":
         cfg = tf.BambaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=4,
                              num_attention_heads=2, num_key_value_heads=1, attn_layer_indices=[1, 3], mamba_n_heads=8,
@@ -374,7 +390,7 @@ def _save_tiny(tmp, kind):
                                   "granite", "gpt_neox", "gptj", "starcoder2", "gpt_bigcode", "mamba",
                                   "falcon_mamba", "mamba2", "stablelm", "olmo", "olmo2", "cohere", "cohere_qknorm", "nemotron",
                                   "glm", "glm4", "gemma3", "falcon_new", "falcon_mq", "falcon_alibi", "bloom",
-                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "minimax", "falcon_h1", "cohere2", "granitemoeshared", "bamba", "zamba2", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
+                                  "mpt", "phi", "olmoe", "granitemoe", "jamba", "minimax", "falcon_h1", "cohere2", "granitemoeshared", "bamba", "zamba2", "gemma3n", "phimoe", "dbrx", "granitemoehybrid", "nemotron_h", "llama4", "llama4_top2", "ernie45", "ernie45_moe",
                                   "dots1", "hunyuan_dense", "hunyuan_moe", "persimmon"])
 def test_greedy_matches_hf(tmp_path, kind):
     path, hf = _save_tiny(str(tmp_path), kind)

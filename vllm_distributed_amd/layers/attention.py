@@ -25,8 +25,13 @@ class Attention(nn.Module):
     def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
                  alibi_slopes: Optional[list[float]] = None, sliding_window: Optional[int] = None,
                  logits_soft_cap: Optional[float] = None, prefix: str = "", cache_dtype: str = "auto",
-                 causal: bool = True, local_chunk: int = 0):
+                 causal: bool = True, local_chunk: int = 0, kv_source: Optional["Attention"] = None):
         super().__init__()
+        # A layer that shares another layer's keys and values (Gemma-3n's last layers): it owns no cache and
+        # writes none, its queries read the source layer's cache, which that layer filled earlier in the same
+        # step (reference: vllm/attention/layer.py kv_sharing_target_layer_name).  Kept in a list so that the
+        # source is not registered as a submodule.
+        self._kv_source = [kv_source] if kv_source is not None else None
         # > 0: chunked local attention (Llama-4 rotary layers): position p sees positions
         # [p - p % local_chunk, p] only; the runner supplies the per-chunk virtual batch
         # (reference: vllm/v1/attention/backends/utils.py:242 make_local_attention_virtual_batches)
@@ -77,11 +82,44 @@ class Attention(nn.Module):
     def bind_kv_cache(self, k_cache: torch.Tensor, v_cache: torch.Tensor) -> None:
         self.k_cache, self.v_cache = k_cache, v_cache
 
+    @property
+    def kv_source(self) -> Optional["Attention"]:
+        return self._kv_source[0] if self._kv_source is not None else None
+
+    def _forward_shared(self, qkv, positions, rotary, md, out):
+        """Queries only (``qkv`` holds [T, Hq * D]): rotate them and attend over the source layer's cache."""
+        src = self._kv_source[0]
+        T, n = qkv.shape[0], md.num_actual_tokens
+        Hq, D = self.num_heads, self.head_size
+        q = qkv[:, : Hq * D]
+        if rotary is not None:
+            rotary(positions[:T], q, None)
+        q = q.reshape(T, Hq, D)
+        nd, ndt, n_pre = md.num_decode_seqs, md.num_decode_tokens, md.num_prefill_seqs
+        ksc, vsc = src._k_scale_float, src._v_scale_float
+        if nd > 0:
+            ops.paged_attention_decode(out[:ndt], q[:ndt], src.k_cache, src.v_cache, md.block_table[:nd],
+                                       md.seq_lens[:nd], md.query_start_loc[:nd + 1], self.scale,
+                                       num_splits=md.decode_num_splits, max_q_len=md.max_decode_query_len,
+                                       window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
+                                       workspace=md.decode_workspace, k_scale=ksc, v_scale=vsc)
+        if n_pre > 0:
+            e = ndt + md.num_prefill_tokens
+            ops.paged_attention_prefill(out[ndt:e], q[ndt:e], src.k_cache, src.v_cache, md.block_table[nd:nd + n_pre],
+                                        md.seq_lens[nd:nd + n_pre], md.prefill_query_start_loc, self.scale,
+                                        window=self.sliding_window, softcap=self.softcap, alibi=self.alibi_slopes,
+                                        k_scale=ksc, v_scale=vsc, causal=self.causal, max_q_len=md.max_query_len)
+        if n < T:
+            out[n:].zero_()
+        return out.view(T, Hq * D)
+
     def forward(self, qkv: torch.Tensor, positions: Optional[torch.Tensor] = None, rotary=None) -> torch.Tensor:
         """qkv: [T, (Hq + 2 Hkv) * D] fused projection output.  Returns [T, Hq * D]."""
         D0, D = self.true_head_size, self.head_size
         if D0 == D:
             return self._forward_native(qkv, positions, rotary)
+        if self._kv_source is not None:
+            raise NotImplementedError("layers that share another layer's keys need a head size the kernels have")
         T = qkv.shape[0]
         Hq, Hkv = self.num_heads, self.num_kv_heads
         if rotary is not None and positions is not None:
@@ -98,6 +136,10 @@ class Attention(nn.Module):
         Hq, Hkv, D = self.num_heads, self.num_kv_heads, self.head_size
         qs, ks = Hq * D, Hkv * D
         out = torch.empty((T, Hq, D), dtype=qkv.dtype, device=qkv.device)
+        if self._kv_source is not None:
+            if md is None or self._kv_source[0].k_cache is None:
+                return out.zero_().view(T, qs)
+            return self._forward_shared(qkv, positions, rotary, md, out)
         if md is None or self.k_cache is None:
             # memory-profiling run: no cache bound yet, the projections are what matters
             if rotary is not None and positions is not None:

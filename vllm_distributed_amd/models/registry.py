@@ -91,6 +91,8 @@ _MODELS: dict[str, tuple[str, str]] = {
     "JambaForCausalLM": ("jamba", "JambaForCausalLM"),
     "BambaForCausalLM": ("jamba", "BambaForCausalLM"),
     "Zamba2ForCausalLM": ("zamba2", "Zamba2ForCausalLM"),
+    "Gemma3nForConditionalGeneration": ("gemma3n", "Gemma3nForConditionalGeneration"),
+    "Gemma3nForCausalLM": ("gemma3n", "Gemma3nForConditionalGeneration"),
     "NemotronHForCausalLM": ("jamba", "NemotronHForCausalLM"),
     "GraniteMoeHybridForCausalLM": ("jamba", "GraniteMoeHybridForCausalLM"),
     "MambaForCausalLM": ("mamba", "MambaForCausalLM"),

@@ -234,8 +234,8 @@ class ModelRunner:
             self.use_graphs, self.capture_sizes = False, []
         # every layer that owns per-request cache memory: attention layers and state-space mixers
         self.attn_layers = {n: m for n, m in self.model.named_modules()
-                            if isinstance(m, Attention) or getattr(m, "is_state_space_layer", False)
-                    or getattr(m, "is_mla", False)}
+                            if (isinstance(m, Attention) or getattr(m, "is_state_space_layer", False)
+                                or getattr(m, "is_mla", False)) and getattr(m, "kv_source", None) is None}
         for n, m in self.attn_layers.items():
             m.layer_name = n
         # heads of a size the kernels do not have run zero-padded (layers/attention.py): size buffers for that
