@@ -1139,3 +1139,48 @@ def test_glm4v_matches_hf(tmp_path):
                           )[0, len(ids):].tolist()
     assert list(o.outputs[0].token_ids) == ref
     llm.shutdown()
+
+
+def test_aria_matches_hf(tmp_path):
+    """Aria: tower over the valid rectangle of a padded square (bucketed position ids), query projector whose
+    query count follows the padded size, expert decoder with shared experts; one small padded image and one large."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.AriaConfig(
+        vision_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                           image_size=56, patch_size=14, model_type="idefics3_vision"),
+        text_config=dict(vocab_size=320, hidden_size=128, intermediate_size=64, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=512,
+                         moe_num_experts=4, moe_topk=2, moe_num_shared_experts=2, pad_token_id=0,
+                         model_type="aria_text"),
+        projector_patch_to_query_dict={16: 4, 64: 8}, image_token_index=300, vision_feature_layer=-1)
+    hf = tf.AriaForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0) if "experts.fc" not in n else p.normal_(0, 0.08)
+        hf.model.multi_modal_projector.query.normal_(0, 1.0)
+    hf = hf.float().eval()
+    path = os.path.join(str(tmp_path), "aria")
+    hf.save_pretrained(path, safe_serialization=True)
+    g = torch.Generator().manual_seed(5)
+    small = torch.zeros(3, 56, 56)
+    small[:, :56, :40] = torch.randn(3, 56, 40, generator=g)             # 4 x 3 valid patches (the last one partly)
+    large = torch.zeros(3, 112, 112)
+    large[:, :70, :112] = torch.randn(3, 70, 112, generator=g)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16)
+    for px, valid, nq in ((small, (56, 40), 4), (large, (70, 112), 8)):
+        p = [5, 17, 300, 9, 11, 250]
+        o = llm.generate([{"prompt_token_ids": p,
+                           "multi_modal_data": {"image": {"pixel_values": px, "valid_size": valid}}}],
+                         SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+        ids = [5, 17] + [300] * nq + [9, 11, 250]
+        assert list(o.prompt_token_ids) == ids
+        mask = torch.zeros(1, px.shape[-2], px.shape[-1], dtype=torch.bool)
+        mask[:, :valid[0], :valid[1]] = True
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), pixel_values=px[None], pixel_mask=mask, max_new_tokens=8,
+                              do_sample=False, pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, valid
+    llm.shutdown()

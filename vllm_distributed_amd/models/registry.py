@@ -141,6 +141,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "PaliGemmaForConditionalGeneration": ("paligemma", "PaliGemmaForConditionalGeneration"),
     "ChameleonForConditionalGeneration": ("chameleon", "ChameleonForConditionalGeneration"),
     "Blip2ForConditionalGeneration": ("blip2", "Blip2ForConditionalGeneration"),
+    "AriaForConditionalGeneration": ("aria", "AriaForConditionalGeneration"),
     "Glm4vForConditionalGeneration": ("glm4v", "Glm4vForConditionalGeneration"),
     "Tarsier2ForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "BartForConditionalGeneration": ("bart", "BartForConditionalGeneration"),

@@ -509,3 +509,11 @@ def _glm4v(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("Glm4vForConditionalGeneration", _glm4v)
+
+
+def _aria(vllm_config):
+    from ..models.aria import aria_processor
+    return aria_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("AriaForConditionalGeneration", _aria)
