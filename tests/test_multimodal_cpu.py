@@ -1184,3 +1184,57 @@ def test_aria_matches_hf(tmp_path):
                               do_sample=False, pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
         assert list(o.outputs[0].token_ids) == ref, valid
     llm.shutdown()
+
+
+def test_granite_speech_matches_hf(tmp_path):
+    """Granite Speech: conformer encoder (block attention with a padded last block, relative positions, batch-norm
+    statistics, CTC feedback), windowed Q-Former projector, Granite decoder; two clips of different lengths.
+    The mel front end is checked for shape only (transformers' needs torchaudio, which is not installed)."""
+    import transformers as tf
+    torch.manual_seed(0)
+    cfg = tf.GraniteSpeechConfig(
+        encoder_config=dict(input_dim=160, num_layers=4, hidden_dim=64, feedforward_mult=2, num_heads=2, dim_head=32,
+                            output_dim=12, context_size=10, max_pos_emb=16, conv_kernel_size=5,
+                            conv_expansion_factor=2),
+        projector_config=dict(model_type="blip_2_qformer", hidden_size=48, num_hidden_layers=2, num_attention_heads=2,
+                              intermediate_size=96, encoder_hidden_size=64, cross_attention_frequency=1,
+                              vocab_size=10),
+        text_config=dict(model_type="granite", vocab_size=320, hidden_size=128, intermediate_size=256,
+                         num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                         max_position_embeddings=512, embedding_multiplier=3.0, residual_multiplier=0.5,
+                         attention_multiplier=0.2, logits_scaling=2.0, pad_token_id=0, tie_word_embeddings=True),
+        audio_token_index=300, downsample_rate=3, window_size=6, has_lora_adapter=False)
+    hf = tf.GraniteSpeechForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+        for m in hf.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+    hf = hf.float().eval()
+    path = os.path.join(str(tmp_path), "gs")
+    hf.save_pretrained(path, safe_serialization=True)
+    g = torch.Generator().manual_seed(5)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16)
+    for frames in (23, 30):
+        feats = torch.randn(frames, 160, generator=g)
+        p = [5, 17, 300, 9, 11, 250]
+        o = llm.generate([{"prompt_token_ids": p, "multi_modal_data": {"audio": {"input_features": feats}}}],
+                         SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+        ntok = -(-frames // 6) * 2
+        ids = [5, 17] + [300] * ntok + [9, 11, 250]
+        assert list(o.prompt_token_ids) == ids
+        with torch.no_grad():
+            ref = hf.generate(input_ids=torch.tensor([ids]), input_features=feats[None],
+                              input_features_mask=torch.ones(1, ntok, dtype=torch.bool), max_new_tokens=8,
+                              do_sample=False, pad_token_id=0, eos_token_id=None)[0, len(ids):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, frames
+    # waveform front end: one second of audio -> 101 mel frames -> 50 stacked frames -> ceil(50 / 6) * 2 tokens
+    from vllm_distributed_amd.multimodal import process_multimodal
+    wave = torch.randn(16000, generator=g).numpy()
+    ids, inputs, _, pos = process_multimodal(llm.llm_engine.vllm_config, [5, 300, 9], {"audio": wave})
+    assert tuple(inputs[0][0].shape) == (50, 160) and pos[0].length == 18 and ids.count(300) == 18
+    llm.shutdown()

@@ -142,6 +142,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "ChameleonForConditionalGeneration": ("chameleon", "ChameleonForConditionalGeneration"),
     "Blip2ForConditionalGeneration": ("blip2", "Blip2ForConditionalGeneration"),
     "AriaForConditionalGeneration": ("aria", "AriaForConditionalGeneration"),
+    "GraniteSpeechForConditionalGeneration": ("granite_speech", "GraniteSpeechForConditionalGeneration"),
     "Glm4vForConditionalGeneration": ("glm4v", "Glm4vForConditionalGeneration"),
     "Tarsier2ForConditionalGeneration": ("qwen2_vl", "Qwen2VLForConditionalGeneration"),
     "BartForConditionalGeneration": ("bart", "BartForConditionalGeneration"),

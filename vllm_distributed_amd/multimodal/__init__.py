@@ -517,3 +517,11 @@ def _aria(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("AriaForConditionalGeneration", _aria)
+
+
+def _granite_speech(vllm_config):
+    from ..models.granite_speech import granite_speech_processor
+    return granite_speech_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("GraniteSpeechForConditionalGeneration", _granite_speech)
