@@ -1238,3 +1238,52 @@ def test_granite_speech_matches_hf(tmp_path):
     ids, inputs, _, pos = process_multimodal(llm.llm_engine.vllm_config, [5, 300, 9], {"audio": wave})
     assert tuple(inputs[0][0].shape) == (50, 160) and pos[0].length == 18 and ids.count(300) == 18
     llm.shutdown()
+
+
+def test_qwen2_5_omni_thinker_matches_hf(tmp_path):
+    """Qwen2.5-Omni thinker: windowed audio encoder (a clip of two full windows and a short one), the vision tower
+    with split q / k / v weights, audio and image in one prompt with multimodal rotary positions."""
+    from transformers.models.qwen2_5_omni import configuration_qwen2_5_omni as c, modeling_qwen2_5_omni as m
+    torch.manual_seed(0)
+    cfg = c.Qwen2_5OmniThinkerConfig(
+        audio_config=dict(num_mel_bins=16, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=64, d_model=32,
+                          output_dim=128, n_window=4, max_source_positions=50),
+        vision_config=dict(depth=2, hidden_size=64, intermediate_size=96, num_heads=2, out_hidden_size=128,
+                           patch_size=14, spatial_merge_size=2, temporal_patch_size=2, window_size=56,
+                           fullatt_block_indexes=[1], in_channels=3),
+        text_config=dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512,
+                         rope_parameters={"rope_type": "default", "mrope_section": [8, 12, 12],
+                                          "rope_theta": 10000.0}),
+        audio_token_id=304, image_token_id=300, video_token_id=301, audio_start_token_id=305, audio_end_token_id=306,
+        vision_start_token_id=302, vision_end_token_id=303)
+    hf = m.Qwen2_5OmniThinkerForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+    hf = hf.float().eval()
+    path = os.path.join(str(tmp_path), "omni")
+    hf.save_pretrained(path, safe_serialization=True)
+    import json
+    cj = json.load(open(os.path.join(path, "config.json")))
+    cj["architectures"] = ["Qwen2_5OmniModel"]
+    json.dump(cj, open(os.path.join(path, "config.json"), "w"))
+    g = torch.Generator().manual_seed(5)
+    mel = torch.randn(16, 21, generator=g)                          # windows of 8 mel frames: 8 + 8 + 5
+    img = {"pixel_values": torch.randn(6 * 10, 1176, generator=g), "image_grid_thw": torch.tensor([1, 6, 10])}
+    p = [5, 305, 304, 306, 17, 302, 300, 303, 9, 11, 250]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=8,
+              max_num_batched_tokens=64, enable_prefix_caching=False, block_size=16)
+    o = llm.generate([{"prompt_token_ids": p, "multi_modal_data": {"audio": {"input_features": mel}, "image": [img]}}],
+                     SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+    na = ((21 - 1) // 2 + 1 - 2) // 2 + 1
+    ids = [5, 305] + [304] * na + [306, 17, 302] + [300] * 15 + [303, 9, 11, 250]
+    assert list(o.prompt_token_ids) == ids
+    with torch.no_grad():
+        ref = hf.generate(input_ids=torch.tensor([ids]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                          eos_token_id=None, pixel_values=img["pixel_values"], image_grid_thw=img["image_grid_thw"][None],
+                          input_features=mel[None], feature_attention_mask=torch.ones(1, 21, dtype=torch.long)
+                          )[0, len(ids):].tolist()
+    assert list(o.outputs[0].token_ids) == ref
+    llm.shutdown()

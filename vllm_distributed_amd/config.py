@@ -134,7 +134,13 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
                 f"{model!r} is neither a local checkpoint directory nor a known preset "
                 f"({', '.join(sorted(PRESETS))})")
         d = copy.deepcopy(PRESETS[key])
+    if "thinker_config" in d:                  # Qwen2.5-Omni: only the thinker generates text
+        d = {**{k: v for k, v in d.items() if k not in ("thinker_config", "talker_config", "token2wav_config")},
+             **{k: v for k, v in d["thinker_config"].items() if k not in ("architectures", "model_type")
+                and v is not None}}
     if "text_config" in d and ("hidden_size" not in d or "num_attention_heads" not in d):
+        if d.get("tie_word_embeddings") is not None:      # the wrapper's own flag (its head may differ from the decoder's)
+            d["top_tie_word_embeddings"] = d["tie_word_embeddings"]
         if "hidden_size" in d:                 # a wrapper-level width (Ultravox: its projector's) stays reachable
             d["top_hidden_size"] = d["hidden_size"]
         d = {**d, **{k: v for k, v in d["text_config"].items()

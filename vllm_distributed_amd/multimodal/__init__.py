@@ -525,3 +525,12 @@ def _granite_speech(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("GraniteSpeechForConditionalGeneration", _granite_speech)
+
+
+def _qwen2_5_omni(vllm_config):
+    from ..models.qwen2_5_omni import qwen2_5_omni_processor
+    return qwen2_5_omni_processor(vllm_config)
+
+
+for _name in ("Qwen2_5OmniForConditionalGeneration", "Qwen2_5OmniModel", "Qwen2_5OmniThinkerForConditionalGeneration"):
+    MULTIMODAL_REGISTRY.register_processor(_name, _qwen2_5_omni)
