@@ -1287,3 +1287,84 @@ def test_qwen2_5_omni_thinker_matches_hf(tmp_path):
                           )[0, len(ids):].tolist()
     assert list(o.outputs[0].token_ids) == ref
     llm.shutdown()
+
+
+def test_qwen_vl_tower_and_engine(tmp_path):
+    """Qwen-VL (first generation).  No transformers class exists (parity unpinned): the 2-D sine / cosine table is
+    checked against the formula written out with numpy, a tower block against attention computed head by head
+    from the head-major fused projection, the resampler against the same steps spelled out with
+    ``F.multi_head_attention_forward``; then a checkpoint written from the module's own weights runs end to end."""
+    import json
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.models.qwen_vl import QueryResampler, QwenVisionTransformer, _Block, sincos_2d
+    torch.manual_seed(0)
+    # position table
+    dim, h, w = 16, 3, 5
+    omega = 1.0 / 10000 ** (np.arange(dim // 4, dtype=np.float32) / (dim / 4.0))
+    ref = np.zeros((h * w, dim), dtype=np.float32)
+    for r in range(h):
+        for c in range(w):
+            ref[r * w + c] = np.concatenate([np.sin(c * omega), np.cos(c * omega), np.sin(r * omega), np.cos(r * omega)])
+    torch.testing.assert_close(sincos_2d(dim, h, w), torch.from_numpy(ref), rtol=1e-5, atol=1e-6)
+    # one block
+    blk = _Block(32, 2, 2.0).eval()
+    x = torch.randn(2, 7, 32)
+    with torch.no_grad():
+        y = blk.ln_1(x)
+        p = blk.attn.in_proj(y).view(2, 7, 2, 48)
+        heads = []
+        for hd in range(2):
+            q, k, v = p[:, :, hd, :16], p[:, :, hd, 16:32], p[:, :, hd, 32:]
+            heads.append(torch.softmax(q @ k.transpose(1, 2) / 4.0, -1) @ v)
+        z = x + blk.attn.out_proj(torch.cat(heads, -1))
+        z = z + blk.mlp.c_proj(torch.nn.functional.gelu(blk.mlp.c_fc(blk.ln_2(z))))
+        torch.testing.assert_close(blk(x), z, rtol=1e-4, atol=1e-5)
+    # resampler
+    rs = QueryResampler(2, 128, 1, 32, post_projection=False).eval()
+    with torch.no_grad():
+        rs.query.normal_()
+        feats = torch.randn(1, 9, 32)
+        kv = rs.ln_kv(rs.kv_proj(feats))[0]
+        from vllm_distributed_amd.models.qwen_vl import resize_positions
+        pos = resize_positions(rs.pos_embed, 3, 3)
+        q = rs.ln_q(rs.query) + rs.pos_embed
+        wq, wk, wv = rs.attn.in_proj_weight.chunk(3)
+        bq, bk, bv = rs.attn.in_proj_bias.chunk(3)
+        a = torch.softmax((q @ wq.t() + bq) @ ((kv + pos) @ wk.t() + bk).t() / 128 ** 0.5, -1) @ (kv @ wv.t() + bv)
+        torch.testing.assert_close(rs(feats)[0], rs.attn.out_proj(a), rtol=1e-4, atol=1e-5)
+    # end to end
+    vis = dict(image_size=56, patch_size=14, width=32, layers=2, heads=2, mlp_ratio=2.0, n_queries=4, output_dim=128,
+               image_start_id=300)
+    cfg = {"architectures": ["QwenVLForConditionalGeneration"], "model_type": "qwen", "vocab_size": 320,
+           "hidden_size": 128, "intermediate_size": 512, "num_hidden_layers": 2, "num_attention_heads": 2,
+           "kv_channels": 64, "layer_norm_epsilon": 1e-6, "rotary_emb_base": 10000, "seq_length": 512,
+           "tie_word_embeddings": False, "visual": vis}
+    path = os.path.join(str(tmp_path), "qwenvl")
+    os.makedirs(path)
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    tower = QwenVisionTransformer(**vis)
+    sd = {"transformer.visual." + n: (torch.randn_like(t) * 0.2) for n, t in tower.state_dict().items()}
+    sd["transformer.wte.weight"] = torch.randn(320, 128) * 0.5
+    sd["transformer.ln_f.weight"] = torch.ones(128)
+    sd["lm_head.weight"] = torch.randn(320, 128) * 0.5
+    for i in range(2):
+        b = f"transformer.h.{i}."
+        sd.update({b + "ln_1.weight": torch.ones(128), b + "ln_2.weight": torch.ones(128),
+                   b + "attn.c_attn.weight": torch.randn(384, 128) * 0.1, b + "attn.c_attn.bias": torch.randn(384) * 0.1,
+                   b + "attn.c_proj.weight": torch.randn(128, 128) * 0.1, b + "mlp.w1.weight": torch.randn(256, 128) * 0.1,
+                   b + "mlp.w2.weight": torch.randn(256, 128) * 0.1, b + "mlp.c_proj.weight": torch.randn(128, 256) * 0.1})
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    img = (np.random.default_rng(3).random((40, 52, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4)
+    out = llm.generate([{"prompt_token_ids": [5, 302, 9, 11], "multi_modal_data": {"image": img}},
+                        {"prompt_token_ids": [5, 9, 11]}],
+                       SamplingParams(temperature=0, max_tokens=4, ignore_eos=True))
+    assert list(out[0].prompt_token_ids) == [5, 300, 302, 302, 302, 302, 301, 9, 11]
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    tower.load_state_dict({n[len("transformer.visual."):]: t for n, t in sd.items() if ".visual." in n})
+    from vllm_distributed_amd.multimodal import process_multimodal
+    _, inputs, _, _ = process_multimodal(llm.llm_engine.vllm_config, [5, 302, 9, 11], {"image": img})
+    with torch.no_grad():
+        torch.testing.assert_close(model.encode_images(inputs[0][None]), tower(inputs[0][None]))
+    assert len(out[0].outputs[0].token_ids) == 4 and out[0].outputs[0].token_ids != out[1].outputs[0].token_ids
+    llm.shutdown()

@@ -534,3 +534,11 @@ def _qwen2_5_omni(vllm_config):
 
 for _name in ("Qwen2_5OmniForConditionalGeneration", "Qwen2_5OmniModel", "Qwen2_5OmniThinkerForConditionalGeneration"):
     MULTIMODAL_REGISTRY.register_processor(_name, _qwen2_5_omni)
+
+
+def _qwen_vl(vllm_config):
+    from ..models.qwen_vl import qwen_vl_processor
+    return qwen_vl_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("QwenVLForConditionalGeneration", _qwen_vl)
