@@ -376,3 +376,76 @@ def test_arctic_matches_dense_form(tmp_path):
             lg = logits(ids)
             assert tok == int(lg.argmax()) or float(lg.max() - lg[tok]) < 1e-4
             ids.append(tok)
+
+
+def test_glm4v_chat_layout_with_eva_tower(tmp_path):
+    """GLM-4V in the ChatGLM layout: the text path must still equal transformers' GLM on the re-laid-out weights, one
+    EVA2-CLIP block is checked against its arithmetic written out (norms BEHIND attention and MLP), and an image
+    request fills begin marker + placeholders + end marker from the tower (parity of the tower: unpinned)."""
+    import numpy as np
+    import transformers as tf
+    from vllm_distributed_amd.models.glm4v_chat import EVA2CLIPModel, _EvaLayer
+    torch.manual_seed(0)
+    m = tf.GlmForCausalLM(tf.GlmConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                                       num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=256,
+                                       head_dim=64, pad_token_id=0, attention_bias=True)).eval()
+    sd = m.state_dict()
+    t = {"transformer.embedding.word_embeddings.weight": sd["model.embed_tokens.weight"],
+         "transformer.encoder.final_layernorm.weight": sd["model.norm.weight"],
+         "transformer.output_layer.weight": sd["lm_head.weight"]}
+    for i, L in _layers(sd, 2):
+        p = f"transformer.encoder.layers.{i}."
+        t[p + "self_attention.query_key_value.weight"] = torch.cat([L[f"self_attn.{x}_proj.weight"] for x in "qkv"])
+        t[p + "self_attention.query_key_value.bias"] = torch.cat([L[f"self_attn.{x}_proj.bias"] for x in "qkv"])
+        t[p + "self_attention.dense.weight"] = L["self_attn.o_proj.weight"]
+        t[p + "input_layernorm.weight"] = L["input_layernorm.weight"]
+        t[p + "post_attention_layernorm.weight"] = L["post_attention_layernorm.weight"]
+        t[p + "mlp.dense_h_to_4h.weight"] = L["mlp.gate_up_proj.weight"]
+        t[p + "mlp.dense_4h_to_h.weight"] = L["mlp.down_proj.weight"]
+    vc = dict(hidden_size=64, num_heads=2, intermediate_size=128, num_hidden_layers=2, image_size=56, patch_size=14,
+              in_channels=3, layer_norm_eps=1e-6, hidden_act="gelu", scaling_factor=8.0, dropout_prob=0.0)
+    cfg = dict(model_type="chatglm", architectures=["GLM4VForCausalLM"], vocab_size=320, padded_vocab_size=320,
+               hidden_size=128, ffn_hidden_size=256, num_layers=2, num_attention_heads=2, kv_channels=64,
+               multi_query_attention=True, multi_query_group_num=1, seq_length=256, layernorm_epsilon=m.config.rms_norm_eps,
+               rmsnorm=True, add_bias_linear=False, add_qkv_bias=True, post_layer_norm=True,
+               apply_residual_connection_post_layernorm=False, original_rope=True, torch_dtype="float32",
+               vision_config=vc, boi_token_id=301, eoi_token_id=302, pad_token_id=300)
+    from types import SimpleNamespace
+    tower = EVA2CLIPModel(SimpleNamespace(vision_config=vc, hidden_size=128, ffn_hidden_size=256)).eval()
+    with torch.no_grad():
+        for p_ in tower.parameters():
+            p_.normal_(0, 0.2)
+    t.update({"transformer.vision." + n: v.detach().clone() for n, v in tower.state_dict().items()})
+    # one block, written out
+    lay = _EvaLayer(vc).eval()
+    x = torch.randn(1, 5, 64)
+    with torch.no_grad():
+        qkv = lay.attention.query_key_value(x)[0]
+        heads = []
+        for h in range(2):
+            q, k, v = (qkv[:, j * 64 + h * 32: j * 64 + (h + 1) * 32] for j in range(3))
+            heads.append(torch.softmax(q @ k.t() / 32 ** 0.5, -1) @ v)
+        y = x + lay.input_layernorm(lay.attention.dense(torch.cat(heads, -1)))[None]
+        y = y + lay.post_attention_layernorm(lay.mlp.fc2(torch.nn.functional.gelu(lay.mlp.fc1(y))))
+        torch.testing.assert_close(lay(x), y, rtol=1e-4, atol=1e-5)
+    path = _write(tmp_path, "glm4v", cfg, t)
+    assert _ours(path) == _hf_tokens(m)
+    img = (np.random.default_rng(3).random((40, 52, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4)
+    try:
+        outs = llm.generate([{"prompt_token_ids": [5, 301, 300, 302, 9], "multi_modal_data": {"image": img}},
+                             {"prompt_token_ids": [5, 300, 9], "multi_modal_data": {"image": img}}],
+                            SamplingParams(temperature=0, max_tokens=4, ignore_eos=True))
+        want = [5, 301] + [300] * 4 + [302, 9]
+        assert list(outs[0].prompt_token_ids) == want and list(outs[1].prompt_token_ids) == want
+        assert list(outs[0].outputs[0].token_ids) == list(outs[1].outputs[0].token_ids)
+        model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+        from vllm_distributed_amd.multimodal import process_multimodal
+        _, inputs, _, pos = process_multimodal(llm.llm_engine.vllm_config, [5, 300, 9], {"image": img})
+        assert pos[0].offset == 1 and pos[0].length == 6
+        with torch.no_grad():
+            feats = model.encode_images(inputs[0][None])
+            torch.testing.assert_close(feats, tower(inputs[0][None]))
+        assert feats.shape == (1, 6, 128)
+    finally:
+        llm.shutdown()

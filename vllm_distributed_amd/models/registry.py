@@ -145,6 +145,7 @@ _MODELS: dict[str, tuple[str, str]] = {
     "GraniteSpeechForConditionalGeneration": ("granite_speech", "GraniteSpeechForConditionalGeneration"),
     "Glm4vForConditionalGeneration": ("glm4v", "Glm4vForConditionalGeneration"),
     "QwenVLForConditionalGeneration": ("qwen_vl", "QwenVLForConditionalGeneration"),
+    "GLM4VForCausalLM": ("glm4v_chat", "GLM4VForCausalLM"),
     "Qwen2_5OmniForConditionalGeneration": ("qwen2_5_omni", "Qwen2_5OmniThinkerForConditionalGeneration"),
     "Qwen2_5OmniModel": ("qwen2_5_omni", "Qwen2_5OmniThinkerForConditionalGeneration"),
     "Qwen2_5OmniThinkerForConditionalGeneration": ("qwen2_5_omni", "Qwen2_5OmniThinkerForConditionalGeneration"),

@@ -542,3 +542,11 @@ def _qwen_vl(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("QwenVLForConditionalGeneration", _qwen_vl)
+
+
+def _glm4v_chat(vllm_config):
+    from ..models.glm4v_chat import glm4v_chat_processor
+    return glm4v_chat_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("GLM4VForCausalLM", _glm4v_chat)
