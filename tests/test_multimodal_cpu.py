@@ -1368,3 +1368,75 @@ def test_qwen_vl_tower_and_engine(tmp_path):
         torch.testing.assert_close(model.encode_images(inputs[0][None]), tower(inputs[0][None]))
     assert len(out[0].outputs[0].token_ids) == 4 and out[0].outputs[0].token_ids != out[1].outputs[0].token_ids
     llm.shutdown()
+
+
+def test_phi3v_hd_stitching_and_engine(tmp_path):
+    """Phi-3-vision.  No transformers class exists (parity unpinned).  The high-resolution size rule is checked on
+    known cases, the 2 x 2 merge + crop stitching + row separators against a loop over crops, rows and columns, and a
+    tiny checkpoint (Phi-3 decoder from transformers, random tower) runs an image request end to end; without images
+    the tokens equal transformers' Phi-3."""
+    import json
+    import transformers as tf
+    from safetensors.torch import load_file, save_file
+    from vllm_distributed_amd.models.phi3v import Phi3HDImageEmbedding, hd_size
+    from vllm_distributed_amd.config import HFConfig
+    assert hd_size(1344, 1344) == (1344, 1344, 1344, 1344)                  # 4 x 4 crops
+    assert hd_size(2000, 500) == (2688, 672, 2688, 672)                     # 8 x 2 crops
+    assert hd_size(500, 2000) == (672, 2688, 672, 2688)
+    assert hd_size(800, 600)[2:] == (1344, 1008)                            # 4 x 3 crops, height padded to 3 crops
+    torch.manual_seed(0)
+    ip = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2, image_size=56,
+              patch_size=14, image_dim_out=32)
+    emb = Phi3HDImageEmbedding(HFConfig(dict(img_processor=ip, hidden_size=128))).eval()
+    with torch.no_grad():
+        for p in emb.parameters():
+            p.normal_(0, 0.3)
+        crops = torch.randn(1 + 6, 3, 56, 56)
+        got = emb(crops, (112, 168))                                        # 2 rows x 3 columns of crops
+        feats = emb.img_processor.vision_model(crops)[:, 1:]               # [7, 16, 32], a 4 x 4 grid per crop
+
+        def merged(f):                                                      # one crop -> [2, 2, 128]
+            f = f.view(4, 4, 32)
+            return torch.stack([torch.stack([torch.cat([f[2 * i, 2 * j], f[2 * i, 2 * j + 1], f[2 * i + 1, 2 * j],
+                                                        f[2 * i + 1, 2 * j + 1]]) for j in range(2)]) for i in range(2)])
+        rows = []
+        for r in range(2):
+            for i in range(2):
+                for c in range(3):
+                    rows.extend(merged(feats[1 + r * 3 + c])[i])
+                rows.append(emb.sub_GN.view(-1))
+        rows.append(emb.glb_GN.view(-1))
+        ov = merged(feats[0])
+        for i in range(2):
+            rows.extend(ov[i])
+            rows.append(emb.sub_GN.view(-1))
+        torch.testing.assert_close(got, emb.img_projection(torch.stack(rows)))
+    assert got.shape[0] == (6 + 1) * 4 + 1 + (2 + 1) * 2
+    # end to end
+    tc = tf.Phi3Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, pad_token_id=0,
+                       bos_token_id=1, eos_token_id=2)
+    hf = tf.Phi3ForCausalLM(tc).float().eval()
+    path = os.path.join(str(tmp_path), "phi3v")
+    hf.save_pretrained(path, safe_serialization=True)
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    sd.update({"model.vision_embed_tokens." + n: t.detach().clone() for n, t in emb.state_dict().items()})
+    save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    cj = json.load(open(os.path.join(path, "config.json")))
+    cj.update(architectures=["Phi3VForCausalLM"], img_processor=ip, image_token_id=300)
+    json.dump(cj, open(os.path.join(path, "config.json"), "w"))
+    img = (np.random.default_rng(3).random((60, 150, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=4,
+              mm_processor_kwargs={"num_crops": 4})
+    outs = llm.generate([{"prompt_token_ids": [5, 300, 9, 11], "multi_modal_data": {"image": img}},
+                         {"prompt_token_ids": [5, 17, 9, 11]}],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    w, h, pw, ph = hd_size(150, 60, 56, 4)
+    n = ((ph // 56) * (pw // 56) + 1) * 4 + 1 + (ph // 56 + 1) * 2
+    assert list(outs[0].prompt_token_ids).count(300) == n and (pw // 56, ph // 56) == (2, 1)
+    with torch.no_grad():
+        ref = hf.generate(torch.tensor([[5, 17, 9, 11]]), max_new_tokens=6, do_sample=False, pad_token_id=0,
+                          eos_token_id=None)[0, 4:].tolist()
+    assert list(outs[1].outputs[0].token_ids) == ref
+    assert len(outs[0].outputs[0].token_ids) == 6
+    llm.shutdown()

@@ -203,6 +203,8 @@ class ModelConfig:
     revision: Optional[str] = None
     #: JSON overrides applied on top of the checkpoint's config.json.
     hf_overrides: Optional[dict] = None
+    #: Keyword overrides for the model's multimodal input processor (e.g. ``{"num_crops": 4}``).
+    mm_processor_kwargs: Optional[dict] = None
     #: "generate", "embed", "classify", "score" or "auto".
     task: str = "auto"
     #: Pooling behaviour overrides for embedding models.

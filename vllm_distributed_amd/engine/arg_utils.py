@@ -60,6 +60,7 @@ class EngineArgs:
     max_logprobs: int = 20
     revision: Optional[str] = None
     hf_overrides: Optional[dict] = None
+    mm_processor_kwargs: Optional[dict] = None
     task: str = "auto"
     generation_config: str = "auto"
     disable_sliding_window: bool = False
@@ -137,7 +138,8 @@ class EngineArgs:
         if self.tokenizer is None:
             self.tokenizer = self.model
         for name in ("speculative_config", "kv_transfer_config", "kv_events_config", "compilation_config",
-                     "hf_overrides", "additional_config", "model_loader_extra_config", "limit_mm_per_prompt"):
+                     "hf_overrides", "additional_config", "model_loader_extra_config", "limit_mm_per_prompt",
+                     "mm_processor_kwargs"):
             v = getattr(self, name)
             if isinstance(v, str):
                 setattr(self, name, json.loads(v))
@@ -198,7 +200,7 @@ class EngineArgs:
             max_logprobs=self.max_logprobs, served_model_name=self.served_model_name, revision=self.revision,
             hf_overrides=self.hf_overrides, task=self.task, generation_config=self.generation_config,
             disable_sliding_window=self.disable_sliding_window, disable_cascade_attn=self.disable_cascade_attn,
-            limit_mm_per_prompt=self.limit_mm_per_prompt)
+            limit_mm_per_prompt=self.limit_mm_per_prompt, mm_processor_kwargs=self.mm_processor_kwargs)
 
     def create_engine_config(self, usage_context=None) -> C.VllmConfig:
         from ..plugins import load_general_plugins

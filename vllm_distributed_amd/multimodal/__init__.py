@@ -550,3 +550,11 @@ def _glm4v_chat(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("GLM4VForCausalLM", _glm4v_chat)
+
+
+def _phi3v(vllm_config):
+    from ..models.phi3v import phi3v_processor
+    return phi3v_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("Phi3VForCausalLM", _phi3v)
