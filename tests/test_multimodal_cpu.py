@@ -1440,3 +1440,93 @@ def test_phi3v_hd_stitching_and_engine(tmp_path):
     assert list(outs[1].outputs[0].token_ids) == ref
     assert len(outs[0].outputs[0].token_ids) == 6
     llm.shutdown()
+
+
+def test_deepseek_vl2_stitching_and_engine(tmp_path):
+    """DeepSeek-VL2.  No transformers class exists (parity unpinned).  The 2 x 2 concatenation of the projector and
+    the overview / tile-map layout with newline and separator vectors are checked against loops; the timm-named
+    SigLIP block against transformers' SigLIP layer with the same weights; then an image request runs end to end on a
+    checkpoint in the family's layout (decoder: a tiny Llama)."""
+    import json
+    import transformers as tf
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.config import HFConfig
+    from vllm_distributed_amd.models.deepseek_vl2 import MlpProjector, SiglipTimmTower, _TimmBlock
+    torch.manual_seed(0)
+    # block == transformers' SigLIP encoder layer
+    sc = tf.SiglipVisionConfig(hidden_size=32, intermediate_size=64, num_attention_heads=2, num_hidden_layers=1,
+                               image_size=28, patch_size=14)
+    from transformers.models.siglip.modeling_siglip import SiglipEncoderLayer
+    ref = SiglipEncoderLayer(sc).eval()
+    blk = _TimmBlock(32, 2, 64).eval()
+    sd = ref.state_dict()
+    with torch.no_grad():
+        blk.attn.qkv.weight.copy_(torch.cat([sd[f"self_attn.{x}_proj.weight"] for x in "qkv"]))
+        blk.attn.qkv.bias.copy_(torch.cat([sd[f"self_attn.{x}_proj.bias"] for x in "qkv"]))
+        blk.attn.proj.load_state_dict({"weight": sd["self_attn.out_proj.weight"], "bias": sd["self_attn.out_proj.bias"]})
+        blk.norm1.load_state_dict({"weight": sd["layer_norm1.weight"], "bias": sd["layer_norm1.bias"]})
+        blk.norm2.load_state_dict({"weight": sd["layer_norm2.weight"], "bias": sd["layer_norm2.bias"]})
+        blk.mlp.fc1.load_state_dict({"weight": sd["mlp.fc1.weight"], "bias": sd["mlp.fc1.bias"]})
+        blk.mlp.fc2.load_state_dict({"weight": sd["mlp.fc2.weight"], "bias": sd["mlp.fc2.bias"]})
+        x = torch.randn(2, 4, 32)
+        out = ref(x, None)
+        torch.testing.assert_close(blk(x), out[0] if isinstance(out, tuple) else out, rtol=1e-4, atol=1e-5)
+    # projector: neighbourhoods of a 3 x 3 grid (padded to 4 x 4), channel-major concatenation
+    pc = HFConfig(dict(projector_type="downsample_mlp_gelu", input_dim=4, n_embed=8, depth=2, mlp_ratio=1,
+                       downsample_ratio=2))
+    proj = MlpProjector(pc).eval()
+    f = torch.randn(1, 9, 4)
+    grid = torch.zeros(4, 4, 4)
+    grid[:3, :3] = f[0].view(3, 3, 4)
+    cells = []
+    for i in range(2):
+        for j in range(2):
+            nb = torch.stack([grid[2 * i, 2 * j], grid[2 * i, 2 * j + 1], grid[2 * i + 1, 2 * j], grid[2 * i + 1, 2 * j + 1]])
+            cells.append(nb.t().reshape(-1))                                 # channel-major
+    with torch.no_grad():
+        torch.testing.assert_close(proj(f)[0], proj.layers(torch.stack(cells)))
+    # end to end
+    tc = tf.LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, head_dim=64,
+                        tie_word_embeddings=False)
+    hf = tf.LlamaForCausalLM(tc).float().eval()
+    vc = dict(model_name="siglip", image_size=56, patch_size=14, width=32, layers=2, heads=2, mlp_ratio=2.0)
+    pcd = dict(projector_type="downsample_mlp_gelu", input_dim=32, n_embed=128, depth=2, mlp_ratio=1,
+               downsample_ratio=2)
+    cfg = dict(architectures=["DeepseekVLV2ForCausalLM"], model_type="deepseek_vl_v2", vision_config=vc,
+               projector_config=pcd, tile_tag="2D", global_view_pos="head", image_token_id=300,
+               candidate_resolutions=[[56, 56], [56, 112], [112, 56], [112, 112]],
+               language_config={**tc.to_dict(), "architectures": ["LlamaForCausalLM"]})
+    path = os.path.join(str(tmp_path), "dsvl2")
+    os.makedirs(path)
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    tower, pr = SiglipTimmTower(HFConfig(vc)), MlpProjector(HFConfig(pcd))
+    sd = {"language." + n: t for n, t in hf.state_dict().items()}
+    sd.update({"vision." + n: torch.randn_like(t) * 0.2 for n, t in tower.state_dict().items()})
+    sd.update({"projector." + n: torch.randn_like(t) * 0.2 for n, t in pr.state_dict().items()})
+    sd["vision.attn_pool.latent"] = torch.zeros(1, 1, 32)                     # present in checkpoints, unused
+    sd["image_newline"], sd["view_seperator"] = torch.randn(128), torch.randn(128)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    img = (np.random.default_rng(3).random((50, 110, 3)) * 255).astype(np.uint8)
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4)
+    outs = llm.generate([{"prompt_token_ids": [5, 300, 9, 11], "multi_modal_data": {"image": img}},
+                         {"prompt_token_ids": [5, 17, 9, 11]}],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    # best resolution for 50 x 110 is 56 x 112: two tiles across, one down; g = ceil(4 / 2) = 2
+    assert list(outs[0].prompt_token_ids).count(300) == 2 * 3 + 1 + 2 * (2 * 2 + 1)
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    from vllm_distributed_amd.multimodal import process_multimodal
+    _, inputs, _, _ = process_multimodal(llm.llm_engine.vllm_config, [5, 300, 9], {"image": img})
+    px, crop = inputs[0]
+    assert px.shape == (3, 3, 56, 56) and crop.tolist() == [2, 1]
+    with torch.no_grad():
+        got = model.encode_mm_items([[px, crop]])[0]
+        e = model.projector(model.vision(px))                                # [3, 4, 128]
+        nl, sep = model.image_newline, model.view_seperator
+        want = [e[0, 0], e[0, 1], nl, e[0, 2], e[0, 3], nl, sep,
+                e[1, 0], e[1, 1], e[2, 0], e[2, 1], nl, e[1, 2], e[1, 3], e[2, 2], e[2, 3], nl]
+        torch.testing.assert_close(got, torch.stack(want))
+        ref = hf.generate(torch.tensor([[5, 17, 9, 11]]), max_new_tokens=6, do_sample=False, pad_token_id=0,
+                          eos_token_id=None)[0, 4:].tolist()
+    assert list(outs[1].outputs[0].token_ids) == ref and len(outs[0].outputs[0].token_ids) == 6
+    llm.shutdown()

@@ -145,6 +145,8 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
             d["top_hidden_size"] = d["hidden_size"]
         d = {**d, **{k: v for k, v in d["text_config"].items()
                      if v is not None and not (k == "architectures" and d.get("architectures"))}}
+    elif "language_config" in d and "hidden_size" not in d:     # DeepSeek-VL2
+        d = {**d, **{k: v for k, v in d["language_config"].items() if k not in ("architectures", "model_type")}}
     elif "llm_config" in d and "hidden_size" not in d:          # InternVL's original layout
         d = {**d, **{k: v for k, v in d["llm_config"].items() if k not in ("architectures", "model_type")}}
     if d.get("model_type") == "whisper" and "hidden_size" not in d:

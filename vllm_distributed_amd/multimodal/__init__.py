@@ -558,3 +558,11 @@ def _phi3v(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("Phi3VForCausalLM", _phi3v)
+
+
+def _deepseek_vl2(vllm_config):
+    from ..models.deepseek_vl2 import deepseek_vl2_processor
+    return deepseek_vl2_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("DeepseekVLV2ForCausalLM", _deepseek_vl2)
