@@ -1530,3 +1530,71 @@ def test_deepseek_vl2_stitching_and_engine(tmp_path):
                           eos_token_id=None)[0, 4:].tolist()
     assert list(outs[1].outputs[0].token_ids) == ref and len(outs[0].outputs[0].token_ids) == 6
     llm.shutdown()
+
+
+def test_kimi_vl_tower_and_engine(tmp_path):
+    """Kimi-VL.  No transformers class exists (parity unpinned).  The 2-D rotary embedding is checked against complex
+    multiplication with cis(column * f_i), cis(row * f_i) alternating, the patch merge against a loop, and an image of
+    a size that needs padding runs end to end (decoder: a tiny Llama under ``language_model.``)."""
+    import json
+    import transformers as tf
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.config import HFConfig
+    from vllm_distributed_amd.models.kimi_vl import MoonViT, rope_2d_angles, rotate_pairs
+    torch.manual_seed(0)
+    h, w, D = 3, 5, 16
+    x = torch.randn(h * w, 2, D)
+    got = rotate_pairs(x, rope_2d_angles(h, w, D))
+    f = 1.0 / 10000.0 ** (torch.arange(0, D, 4).float() / D)
+    xc = torch.view_as_complex(x.view(h * w, 2, D // 2, 2).contiguous())
+    want = torch.empty_like(xc)
+    for r in range(h):
+        for c in range(w):
+            cis = torch.stack([torch.polar(torch.ones(D // 4), c * f), torch.polar(torch.ones(D // 4), r * f)], -1).reshape(-1)
+            want[r * w + c] = xc[r * w + c] * cis
+    torch.testing.assert_close(got, torch.view_as_real(want).flatten(-2), rtol=1e-5, atol=1e-5)
+    vc = dict(hidden_size=32, num_attention_heads=2, intermediate_size=64, num_hidden_layers=2, patch_size=14,
+              init_pos_emb_height=4, init_pos_emb_width=4, merge_kernel_size=[2, 2])
+    tower = MoonViT(HFConfig(vc)).eval()
+    with torch.no_grad():
+        for p in tower.parameters():
+            p.normal_(0, 0.2)
+        patches = torch.randn(4 * 6 + 2 * 2, 3, 14, 14)
+        outs = tower(patches, [(4, 6), (2, 2)])
+        assert [tuple(o.shape) for o in outs] == [(6, 4, 32), (1, 4, 32)]
+        alone = tower(patches[24:], [(2, 2)])[0]                             # images do not see each other
+        torch.testing.assert_close(outs[1], alone, rtol=1e-4, atol=1e-5)
+        # merged cell (1, 2) of the first image = patches (2, 4), (2, 5), (3, 4), (3, 5) of the 4 x 6 grid
+        tower.merge = (1, 1)
+        per_patch = tower(patches[:24], [(4, 6)])[0].view(4, 6, 32)
+        tower.merge = (2, 2)
+        torch.testing.assert_close(outs[0][1 * 3 + 2], torch.stack([per_patch[2, 4], per_patch[2, 5], per_patch[3, 4],
+                                                                   per_patch[3, 5]]), rtol=1e-4, atol=1e-5)
+    tc = tf.LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=512, head_dim=64,
+                        tie_word_embeddings=False)
+    hf = tf.LlamaForCausalLM(tc).float().eval()
+    cfg = dict(architectures=["KimiVLForConditionalGeneration"], model_type="kimi_vl", vision_config=vc,
+               media_placeholder_token_id=300, text_config={**tc.to_dict(), "architectures": ["LlamaForCausalLM"]})
+    path = os.path.join(str(tmp_path), "kimi")
+    os.makedirs(path)
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    sd = {"language_model." + n: t for n, t in hf.state_dict().items()}
+    sd.update({"vision_tower." + n: t.detach().clone() for n, t in tower.state_dict().items()})
+    sd.update({"multi_modal_projector.pre_norm.weight": torch.ones(32), "multi_modal_projector.pre_norm.bias": torch.zeros(32),
+               "multi_modal_projector.linear_1.weight": torch.randn(128, 128) * 0.1,
+               "multi_modal_projector.linear_1.bias": torch.zeros(128),
+               "multi_modal_projector.linear_2.weight": torch.randn(128, 128) * 0.1,
+               "multi_modal_projector.linear_2.bias": torch.zeros(128)})
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    img = (np.random.default_rng(3).random((50, 75, 3)) * 255).astype(np.uint8)       # 4 x 6 patches after padding
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4)
+    outs = llm.generate([{"prompt_token_ids": [5, 300, 9, 11], "multi_modal_data": {"image": img}},
+                         {"prompt_token_ids": [5, 17, 9, 11]}],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    assert list(outs[0].prompt_token_ids).count(300) == 2 * 3
+    with torch.no_grad():
+        ref = hf.generate(torch.tensor([[5, 17, 9, 11]]), max_new_tokens=6, do_sample=False, pad_token_id=0,
+                          eos_token_id=None)[0, 4:].tolist()
+    assert list(outs[1].outputs[0].token_ids) == ref and len(outs[0].outputs[0].token_ids) == 6
+    llm.shutdown()

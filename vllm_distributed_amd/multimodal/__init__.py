@@ -566,3 +566,11 @@ def _deepseek_vl2(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("DeepseekVLV2ForCausalLM", _deepseek_vl2)
+
+
+def _kimi_vl(vllm_config):
+    from ..models.kimi_vl import kimi_vl_processor
+    return kimi_vl_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("KimiVLForConditionalGeneration", _kimi_vl)
