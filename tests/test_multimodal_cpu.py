@@ -1598,3 +1598,80 @@ def test_kimi_vl_tower_and_engine(tmp_path):
                           eos_token_id=None)[0, 4:].tolist()
     assert list(outs[1].outputs[0].token_ids) == ref and len(outs[0].outputs[0].token_ids) == 6
     llm.shutdown()
+
+
+def test_minicpmv_slicing_and_engine(tmp_path):
+    """MiniCPM-V 2.6.  No transformers class exists (parity unpinned).  The slice-grid rule on known cases, the
+    resampler against its steps written out, the tower's bucketed position ids against transformers' Idefics2
+    embedding, and an image large enough to be sliced end to end (decoder: Qwen2 from transformers under ``llm.``)."""
+    import json
+    import transformers as tf
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.config import HFConfig
+    from vllm_distributed_amd.models.minicpmv import MiniCPMVTower, best_resize, refine_size, slice_grid
+    from vllm_distributed_amd.models.qwen_vl import QueryResampler, sincos_2d
+    assert slice_grid((400, 300), 9, 448) is None
+    assert slice_grid((1344, 896), 9, 448) == (3, 2)                         # 6 slices at a 3 : 2 aspect ratio
+    assert slice_grid((4000, 500), 9, 448) == (8, 1)
+    assert best_resize((1344, 896), 448, 14) == (546, 364)
+    assert refine_size((1344, 896), (3, 2), 448, 14) == (3 * 448, 2 * 448)
+    torch.manual_seed(0)
+    # resampler: 5 queries without positions, keys with the table of their own 2 x 3 grid
+    rs = QueryResampler(0, 128, 1, 32, post_projection=True, adaptive=True, num_queries=5).eval()
+    with torch.no_grad():
+        rs.query.normal_()
+        rs.proj.normal_(0, 0.1)
+        feats = torch.randn(6, 32)
+        kv = rs.ln_kv(rs.kv_proj(feats))
+        wq, wk, wv = rs.attn.in_proj_weight.chunk(3)
+        bq, bk, bv = rs.attn.in_proj_bias.chunk(3)
+        a = torch.softmax((rs.ln_q(rs.query) @ wq.t() + bq) @ ((kv + sincos_2d(128, 2, 3)) @ wk.t() + bk).t() / 128 ** 0.5, -1)
+        want = rs.ln_post(rs.attn.out_proj(a @ (kv @ wv.t() + bv))) @ rs.proj
+        torch.testing.assert_close(rs(feats[None], (2, 3))[0], want, rtol=1e-4, atol=1e-5)
+    # tower position ids == transformers' Idefics2 embedding for a 2 x 3 slice on a 4 x 4 table
+    vc = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, image_size=56,
+              patch_size=14, hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6)
+    tower = MiniCPMVTower(HFConfig(vc), drop_last=False).eval()
+    from transformers.models.idefics2.modeling_idefics2 import Idefics2VisionEmbeddings
+    emb = Idefics2VisionEmbeddings(tf.Idefics2VisionConfig(hidden_size=32, image_size=56, patch_size=14)).eval()
+    with torch.no_grad():
+        for p in tower.parameters():
+            p.normal_(0, 0.2)
+        emb.patch_embedding.load_state_dict(tower.embeddings.patch_embedding.state_dict())
+        emb.position_embedding.load_state_dict(tower.embeddings.position_embedding.state_dict())
+        px = torch.randn(3, 28, 42)
+        ref = emb(px[None], torch.ones(1, 2, 3, dtype=torch.bool))[0]
+        e = tower.embeddings
+        mine = e.patch_embedding(px[None]).flatten(2).transpose(1, 2)[0] + e.position_embedding(tower._position_ids(2, 3, "cpu"))
+        torch.testing.assert_close(mine, ref, rtol=1e-5, atol=1e-5)
+    tc = tf.Qwen2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=1024,
+                        tie_word_embeddings=False)
+    hf = tf.Qwen2ForCausalLM(tc).float().eval()
+    cfg = {**tc.to_dict(), "architectures": ["MiniCPMV"], "model_type": "minicpmv", "version": 2.6, "query_num": 5,
+           "vision_config": vc, "drop_vision_last_layer": False, "image_size": 56, "patch_size": 14,
+           "slice_config": {"max_slice_nums": 9, "scale_resolution": 56, "patch_size": 14}}
+    path = os.path.join(str(tmp_path), "minicpmv")
+    os.makedirs(path)
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    sd = {"llm." + n: t for n, t in hf.state_dict().items()}
+    sd.update({"vpm." + n: t.detach().clone() for n, t in tower.state_dict().items()})
+    sd.update({"resampler." + n: t.detach().clone() for n, t in rs.state_dict().items()})
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    img = (np.random.default_rng(3).random((100, 150, 3)) * 255).astype(np.uint8)      # about 4.8 scale areas
+    marks = {"im_start_id": 301, "im_end_id": 302, "slice_start_id": 303, "slice_end_id": 304, "unk_id": 300,
+             "newline_id": 305}
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=4,
+              mm_processor_kwargs=marks)
+    outs = llm.generate([{"prompt_token_ids": [5, 301, 300, 302, 9, 11], "multi_modal_data": {"image": img}},
+                         {"prompt_token_ids": [5, 17, 9, 11]}],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    ids = list(outs[0].prompt_token_ids)
+    cols, rows = slice_grid((150, 100), 9, 56)
+    assert (cols, rows) == (3, 2) and ids.count(300) == 5 * (1 + cols * rows)
+    assert ids.count(303) == 6 and ids.count(305) == 1 and ids[1] == 301 and ids[7] == 302
+    with torch.no_grad():
+        ref = hf.generate(torch.tensor([[5, 17, 9, 11]]), max_new_tokens=6, do_sample=False, pad_token_id=0,
+                          eos_token_id=None)[0, 4:].tolist()
+    assert list(outs[1].outputs[0].token_ids) == ref and len(outs[0].outputs[0].token_ids) == 6
+    llm.shutdown()

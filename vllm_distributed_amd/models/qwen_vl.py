@@ -48,14 +48,16 @@ class QueryResampler(nn.Module):
     """grid^2 learned queries cross-attend once to the patch features; optional LayerNorm + projection behind."""
 
     def __init__(self, grid: int, dim: int, heads: int, kv_dim: int, post_projection: bool, adaptive: bool = False,
-                 eps: float = 1e-6):
+                 eps: float = 1e-6, num_queries: Optional[int] = None):
+        """``num_queries`` given: that many queries WITHOUT a position table of their own (MiniCPM-V 2.5+), keys
+        positioned by a table computed for the input's own grid (``adaptive``)."""
         super().__init__()
         self.dim, self.adaptive = dim, adaptive
-        self.query = nn.Parameter(torch.zeros(grid * grid, dim))
+        self.query = nn.Parameter(torch.zeros(num_queries or grid * grid, dim))
         self.kv_proj = nn.Linear(kv_dim, dim, bias=False) if kv_dim != dim else nn.Identity()
         self.attn = nn.MultiheadAttention(dim, heads)
         self.ln_q, self.ln_kv = nn.LayerNorm(dim, eps=eps), nn.LayerNorm(dim, eps=eps)
-        self.pos_embed = nn.Parameter(sincos_2d(dim, grid, grid), requires_grad=False)
+        self.pos_embed = nn.Parameter(sincos_2d(dim, grid, grid), requires_grad=False) if num_queries is None else None
         if post_projection:
             self.ln_post = nn.LayerNorm(dim, eps=eps)
             self.proj = nn.Parameter(torch.zeros(dim, dim))
@@ -67,7 +69,9 @@ class QueryResampler(nn.Module):
         h, w = size if size is not None else (int(math.sqrt(x.shape[1])),) * 2
         pos = sincos_2d(self.dim, h, w).to(x.device) if self.adaptive else resize_positions(self.pos_embed, h, w)
         kv = self.ln_kv(self.kv_proj(x)).transpose(0, 1)                       # [N, B, dim]
-        q = self.ln_q(self.query)[:, None].expand(-1, x.shape[0], -1) + self.pos_embed[:, None].to(kv.dtype)
+        q = self.ln_q(self.query)[:, None].expand(-1, x.shape[0], -1)
+        if self.pos_embed is not None:
+            q = q + self.pos_embed[:, None].to(kv.dtype)
         out = self.attn(q, kv + pos[:, None].to(kv.dtype), kv, need_weights=False)[0].transpose(0, 1)
         if self.proj is not None:
             out = self.ln_post(out) @ self.proj

@@ -574,3 +574,11 @@ def _kimi_vl(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("KimiVLForConditionalGeneration", _kimi_vl)
+
+
+def _minicpmv(vllm_config):
+    from ..models.minicpmv import minicpmv_processor
+    return minicpmv_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("MiniCPMV", _minicpmv)
