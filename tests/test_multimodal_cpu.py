@@ -1675,3 +1675,79 @@ def test_minicpmv_slicing_and_engine(tmp_path):
                           eos_token_id=None)[0, 4:].tolist()
     assert list(outs[1].outputs[0].token_ids) == ref and len(outs[0].outputs[0].token_ids) == 6
     llm.shutdown()
+
+
+def test_minicpmo_audio_path_and_engine(tmp_path):
+    """MiniCPM-o 2.6 (parity unpinned).  The audio path against transformers' Whisper encoder driven with the same
+    chunk mask, then projector and pooling written out; a prompt with an image in front of an audio clip end to end."""
+    import json
+    import transformers as tf
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.config import HFConfig
+    from vllm_distributed_amd.models.minicpmv import MiniCPMVTower
+    from vllm_distributed_amd.models.qwen_vl import QueryResampler
+    torch.manual_seed(0)
+    ac = tf.WhisperConfig(num_mel_bins=16, d_model=32, encoder_layers=2, encoder_attention_heads=2, encoder_ffn_dim=128,
+                          max_source_positions=60, decoder_layers=1, decoder_attention_heads=2, decoder_ffn_dim=64,
+                          vocab_size=100)
+    from transformers.models.whisper.modeling_whisper import WhisperEncoder as HFEncoder
+    enc = HFEncoder(ac).float().eval()
+    vc = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=56,
+              patch_size=14, hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6)
+    tc = tf.Qwen2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=1024,
+                        tie_word_embeddings=False)
+    hf = tf.Qwen2ForCausalLM(tc).float().eval()
+    cfg = {**tc.to_dict(), "architectures": ["MiniCPMO"], "model_type": "minicpmo", "version": 2.6, "query_num": 5,
+           "vision_config": vc, "audio_config": ac.to_dict(), "drop_vision_last_layer": False, "image_size": 56,
+           "patch_size": 14, "audio_pool_step": 2, "audio_chunk_length": 0.2,
+           "slice_config": {"max_slice_nums": 9, "scale_resolution": 56, "patch_size": 14}}
+    path = os.path.join(str(tmp_path), "minicpmo")
+    os.makedirs(path)
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    tower = MiniCPMVTower(HFConfig(vc), drop_last=False)
+    rs = QueryResampler(0, 128, 1, 32, post_projection=True, adaptive=True, num_queries=5)
+    sd = {"llm." + n: t for n, t in hf.state_dict().items()}
+    sd.update({"vpm." + n: torch.randn_like(t) * 0.2 for n, t in tower.state_dict().items()})
+    sd.update({"resampler." + n: torch.randn_like(t) * 0.2 for n, t in rs.state_dict().items()})
+    sd.update({"apm." + n: t.detach().clone() for n, t in enc.state_dict().items()})
+    proj = {"audio_projection_layer.linear1.weight": torch.randn(128, 32) * 0.2,
+            "audio_projection_layer.linear1.bias": torch.randn(128) * 0.1,
+            "audio_projection_layer.linear2.weight": torch.randn(128, 128) * 0.2,
+            "audio_projection_layer.linear2.bias": torch.randn(128) * 0.1}
+    sd.update(proj)
+    sd["tts.some.weight"] = torch.zeros(2)                                    # the speech half is ignored
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    marks = {"im_start_id": 301, "im_end_id": 302, "slice_start_id": 303, "slice_end_id": 304, "unk_id": 300,
+             "newline_id": 305, "audio_start_id": 306, "audio_end_id": 307}
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=512, max_num_seqs=4,
+              mm_processor_kwargs=marks)
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    mel = torch.randn(16, 47, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        got = model.encode_audio(mel)
+        # transformers' encoder wants max_source_positions * 2 mel frames: run its pieces by hand with the chunk mask
+        x = torch.nn.functional.gelu(enc.conv1(mel[None]))
+        x = torch.nn.functional.gelu(enc.conv2(x)).permute(0, 2, 1)
+        S = x.shape[1]
+        x = x + enc.embed_positions.weight[:S]
+        idx = torch.arange(S)
+        visible = idx[None, :] < ((idx // 10 + 1) * 10)[:, None]             # 0.2 s chunks = 10 frames
+        m = torch.zeros(1, 1, S, S).masked_fill_(~visible, float("-inf"))
+        for layer in enc.layers:
+            out = layer(x, m)
+            x = out[0] if isinstance(out, tuple) else out
+        x = enc.layer_norm(x)
+        y = torch.relu(x @ proj["audio_projection_layer.linear1.weight"].t() + proj["audio_projection_layer.linear1.bias"])
+        y = y @ proj["audio_projection_layer.linear2.weight"].t() + proj["audio_projection_layer.linear2.bias"]
+        want = torch.stack([(y[0, 2 * i] + y[0, 2 * i + 1]) / 2 for i in range((S - 2) // 2 + 1)])
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+    img = (np.random.default_rng(3).random((40, 52, 3)) * 255).astype(np.uint8)
+    out = llm.generate([{"prompt_token_ids": [5, 301, 300, 302, 9, 306, 300, 307, 11],
+                         "multi_modal_data": {"image": img, "audio": {"audio_features": mel}}}],
+                       SamplingParams(temperature=0, max_tokens=4, ignore_eos=True))[0]
+    ids = list(out.prompt_token_ids)
+    na = ((47 - 1) // 2 + 1 - 2) // 2 + 1
+    assert ids == [5, 301] + [300] * 5 + [302, 9, 306] + [300] * na + [307, 11]
+    assert len(out.outputs[0].token_ids) == 4
+    llm.shutdown()

@@ -253,3 +253,133 @@ def minicpmv_processor(vllm_config):
         return out, inputs, hashes, ranges
 
     return process
+
+
+# ---- MiniCPM-o: the same model plus an audio path ---------------------------------------------------------
+class MiniCPMO(MiniCPMV):
+    """MiniCPM-o 2.6.  Audio: Whisper encoder whose frames attend to their own and all earlier chunks of
+    ``audio_chunk_length`` seconds (50 frames per second), a two-layer ReLU projector, average pooling over
+    ``audio_pool_step`` frames."""
+
+    def __init__(self, vllm_config: VllmConfig, prefix: str = ""):
+        super().__init__(vllm_config, prefix)
+        from .qwen2_audio import WhisperEncoder
+        hf = self.config
+        ac = _cfg(hf.audio_config)
+        self.apm = WhisperEncoder(ac, avg_pool=False)
+        d_audio, d = int(ac.encoder_ffn_dim) // 4, int(hf.hidden_size)
+        self.audio_projection_layer = nn.Module()
+        self.audio_projection_layer.linear1 = nn.Linear(d_audio, d)
+        self.audio_projection_layer.linear2 = nn.Linear(d, d)
+        self.pool = int(getattr(hf, "audio_pool_step", 2))
+        self.chunk_frames = int(float(getattr(hf, "audio_chunk_length", 1.0)) * 50)
+
+    def encode_audio(self, mel: torch.Tensor) -> torch.Tensor:
+        """[n_mels, T] of one clip (at most 30 s) -> [((T - 1) // 2 + 1 - pool) // pool + 1, H]"""
+        a = self.apm
+        x = F.gelu(a.conv1(mel[None].to(a.conv1.weight.dtype)))
+        x = F.gelu(a.conv2(x)).permute(0, 2, 1)
+        S = x.shape[1]
+        x = x + a.embed_positions.weight[:S]
+        mask = None
+        if self.chunk_frames > 0:
+            idx = torch.arange(S, device=x.device)
+            visible = idx[None, :] < ((idx // self.chunk_frames + 1) * self.chunk_frames)[:, None]
+            mask = torch.zeros(1, 1, S, S, dtype=x.dtype, device=x.device).masked_fill_(~visible, float("-inf"))
+        for layer in a.layers:
+            x = layer(x, mask)
+        x = a.layer_norm(x)
+        p = self.audio_projection_layer
+        x = p.linear2(F.relu(p.linear1(x)))
+        return F.avg_pool1d(x.transpose(1, 2), self.pool, stride=self.pool).transpose(1, 2)[0]
+
+    def encode_mm_items(self, items: list) -> list[torch.Tensor]:
+        outs: list = [None] * len(items)
+        vis = [i for i, it in enumerate(items) if len(it) == 1]
+        for i, e in zip(vis, super().encode_mm_items([items[i] for i in vis])):
+            outs[i] = e
+        for i, it in enumerate(items):
+            if outs[i] is None:
+                mel, n = it
+                outs[i] = self.encode_audio(mel[:, : int(n)])
+        return outs
+
+    def _skip(self, name: str) -> bool:
+        return super()._skip(name) or name.startswith(("apm.proj_out.", "apm.decoder."))
+
+
+
+def minicpmo_processor(vllm_config):
+    """Images as for MiniCPM-V; audio: ``<|audio_start|>`` + placeholder(s) + ``<|audio_end|>`` -> one run per clip
+    sized to the pooled encoder output (clips longer than 30 s must be split by the caller).  Marker ids
+    ``audio_start_id`` / ``audio_end_id`` come from the config, ``mm_processor_kwargs`` or the tokenizer."""
+    from ..multimodal import AudioTokenProcessor, PlaceholderRange, hash_item
+    hf = vllm_config.model_config.hf_config
+    image = minicpmv_processor(vllm_config)
+    ac = _cfg(hf.audio_config)
+    pool = int(getattr(hf, "audio_pool_step", 2))
+    kw = dict(getattr(vllm_config.model_config, "mm_processor_kwargs", None) or {})
+    audio = AudioTokenProcessor(-1, int(ac.num_mel_bins))
+
+    def marker(name, token):
+        if name in kw:
+            return int(kw[name])
+        if getattr(hf, name, None) is not None:
+            return int(getattr(hf, name))
+        from ..engine.processor import get_tokenizer
+        mc = vllm_config.model_config
+        return int(get_tokenizer(mc.tokenizer or mc.model, mc.tokenizer_mode).convert_tokens_to_ids(token))
+
+    def process(ids, mm_data):
+        out_ranges, out_inputs, out_hashes = [], [], []
+        if mm_data.get("image") is not None:
+            ids, inputs, hashes, ranges = image(ids, {"image": mm_data["image"]})
+            out_ranges, out_inputs, out_hashes = list(ranges), list(inputs), list(hashes)
+        clips = mm_data.get("audio")
+        if clips is None:
+            if not out_ranges:
+                raise ValueError("multi_modal_data needs an 'image' or an 'audio' entry")
+            return ids, out_inputs, out_hashes, out_ranges
+        clips = clips if isinstance(clips, list) else [clips]
+        a_s, a_e, unk = marker("audio_start_id", "<|audio_start|>"), marker("audio_end_id", "<|audio_end|>"), \
+            marker("unk_id", "<unk>")
+        new, shift_at, i, k = [], [], 0, 0                      # shift_at: (position in ids, tokens added)
+        a_ranges, a_inputs, a_hashes = [], [], []
+        while i < len(ids):
+            j = i + 1
+            while ids[i] == a_s and j < len(ids) and ids[j] == unk:
+                j += 1
+            if ids[i] != a_s or j >= len(ids) or ids[j] != a_e:
+                new.append(ids[i])
+                i += 1
+                continue
+            if k >= len(clips):
+                raise ValueError("more audio placeholders than clips")
+            clip = clips[k]
+            if isinstance(clip, dict):
+                mel = torch.as_tensor(clip["audio_features"]).float()
+                n = int(clip.get("audio_feature_lens", mel.shape[-1]))
+                key = mel
+            else:
+                mel, n = audio.features(clip)
+                key = audio._waveform(clip)
+            ntok = (((n - 1) // 2 + 1) - pool) // pool + 1
+            new.append(a_s)
+            a_ranges.append(PlaceholderRange(offset=len(new), length=ntok))
+            new.extend([unk] * ntok)
+            new.append(a_e)
+            shift_at.append((i, ntok - (j - i - 1)))
+            a_inputs.append([mel, torch.tensor(n, dtype=torch.int64)])
+            a_hashes.append(hash_item(key))
+            k, i = k + 1, j + 1
+        if k != len(clips):
+            raise ValueError(f"prompt has {k} audio placeholders but {len(clips)} clips were given")
+        # image ranges were computed before the audio runs grew: move those that lie behind one
+        moved = []
+        for r in out_ranges:
+            off = r.offset + sum(d for pos, d in shift_at if pos < r.offset)
+            moved.append(PlaceholderRange(offset=off, length=r.length))
+        merged = sorted(zip(moved + a_ranges, out_inputs + a_inputs, out_hashes + a_hashes), key=lambda t: t[0].offset)
+        return new, [m[1] for m in merged], [m[2] for m in merged], [m[0] for m in merged]
+
+    return process

@@ -582,3 +582,11 @@ def _minicpmv(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("MiniCPMV", _minicpmv)
+
+
+def _minicpmo(vllm_config):
+    from ..models.minicpmv import minicpmo_processor
+    return minicpmo_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("MiniCPMO", _minicpmo)
