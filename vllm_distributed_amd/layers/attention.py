@@ -25,8 +25,14 @@ class Attention(nn.Module):
     def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
                  alibi_slopes: Optional[list[float]] = None, sliding_window: Optional[int] = None,
                  logits_soft_cap: Optional[float] = None, prefix: str = "", cache_dtype: str = "auto",
-                 causal: bool = True, local_chunk: int = 0, kv_source: Optional["Attention"] = None):
+                 causal: bool = True, local_chunk: int = 0, kv_source: Optional["Attention"] = None,
+                 blocksparse: Optional[dict] = None):
         super().__init__()
+        # Block-sparse causal pattern (Phi-3-small): a query block sees the last ``local_blocks`` key blocks and, per
+        # head, every ``vert_stride``-th key block.  Keys: block_size, local_blocks, vert_stride, homo_head,
+        # total_heads, first_head (this rank's first head).  Sequences that fit the local span see every causal key
+        # and take the MFMA kernels; longer ones run the masked PyTorch form over the paged cache (eager only).
+        self.blocksparse = dict(blocksparse) if blocksparse else None
         # A layer that shares another layer's keys and values (Gemma-3n's last layers): it owns no cache and
         # writes none, its queries read the source layer's cache, which that layer filled earlier in the same
         # step (reference: vllm/attention/layer.py kv_sharing_target_layer_name).  Kept in a list so that the
@@ -81,6 +87,25 @@ class Attention(nn.Module):
 
     def bind_kv_cache(self, k_cache: torch.Tensor, v_cache: torch.Tensor) -> None:
         self.k_cache, self.v_cache = k_cache, v_cache
+
+    def _forward_blocksparse(self, out, q, md, n, ksc, vsc) -> None:
+        from ..ops import reference
+        bp = self.blocksparse
+        bs, local, stride = int(bp["block_size"]), int(bp["local_blocks"]), int(bp["vert_stride"])
+        step = 0 if bp.get("homo_head", False) else max(1, stride // int(bp["total_heads"]))
+        heads = torch.arange(self.num_heads, device=q.device) + int(bp.get("first_head", 0))
+
+        def visible(pos, key):
+            qb, kb = pos // bs, key // bs
+            near = (qb - kb) < local                                             # [ql, sl]
+            stripe = ((kb[None] + heads[:, None, None] * step + 1) % stride) == 0      # [H, 1, sl]
+            return near[None] | stripe
+        if torch.cuda.is_available() and q.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("block-sparse attention beyond the local span cannot be captured in a graph")
+        S = md.num_decode_seqs + md.num_prefill_seqs
+        out[:n] = reference.paged_attention(q[:n], self.k_cache, self.v_cache, md.block_table[:S], md.seq_lens[:S],
+                                            md.query_start_loc[:S + 1], self.scale, k_scale=ksc, v_scale=vsc,
+                                            visible=visible)
 
     @property
     def kv_source(self) -> Optional["Attention"]:
@@ -171,7 +196,10 @@ class Attention(nn.Module):
                 raise RuntimeError("chunked local attention needs the runner's per-chunk batch layout")
             bt, sl, qsl = md.block_table, md.seq_lens, md.query_start_loc
             pqsl, n_pre = md.prefill_query_start_loc, md.num_prefill_seqs
-        if md.cascade_prefix_len and not self.sliding_window and self.causal and not self.local_chunk:
+        if self.blocksparse is not None and \
+                md.max_seq_len > self.blocksparse["block_size"] * self.blocksparse["local_blocks"]:
+            self._forward_blocksparse(out, q, md, n, ksc, vsc)
+        elif md.cascade_prefix_len and not self.sliding_window and self.causal and not self.local_chunk:
             self._cascade(out, q, md, n, ksc, vsc)
         else:
             if nd > 0:

@@ -88,7 +88,8 @@ class LlamaAttention(nn.Module):
                  sliding_window: Optional[int] = None, quant_config=None, prefix: str = "", qk_norm: bool = False,
                  cache_dtype: str = "auto", attention_only: bool = False, scale: Optional[float] = None,
                  logits_soft_cap: Optional[float] = None, neox_style: bool = True,
-                 qkv_clip: Optional[float] = None, alibi_slopes: Optional[list] = None, use_rope: bool = True):
+                 qkv_clip: Optional[float] = None, alibi_slopes: Optional[list] = None, use_rope: bool = True,
+                 blocksparse: Optional[dict] = None):
         super().__init__()
         tp = get_tensor_model_parallel_world_size()
         self.qkv_clip = qkv_clip
@@ -122,7 +123,8 @@ class LlamaAttention(nn.Module):
         else:
             self.attn = Attention(self.num_heads, self.head_dim, scale if scale is not None else self.head_dim ** -0.5,
                                   self.num_kv_heads, alibi_slopes=alibi_slopes, sliding_window=sliding_window,
-                                  logits_soft_cap=logits_soft_cap, prefix=f"{prefix}.attn", cache_dtype=cache_dtype)
+                                  logits_soft_cap=logits_soft_cap, prefix=f"{prefix}.attn", cache_dtype=cache_dtype,
+                                  blocksparse=blocksparse)
         # True: RMSNorm per head (Qwen3); "gemma": the (1 + w) form per head; "full": one RMSNorm over the
         # whole q / k projection (OLMo-2); "layernorm" / "layernorm_nobias": LayerNorm over the head dimension
         # with per-head scale (and shift)

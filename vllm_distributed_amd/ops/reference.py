@@ -129,9 +129,10 @@ def transfer_blocks(dst, src, dst_ids, src_ids):
 # ---- attention -------------------------------------------------------------------
 def paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale,
                     window: int = 0, softcap: float = 0.0, alibi=None, return_lse: bool = False,
-                    k_scale: float = 1.0, v_scale: float = 1.0, causal: bool = True):
+                    k_scale: float = 1.0, v_scale: float = 1.0, causal: bool = True, visible=None):
     """Attention of the new tokens of every sequence against its paged K/V (which already contain
-    the new tokens); causal, or over every key of the sequence.  q: [T, Hq, D] -> [T, Hq, D]."""
+    the new tokens); causal, or over every key of the sequence.  q: [T, Hq, D] -> [T, Hq, D].
+    ``visible(pos [ql, 1], key [1, sl]) -> bool [Hq, ql, sl]``: an extra per-head visibility pattern."""
     T, Hq, D = q.shape
     Hkv, bs = k_cache.shape[1], k_cache.shape[2]
     G = Hq // Hkv
@@ -163,6 +164,8 @@ def paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, sca
         if window > 0:
             mask &= key > pos - window
         sc = sc.masked_fill(~mask[None], float("-inf"))
+        if visible is not None:
+            sc = sc.masked_fill(~visible(pos, key), float("-inf"))
         lse[:, a:b] = torch.logsumexp(sc, dim=-1)
         p = torch.softmax(sc, dim=-1)
         out[a:b] = torch.matmul(p, v).permute(1, 0, 2).to(q.dtype)

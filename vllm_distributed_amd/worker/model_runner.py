@@ -229,6 +229,9 @@ class ModelRunner:
         from ..layers.moe import FusedMoE
         from ..parallel.state import get_dp_group
         self._dp_moe = get_dp_group().world_size > 1 and any(isinstance(m, FusedMoE) for m in self.model.modules())
+        if getattr(self.model, "requires_eager", False) and self.use_graphs:
+            logger.info("%s runs without decode graphs", type(self.model).__name__)
+            self.use_graphs, self.capture_sizes = False, []
         if self._dp_moe and self.use_graphs:
             logger.info("data-parallel attention with expert layers: decode graphs off")
             self.use_graphs, self.capture_sizes = False, []
