@@ -1751,3 +1751,73 @@ def test_minicpmo_audio_path_and_engine(tmp_path):
     assert ids == [5, 301] + [300] * 5 + [302, 9, 306] + [300] * na + [307, 11]
     assert len(out.outputs[0].token_ids) == 4
     llm.shutdown()
+
+
+def test_ovis_soft_tokens_and_engine(tmp_path):
+    """Ovis (parity unpinned).  The partition rule on known cases, the marker order, the 2 x 2 neighbourhood merge and
+    the softmax-weighted lookup against loops, then an image that is partitioned end to end (decoder: Qwen2 under
+    ``llm.``)."""
+    import json
+    import transformers as tf
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.config import HFConfig
+    from vllm_distributed_amd.models.ovis import VisualTokenizer, best_partition, marker_rows
+    assert best_partition(448, 448, 448) == (1, 1)
+    assert best_partition(896, 448, 448) == (1, 2)
+    assert best_partition(448, 1344, 448) == (3, 1)
+    V = 40
+    assert marker_rows(1, (1, 1), V) == [39, 38, 35]
+    assert marker_rows(5, (2, 2), V) == [39, 38, 37, 36, 37, 35]              # start, prefix, col, row, col, end
+    torch.manual_seed(0)
+    bc = dict(model_type="aimv2", hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+              image_size=56, patch_size=14, rms_norm_eps=1e-5, qkv_bias=False, use_bias=False, num_channels=3)
+    vt = dict(backbone_config=bc, hidden_stride=2, vocab_size=V, tokenize_function="softmax", drop_cls_token=False)
+    tokz = VisualTokenizer(HFConfig(vt)).eval()
+    with torch.no_grad():
+        for p in tokz.parameters():
+            p.normal_(0, 0.3)
+        px = torch.randn(2, 3, 56, 56)
+        raw = tokz.backbone(px)                                              # [2, 16, 32], a 4 x 4 grid
+        f = tokz.features(px)
+        for i in range(2):
+            for j in range(2):
+                g = raw[0].view(4, 4, 32)
+                want = torch.cat([g[2 * i, 2 * j], g[2 * i, 2 * j + 1], g[2 * i + 1, 2 * j], g[2 * i + 1, 2 * j + 1]])
+                torch.testing.assert_close(f[0, i * 2 + j], want)
+        probs = tokz(px)
+        assert probs.shape == (2, 4, V) and torch.allclose(probs.sum(-1), torch.ones(2, 4)) and \
+            float(probs[..., -5:].abs().max()) == 0.0
+    tc = tf.Qwen2Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=1024,
+                        tie_word_embeddings=False)
+    hf = tf.Qwen2ForCausalLM(tc).float().eval()
+    cfg = dict(architectures=["Ovis"], model_type="ovis", visual_tokenizer_config=vt, image_pad_token_id=300,
+               llm_config={**tc.to_dict(), "architectures": ["Qwen2ForCausalLM"]})
+    path = os.path.join(str(tmp_path), "ovis")
+    os.makedirs(path)
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    sd = {"llm." + n: t for n, t in hf.state_dict().items()}
+    sd.update({"visual_tokenizer." + n: t.detach().clone() for n, t in tokz.state_dict().items()})
+    sd["visual_tokenizer.backbone.trunk.post_trunk_norm.weight"] = torch.ones(32)      # in checkpoints, unused
+    sd["vte.weight"] = torch.randn(V, 128)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    img = (np.random.default_rng(3).random((56, 112, 3)) * 255).astype(np.uint8)        # partitioned 1 x 2
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4)
+    outs = llm.generate([{"prompt_token_ids": [5, 300, 9, 11], "multi_modal_data": {"image": img}},
+                         {"prompt_token_ids": [5, 17, 9, 11]}],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    assert best_partition(112, 56, 56) == (1, 2) and best_partition(115, 60, 56) == (2, 2)
+    assert list(outs[0].prompt_token_ids).count(300) == 3 * 4 + 4             # overview + 2 crops, 4 markers
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    from vllm_distributed_amd.multimodal import process_multimodal
+    _, inputs, _, _ = process_multimodal(llm.llm_engine.vllm_config, [5, 300, 9], {"image": img})
+    with torch.no_grad():
+        got = model.encode_mm_items([inputs[0]])[0]
+        words = model.visual_tokenizer(inputs[0][0]) @ model.vte.weight
+        w = model.vte.weight
+        want = torch.cat([w[39:40], words[0], w[38:39], words[1], w[37:38], words[2], w[35:36]])
+        torch.testing.assert_close(got, want)
+        ref = hf.generate(torch.tensor([[5, 17, 9, 11]]), max_new_tokens=6, do_sample=False, pad_token_id=0,
+                          eos_token_id=None)[0, 4:].tolist()
+    assert list(outs[1].outputs[0].token_ids) == ref and len(outs[0].outputs[0].token_ids) == 6
+    llm.shutdown()

@@ -590,3 +590,11 @@ def _minicpmo(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("MiniCPMO", _minicpmo)
+
+
+def _ovis(vllm_config):
+    from ..models.ovis import ovis_processor
+    return ovis_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("Ovis", _ovis)
