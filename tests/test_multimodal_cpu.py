@@ -1821,3 +1821,55 @@ def test_ovis_soft_tokens_and_engine(tmp_path):
                           eos_token_id=None)[0, 4:].tolist()
     assert list(outs[1].outputs[0].token_ids) == ref and len(outs[0].outputs[0].token_ids) == 6
     llm.shutdown()
+
+
+def test_mllama_matches_hf(tmp_path):
+    """Llama-3.2-Vision: tile tower with gated position embeddings and the "both padding" mask, intermediate taps,
+    tanh-gated cross-attention layers fed from the per-request slot cache, a text-only request in the same batch.
+    Image-first prompts (the family's chat format), where the original model and transformers agree on which rows see
+    the image.  The tower taps the state ENTERING layer i as the original model does; transformers 5 collects the
+    state LEAVING layer i, so the checkpoint config written for the engine carries transformers' indices + 1."""
+    import json
+    import transformers as tf
+    torch.manual_seed(0)
+    vc = dict(hidden_size=32, num_hidden_layers=4, num_global_layers=2, attention_heads=2, intermediate_size=64,
+              vision_output_dim=32 * 3, image_size=28, patch_size=14, max_num_tiles=4, intermediate_layers_indices=[0, 2],
+              supported_aspect_ratios=[[1, 1], [1, 2], [1, 3], [1, 4], [2, 1], [2, 2], [3, 1], [4, 1]])
+    tc = dict(vocab_size=320, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, num_key_value_heads=1,
+              intermediate_size=256, cross_attention_layers=[1, 3], max_position_embeddings=512, pad_token_id=0,
+              bos_token_id=1, eos_token_id=2, rope_parameters={"rope_theta": 10000.0, "rope_type": "default"})
+    cfg = tf.MllamaConfig(vision_config=vc, text_config=tc, image_token_index=320)
+    hf = tf.MllamaForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+            elif "gate" in n:
+                p.fill_(0.7)
+    hf = hf.float().eval()
+    path = os.path.join(str(tmp_path), "mllama")
+    hf.save_pretrained(path, safe_serialization=True)
+    cj = json.load(open(os.path.join(path, "config.json")))
+    cj["vision_config"]["intermediate_layers_indices"] = [1, 3]
+    json.dump(cj, open(os.path.join(path, "config.json"), "w"))
+    g = torch.Generator().manual_seed(5)
+    px = torch.zeros(4, 3, 28, 28)
+    px[:2] = torch.randn(2, 3, 28, 28, generator=g)                           # aspect ratio (1, 2): id 2, two tiles
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4,
+              max_num_batched_tokens=64, block_size=16)
+    prompts = [{"prompt_token_ids": [320, 1, 17, 45, 108],
+                "multi_modal_data": {"image": {"pixel_values": px, "aspect_ratio_id": 2, "num_tiles": 2}}},
+               {"prompt_token_ids": [1, 17, 45, 108, 9]}]
+    outs = llm.generate(prompts, SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    llm.shutdown()
+    with torch.no_grad():
+        ids = torch.tensor([[320, 1, 17, 45, 108]])
+        mask = torch.zeros(1, 5, 1, 4, dtype=torch.long)
+        mask[:, :, 0, :2] = 1
+        ref = hf.generate(input_ids=ids, pixel_values=px[None, None], aspect_ratio_ids=torch.tensor([[2]]),
+                          aspect_ratio_mask=torch.tensor([[[1, 1, 0, 0]]]), cross_attention_mask=mask,
+                          max_new_tokens=8, do_sample=False, eos_token_id=None, pad_token_id=0)[0, 5:].tolist()
+        ref_text = hf.generate(input_ids=torch.tensor([[1, 17, 45, 108, 9]]), max_new_tokens=8, do_sample=False,
+                               eos_token_id=None, pad_token_id=0)[0, 5:].tolist()
+    assert list(outs[0].outputs[0].token_ids) == ref
+    assert list(outs[1].outputs[0].token_ids) == ref_text

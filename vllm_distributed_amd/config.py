@@ -322,7 +322,8 @@ class ModelConfig:
         return any(a in ("JambaForCausalLM", "BambaForCausalLM", "GraniteMoeHybridForCausalLM", "NemotronHForCausalLM",
                          "MiniMaxForCausalLM", "MiniMaxText01ForCausalLM", "MiniMaxM1ForCausalLM", "FalconH1ForCausalLM", "MiniMaxVL01ForConditionalGeneration",
                          # encoder-decoder: the cross-attention cache is per-request state of the same kind
-                         "WhisperForConditionalGeneration", "BartForConditionalGeneration", "BartModel")
+                         "WhisperForConditionalGeneration", "BartForConditionalGeneration", "BartModel",
+                         "MllamaForConditionalGeneration", "Zamba2ForCausalLM")
                    for a in self.architectures)
 
     @property

@@ -141,7 +141,12 @@ class Processor:
         V = self.model_config.get_vocab_size()
         mx = max(ids)
         if mx >= V or min(ids) < 0:
-            raise ValueError(f"token id {mx} is out of vocabulary (size {V})")
+            # placeholder tokens of multimodal checkpoints may sit just behind the text vocabulary
+            hf = self.model_config.hf_config
+            marks = {int(v) for k, v in hf.to_dict().items()
+                     if k.endswith(("_token_id", "_token_index")) and isinstance(v, int) and not isinstance(v, bool)}
+            if min(ids) < 0 or any(t >= V and t not in marks for t in ids):
+                raise ValueError(f"token id {mx} is out of vocabulary (size {V})")
         max_len = self.model_config.max_model_len
         if len(ids) >= max_len and isinstance(params, SamplingParams):
             raise ValueError(f"the prompt has {len(ids)} tokens but the model's context is {max_len}; "

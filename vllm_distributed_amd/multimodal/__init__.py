@@ -598,3 +598,11 @@ def _ovis(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("Ovis", _ovis)
+
+
+def _mllama(vllm_config):
+    from ..models.mllama import mllama_processor
+    return mllama_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("MllamaForConditionalGeneration", _mllama)

@@ -957,7 +957,7 @@ class ModelRunner:
         self._next_stage()
         req_ids, rows, n_sched, cu, S, T, logits_idx, att, tmd = self._prepare_inputs(so)
         inputs_embeds = None
-        encoder_outputs = ()
+        encoder_outputs, starting_seqs = (), ()
         if getattr(self.model, "is_multimodal", False):
             self._run_mm_encoder(so)
             if getattr(self.model, "is_encoder_decoder", False):
@@ -966,6 +966,8 @@ class ModelRunner:
                 encoder_outputs = [(k, self.encoder_cache[rid][0]) for k, rid in enumerate(req_ids)
                                    if self.input_batch.num_computed[rows[k]] == 0
                                    and 0 in self.encoder_cache.get(rid, {})]
+                # every request whose first token runs in this step: models with per-slot book-keeping reset it
+                starting_seqs = [k for k in range(len(req_ids)) if self.input_batch.num_computed[rows[k]] == 0]
             else:
                 mm_e, mm_mask = self._gather_mm_embeddings(req_ids, rows, n_sched, cu)
                 if mm_e is not None:
@@ -1046,6 +1048,8 @@ class ModelRunner:
                                      dp=self._dp_metadata(T_in)) as fctx:
                 if encoder_outputs:
                     fctx.extra["encoder_outputs"] = encoder_outputs
+                if starting_seqs:
+                    fctx.extra["starting_seqs"] = starting_seqs
                 if conn is not None:
                     conn.start_load_kv()
                 extra = {}
