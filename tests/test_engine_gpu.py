@@ -22,7 +22,7 @@ def _llm(path, **kw):
 
 @pytest.mark.parametrize("kind", ["llama", "qwen2", "mixtral", "mamba", "mamba2", "deepseek_v2_mla", "bloom", "cohere",
                                   "gemma3", "olmo2", "falcon_new", "jamba", "bamba", "dbrx", "nemotron_h",
-                                  "granitemoehybrid", "llama4", "minimax", "falcon_h1"])
+                                  "granitemoehybrid", "llama4", "minimax", "falcon_h1", "zamba2", "gemma3n"])
 def test_gpu_logprobs_match_hf_and_graphs_match_eager(tmp_path, kind):
     import transformers as tf
     from vllm_distributed_amd import SamplingParams
@@ -403,3 +403,108 @@ def test_gpu_eagle3_speculative_tokens_equal_plain_greedy(tmp_path):
     # verification runs the target on several tokens per step (other kernels than one-token decode): allow one
     # sequence to part ways at a bf16 near-tie
     assert same >= len(ref) - 1, (got, ref)
+
+
+def test_mllama_cross_attention_on_gpu(tmp_path):
+    """Llama-3.2-Vision on the GPU: the cross-attention layers read the per-request slot cache through the paged
+    MFMA kernels (decode graphs included), an image request and a text-only request side by side; log-probabilities
+    against transformers in fp32."""
+    import json
+    import transformers as tf
+    from vllm_distributed_amd import SamplingParams
+    torch.manual_seed(0)
+    vc = dict(hidden_size=32, num_hidden_layers=4, num_global_layers=2, attention_heads=2, intermediate_size=64,
+              vision_output_dim=32 * 3, image_size=28, patch_size=14, max_num_tiles=4, intermediate_layers_indices=[0, 2],
+              supported_aspect_ratios=[[1, 1], [1, 2], [1, 3], [1, 4], [2, 1], [2, 2], [3, 1], [4, 1]])
+    tc = dict(vocab_size=320, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, num_key_value_heads=1,
+              intermediate_size=256, cross_attention_layers=[1, 3], max_position_embeddings=512, pad_token_id=0,
+              bos_token_id=1, eos_token_id=2, rope_parameters={"rope_theta": 10000.0, "rope_type": "default"})
+    hf = tf.MllamaForConditionalGeneration(tf.MllamaConfig(vision_config=vc, text_config=tc, image_token_index=320))
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2:
+                p.mul_(2.0)
+            elif "gate" in n:
+                p.fill_(0.7)
+    hf = hf.float().eval()
+    path = os.path.join(tmp_path, "mllama")
+    hf.save_pretrained(path, safe_serialization=True)
+    cj = json.load(open(os.path.join(path, "config.json")))
+    cj["vision_config"]["intermediate_layers_indices"] = [1, 3]        # state entering layer i (see the CPU test)
+    json.dump(cj, open(os.path.join(path, "config.json"), "w"))
+    px = torch.zeros(4, 3, 28, 28)
+    px[:2] = torch.randn(2, 3, 28, 28, generator=torch.Generator().manual_seed(5))
+    llm = _llm(path, max_model_len=128)
+    mr = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner
+    prompts = [{"prompt_token_ids": [320, 1, 17, 45, 108],
+                "multi_modal_data": {"image": {"pixel_values": px, "aspect_ratio_id": 2, "num_tiles": 2}}},
+               {"prompt_token_ids": [1, 17, 45, 108, 9]}]
+    outs = llm.generate(prompts, SamplingParams(temperature=0, max_tokens=10, ignore_eos=True, logprobs=0))
+    assert mr.graphs, "decode graphs expected"
+    llm.shutdown()
+    mask = torch.zeros(1, 15, 1, 4, dtype=torch.long)
+    mask[:, :, 0, :2] = 1
+    worst = 0.0
+    for k, o in enumerate(outs):
+        p, gen = prompts[k]["prompt_token_ids"], list(o.outputs[0].token_ids)
+        kw = dict(pixel_values=px[None, None], aspect_ratio_ids=torch.tensor([[2]]),
+                  aspect_ratio_mask=torch.tensor([[[1, 1, 0, 0]]]), cross_attention_mask=mask) if k == 0 else {}
+        with torch.no_grad():
+            lp = torch.log_softmax(hf(input_ids=torch.tensor([p + gen]), **kw).logits[0].float(), -1)
+        for j, t in enumerate(gen):
+            worst = max(worst, abs(float(lp[len(p) + j - 1, t]) - o.outputs[0].logprobs[j][t].logprob))
+    assert worst < 0.1, worst
+
+
+def test_phi3_small_blocksparse_on_gpu(tmp_path):
+    """Phi-3-small on the GPU: prompts inside the local span take the MFMA kernels, a longer one the masked PyTorch
+    form over the paged cache; log-probabilities against the dense fp32 definition of the CPU test."""
+    import json
+    from safetensors.torch import save_file
+    from tests.test_phi3_small_cpu import CFG, _dense_forward, _weights
+    from vllm_distributed_amd import SamplingParams
+    path = os.path.join(tmp_path, "phi3small")
+    os.makedirs(path)
+    json.dump(CFG, open(os.path.join(path, "config.json"), "w"))
+    sd = _weights()
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    prompts = [[5, 17, 99, 3, 250], [(7 * i + 3) % 300 for i in range(37)]]
+    llm = _llm(path, max_model_len=128, max_num_batched_tokens=16, enable_prefix_caching=False)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=6,
+                                                                                   ignore_eos=True, logprobs=0))
+    llm.shutdown()
+    worst = 0.0
+    for p, o in zip(prompts, outs):
+        ids = list(p)
+        for k, t in enumerate(o.outputs[0].token_ids):
+            lp = torch.log_softmax(_dense_forward(sd, ids).float(), -1)
+            worst = max(worst, abs(float(lp[t]) - o.outputs[0].logprobs[k][t].logprob))
+            ids.append(t)
+    assert worst < 0.1, worst
+
+
+def test_plamo2_hybrid_on_gpu(tmp_path):
+    """PLaMo 2 on the GPU: the HIP convolution and scan kernels with per-head time steps computed from the convolved
+    signal, chunked prefill, hipGraph decode; log-probabilities against the fp32 recurrence of the CPU test."""
+    import json
+    from safetensors.torch import save_file
+    from tests.test_plamo2_cpu import CFG, _dense_forward, _weights
+    from vllm_distributed_amd import SamplingParams
+    path = os.path.join(tmp_path, "plamo2")
+    os.makedirs(path)
+    json.dump(CFG, open(os.path.join(path, "config.json"), "w"))
+    sd = _weights()
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    prompts = [[5, 17, 99, 3, 250], [(7 * i + 3) % 300 for i in range(37)]]
+    llm = _llm(path, max_model_len=128, max_num_batched_tokens=16)
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0, max_tokens=6,
+                                                                                   ignore_eos=True, logprobs=0))
+    llm.shutdown()
+    worst = 0.0
+    for p, o in zip(prompts, outs):
+        ids = list(p)
+        for k, t in enumerate(o.outputs[0].token_ids):
+            lp = torch.log_softmax(_dense_forward(sd, ids).float(), -1)
+            worst = max(worst, abs(float(lp[t]) - o.outputs[0].logprobs[k][t].logprob))
+            ids.append(t)
+    assert worst < 0.1, worst

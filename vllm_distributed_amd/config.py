@@ -323,7 +323,7 @@ class ModelConfig:
                          "MiniMaxForCausalLM", "MiniMaxText01ForCausalLM", "MiniMaxM1ForCausalLM", "FalconH1ForCausalLM", "MiniMaxVL01ForConditionalGeneration",
                          # encoder-decoder: the cross-attention cache is per-request state of the same kind
                          "WhisperForConditionalGeneration", "BartForConditionalGeneration", "BartModel",
-                         "MllamaForConditionalGeneration", "Zamba2ForCausalLM")
+                         "MllamaForConditionalGeneration", "Zamba2ForCausalLM", "Plamo2ForCausalLM")
                    for a in self.architectures)
 
     @property
