@@ -510,3 +510,26 @@ def test_plamo2_hybrid_on_gpu(tmp_path):
             worst = max(worst, abs(float(lp[t]) - o.outputs[0].logprobs[k][t].logprob))
             ids.append(t)
     assert worst < 0.1, worst
+
+
+def test_gpu_sparse_dual_chunk_prefill(tmp_path):
+    """Vertical-slash sparse prefill of dual-chunk attention on the GPU: with a budget that covers every key the
+    tokens follow the dense definition; with a small one they follow the selection written out row by row."""
+    from tests.test_dual_chunk_cpu import _with_sparse, dense_dual_chunk_logits, save_tiny_dual_chunk
+    from vllm_distributed_amd import SamplingParams
+    g = torch.Generator().manual_seed(3)
+    p = torch.randint(3, 300, (500,), generator=g).tolist()
+    for k, (budget, oracle) in enumerate((((4096, 4096), None), ((34, 104), (34, 104, 8)))):
+        path, hf = save_tiny_dual_chunk(os.path.join(tmp_path, str(k)), 0)
+        _with_sparse(path, *budget, False)
+        llm = _llm(path, max_model_len=512, max_num_seqs=1, enable_prefix_caching=False, max_num_batched_tokens=512)
+        out = llm.generate([{"prompt_token_ids": p}],
+                           SamplingParams(temperature=0, max_tokens=3, ignore_eos=True, logprobs=0))[0]
+        llm.shutdown()
+        ids, worst = list(p), 0.0
+        with torch.no_grad():
+            for j, tok in enumerate(out.outputs[0].token_ids):
+                lp = torch.log_softmax(dense_dual_chunk_logits(hf, ids, 64, 16, 0, len(p), sparse_budget=oracle), -1)
+                worst = max(worst, abs(float(lp[tok]) - out.outputs[0].logprobs[j][tok].logprob))
+                ids.append(tok)
+        assert worst < 0.1, (budget, worst)

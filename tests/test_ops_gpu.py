@@ -233,6 +233,57 @@ def test_paged_attention_prefill_bidirectional_and_lse(dt, Hq, Hkv, D):
         torch.testing.assert_close(lse, lref, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Hq,Hkv,D,bs", [(8, 2, 128, 16), (4, 4, 64, 32), (14, 2, 128, 64)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_paged_attention_prefill_sparse(dt, Hq, Hkv, D, bs, causal):
+    """Vertical-slash sparse prefill: LDS bitmap of 32-key steps per (128-row tile, head) against the masked fp32
+    form; sequences whose tables start at different absolute keys, partial tiles, heads with empty lists."""
+    seq_lens, q_lens = [700, 300, 1200, 40], [700, 130, 257, 40]
+    q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, q_lens, Hq, Hkv, D, bs, dt)
+    S, NV, NS = len(seq_lens), 24, 12
+    g = torch.Generator(device="cpu").manual_seed(5)
+    key_base = torch.tensor([0, 64, 0, 512], dtype=torch.int32)
+    ctx = torch.tensor([s - ql for s, ql in zip(seq_lens, q_lens)], dtype=torch.int32)
+    q_base = key_base + ctx if causal else key_base + torch.tensor(seq_lens, dtype=torch.int32) + 100
+    vert = torch.randint(0, 1400, (S, Hq, NV), generator=g).int()
+    slash = torch.randint(0, 1400, (S, Hq, NS), generator=g).int()
+    vcount = torch.randint(0, NV + 1, (S, Hq), generator=g).int()
+    scount = torch.randint(0, NS + 1, (S, Hq), generator=g).int()
+    vcount[0, 0] = scount[0, 0] = 0                     # a head that sees only its diagonal (or nothing)
+    args = [t.to(DEV) for t in (vert, vcount, slash, scount, key_base, q_base)]
+    scale = 1.0 / math.sqrt(D)
+    out = torch.full_like(q, float("nan"))
+    _, lse = ops.paged_attention_prefill_sparse(out, q, kc, vc, bt, sl, qsl, scale, *args, causal=causal)
+    ref, lref = R.paged_attention_sparse(q, kc, vc, bt, sl, qsl, scale, *args, causal=causal)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+    seen = ~torch.isinf(lref)
+    assert bool(seen.any()) and torch.equal(seen, ~torch.isinf(lse))
+    torch.testing.assert_close(lse[seen], lref[seen], atol=2e-2, rtol=2e-2)
+    if causal:                                          # the selection really leaves keys out
+        dense = R.paged_attention(q, kc, vc, bt, sl, qsl, scale)
+        assert float((dense.float() - ref.float()).abs().max()) > 0.05
+
+
+def test_paged_attention_prefill_sparse_fp8_cache():
+    dt, Hq, Hkv, D, bs = torch.bfloat16, 8, 2, 128, 16
+    seq_lens, q_lens = [900, 300], [900, 140]
+    q, kc, vc, bt, sl, qsl = _paged_problem(seq_lens, q_lens, Hq, Hkv, D, bs, dt)
+    kc, vc = (kc / 0.05).to(torch.float8_e4m3fn), (vc / 0.02).to(torch.float8_e4m3fn)
+    g = torch.Generator(device="cpu").manual_seed(6)
+    vert = torch.randint(0, 900, (2, Hq, 16), generator=g).int().to(DEV)
+    slash = torch.randint(0, 900, (2, Hq, 8), generator=g).int().to(DEV)
+    vcount = torch.full((2, Hq), 16, dtype=torch.int32, device=DEV)
+    scount = torch.full((2, Hq), 8, dtype=torch.int32, device=DEV)
+    key_base = torch.zeros(2, dtype=torch.int32, device=DEV)
+    q_base = torch.tensor([0, 160], dtype=torch.int32, device=DEV)
+    args = (vert, vcount, slash, scount, key_base, q_base)
+    out = torch.full_like(q, float("nan"))
+    ops.paged_attention_prefill_sparse(out, q, kc, vc, bt, sl, qsl, 0.09, *args, k_scale=0.05, v_scale=0.02)
+    ref, _ = R.paged_attention_sparse(q, kc, vc, bt, sl, qsl, 0.09, *args, k_scale=0.05, v_scale=0.02)
+    torch.testing.assert_close(out.float(), ref.float(), **tol(dt))
+
+
 def test_cascade_composition_equals_plain_attention():
     """Shared prefix of P keys attended once by every query token (one bidirectional pseudo-sequence),
     per-sequence suffixes through a block table that starts behind the prefix, merged by log-sum-exp:

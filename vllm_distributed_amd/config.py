@@ -134,6 +134,13 @@ def load_hf_config(model: str, overrides: Optional[dict] = None) -> HFConfig:
                 f"{model!r} is neither a local checkpoint directory nor a known preset "
                 f"({', '.join(sorted(PRESETS))})")
         d = copy.deepcopy(PRESETS[key])
+    dca = d.get("dual_chunk_attention_config")
+    side = os.path.join(model, "sparse_attention_config.json")
+    if isinstance(dca, dict) and "sparse_attention_config" not in dca and os.path.isfile(side):
+        # per layer, per head: ["vertical_and_slash", vertical lines, slash lines, score] (reference:
+        # vllm/config.py:1036-1045, model_loader/weight_utils.py:226-262)
+        with open(side) as f:
+            dca["sparse_attention_config"] = json.load(f)
     if "thinker_config" in d:                  # Qwen2.5-Omni: only the thinker generates text
         d = {**{k: v for k, v in d.items() if k not in ("thinker_config", "talker_config", "token2wav_config")},
              **{k: v for k, v in d["thinker_config"].items() if k not in ("architectures", "model_type")

@@ -261,16 +261,91 @@ class DualChunkAttention(Attention):
     0.1 ln(len / original_max) + 1 (at least 1) of their sequence; the runner supplies that factor per token.
     Reference: vllm/attention/backends/dual_chunk_flash_attn.py (_dual_chunk_flash_attn_prefill_func :705-1145 dense
     branch, _dual_chunk_flash_attn_decoding :1283-1377), vllm/model_executor/layers/rotary_embedding.py:1679-1845.
-    The reference's sparse (vertical-slash) prefill estimate is not built: every pass is dense."""
+
+    Sparse prefill (``sparse``: per head of this rank a (vertical lines, slash lines) budget, a length threshold and
+    the number of probe rows): a prefill step of ONE request longer than the threshold first scores the last probe
+    rows of every query chunk against all keys before them (probe queries rotated like the dense passes, except that
+    the older two passes use an unclamped in-chunk position + chunk_len and in-chunk position + chunk_size), sums the
+    softmax over rows (vertical lines: key positions) and over diagonals (slash lines: query minus key distance),
+    keeps the best of each per head (the first 30 keys and the nearest 100 diagonals always), and runs the three
+    passes over only those lines (``ops.paged_attention_prefill_sparse``: 32-key steps per 128-row tile, bitmap built
+    in LDS by the attention kernel itself).  Steps of several requests, decode steps and shorter requests stay dense.
+    Reference: dual_chunk_flash_attn.py :606-662 (budgets), :763-1045 (estimate and split per pass),
+    _vertical_slash_sparse_attention :1407-1490, csrc/attention/vertical_slash_index.cu."""
     dual_chunk = True
 
-    def __init__(self, *args, chunk_size: int, local_size: int, original_max_position_embeddings: int = 0, **kw):
+    def __init__(self, *args, chunk_size: int, local_size: int, original_max_position_embeddings: int = 0,
+                 sparse: Optional[dict] = None, **kw):
         super().__init__(*args, **kw)
         if self.sliding_window or self.alibi_slopes is not None:
             raise ValueError("dual-chunk attention takes neither a sliding window nor ALiBi")
         self.chunk_size, self.chunk_len = int(chunk_size), int(chunk_size) - int(local_size)
         self.local_chunk = self.chunk_len           # the runner cuts the step into (sequence, chunk) pairs
         self.original_max = int(original_max_position_embeddings or 0)
+        self.sparse = None
+        if sparse and sparse.get("heads"):
+            heads = [(int(v) + (100 if int(v) == 30 else 0), int(sl)) for v, sl in sparse["heads"]]
+            if len(heads) != self.num_heads:
+                raise ValueError("sparse attention config must list every head of the layer")
+            self.sparse = dict(heads=heads, threshold=int(sparse.get("threshold", 32768)),
+                               last_q=int(sparse.get("last_q", 64)))
+
+    def _sparse_lines(self, raw_last, rows, chunks, positions, rotary, md, S: int, n: int):
+        """Vertical / slash lines of every query chunk of the step's single request.  ``rows``: per chunk the
+        (first, end) token rows of the step, ``raw_last``: their probe rows before rotation, concatenated.
+        Returns int32 (vert [C, Hq, NV], vcount [C, Hq], slash [C, Hq, NS], scount [C, Hq])."""
+        Hq, Hkv, D, L = self.num_heads, self.num_kv_heads, self.head_size, self.chunk_len
+        G = Hq // Hkv
+        dev = raw_last.device
+        table, rd, neox = rotary.cos_sin_cache, rotary.rotary_dim, rotary.is_neox_style
+        bs = self.k_cache.shape[2]
+        nb = (S + bs - 1) // bs
+        keys = self.k_cache[md.block_table[0, :nb].long()].permute(1, 0, 2, 3).reshape(Hkv, nb * bs, D)[:, :S]
+        if keys.dtype == torch.float8_e4m3fn:
+            keys = keys.to(raw_last.dtype) * self._k_scale_float
+        lasts = [min(self.sparse["last_q"], e - b) for b, e in rows]
+        idx = torch.cat([torch.arange(e - m, e, device=dev) for (b, e), m in zip(rows, lasts)])
+        p_in = positions[idx] % L
+        probes = []
+        for shift in (None, L, self.chunk_size):            # own chunk, chunk before (unclamped), everything older
+            q = raw_last.clone()
+            ops.rotary_embedding(p_in if shift is None else p_in + shift, q, None, table, rd, D, neox)
+            probes.append(q.view(-1, Hkv, G, D))
+        vmax, smax = max(v for v, _ in self.sparse["heads"]), max(sl for _, sl in self.sparse["heads"])
+        vsz = torch.tensor([v for v, _ in self.sparse["heads"]], device=dev)
+        ssz = torch.tensor([sl for _, sl in self.sparse["heads"]], device=dev)
+        verts, vcs, slashes, scs = [], [], [], []
+        o = 0
+        for (b, e), m, c in zip(rows, lasts, chunks):
+            end = S - n + e                                   # keys before (and at) the last probe row
+            cut = [0, max(0, (c - 1) * L), c * L, end]        # older | chunk before | own chunk
+            vert_score = torch.empty((Hq, end), dtype=torch.float32, device=dev)
+            slash_score = torch.zeros((Hq, end), dtype=torch.float32, device=dev)
+            for kv in range(Hkv):                              # one KV head at a time bounds the score matrix
+                sc = torch.cat([
+                    torch.matmul(probes[2 - j][o:o + m, kv].permute(1, 0, 2).reshape(G * m, D).float(),
+                                 keys[kv, cut[j]:cut[j + 1]].float().t()) for j in range(3)], -1) * self.scale
+                sc = sc.view(G, m, end)
+                tri = torch.ones((m, m), dtype=torch.bool, device=dev).tril()
+                sc[:, :, end - m:] = sc[:, :, end - m:].masked_fill(~tri, float("-inf"))
+                pr = torch.softmax(sc, -1)
+                vert_score[kv * G:(kv + 1) * G] = pr.sum(1)
+                fl = pr.flip(-1)                                # column t: the key at distance t from the last row
+                for r in range(m):
+                    off = m - 1 - r
+                    slash_score[kv * G:(kv + 1) * G, : end - off] += fl[:, r, off:]
+            vert_score[:, :30] = float("inf")
+            slash_score[:, :100] = float("inf")
+            nv, ns = min(vmax, end), min(smax, end)
+            v_idx = torch.topk(vert_score, nv, -1).indices.int()
+            s_idx = torch.topk(slash_score, ns, -1).indices.int()
+            verts.append(torch.nn.functional.pad(v_idx, (0, vmax - nv)))
+            slashes.append(torch.nn.functional.pad(s_idx, (0, smax - ns)))
+            vcs.append(vsz.clamp(max=nv).int())
+            scs.append(ssz.clamp(max=ns).int())
+            o += m
+        return (torch.stack(verts).contiguous(), torch.stack(vcs).contiguous(), torch.stack(slashes).contiguous(),
+                torch.stack(scs).contiguous())
 
     def _forward_native(self, qkv: torch.Tensor, positions: Optional[torch.Tensor] = None, rotary=None) -> torch.Tensor:
         ctx = get_forward_context()
@@ -293,6 +368,18 @@ class DualChunkAttention(Attention):
         q_succ, q_inter = raw.clone(), raw.clone()
         p_in = positions[:n] % L
         table, rd, neox = rotary.cos_sin_cache, rotary.rotary_dim, rotary.is_neox_style
+        S = md.max_seq_len
+        sparse = (self.sparse is not None and md.num_decode_seqs == 0 and md.seq_lens.shape[0] == 1
+                  and S > self.sparse["threshold"])
+        if sparse:
+            if torch.cuda.is_available() and qkv.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("sparse dual-chunk prefill sizes its lists on the host: not capturable")
+            # the step's query chunks of the one request: chunk number and token rows, on the host
+            first = S - n
+            chunks = list(range(first // L, (S - 1) // L + 1))
+            rows = [(max(c * L, first) - first, min((c + 1) * L, S) - first) for c in chunks]
+            m = self.sparse["last_q"]
+            raw_last = torch.cat([raw[max(b, e - m):e] for b, e in rows]).clone()
         ops.rope_and_cache(p_in, qkv[:n], table, self.k_cache, self.v_cache, md.slot_mapping[:n], rd, D, Hq, Hkv,
                            neox, ksc, vsc)
         out = torch.empty((T, Hq, D), dtype=qkv.dtype, device=qkv.device)
@@ -301,7 +388,7 @@ class DualChunkAttention(Attention):
         qsl = md.local_query_start_loc
         kw = dict(softcap=self.softcap, k_scale=ksc, v_scale=vsc, return_lse=True)
         q = qkv[:n, :qs].view(n, Hq, D)
-        if md.dca_passes == 1:
+        if md.dca_passes == 1 and not sparse:
             # no sequence of the step has an older chunk: plain chunked local attention, decode kernel included
             nd, ndt, n_pre = md.num_decode_seqs, md.num_decode_tokens, md.local_num_prefill_seqs
             if nd > 0:
@@ -316,10 +403,30 @@ class DualChunkAttention(Attention):
                                             md.local_block_table[nd:nd + n_pre], md.local_seq_lens[nd:nd + n_pre],
                                             md.local_prefill_query_start_loc, self.scale, softcap=self.softcap,
                                             k_scale=ksc, v_scale=vsc, causal=True)
-        else:
+        elif md.dca_passes != 1:
             ops.rotary_embedding((p_in + L).clamp_(max=self.chunk_size), q_succ, None, table, rd, D, neox)
             ops.rotary_embedding(torch.full_like(p_in, min(2 * L - 1, self.chunk_size)), q_inter, None, table, rd, D,
                                  neox)
+        if sparse:
+            lines = self._sparse_lines(raw_last, rows, chunks, positions, rotary, md, S, n)
+            i32 = dict(dtype=torch.int32, device=qkv.device)
+            q_base = torch.tensor([first + b for b, _ in rows], **i32)
+            skw = dict(softcap=self.softcap, k_scale=ksc, v_scale=vsc)
+            passes = [(q, md.local_block_table, md.local_seq_lens, [c * L for c in chunks], True)]
+            if md.dca_passes != 1:
+                passes += [(q_succ.view(n, Hq, D), md.dca_succ_block_table, md.dca_succ_lens,
+                            [(c - 1) * L for c in chunks], False),
+                           (q_inter.view(n, Hq, D), md.dca_inter_block_table, md.dca_inter_lens, [0] * len(chunks), False)]
+            parts = [ops.paged_attention_prefill_sparse(
+                torch.zeros_like(out[:n]), qq, self.k_cache, self.v_cache, tbl, lens, qsl, self.scale, *lines,
+                torch.tensor(base, **i32), q_base, causal=causal, max_keys=S, **skw)
+                for qq, tbl, lens, base, causal in passes]
+            if len(parts) == 1:
+                out[:n] = parts[0][0]
+            else:
+                o12, l12 = ops.merge_attn_states(parts[0][0], parts[0][1], parts[1][0], parts[1][1], return_lse=True)
+                out[:n] = ops.merge_attn_states(o12, l12, parts[2][0], parts[2][1])
+        elif md.dca_passes != 1:
             o1, l1 = ops.paged_attention_prefill(torch.zeros_like(out[:n]), q, self.k_cache, self.v_cache,
                                                  md.local_block_table, md.local_seq_lens, qsl, self.scale,
                                                  causal=True, **kw)

@@ -115,11 +115,26 @@ class LlamaAttention(nn.Module):
             # (reference: vllm/model_executor/models/qwen2.py:117-175 passes the same dict to rope and attention)
             from ..layers.attention import DualChunkAttention
             cs, ls = int(dca.get("chunk_size", 8192)), int(dca.get("local_size", 1024))
-            self.rotary_emb = get_rope(self.head_dim, self.head_dim, cs + 1, rope_theta, neox_style, None, partial)
+            # sparse prefill (optional): per layer {head: [kind, vertical lines, slash lines, score]}; its probe
+            # rotations reach position chunk_size + chunk_len
+            sparse, per_layer = None, dca.get("sparse_attention_config")
+            if per_layer and dca.get("sparse_attention_enabled", True):
+                import re
+                layer = int(re.search(r"layers\.(\d+)\.", prefix).group(1))
+                row = {int(h): v for h, v in per_layer[layer].items()}
+                h0 = get_tensor_model_parallel_rank() * self.num_heads
+                if any(row[h][0] != "vertical_and_slash" for h in range(h0, h0 + self.num_heads)):
+                    raise ValueError("sparse attention config: only the vertical_and_slash pattern is served")
+                sparse = dict(heads=[(row[h][1], row[h][2]) for h in range(h0, h0 + self.num_heads)],
+                              threshold=dca.get("sparse_attention_threshold", 32768),
+                              last_q=dca.get("sparse_attention_last_q", 64))
+            self.rotary_emb = get_rope(self.head_dim, self.head_dim, 2 * cs - ls + 1, rope_theta, neox_style, None,
+                                       partial)
             self.attn = DualChunkAttention(
                 self.num_heads, self.head_dim, scale if scale is not None else self.head_dim ** -0.5, self.num_kv_heads,
                 logits_soft_cap=logits_soft_cap, prefix=f"{prefix}.attn", cache_dtype=cache_dtype, chunk_size=cs,
-                local_size=ls, original_max_position_embeddings=int(dca.get("original_max_position_embeddings", 0)))
+                local_size=ls, original_max_position_embeddings=int(dca.get("original_max_position_embeddings", 0)),
+                sparse=sparse)
         else:
             self.attn = Attention(self.num_heads, self.head_dim, scale if scale is not None else self.head_dim ** -0.5,
                                   self.num_kv_heads, alibi_slopes=alibi_slopes, sliding_window=sliding_window,

@@ -292,6 +292,35 @@ def paged_attention_prefill(out, q, k_cache, v_cache, block_table, seq_lens, q_s
     return (out, lse) if return_lse else out
 
 
+def paged_attention_prefill_sparse(out, q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale: float, vert,
+                                   vcount, slash, scount, key_base, q_base, causal: bool = True, softcap: float = 0.0,
+                                   k_scale: float = 1.0, v_scale: float = 1.0, max_keys: int = 0):
+    """Vertical-slash sparse prefill over the paged cache: per (sequence, head) a list of key positions ``vert``
+    [S, Hq, NV] (counts ``vcount`` [S, Hq]) and a list of query-minus-key distances ``slash`` [S, Hq, NS]
+    (``scount``), int32, in absolute positions of the request; ``key_base`` / ``q_base`` [S] give the absolute position
+    of key 0 of the sequence's table and of its first query row.  A 128-row query tile visits the 32-key steps that
+    hold a listed position or that a listed diagonal crosses inside the tile.  Returns (out, lse [Hq, T])."""
+    T, Hq, D = q.shape
+    if not _dev(q):
+        o, lse = R.paged_attention_sparse(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, vert, vcount,
+                                          slash, scount, key_base, q_base, causal, softcap, k_scale, v_scale)
+        out.copy_(o)
+        return out, lse
+    S = seq_lens.shape[0]
+    for t in (vert, vcount, slash, scount, key_base, q_base):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.device == q.device
+    assert vert.shape[:2] == (S, Hq) and slash.shape[:2] == (S, Hq) and vcount.shape == (S, Hq) == scount.shape
+    assert key_base.shape == (S,) == q_base.shape and q.stride(1) == D and out.stride(1) == D
+    lse = torch.full((Hq, T), float("-inf"), dtype=torch.float32, device=q.device)
+    N.call("vda_paged_attention_prefill_sparse", out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+           block_table.data_ptr(), seq_lens.data_ptr(), q_start_loc.data_ptr(), vert.data_ptr(), vcount.data_ptr(),
+           slash.data_ptr(), scount.data_ptr(), key_base.data_ptr(), q_base.data_ptr(), vert.shape[2], slash.shape[2],
+           S, T, Hq, k_cache.shape[1], D, k_cache.shape[2], block_table.stride(0), q.stride(0), out.stride(0), scale,
+           softcap, N.dt(q.dtype), _kv_fp8(k_cache), k_scale, v_scale, int(bool(causal)), lse.data_ptr(),
+           int(max_keys or block_table.shape[1] * k_cache.shape[2]), N.stream())
+    return out, lse
+
+
 def merge_attn_states(prefix, prefix_lse, suffix, suffix_lse, return_lse: bool = False):
     if not _dev(prefix):
         o, l = R.merge_attn_states(prefix, prefix_lse, suffix, suffix_lse)

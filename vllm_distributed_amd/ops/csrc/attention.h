@@ -30,6 +30,19 @@ struct AttnParams {
   int max_q_len;            // longest query run of the batch when the host knows it, else 0 (wide prefill form)
 };
 
+// Key selection of the sparse prefill form: per (sequence, head) a list of single key positions ("vertical" lines of
+// the score matrix) and a list of query-minus-key distances ("slash" lines), both in absolute positions of the
+// request; key_base / q_base place the sequence's table and its first query row on that axis.
+struct SparseSel {
+  const int* vert;      // [S, Hq, NV]
+  const int* vcount;    // [S, Hq]
+  const int* slash;     // [S, Hq, NS]
+  const int* scount;    // [S, Hq]
+  const int* key_base;  // [S]
+  const int* q_base;    // [S]
+  int NV, NS;
+};
+
 // Wide prefill form (attention_prefill.hip): 512 threads, 256 query columns per workgroup, head size 128.
 // Returns -100 when the shape is outside what that kernel serves (the caller then takes the 4-wave form).
 int vda_launch_prefill_wide(const AttnParams& p, int block_size, int dtype, int kv_fp8, hipStream_t st);

@@ -304,8 +304,17 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
 #ifndef PREFILL_WGS_PER_CU
 #define PREFILL_WGS_PER_CU 2
 #endif
-template <typename T, int D, int BS, bool F8>
-__global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_kernel(AttnParams p) {
+//
+// SPARSE: vertical-slash selection for very long prompts.  A workgroup serves 128 query rows of ONE head (the
+// selection is per head, so the rows of a GQA group no longer share their keys) and visits only the 32-key steps that
+// hold a selected key position or that a selected diagonal crosses inside its rows; it marks them in an LDS bitmap
+// built from the two lists when it starts (no index arrays in memory: the reference's block_offset / column_index,
+// csrc/attention/vertical_slash_index.cu:26-150, grow with rows x list length) and walks the set bits in order.
+// Inside a visited step every key is seen (subject to the causal limit), so the pattern is a superset of the exact
+// lines at 32-key granularity.
+constexpr int SPARSE_BM_WORDS = 4096;        // 4096 x 32 steps x 32 keys = 4 Mi keys per table
+template <typename T, int D, int BS, bool F8, bool SPARSE = false>
+__global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_kernel(AttnParams p, SparseSel sp) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   using CT = typename KVElem<T, F8>::type;
@@ -320,8 +329,9 @@ __global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_ker
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int kvh = blockIdx.y;
-  const int G = p.Hq / p.Hkv;
+  const int G = SPARSE ? 1 : p.Hq / p.Hkv;
+  const int kvh = SPARSE ? blockIdx.y / (p.Hq / p.Hkv) : blockIdx.y;
+  const int head0 = SPARSE ? blockIdx.y : kvh * G;        // first query head of this workgroup's columns
 
   const int tile = blockIdx.x;
   int lo = 0, hi = p.num_seqs;
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_ker
     const bool valid = qt < qt_end;
     limit[ct] = valid ? (p.causal ? ctx + qt + 1 : seq_len) : 0;
     lower[ct] = (valid && p.window > 0) ? max(0, limit[ct] - p.window) : 0;
-    const int head = kvh * G + h;
+    const int head = head0 + h;
     slope[ct] = (p.alibi && valid) ? p.alibi[head] : 0.f;
     const T* qp = (const T*)p.q + (long)(qs + (valid ? qt : q0)) * p.q_stride + (long)head * D + g * DQ;
 #pragma unroll
@@ -370,6 +380,35 @@ __global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_ker
   const int wg_hi = p.causal ? ctx + qt_end : seq_len;
   const int wg_lo = p.window > 0 ? max(0, ctx + q0 + 1 - p.window) : 0;
   const int step_lo = wg_lo / 32, step_hi = (wg_hi + 31) / 32;
+
+  __shared__ unsigned bm[SPARSE ? SPARSE_BM_WORDS : 1];
+  if constexpr (SPARSE) {
+    const int nwords = (step_hi + 31) >> 5;
+    for (int i = tid; i < nwords; i += 256) bm[i] = 0u;
+    __syncthreads();
+    auto mark = [&](int a, int b) {            // steps of the keys a..b of this table (clipped to what is visible)
+      a = max(a, 0); b = min(b, wg_hi - 1);
+      for (int s = a >> 5; a <= b && s <= (b >> 5); ++s) atomicOr(&bm[s >> 5], 1u << (s & 31));
+    };
+    const long sh = (long)seq * p.Hq + head0;
+    const int kb = sp.key_base[seq];
+    const int qa0 = sp.q_base[seq] + q0 - kb, qa1 = sp.q_base[seq] + qt_end - 1 - kb;
+    const int nv = min(sp.vcount[sh], sp.NV), ns = min(sp.scount[sh], sp.NS);
+    for (int i = tid; i < nv; i += 256) { const int k = sp.vert[sh * sp.NV + i] - kb; mark(k, k); }
+    for (int i = tid; i < ns; i += 256) { const int d = sp.slash[sh * sp.NS + i]; if (d >= 0) mark(qa0 - d, qa1 - d); }
+    if (p.causal && tid == 0) mark(qa0, qa1);              // a row always sees itself
+    __syncthreads();
+  }
+  // first step >= from that is to be visited (step_hi: none)
+  auto next_step = [&](int from) -> int {
+    if constexpr (!SPARSE) return from;
+    if (from >= step_hi) return step_hi;
+    int w = from >> 5;
+    const int nwords = (step_hi + 31) >> 5;
+    unsigned x = bm[w] & (~0u << (from & 31));
+    while (!x) { if (++w >= nwords) return step_hi; x = bm[w]; }
+    return min(step_hi, (w << 5) + __ffs(x) - 1);
+  };
 
   float m[NCT], l[NCT];
   f32x4 acc[NCT][NT];
@@ -520,6 +559,7 @@ __global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_ker
   };
 
 #if PREFILL_REG_STAGES == 2
+  static_assert(!SPARSE, "the sparse form walks its step list with one register stage");
   // prologue: tile 0 -> LDS buffer 0, tile 1 -> register stage A
   if (step_lo < step_hi) {
     gload(step_lo, rkA, rvA);
@@ -545,17 +585,19 @@ __global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_ker
   // softmax latency is covered by the other wave of its SIMD rather than by a deeper software pipeline).
   // Tile t+1 sits in registers while tile t is consumed, then moves to the other LDS buffer and tile t+2
   // is requested.
-  if (step_lo < step_hi) {
-    gload(step_lo, rkA, rvA);
+  int s0 = next_step(step_lo), s1 = next_step(s0 + 1), s2 = next_step(s1 + 1);
+  if (s0 < step_hi) {
+    gload(s0, rkA, rvA);
     sstore(0, rkA, rvA);
-    if (step_lo + 1 < step_hi) gload(step_lo + 1, rkA, rvA);
+    if (s1 < step_hi) gload(s1, rkA, rvA);
   }
   __syncthreads();
-  for (int step = step_lo, buf = 0; step < step_hi; ++step, buf ^= 1) {
-    compute(step, buf);
-    if (step + 1 < step_hi) sstore(buf ^ 1, rkA, rvA);
-    if (step + 2 < step_hi) gload(step + 2, rkA, rvA);
+  for (int buf = 0; s0 < step_hi; buf ^= 1) {
+    compute(s0, buf);
+    if (s1 < step_hi) sstore(buf ^ 1, rkA, rvA);
+    if (s2 < step_hi) gload(s2, rkA, rvA);
     __syncthreads();
+    s0 = s1; s1 = s2; s2 = next_step(s2 + 1);
   }
 #endif
 
@@ -568,7 +610,7 @@ __global__ __launch_bounds__(256, PREFILL_WGS_PER_CU) void paged_prefill_lds_ker
   for (int ct = 0; ct < NCT; ++ct) {
     if (col_off[ct] < 0) continue;
     const int c = wave * COLS + ct * 16 + r;
-    const int head = kvh * G + c % G;
+    const int head = head0 + c % G;
     const float inv = l[ct] > 0.f ? p.v_scale / l[ct] : 0.f;
     T* op = (T*)p.out + col_off[ct] * p.out_stride + (long)head * D + 4 * g;
 #pragma unroll
@@ -672,7 +714,7 @@ static int launch_attn(const AttnParams& p, int form, int grid_x, hipStream_t st
   } else if (form == 3) {
     dim3 grid(grid_x, p.Hkv, 1);
     if constexpr (D == 64 || D == 128) {          // the LDS tile layout is built for rows of 8 or 16 pieces
-      hipLaunchKernelGGL((paged_prefill_lds_kernel<T, D, BS, F8>), grid, block, 0, st, p);
+      hipLaunchKernelGGL((paged_prefill_lds_kernel<T, D, BS, F8>), grid, block, 0, st, p, SparseSel{});
     } else {
       hipLaunchKernelGGL((paged_attn_kernel<T, D, BS, 2, false, F8>), grid, block, 0, st, p);
     }
@@ -798,6 +840,45 @@ VDA_EXPORT int vda_paged_attention_prefill(
   const int form = g_prefill_variant == 0 ? 2 : 3;
   return dtype == VDA_BF16 ? dispatch_d<bf16_t>(p, D, block_size, form, grid_x, st, kv_fp8)
                            : dispatch_d<f16_t>(p, D, block_size, form, grid_x, st, kv_fp8);
+}
+
+// Sparse (vertical-slash) prefill: the 4-wave LDS form, one head per workgroup, visiting only the selected 32-key
+// steps (see paged_prefill_lds_kernel).  max_keys: the longest table of the batch (sizes the LDS bitmap check).
+template <typename T, int D, bool F8>
+static int launch_sparse(const AttnParams& p, const SparseSel& sp, int bs, dim3 grid, hipStream_t st) {
+  switch (bs) {
+    case 16: hipLaunchKernelGGL((paged_prefill_lds_kernel<T, D, 16, F8, true>), grid, dim3(256), 0, st, p, sp); break;
+    case 32: hipLaunchKernelGGL((paged_prefill_lds_kernel<T, D, 32, F8, true>), grid, dim3(256), 0, st, p, sp); break;
+    case 64: hipLaunchKernelGGL((paged_prefill_lds_kernel<T, D, 64, F8, true>), grid, dim3(256), 0, st, p, sp); break;
+    default: return -2;
+  }
+  VDA_CHECK_LAUNCH();
+  return 0;
+}
+
+VDA_EXPORT int vda_paged_attention_prefill_sparse(
+    void* out, const void* q, const void* k_cache, const void* v_cache, const int* block_table,
+    const int* seq_lens, const int* q_start_loc, const int* vert, const int* vcount, const int* slash,
+    const int* scount, const int* key_base, const int* q_base, int NV, int NS, int num_seqs, int num_tokens,
+    int Hq, int Hkv, int D, int block_size, int max_blocks, long q_stride, long out_stride, float scale,
+    float softcap, int dtype, int kv_fp8, float k_scale, float v_scale, int causal, float* lse_out, long max_keys,
+    hipStream_t st) {
+  if (Hq % Hkv) return -1;
+  if (D != 64 && D != 128) return -3;
+  if (max_keys > (long)SPARSE_BM_WORDS * 32 * 32 || (long)max_blocks * block_size > (long)SPARSE_BM_WORDS * 1024)
+    return -7;
+  AttnParams p{q, k_cache, v_cache, out, nullptr, nullptr, block_table, seq_lens, q_start_loc, nullptr,
+               num_seqs, Hq, Hkv, max_blocks, 1, q_stride, out_stride, scale * (kv_fp8 ? k_scale : 1.f), softcap,
+               kv_fp8 ? v_scale : 1.f, 0, 128, causal, num_tokens, lse_out, 0};
+  SparseSel sp{vert, vcount, slash, scount, key_base, q_base, NV, NS};
+  dim3 grid(num_tokens / 128 + num_seqs, Hq, 1);
+#define SPARSE_GO(TT) \
+  (D == 64 ? (kv_fp8 ? launch_sparse<TT, 64, true>(p, sp, block_size, grid, st)                \
+                     : launch_sparse<TT, 64, false>(p, sp, block_size, grid, st))              \
+           : (kv_fp8 ? launch_sparse<TT, 128, true>(p, sp, block_size, grid, st)               \
+                     : launch_sparse<TT, 128, false>(p, sp, block_size, grid, st)))
+  return dtype == VDA_BF16 ? SPARSE_GO(bf16_t) : SPARSE_GO(f16_t);
+#undef SPARSE_GO
 }
 
 VDA_EXPORT int vda_merge_attn_states(void* out, float* out_lse, const void* pre, const float* pre_lse,

@@ -41,6 +41,7 @@ _SIGS = {
     "vda_paged_attention_decode": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, P],
     "vda_paged_attention_prefill": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, L, L, F, F, I, I, I, F, F, I, P,
                                     I, P],
+    "vda_paged_attention_prefill_sparse": [P] * 13 + [I] * 9 + [L, L, F, F, I, I, F, F, I, P, L, P],
     "vda_set_prefill_variant": [I],
     "vda_int8_quant_azp": [P, P, P, P, P, P, I, I, L, L, I, P],
     "vda_permute_cols": [P, P, P, I, I, L, L, P],

@@ -172,6 +172,59 @@ def paged_attention(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, sca
     return (out, lse) if return_lse else out
 
 
+def sparse_step_selection(vert, vcount, slash, scount, key_base: int, q_base: int, ql: int, sl: int, causal: bool):
+    """Which 32-key steps each 128-row query tile of one sequence visits, per head: bool [Hq, tiles, steps].
+    A step is visited when it holds a selected key position, or when a selected diagonal (query position minus key
+    position) crosses it inside the tile's rows; causal passes always visit the tile's own diagonal."""
+    Hq = vert.shape[0]
+    tiles, steps = (ql + 127) // 128, (sl + 31) // 32
+    sel = torch.zeros((Hq, tiles, steps), dtype=torch.bool, device=vert.device)
+    t = torch.arange(tiles, device=vert.device)
+    qa0 = q_base + t * 128 - key_base                                        # [tiles] first / last row, on the key axis
+    qa1 = q_base + torch.clamp((t + 1) * 128, max=ql) - 1 - key_base
+    for h in range(Hq):
+        k = vert[h, : int(vcount[h])].long() - key_base
+        k = k[(k >= 0) & (k < sl)]
+        sel[h, :, k // 32] = True
+        d = slash[h, : int(scount[h])].long()
+        d = d[d >= 0]
+        bands = [(qa0[:, None] - d[None], qa1[:, None] - d[None])]
+        if causal:
+            bands.append((qa0[:, None], qa1[:, None]))
+        for a, b in bands:
+            a, b = a.clamp(min=0), b.clamp(max=sl - 1)
+            for j in range(6):                                              # a band of <= 128 keys touches <= 5 steps
+                st = a // 32 + j
+                ok = (a <= b) & (st <= b // 32)
+                ti = t[:, None].expand_as(st)[ok]
+                sel[h, ti, st[ok]] = True
+    return sel
+
+
+def paged_attention_sparse(q, k_cache, v_cache, block_table, seq_lens, q_start_loc, scale, vert, vcount, slash, scount,
+                           key_base, q_base, causal: bool = True, softcap: float = 0.0, k_scale: float = 1.0,
+                           v_scale: float = 1.0):
+    """Vertical-slash sparse attention at 32-key granularity (see ``sparse_step_selection``); vert / slash
+    [S, Hq, N] with counts [S, Hq], key_base / q_base [S].  Returns (out [T, Hq, D], lse [Hq, T])."""
+    out = torch.zeros_like(q)
+    lse = torch.full((q.shape[1], q.shape[0]), float("-inf"), dtype=torch.float32, device=q.device)
+    qsl, sls = q_start_loc.tolist(), seq_lens.tolist()
+    for s, sl in enumerate(sls):
+        a, b = qsl[s], qsl[s + 1]
+        if a == b or sl == 0:
+            continue
+        sel = sparse_step_selection(vert[s], vcount[s], slash[s], scount[s], int(key_base[s]), int(q_base[s]), b - a, sl,
+                                    causal)
+
+        def visible(pos, key, sel=sel, lo=sl - (b - a)):
+            return sel[:, (pos[:, 0] - lo) // 128][:, :, key[0] // 32]
+        o, l = paged_attention(q[a:b], k_cache, v_cache, block_table[s:s + 1], seq_lens[s:s + 1],
+                               torch.tensor([0, b - a], dtype=torch.int32, device=q.device), scale, softcap=softcap,
+                               return_lse=True, k_scale=k_scale, v_scale=v_scale, causal=causal, visible=visible)
+        out[a:b], lse[:, a:b] = torch.nan_to_num(o), l
+    return out, lse
+
+
 def merge_attn_states(prefix, prefix_lse, suffix, suffix_lse):
     """prefix/suffix: [T, H, D]; lse: [H, T]."""
     a = torch.where(torch.isposinf(prefix_lse), torch.full_like(prefix_lse, float("-inf")), prefix_lse)
