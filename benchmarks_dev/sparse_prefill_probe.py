@@ -20,11 +20,21 @@ q = torch.randn(S, Hq, D, device=dev, dtype=dt)
 sl = torch.tensor([S], dtype=torch.int32, device=dev)
 qsl = torch.tensor([0, S], dtype=torch.int32, device=dev)
 g = torch.Generator(device="cpu").manual_seed(0)
-vert = torch.randint(0, S, (1, Hq, NV), generator=g).int().to(dev)
-# slash lines cluster near the diagonal in practice: half of them within the nearest 4096 distances
-near = torch.randint(0, 4096, (1, Hq, NS // 2), generator=g)
-far = torch.randint(0, S, (1, Hq, NS - NS // 2), generator=g)
-slash = torch.cat([near, far], -1).int().to(dev)
+MODE = sys.argv[4] if len(sys.argv) > 4 else "random"
+if MODE == "random":        # worst case: every far line lands in steps of its own
+    vert = torch.randint(0, S, (1, Hq, NV), generator=g)
+    near = torch.randint(0, 4096, (1, Hq, NS // 2), generator=g)
+    far = torch.randint(0, S, (1, Hq, NS - NS // 2), generator=g)
+    slash = torch.cat([near, far], -1)
+else:                       # what trained heads show: the first keys, the nearest distances, a few runs of neighbours
+    def runs(total, head_run, run):
+        n = (total - head_run) // run
+        starts = torch.randint(head_run, S - run, (1, Hq, n), generator=g)
+        far = (starts[..., None] + torch.arange(run)).flatten(2)
+        first = torch.arange(total - far.shape[-1]).expand(1, Hq, -1)
+        return torch.cat([first, far], -1)
+    vert, slash = runs(NV, NV // 4, 25), runs(NS, NS // 3, 127)
+vert, slash = vert.int().contiguous().to(dev), slash.int().contiguous().to(dev)
 vcount = torch.full((1, Hq), NV, dtype=torch.int32, device=dev)
 scount = torch.full((1, Hq), NS, dtype=torch.int32, device=dev)
 zero = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -46,5 +56,5 @@ td = timed(lambda: ops.paged_attention_prefill(out, q, kc, vc, bt, sl, qsl, scal
 ts = timed(lambda: ops.paged_attention_prefill_sparse(out, q, kc, vc, bt, sl, qsl, scale, vert, vcount, slash, scount,
                                                       zero, zero))
 flops = 4.0 * S * S / 2 * Hq * D
-print(f"S={S} lines v={NV} s={NS}: dense {td:.1f} ms ({flops / td / 1e9:.0f} TF/s), sparse {ts:.1f} ms "
+print(f"S={S} lines v={NV} s={NS} ({MODE}): dense {td:.1f} ms ({flops / td / 1e9:.0f} TF/s), sparse {ts:.1f} ms "
       f"-> {td / ts:.2f}x", flush=True)
