@@ -1873,3 +1873,87 @@ def test_mllama_matches_hf(tmp_path):
                                eos_token_id=None, pad_token_id=0)[0, 5:].tolist()
     assert list(outs[0].outputs[0].token_ids) == ref
     assert list(outs[1].outputs[0].token_ids) == ref_text
+
+
+def test_florence2_matches_hf(tmp_path):
+    """Florence-2: DaViT tower (window attention with padding, channel-group attention, pre- and post-norm patch
+    convolutions), position / frame embeddings and the two pooled sources, BART encoder over image vectors + prompt,
+    decoder through the slot cache.  Greedy tokens against transformers, in its layout and in the original one."""
+    import json
+    import transformers as tf
+    from safetensors.torch import load_file, save_file
+    torch.manual_seed(0)
+    vc = dict(in_channels=3, depths=[1, 2], patch_size=[7, 3], patch_stride=[4, 2], patch_padding=[3, 1],
+              patch_prenorm=[False, True], embed_dim=[32, 64], num_heads=[2, 4], num_groups=[2, 4], window_size=3,
+              projection_dim=128, max_temporal_embeddings=10, max_position_embeddings=20, drop_path_rate=0.0)
+    tc = dict(model_type="bart", vocab_size=200, d_model=128, encoder_layers=2, decoder_layers=2,
+              encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=64, decoder_ffn_dim=64,
+              max_position_embeddings=128, pad_token_id=1, bos_token_id=0, eos_token_id=2, decoder_start_token_id=2,
+              forced_eos_token_id=None)
+    cfg = tf.Florence2Config(vision_config=vc, text_config=tc, image_token_id=199)
+    hf = tf.Florence2ForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for p in hf.parameters():
+            if p.dim() >= 2:
+                p.mul_(3.0)
+    hf = hf.float().eval()
+    path = os.path.join(str(tmp_path), "florence2")
+    hf.save_pretrained(path, safe_serialization=True)
+    g = torch.Generator().manual_seed(7)
+    px = torch.randn(3, 40, 32, generator=g)                                  # 10 x 8 -> 5 x 4 positions (+ 1 pooled)
+    text = [0, 17, 45, 108, 9, 2]
+    with torch.no_grad():
+        ref = hf.generate(input_ids=torch.tensor([[199] * 21 + text]), pixel_values=px[None], max_new_tokens=8,
+                          do_sample=False, num_beams=1, eos_token_id=None, pad_token_id=1)[0, 1:].tolist()
+        ref_text = hf.generate(input_ids=torch.tensor([text]), max_new_tokens=8, do_sample=False, num_beams=1,
+                               eos_token_id=None, pad_token_id=1)[0, 1:].tolist()
+
+    def run(model_path):
+        llm = LLM(model=model_path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128,
+                  max_num_seqs=4, block_size=16)
+        outs = llm.generate([{"prompt_token_ids": text, "multi_modal_data": {"image": px}},
+                             {"prompt_token_ids": text}], SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+        llm.shutdown()
+        return [list(o.outputs[0].token_ids) for o in outs]
+    assert run(path) == [ref, ref_text]
+
+    # the original checkpoint layout (what the reference reads)
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    swaps = ((".conv1.", ".conv1.fn.dw."), (".conv2.", ".conv2.fn.dw."), (".window_attn.", ".window_attn.fn."),
+             (".channel_attn.", ".channel_attn.fn."), (".ffn.", ".ffn.fn.net."))
+    old = {}
+    for n, t in sd.items():
+        n = n[len("model."):] if n.startswith("model.") else n
+        if n.startswith("language_model."):
+            n = "language_model.model." + n[len("language_model."):]
+        elif n == "lm_head.weight":
+            n = "language_model.lm_head.weight"
+        elif n.startswith("vision_tower.blocks."):
+            kind = "window_attn" if ".spatial_block." in n else "channel_attn"
+            n = n.replace(".norm1.", f".{kind}.norm.").replace(".norm2.", ".ffn.norm.") if ".norm" in n else n
+            if ".norm." not in n:
+                for a, b in swaps:
+                    n = n.replace(a, b)
+        elif n.startswith("vision_tower.convs."):
+            n = n.replace(".conv.", ".proj.")
+        elif n == "multi_modal_projector.image_projection.weight":
+            n, t = "image_projection", t.t().contiguous()
+        elif n.startswith("multi_modal_projector.image_proj_norm."):
+            n = n[len("multi_modal_projector."):]
+        elif n.startswith("multi_modal_projector.image_position_embed."):
+            n = "image_pos_embed." + n[len("multi_modal_projector.image_position_embed."):]
+        elif n.endswith("pos_idx_to_embed"):
+            n = "visual_temporal_embed.pos_idx_to_embed"
+        old[n] = t.contiguous()
+    path2 = os.path.join(str(tmp_path), "florence2_orig")
+    os.makedirs(path2)
+    save_file(old, os.path.join(path2, "model.safetensors"))
+    cj = json.load(open(os.path.join(path, "config.json")))
+    v = cj["vision_config"]
+    v["dim_embed"] = v.pop("embed_dim")
+    v["image_pos_embed"] = {"type": "learned_abs_2d", "max_pos_embeddings": v.pop("max_position_embeddings")}
+    v["visual_temporal_embedding"] = {"type": "COSINE", "max_temporal_embeddings": v.pop("max_temporal_embeddings")}
+    v["image_feature_source"] = ["spatial_avg_pool", "temporal_avg_pool"]
+    cj["projection_dim"] = v["projection_dim"]
+    json.dump(cj, open(os.path.join(path2, "config.json"), "w"))
+    assert run(path2) == [ref, ref_text]

@@ -330,13 +330,15 @@ class ModelConfig:
                          "MiniMaxForCausalLM", "MiniMaxText01ForCausalLM", "MiniMaxM1ForCausalLM", "FalconH1ForCausalLM", "MiniMaxVL01ForConditionalGeneration",
                          # encoder-decoder: the cross-attention cache is per-request state of the same kind
                          "WhisperForConditionalGeneration", "BartForConditionalGeneration", "BartModel",
-                         "MllamaForConditionalGeneration", "Zamba2ForCausalLM", "Plamo2ForCausalLM")
+                         "MllamaForConditionalGeneration", "Zamba2ForCausalLM", "Plamo2ForCausalLM",
+                         "Florence2ForConditionalGeneration")
                    for a in self.architectures)
 
     @property
     def is_text_encoder_decoder(self) -> bool:
         """Encoder-decoder over text: a request's plain prompt is the encoder's input."""
-        return any(a in ("BartForConditionalGeneration", "BartModel") for a in self.architectures)
+        return any(a in ("BartForConditionalGeneration", "BartModel", "Florence2ForConditionalGeneration")
+                   for a in self.architectures)
 
     def get_total_num_attention_heads(self) -> int:
         if self.is_attention_free:

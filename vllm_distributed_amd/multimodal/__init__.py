@@ -606,3 +606,11 @@ def _mllama(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("MllamaForConditionalGeneration", _mllama)
+
+
+def _florence2(vllm_config):
+    from ..models.florence2 import florence2_processor
+    return florence2_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("Florence2ForConditionalGeneration", _florence2)
