@@ -1957,3 +1957,137 @@ def test_florence2_matches_hf(tmp_path):
     cj["projection_dim"] = v["projection_dim"]
     json.dump(cj, open(os.path.join(path2, "config.json"), "w"))
     assert run(path2) == [ref, ref_text]
+
+
+def test_keye_tower_projector_and_engine(tmp_path):
+    """Keye-VL (parity unpinned): the NaViT SigLIP tower and the 2 x 2 projector against the arithmetic written out
+    (separate q / k / v, complex rotations, per-head loops); then through the engine: a text-only request follows
+    transformers' Qwen3, an image request equals the decoder run on the hand-assembled embeddings."""
+    import json
+    import math
+    import torch.nn.functional as F
+    import transformers as tf
+    from safetensors.torch import save_file
+    torch.manual_seed(0)
+    tcfg = tf.Qwen3Config(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                          num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=512,
+                          tie_word_embeddings=False,
+                          rope_parameters={"rope_type": "default", "rope_theta": 10000.0, "mrope_section": [8, 12, 12]})
+    lm = tf.Qwen3ForCausalLM(tcfg).float().eval()
+    V, H, L, P, S = 32, 2, 2, 14, 4                                            # tower width, heads, layers, patch, table side
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.3                          # noqa: E731
+    sd = {"model." + k if not k.startswith("lm_head") else k: v for k, v in
+          {k[len("model."):] if k.startswith("model.") else k: v for k, v in lm.state_dict().items()}.items()}
+    vp = "visual.vision_model."
+    sd.update({vp + "embeddings.patch_embedding.weight": r(V, 3, P, P), vp + "embeddings.patch_embedding.bias": r(V),
+               vp + "embeddings.position_embedding.weight": r(S * S, V),
+               vp + "embeddings.packing_position_embedding.weight": r(8, V),
+               vp + "post_layernorm.weight": 1 + r(V) * 0.1, vp + "post_layernorm.bias": r(V) * 0.1,
+               vp + "head.probe": r(1, 1, V),
+               "mlp_AR.pre_norm.weight": 1 + r(V) * 0.1, "mlp_AR.pre_norm.bias": r(V) * 0.1,
+               "mlp_AR.linear_1.weight": r(4 * V, 4 * V), "mlp_AR.linear_1.bias": r(4 * V),
+               "mlp_AR.linear_2.weight": r(128, 4 * V), "mlp_AR.linear_2.bias": r(128)})
+    for i in range(L):
+        lp = f"{vp}encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[lp + f"self_attn.{n}.weight"], sd[lp + f"self_attn.{n}.bias"] = r(V, V), r(V) * 0.1
+        for n in ("layer_norm1", "layer_norm2"):
+            sd[lp + n + ".weight"], sd[lp + n + ".bias"] = 1 + r(V) * 0.1, r(V) * 0.1
+        sd[lp + "mlp.fc1.weight"], sd[lp + "mlp.fc1.bias"] = r(48, V), r(48) * 0.1
+        sd[lp + "mlp.fc2.weight"], sd[lp + "mlp.fc2.bias"] = r(V, 48), r(V) * 0.1
+    path = os.path.join(str(tmp_path), "keye")
+    os.makedirs(path)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    cj = tcfg.to_dict()
+    cj.update(architectures=["KeyeForConditionalGeneration"], model_type="Keye", image_token_id=300, video_token_id=301,
+              rope_scaling={"type": "mrope", "mrope_section": [8, 12, 12]}, rope_theta=10000.0,
+              vision_config=dict(hidden_size=V, num_attention_heads=H, num_hidden_layers=L, intermediate_size=48,
+                                 patch_size=P, image_size=P * S, num_channels=3, hidden_act="gelu_pytorch_tanh",
+                                 layer_norm_eps=1e-6))
+    cj.pop("rope_parameters", None)
+    json.dump(cj, open(os.path.join(path, "config.json"), "w"))
+
+    def tower(px, t, h, w):                                                     # px [t * h * w, 3 * P * P] row-major
+        x = px @ sd[vp + "embeddings.patch_embedding.weight"].reshape(V, -1).t() + sd[vp + "embeddings.patch_embedding.bias"]
+        tab = sd[vp + "embeddings.position_embedding.weight"].view(1, S, S, V).permute(0, 3, 1, 2)
+        pos = F.interpolate(tab, size=(h, w), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).reshape(h * w, V)
+        x = x + pos.repeat(t, 1)
+        hd = V // H
+        freq = 1.0 / 10000.0 ** (torch.arange(hd // 4).float() * 2 / (hd // 2))
+        N = t * h * w
+        rot = torch.zeros(N, hd // 2, dtype=torch.complex64)
+        for n in range(N):
+            row, col = (n % (h * w)) // w, n % w
+            rot[n] = torch.polar(torch.ones(hd // 2), torch.cat([row * freq, col * freq]))
+        for i in range(L):
+            lp = f"{vp}encoder.layers.{i}."
+            hcur = F.layer_norm(x, (V,), sd[lp + "layer_norm1.weight"], sd[lp + "layer_norm1.bias"], 1e-6)
+            heads = []
+            for hh in range(H):
+                sl = slice(hh * hd, (hh + 1) * hd)
+                q, k, v = (hcur @ sd[lp + f"self_attn.{n}.weight"][sl].t() + sd[lp + f"self_attn.{n}.bias"][sl]
+                           for n in ("q_proj", "k_proj", "v_proj"))
+                def turn(a):                                                      # pairs (i, i + hd / 2)
+                    c = torch.complex(a[:, : hd // 2], a[:, hd // 2:]) * rot
+                    return torch.cat([c.real, c.imag], -1)
+                att = torch.softmax(turn(q) @ turn(k).t() / math.sqrt(hd), -1)
+                heads.append(att @ v)
+            x = x + torch.cat(heads, -1) @ sd[lp + "self_attn.out_proj.weight"].t() + sd[lp + "self_attn.out_proj.bias"]
+            hcur = F.layer_norm(x, (V,), sd[lp + "layer_norm2.weight"], sd[lp + "layer_norm2.bias"], 1e-6)
+            hcur = F.gelu(hcur @ sd[lp + "mlp.fc1.weight"].t() + sd[lp + "mlp.fc1.bias"], approximate="tanh")
+            x = x + hcur @ sd[lp + "mlp.fc2.weight"].t() + sd[lp + "mlp.fc2.bias"]
+        x = F.layer_norm(x, (V,), sd[vp + "post_layernorm.weight"], sd[vp + "post_layernorm.bias"], 1e-6)
+        x = F.layer_norm(x, (V,), sd["mlp_AR.pre_norm.weight"], sd["mlp_AR.pre_norm.bias"], 1e-5)
+        out = []
+        for tt in range(t):
+            for a in range(h // 2):
+                for b in range(w // 2):
+                    idx = [tt * h * w + (2 * a + da) * w + 2 * b + db for da in range(2) for db in range(2)]
+                    out.append(torch.cat([x[j] for j in idx]))
+        y = torch.stack(out) @ sd["mlp_AR.linear_1.weight"].t() + sd["mlp_AR.linear_1.bias"]
+        return F.gelu(y) @ sd["mlp_AR.linear_2.weight"].t() + sd["mlp_AR.linear_2.bias"]
+
+    img = (torch.rand(56, 84, 3, generator=g) * 255).to(torch.uint8).numpy()    # already a multiple of 28: 4 x 6 patches
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=4,
+              block_size=16, mm_processor_kwargs={"min_pixels": 28 * 28})
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    proc = __import__("vllm_distributed_amd.multimodal", fromlist=["x"]).MULTIMODAL_REGISTRY.get_processor(
+        llm.llm_engine.vllm_config)
+    ids, inputs, _, ranges = proc([5, 300, 17, 45], {"image": img})
+    assert ids == [5] + [300] * 6 + [17, 45] and (ranges[0].offset, ranges[0].length) == (1, 6)
+    px, grid = inputs[0]
+    assert grid.tolist() == [1, 4, 6] and px.shape == (24, 3 * P * P)
+    t0 = torch.as_tensor(img).permute(2, 0, 1).float() / 255.0
+    assert torch.allclose(px[7].view(3, P, P), ((t0 - 0.5) / 0.5)[:, P:2 * P, P:2 * P], atol=1e-6)   # row 1, column 1
+    with torch.no_grad():
+        got = model.encode_mm_items([[px, grid]])[0]
+        want = tower(px, 1, 4, 6)
+    torch.testing.assert_close(got, want, atol=2e-4, rtol=2e-4)
+    vid = (torch.rand(2, 56, 56, 3, generator=g) * 255).to(torch.uint8).numpy()
+    vids, vin, _, vr = proc([301, 9], {"video": vid})
+    assert vin[0][1].tolist() == [2, 4, 4] and vr[0].length == 8
+    with torch.no_grad():
+        torch.testing.assert_close(model.encode_mm_items([vin[0]])[0], tower(vin[0][0], 2, 4, 4), atol=2e-4, rtol=2e-4)
+
+    # a 28 x 28 image is one token after the projector: its three position axes coincide, so transformers' Qwen3
+    # (plain positions) serves as the decoder reference for the merged embeddings; multi-axis positions are the
+    # inherited Qwen2-VL rule, tested with that family
+    small = (torch.rand(28, 28, 3, generator=g) * 255).to(torch.uint8).numpy()
+    sid, sin_, _, _ = proc([5, 300, 17, 45], {"image": small})
+    assert sid == [5, 300, 17, 45] and sin_[0][1].tolist() == [1, 2, 2]
+    outs = llm.generate([{"prompt_token_ids": [5, 300, 17, 45], "multi_modal_data": {"image": small}},
+                         {"prompt_token_ids": [5, 9, 17, 45, 77]},
+                         {"prompt_token_ids": [5, 300, 17, 45], "multi_modal_data": {"image": img}}],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    llm.shutdown()
+    with torch.no_grad():
+        ref_text = lm.generate(torch.tensor([[5, 9, 17, 45, 77]]), max_new_tokens=6, do_sample=False,
+                               eos_token_id=None, pad_token_id=0)[0, 5:].tolist()
+        emb = lm.model.embed_tokens(torch.tensor([sid]))
+        emb[0, 1] = tower(sin_[0][0], 1, 2, 2)[0]
+        ref_img = lm.generate(inputs_embeds=emb, max_new_tokens=6, do_sample=False, eos_token_id=None,
+                              pad_token_id=0)[0].tolist()
+    assert list(outs[1].outputs[0].token_ids) == ref_text
+    assert list(outs[0].outputs[0].token_ids) == ref_img
+    assert len(outs[2].outputs[0].token_ids) == 6

@@ -614,3 +614,11 @@ def _florence2(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("Florence2ForConditionalGeneration", _florence2)
+
+
+def _keye(vllm_config):
+    from ..models.keye import keye_processor
+    return keye_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("KeyeForConditionalGeneration", _keye)
