@@ -2091,3 +2091,222 @@ def test_keye_tower_projector_and_engine(tmp_path):
     assert list(outs[1].outputs[0].token_ids) == ref_text
     assert list(outs[0].outputs[0].token_ids) == ref_img
     assert len(outs[2].outputs[0].token_ids) == 6
+
+
+def test_molmo_backbone_layout_and_engine(tmp_path):
+    """Molmo (parity unpinned): tower + 2 x 2 attention pooling + projector against the arithmetic written out; the
+    crop / token layout against properties that follow from its definition (every pooled vector inside the used
+    region is used exactly once, rows read across crops); the decoder (fused att_proj, [up | gate] ff_proj, 128
+    extra embedding rows) against transformers' Qwen2 on a text-only prompt and on hand-assembled embeddings."""
+    import json
+    import math
+    import torch.nn.functional as F
+    import transformers as tf
+    from safetensors.torch import save_file
+    from vllm_distributed_amd.models.molmo import crops_and_layout, select_tiling
+    torch.manual_seed(0)
+    E, D, FF = 300, 128, 96
+    tcfg = tf.Qwen2Config(vocab_size=E + 128, hidden_size=D, intermediate_size=FF, num_hidden_layers=2,
+                          num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=2048,
+                          tie_word_embeddings=False, rope_parameters={"rope_type": "default", "rope_theta": 10000.0})
+    lm = tf.Qwen2ForCausalLM(tcfg).float().eval()
+    hsd = lm.state_dict()
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.2                          # noqa: E731
+    V = dict(size=56, patch=14, dim=32, heads=2, layers=10, mlp=48, num_pos=17, eps=1e-5)    # 4 x 4 patches, 2 x 2 pooled
+    sd = {"model.transformer.wte.embedding": hsd["model.embed_tokens.weight"][:E],
+          "model.transformer.wte.new_embedding": hsd["model.embed_tokens.weight"][E:],
+          "model.transformer.ln_f.weight": hsd["model.norm.weight"],
+          "model.transformer.ff_out.weight": hsd["lm_head.weight"][:E]}
+    for i in range(2):
+        a, b = f"model.layers.{i}.", f"model.transformer.blocks.{i}."
+        sd[b + "att_proj.weight"] = torch.cat([hsd[a + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        sd[b + "att_proj.bias"] = torch.cat([hsd[a + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        sd[b + "attn_out.weight"] = hsd[a + "self_attn.o_proj.weight"]
+        sd[b + "ff_proj.weight"] = torch.cat([hsd[a + "mlp.up_proj.weight"], hsd[a + "mlp.gate_proj.weight"]], 0)
+        sd[b + "ff_out.weight"] = hsd[a + "mlp.down_proj.weight"]
+        sd[b + "attn_norm.weight"], sd[b + "ff_norm.weight"] = hsd[a + "input_layernorm.weight"], \
+            hsd[a + "post_attention_layernorm.weight"]
+    vb = "model.vision_backbone."
+    d = V["dim"]
+    sd.update({vb + "image_vit.class_embedding": r(d), vb + "image_vit.positional_embedding": r(17, d),
+               vb + "image_vit.patch_embedding.weight": r(d, 588), vb + "image_vit.pre_ln.weight": 1 + r(d) * 0.1,
+               vb + "image_vit.pre_ln.bias": r(d) * 0.1, vb + "pad_embed": r(2, 2 * d)})
+    for i in range(V["layers"]):
+        p = f"{vb}image_vit.transformer.resblocks.{i}."
+        for n in ("wq", "wk", "wv", "wo"):
+            sd[p + f"attention.{n}.weight"], sd[p + f"attention.{n}.bias"] = r(d, d), r(d) * 0.1
+        sd[p + "feed_forward.w1.weight"], sd[p + "feed_forward.w1.bias"] = r(48, d), r(48) * 0.1
+        sd[p + "feed_forward.w2.weight"], sd[p + "feed_forward.w2.bias"] = r(d, 48), r(d) * 0.1
+        for n in ("attention_norm", "ffn_norm"):
+            sd[p + n + ".weight"], sd[p + n + ".bias"] = 1 + r(d) * 0.1, r(d) * 0.1
+    for n, shape in (("wq", (d, 2 * d)), ("wk", (d, 2 * d)), ("wv", (d, 2 * d)), ("wo", (d, d))):
+        sd[vb + f"image_pooling_2d.{n}.weight"], sd[vb + f"image_pooling_2d.{n}.bias"] = r(*shape), r(d) * 0.1
+    sd[vb + "image_projector.w1.weight"], sd[vb + "image_projector.w3.weight"] = r(FF, d), r(FF, d)
+    sd[vb + "image_projector.w2.weight"] = r(D, FF)
+    path = os.path.join(str(tmp_path), "molmo")
+    os.makedirs(path)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    cj = dict(architectures=["MolmoForCausalLM"], model_type="molmo", vocab_size=E, embedding_size=E, hidden_size=D,
+              intermediate_size=2 * FF, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+              max_position_embeddings=2048, rope_theta=10000.0, layer_norm_eps=1e-6, layer_norm_type="rms",
+              qkv_bias=True, attention_layer_norm=False, norm_after=False, weight_tying=False, torch_dtype="float32",
+              vision_backbone=V, image_start_token_id=E, image_end_token_id=E + 1, image_patch_token_id=E + 2,
+              image_col_token_id=E + 3)
+    json.dump(cj, open(os.path.join(path, "config.json"), "w"))
+
+    # ---- layout -------------------------------------------------------------------------------------------------
+    assert select_tiling(100, 100, 224, 12) == (1, 1) and select_tiling(300, 700, 224, 12) == (2, 4)
+    assert select_tiling(5000, 5000, 224, 12) == (3, 4) or select_tiling(5000, 5000, 224, 12) == (3, 3)
+    img = torch.rand(3, 500, 900, generator=g)
+    patches, mask, order, rows, cols = crops_and_layout(img)                  # the released geometry: 336 / 14 / 4 + 4
+    th, tw = select_tiling(500 - 112, 900 - 112, 224, 12)
+    assert patches.shape == (1 + th * tw, 576, 588) and mask.shape == (1 + th * tw, 576)
+    assert (rows, cols) == ((th * 16 + 8 + 1) // 2, (tw * 16 + 8 + 1) // 2) and order.numel() == 144 + rows * cols
+    assert order[:144].tolist() == list(range(144)) and order.unique().numel() == order.numel()
+    crop, posn = (order[144:] - 144) // 144, (order[144:] - 144) % 144
+    grid_c = crop.view(rows, cols)
+    assert (grid_c[0] // tw == 0).all() and (grid_c[-1] // tw == th - 1).all()       # top / bottom rows of crops
+    assert (grid_c[:, 0] % tw == 0).all() and (grid_c[:, -1] % tw == tw - 1).all()
+    # inside one crop the used block is contiguous; an inner crop starts 2 pooled positions in (its 4-patch margin)
+    y, x = posn.view(rows, cols) // 12, posn.view(rows, cols) % 12
+    assert int(x[0, 0]) == 0 and int(y[0, 0]) == 0
+    if tw > 1:
+        first_of_second = (grid_c[0] == 1).nonzero()[0, 0]
+        assert int(x[0, first_of_second]) == 2 and int(first_of_second) == 10          # 4 + 16 patches -> 10 pooled
+    assert mask[-1].eq(-1).all() and mask[:-1].min() >= 0 and mask[:-1].max() == 1
+
+    # ---- tower, pooling, projector ----------------------------------------------------------------------------------
+    def backbone(images, masks):
+        T = images.shape[0]
+        x = images @ sd[vb + "image_vit.patch_embedding.weight"].t()
+        x = torch.cat([sd[vb + "image_vit.class_embedding"].expand(T, 1, d), x], 1) + sd[vb + "image_vit.positional_embedding"]
+        x = F.layer_norm(x, (d,), sd[vb + "image_vit.pre_ln.weight"], sd[vb + "image_vit.pre_ln.bias"], 1e-5)
+
+        def mha(pre, q_in, kv_in, heads=2):
+            q, k, v = (t @ sd[pre + f"{n}.weight"].t() + sd[pre + f"{n}.bias"] for n, t in
+                       (("wq", q_in), ("wk", kv_in), ("wv", kv_in)))
+            outs = []
+            for hh in range(heads):
+                sl = slice(hh * d // heads, (hh + 1) * d // heads)
+                att = torch.softmax(q[..., sl] @ k[..., sl].transpose(-1, -2) / math.sqrt(d // heads), -1)
+                outs.append(att @ v[..., sl])
+            return torch.cat(outs, -1) @ sd[pre + "wo.weight"].t() + sd[pre + "wo.bias"]
+        states = []
+        for i in range(V["layers"]):
+            p = f"{vb}image_vit.transformer.resblocks.{i}."
+            h = F.layer_norm(x, (d,), sd[p + "attention_norm.weight"], sd[p + "attention_norm.bias"], 1e-5)
+            x = x + mha(p + "attention.", h, h)
+            h = F.layer_norm(x, (d,), sd[p + "ffn_norm.weight"], sd[p + "ffn_norm.bias"], 1e-5)
+            h = h @ sd[p + "feed_forward.w1.weight"].t() + sd[p + "feed_forward.w1.bias"]
+            x = x + (h * torch.sigmoid(1.702 * h)) @ sd[p + "feed_forward.w2.weight"].t() + sd[p + "feed_forward.w2.bias"]
+            states.append(x)
+        f = torch.cat([states[-2], states[-9]], -1)[:, 1:]
+        pe = sd[vb + "pad_embed"]
+        f = f + pe[0] * (masks == 0).float()[..., None] + pe[1] * ((masks < 1) & (masks != 0)).float()[..., None]
+        out = []
+        for t in range(T):
+            for a in range(2):
+                for b in range(2):
+                    blk = torch.stack([f[t, (2 * a + da) * 4 + 2 * b + db] for da in range(2) for db in range(2)])
+                    out.append(mha(vb + "image_pooling_2d.", blk.mean(0, keepdim=True), blk)[0])
+        o = torch.stack(out).view(T, 4, d)
+        w1, w3, w2 = (sd[vb + f"image_projector.{n}.weight"] for n in ("w1", "w3", "w2"))
+        return (F.silu(o @ w1.t()) * (o @ w3.t())) @ w2.t()
+
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              block_size=16, mm_processor_kwargs={"max_crops": 4, "overlap_margins": [2, 0]})
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    small = torch.rand(3, 60, 100, generator=g)
+    pt, mk, od, rr, cc = crops_and_layout(small, 4, 56, 14, (2, 0))
+    with torch.no_grad():
+        got = model.vision_backbone(pt, mk)
+    torch.testing.assert_close(got, backbone(pt, mk), atol=2e-4, rtol=2e-4)
+
+    # ---- engine -----------------------------------------------------------------------------------------------------
+    text = [5, 17, 45, 108, 9]
+    pre = {"images": pt, "image_masks": mk,
+           "image_input_idx": torch.full((pt.shape[0], 4), -100, dtype=torch.long)}
+    # the checkpoint's own processor output: vector k of crop c lands on prompt position image_input_idx[c, k]
+    prompt = [5, E] + [E + 2, E + 2, E + 3] * 2 + [E + 1, 17, 45]
+    patch_pos = [i for i, t in enumerate(prompt) if t == E + 2]
+    pre["image_input_idx"][0] = torch.tensor(patch_pos)
+    outs = llm.generate([{"prompt_token_ids": text},
+                         {"prompt_token_ids": prompt, "multi_modal_data": {"image": pre}},
+                         {"prompt_token_ids": [5, E + 2, 17, 45], "multi_modal_data": {"image": small}}],
+                        SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+    llm.shutdown()
+    with torch.no_grad():
+        def greedy(cur):                                                      # the head has only the first E rows
+            toks = []
+            for _ in range(6):
+                toks.append(int(lm(inputs_embeds=cur).logits[0, -1, :E].argmax()))
+                cur = torch.cat([cur, lm.model.embed_tokens(torch.tensor([[toks[-1]]]))], 1)
+            return toks
+        ref_text = greedy(lm.model.embed_tokens(torch.tensor([text])))
+        emb = lm.model.embed_tokens(torch.tensor([prompt]))
+        emb[0, patch_pos] = backbone(pt, mk)[0]
+        ref_img = greedy(emb)
+    assert list(outs[0].outputs[0].token_ids) == ref_text
+    assert list(outs[1].outputs[0].token_ids) == ref_img
+    # the raw image: brackets, rows closed by column tokens, vectors placed by ``order``
+    full = [5, E] + ([E + 2] * 2 + [E + 3]) * 2 + [E + 1, E] + ([E + 2] * cc + [E + 3]) * rr + [E + 1, 17, 45]
+    with torch.no_grad():
+        emb = lm.model.embed_tokens(torch.tensor([full]))
+        spots = [i for i, t in enumerate(full) if t == E + 2]
+        emb[0, spots] = backbone(pt, mk).flatten(0, 1)[od]
+        ref_raw = greedy(emb)
+    assert list(outs[2].outputs[0].token_ids) == ref_raw
+
+
+def test_molmo_norm_after_variant_follows_olmo2(tmp_path):
+    """The OLMo-based Molmo decoder (norms behind attention and MLP, full-width q / k norms, no biases) is OLMo-2's
+    block: a text-only prompt must follow transformers' Olmo2 with the weights renamed to Molmo's layout."""
+    import json
+    import transformers as tf
+    from safetensors.torch import save_file
+    torch.manual_seed(0)
+    E, D, FF = 300, 128, 96
+    cfg = tf.Olmo2Config(vocab_size=E + 128, hidden_size=D, intermediate_size=FF, num_hidden_layers=2,
+                         num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-6,
+                         tie_word_embeddings=False, rope_parameters={"rope_type": "default", "rope_theta": 10000.0})
+    lm = tf.Olmo2ForCausalLM(cfg).float().eval()
+    with torch.no_grad():
+        for n, p in lm.named_parameters():
+            if "norm" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+    h = lm.state_dict()
+    sd = {"model.transformer.wte.embedding": h["model.embed_tokens.weight"][:E],
+          "model.transformer.wte.new_embedding": h["model.embed_tokens.weight"][E:],
+          "model.transformer.ln_f.weight": h["model.norm.weight"], "model.transformer.ff_out.weight": h["lm_head.weight"][:E]}
+    for i in range(2):
+        a, b = f"model.layers.{i}.", f"model.transformer.blocks.{i}."
+        sd[b + "att_proj.weight"] = torch.cat([h[a + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        sd[b + "attn_out.weight"] = h[a + "self_attn.o_proj.weight"]
+        sd[b + "q_norm.weight"], sd[b + "k_norm.weight"] = h[a + "self_attn.q_norm.weight"], h[a + "self_attn.k_norm.weight"]
+        sd[b + "ff_proj.weight"] = torch.cat([h[a + "mlp.up_proj.weight"], h[a + "mlp.gate_proj.weight"]], 0)
+        sd[b + "ff_out.weight"] = h[a + "mlp.down_proj.weight"]
+        sd[b + "attn_norm.weight"] = h[a + "post_attention_layernorm.weight"]
+        sd[b + "ff_norm.weight"] = h[a + "post_feedforward_layernorm.weight"]
+    path = os.path.join(str(tmp_path), "molmo_o")
+    os.makedirs(path)
+    V = dict(size=56, patch=14, dim=32, heads=2, layers=10, mlp=48, num_pos=17, eps=1e-5)
+    from vllm_distributed_amd.models.molmo import MolmoVisionBackbone
+    sd.update({"model.vision_backbone." + k: v for k, v in MolmoVisionBackbone(D, FF, V).state_dict().items()})
+    json.dump(dict(architectures=["MolmoForCausalLM"], model_type="molmo", vocab_size=E, embedding_size=E, hidden_size=D,
+                   intermediate_size=2 * FF, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                   max_position_embeddings=512, rope_theta=10000.0, layer_norm_eps=1e-6, layer_norm_type="rms",
+                   qkv_bias=False, attention_layer_norm=True, norm_after=True, weight_tying=False,
+                   torch_dtype="float32", vision_backbone=V), open(os.path.join(path, "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=128, max_num_seqs=2,
+              block_size=16, load_format="auto")
+    text = [5, 17, 45, 108, 9]
+    out = llm.generate([{"prompt_token_ids": text}], SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))[0]
+    llm.shutdown()
+    with torch.no_grad():
+        cur, ref = torch.tensor([text]), []
+        for _ in range(6):
+            ref.append(int(lm(cur).logits[0, -1, :E].argmax()))
+            cur = torch.cat([cur, torch.tensor([[ref[-1]]])], 1)
+    assert list(out.outputs[0].token_ids) == ref

@@ -145,6 +145,9 @@ class Processor:
             hf = self.model_config.hf_config
             marks = {int(v) for k, v in hf.to_dict().items()
                      if k.endswith(("_token_id", "_token_index")) and isinstance(v, int) and not isinstance(v, bool)}
+            if "MolmoForCausalLM" in (self.model_config.architectures or []):
+                # its image bracket / patch / column tokens live in 128 embedding rows the head does not have
+                V = int(hf.get("embedding_size") or V) + 128
             if min(ids) < 0 or any(t >= V and t not in marks for t in ids):
                 raise ValueError(f"token id {mx} is out of vocabulary (size {V})")
         max_len = self.model_config.max_model_len

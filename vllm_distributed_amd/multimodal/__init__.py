@@ -622,3 +622,11 @@ def _keye(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("KeyeForConditionalGeneration", _keye)
+
+
+def _molmo(vllm_config):
+    from ..models.molmo import molmo_processor
+    return molmo_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("MolmoForCausalLM", _molmo)
