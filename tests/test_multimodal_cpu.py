@@ -2310,3 +2310,114 @@ def test_molmo_norm_after_variant_follows_olmo2(tmp_path):
             ref.append(int(lm(cur).logits[0, -1, :E].argmax()))
             cur = torch.cat([cur, torch.tensor([[ref[-1]]])], 1)
     assert list(out.outputs[0].token_ids) == ref
+
+
+def _tiny_phi4mm(tmp_path, name="phi4mm"):
+    import transformers as tf
+    torch.manual_seed(0)
+    vc = dict(hidden_size=32, intermediate_size=48, num_hidden_layers=3, num_attention_heads=2, image_size=56,
+              patch_size=14, crop_size=56, feature_layer=-2, image_token_id=300)
+    ac = dict(hidden_size=32, intermediate_size=48, num_blocks=2, num_attention_heads=2, input_size=80,
+              nemo_conv_channels=8, nemo_final_size=10, time_reduction=8, ext_pw_out_channel=32,
+              depthwise_separable_out_channel=32, kernel_size=3, bias_max_distance=10, chunk_size=-1, left_chunk=18,
+              downsample_rate=1, audio_token_id=301)
+    cfg = tf.Phi4MultimodalConfig(vocab_size=320, hidden_size=128, intermediate_size=96, num_hidden_layers=2,
+                                  num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=1024,
+                                  original_max_position_embeddings=1024, vision_config=vc, audio_config=ac,
+                                  pad_token_id=0, bos_token_id=1, eos_token_id=2, tie_word_embeddings=False,
+                                  rope_parameters={"rope_type": "default", "rope_theta": 10000.0,
+                                                   "partial_rotary_factor": 0.75})
+    hf = tf.Phi4MultimodalForCausalLM(cfg)
+    with torch.no_grad():
+        for n, p in hf.named_parameters():
+            if p.dim() >= 2 and "embed_tokens.weight" not in n:
+                p.mul_(2.0)
+            if "feature_extensor" in n or n.endswith((".b1", ".b2")):
+                p.normal_(0, 0.5)
+        enc = hf.model.embed_tokens_extend.audio_embed.encoder.encoder_embedding
+        enc.global_mean.normal_(8, 1)
+        enc.global_invstd.uniform_(0.2, 0.4)
+    hf = hf.float().eval()
+    path = os.path.join(str(tmp_path), name)
+    hf.save_pretrained(path, safe_serialization=True)
+    return path, hf
+
+
+def test_phi4mm_matches_hf(tmp_path):
+    """Phi-4-multimodal: masked NaViT SigLIP crops + HD arrangement, the conformer audio encoder (windows of 500 frames
+    included), both projector pairs; greedy tokens against transformers for an image prompt with a partly padded
+    canvas, a speech prompt, a prompt with both and a text prompt; the log-mel front end against transformers'
+    feature extractor; the original checkpoint layout."""
+    import json
+    import transformers as tf
+    from safetensors.torch import load_file, save_file
+    from vllm_distributed_amd.models.phi4mm import hd_preprocess, image_token_count, log_mel_frames
+    path, hf = _tiny_phi4mm(tmp_path)
+    g = torch.Generator().manual_seed(3)
+    img = (torch.rand(3, 80, 150, generator=g) * 255).round()                  # 2 x 3 crops, the bottom part padded
+    px, size, masks = hd_preprocess(img, 56, 14, 36)
+    assert size == (112, 168) and px.shape == (7, 3, 56, 56) and masks.shape == (7, 4, 4)
+    # the image fills 89 of the canvas' 112 rows: one whole patch row of padding, masked in the bottom crops
+    assert masks[0].all() and masks[1:4].all() and not masks[4:, 3, :].any() and masks[4:, :3, :].all()
+    n_img = image_token_count(size, masks, 56)
+    assert n_img == 4 * (6 + 1) + 1 + 2 * 3             # pooled rows 0 / 2 of the bottom crops count: 4 rows of 6; global 2 x 2
+    wave = torch.randn(16000 * 3 // 2, generator=g) * 0.1
+    feats = log_mel_frames(wave)
+    fe = tf.Phi4MultimodalFeatureExtractor()
+    want = fe(wave.numpy(), sampling_rate=16000, return_tensors="pt")
+    torch.testing.assert_close(feats, want["audio_input_features"][0], atol=1e-4, rtol=1e-4)
+    n_aud = int(want["audio_embed_sizes"][0])
+    long_feats = torch.randn(4100, 80, generator=g) * 2 + 8                     # 513 frames after reduction: two windows
+
+    text = [1, 17, 45, 108, 9]
+    p_img, p_aud, p_both = [1, 300, 17, 45], [1, 301, 17, 45], [1, 300, 5, 301, 17]
+    kw = dict(max_new_tokens=6, do_sample=False, eos_token_id=None, pad_token_id=0)
+    ip = dict(image_pixel_values=px[None], image_sizes=torch.tensor([size]), image_attention_mask=masks[None].float())
+    with torch.no_grad():
+        r_text = hf.generate(torch.tensor([text]), **kw)[0, len(text):].tolist()
+        ids = [1] + [300] * n_img + [17, 45]
+        r_img = hf.generate(torch.tensor([ids]), **ip, **kw)[0, len(ids):].tolist()
+        ids = [1] + [301] * n_aud + [17, 45]
+        r_aud = hf.generate(torch.tensor([ids]), audio_input_features=feats[None], audio_embed_sizes=torch.tensor([n_aud]),
+                            **kw)[0, len(ids):].tolist()
+        ids = [1] + [301] * 513 + [17, 45]
+        r_long = hf.generate(torch.tensor([ids]), audio_input_features=long_feats[None],
+                             audio_embed_sizes=torch.tensor([513]), **kw)[0, len(ids):].tolist()
+        ids = [1] + [300] * n_img + [5] + [301] * n_aud + [17]
+        r_both = hf.generate(torch.tensor([ids]), **ip, audio_input_features=feats[None],
+                             audio_embed_sizes=torch.tensor([n_aud]), **kw)[0, len(ids):].tolist()
+
+    def run(model_path):
+        llm = LLM(model=model_path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=1024,
+                  max_num_seqs=4, block_size=16)
+        outs = llm.generate([{"prompt_token_ids": text},
+                             {"prompt_token_ids": p_img, "multi_modal_data": {"image": img}},
+                             {"prompt_token_ids": p_aud, "multi_modal_data": {"audio": (wave.numpy(), 16000)}},
+                             {"prompt_token_ids": p_aud, "multi_modal_data": {"audio": {"audio_input_features": long_feats}}},
+                             {"prompt_token_ids": p_both, "multi_modal_data": {"image": img, "audio": (wave.numpy(), 16000)}}],
+                            SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+        llm.shutdown()
+        return [list(o.outputs[0].token_ids) for o in outs]
+    assert run(path) == [r_text, r_img, r_aud, r_long, r_both]
+
+    # the original layout: Sequential projections, glb_GN / sub_GN, base_layer in the decoder's linear names
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    swaps = ((".img_projection_up.", ".img_projection.0."), (".img_projection_down.", ".img_projection.2."),
+             (".up_proj_for_speech.", ".audio_projection.speech.0."), (".down_proj_for_speech.", ".audio_projection.speech.2."),
+             (".up_proj_for_vision_speech.", ".audio_projection.vision.0."),
+             (".down_proj_for_vision_speech.", ".audio_projection.vision.2."),
+             (".global_img_feature_extensor", ".glb_GN"), (".sub_img_feature_extensor", ".sub_GN"))
+    old = {}
+    for n, t in sd.items():
+        for a, b in swaps:
+            n = n.replace(a, b)
+        if n.startswith("model.layers.") and n.endswith("_proj.weight"):
+            n = n.replace("_proj.weight", "_proj.base_layer.weight")
+        old[n] = t.contiguous()
+    path2 = os.path.join(str(tmp_path), "phi4mm_orig")
+    os.makedirs(path2)
+    save_file(old, os.path.join(path2, "model.safetensors"))
+    cj = json.load(open(os.path.join(path, "config.json")))
+    cj["architectures"] = ["Phi4MMForCausalLM"]
+    json.dump(cj, open(os.path.join(path2, "config.json"), "w"))
+    assert run(path2) == [r_text, r_img, r_aud, r_long, r_both]

@@ -630,3 +630,12 @@ def _molmo(vllm_config):
 
 
 MULTIMODAL_REGISTRY.register_processor("MolmoForCausalLM", _molmo)
+
+
+def _phi4mm(vllm_config):
+    from ..models.phi4mm import phi4mm_processor
+    return phi4mm_processor(vllm_config)
+
+
+MULTIMODAL_REGISTRY.register_processor("Phi4MMForCausalLM", _phi4mm)
+MULTIMODAL_REGISTRY.register_processor("Phi4MultimodalForCausalLM", _phi4mm)
