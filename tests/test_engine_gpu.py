@@ -533,3 +533,48 @@ def test_gpu_sparse_dual_chunk_prefill(tmp_path):
                 worst = max(worst, abs(float(lp[tok]) - out.outputs[0].logprobs[j][tok].logprob))
                 ids.append(tok)
         assert worst < 0.1, (budget, worst)
+
+
+def test_gpu_florence2_and_phi4mm_follow_hf(tmp_path):
+    """The towers written in plain PyTorch (DaViT, masked SigLIP crops, conformer) on the GPU in bf16, their vectors
+    through the HIP decoder path: teacher-forced log-probabilities against transformers in fp32."""
+    from tests.test_multimodal_cpu import _tiny_florence2, _tiny_phi4mm
+    from vllm_distributed_amd import SamplingParams
+    from vllm_distributed_amd.models.phi4mm import hd_preprocess, image_token_count, log_mel_frames
+    sp = SamplingParams(temperature=0, max_tokens=6, ignore_eos=True, logprobs=0)
+    g = torch.Generator().manual_seed(7)
+
+    # Florence-2 (encoder-decoder: the decoder starts from its start token)
+    path, hf = _tiny_florence2(os.path.join(tmp_path, "f"))
+    px, text = torch.randn(3, 40, 32, generator=g), [0, 17, 45, 108, 9, 2]
+    llm = _llm(path, max_model_len=128, max_num_seqs=2)
+    out = llm.generate([{"prompt_token_ids": text, "multi_modal_data": {"image": px}}], sp)[0].outputs[0]
+    llm.shutdown()
+    gen = list(out.token_ids)
+    with torch.no_grad():
+        lg = hf(input_ids=torch.tensor([[199] * 21 + text]), pixel_values=px[None],
+                decoder_input_ids=torch.tensor([[2] + gen[:-1]])).logits[0]
+    lp = torch.log_softmax(lg.float(), -1)
+    worst = max(abs(float(lp[k, t]) - out.logprobs[k][t].logprob) for k, t in enumerate(gen))
+    assert worst < 0.1, ("florence2", worst)
+
+    # Phi-4-multimodal: image + speech in one prompt
+    path, hf = _tiny_phi4mm(os.path.join(tmp_path, "p"))
+    img = (torch.rand(3, 80, 150, generator=g) * 255).round()
+    wave = torch.randn(16000, generator=g) * 0.1
+    pxs, size, masks = hd_preprocess(img, 56, 14, 36)
+    feats = log_mel_frames(wave)
+    n_img, n_aud = image_token_count(size, masks, 56), -(-feats.shape[0] // 8)
+    llm = _llm(path, max_model_len=512, max_num_seqs=2)
+    out = llm.generate([{"prompt_token_ids": [1, 300, 5, 301, 17],
+                         "multi_modal_data": {"image": img, "audio": (wave.numpy(), 16000)}}], sp)[0].outputs[0]
+    llm.shutdown()
+    gen = list(out.token_ids)
+    ids = [1] + [300] * n_img + [5] + [301] * n_aud + [17]
+    with torch.no_grad():
+        lg = hf(input_ids=torch.tensor([ids + gen[:-1]]), image_pixel_values=pxs[None], image_sizes=torch.tensor([size]),
+                image_attention_mask=masks[None].float(), audio_input_features=feats[None],
+                audio_embed_sizes=torch.tensor([n_aud])).logits[0, len(ids) - 1:]
+    lp = torch.log_softmax(lg.float(), -1)
+    worst = max(abs(float(lp[k, t]) - out.logprobs[k][t].logprob) for k, t in enumerate(gen))
+    assert worst < 0.1, ("phi4mm", worst)

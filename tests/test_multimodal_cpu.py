@@ -1875,13 +1875,8 @@ def test_mllama_matches_hf(tmp_path):
     assert list(outs[1].outputs[0].token_ids) == ref_text
 
 
-def test_florence2_matches_hf(tmp_path):
-    """Florence-2: DaViT tower (window attention with padding, channel-group attention, pre- and post-norm patch
-    convolutions), position / frame embeddings and the two pooled sources, BART encoder over image vectors + prompt,
-    decoder through the slot cache.  Greedy tokens against transformers, in its layout and in the original one."""
-    import json
+def _tiny_florence2(tmp_path):
     import transformers as tf
-    from safetensors.torch import load_file, save_file
     torch.manual_seed(0)
     vc = dict(in_channels=3, depths=[1, 2], patch_size=[7, 3], patch_stride=[4, 2], patch_padding=[3, 1],
               patch_prenorm=[False, True], embed_dim=[32, 64], num_heads=[2, 4], num_groups=[2, 4], window_size=3,
@@ -1899,6 +1894,16 @@ def test_florence2_matches_hf(tmp_path):
     hf = hf.float().eval()
     path = os.path.join(str(tmp_path), "florence2")
     hf.save_pretrained(path, safe_serialization=True)
+    return path, hf
+
+
+def test_florence2_matches_hf(tmp_path):
+    """Florence-2: DaViT tower (window attention with padding, channel-group attention, pre- and post-norm patch
+    convolutions), position / frame embeddings and the two pooled sources, BART encoder over image vectors + prompt,
+    decoder through the slot cache.  Greedy tokens against transformers, in its layout and in the original one."""
+    import json
+    from safetensors.torch import load_file, save_file
+    path, hf = _tiny_florence2(tmp_path)
     g = torch.Generator().manual_seed(7)
     px = torch.randn(3, 40, 32, generator=g)                                  # 10 x 8 -> 5 x 4 positions (+ 1 pooled)
     text = [0, 17, 45, 108, 9, 2]
