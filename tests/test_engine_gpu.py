@@ -544,10 +544,12 @@ def test_gpu_florence2_and_phi4mm_follow_hf(tmp_path):
     sp = SamplingParams(temperature=0, max_tokens=6, ignore_eos=True, logprobs=0)
     g = torch.Generator().manual_seed(7)
 
-    # Florence-2 (encoder-decoder: the decoder starts from its start token)
+    # Florence-2 (encoder-decoder: the decoder starts from its start token alone, so the request's first step has the
+    # shape of a decode step; it must not be served by a captured graph, which cannot hold the cross-attention write)
     path, hf = _tiny_florence2(os.path.join(tmp_path, "f"))
     px, text = torch.randn(3, 40, 32, generator=g), [0, 17, 45, 108, 9, 2]
     llm = _llm(path, max_model_len=128, max_num_seqs=2)
+    assert llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.graphs
     out = llm.generate([{"prompt_token_ids": text, "multi_modal_data": {"image": px}}], sp)[0].outputs[0]
     llm.shutdown()
     gen = list(out.token_ids)

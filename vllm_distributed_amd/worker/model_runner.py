@@ -980,7 +980,9 @@ class ModelRunner:
         if tmd is not None:
             graph_bs = self._tknp_step_bs if self.tk_rx is not None else None     # decided on the global batch
         elif self.use_graphs and pure_decode and S <= (self.capture_sizes[0] if self.capture_sizes else 0) \
-                and self.graphs and self.lora_manager is None and inputs_embeds is None:
+                and self.graphs and self.lora_manager is None and inputs_embeds is None and not starting_seqs:
+            # (a one-token decoder prompt looks like a decode step, but the step in which an encoder-decoder request
+            # starts writes its cross-attention keys from Python: that is not in any captured graph)
             graph_bs = self.vllm_config.pad_for_cudagraph(S)
         if self.lora_manager is not None:
             self.lora_manager.set_active(req_ids, rows, n_sched, ib)
