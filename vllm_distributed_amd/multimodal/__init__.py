@@ -75,13 +75,20 @@ class MultiModalRegistry:
         return arch in self._factories
 
     def get_processor(self, vllm_config):
-        key = id(vllm_config.model_config)
-        if key not in self._cache:
-            arch = (vllm_config.model_config.architectures or [""])[0]
-            if arch not in self._factories:
-                raise ValueError(f"{arch} takes no multimodal inputs")
-            self._cache[key] = self._factories[arch](vllm_config)
-        return self._cache[key]
+        # keyed by id() but checked against a weak reference: a bare id() table would hand a dead config's
+        # processor to a new config that happens to be allocated at the same address
+        import weakref
+        mc = vllm_config.model_config
+        hit = self._cache.get(id(mc))
+        if hit is not None and hit[0]() is mc:
+            return hit[1]
+        arch = (mc.architectures or [""])[0]
+        if arch not in self._factories:
+            raise ValueError(f"{arch} takes no multimodal inputs")
+        proc = self._factories[arch](vllm_config)
+        self._cache = {k: v for k, v in self._cache.items() if v[0]() is not None}
+        self._cache[id(mc)] = (weakref.ref(mc), proc)
+        return proc
 
 
 MULTIMODAL_REGISTRY = MultiModalRegistry()
