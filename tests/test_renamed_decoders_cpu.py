@@ -444,8 +444,9 @@ def test_glm4v_chat_layout_with_eva_tower(tmp_path):
         _, inputs, _, pos = process_multimodal(llm.llm_engine.vllm_config, [5, 300, 9], {"image": img})
         assert pos[0].offset == 1 and pos[0].length == 6
         with torch.no_grad():
-            feats = model.encode_images(inputs[0][None])
-            torch.testing.assert_close(feats, tower(inputs[0][None]))
+            dev = next(model.parameters()).device          # these tests also run with the engine on the GPU
+            feats = model.encode_images(inputs[0][None].to(dev)).cpu()
+            torch.testing.assert_close(feats, tower(inputs[0][None]), atol=1e-4, rtol=1e-4)
         assert feats.shape == (1, 6, 128)
     finally:
         llm.shutdown()
