@@ -128,19 +128,26 @@ def test_sequence_parallel_on_one_gpu(tmp_path, eager):
     assert gap < 0.1, gap
 
 
-@pytest.mark.parametrize("world,eager", [(2, False), (2, True)])
-def test_expert_parallel_on_one_gpu(tmp_path, world, eager):
+@pytest.mark.parametrize("world,eager,quant", [(2, False, None), (2, True, None), (2, False, "fp8")])
+def test_expert_parallel_on_one_gpu(tmp_path, world, eager, quant):
     """Expert parallelism with token routing: every rank sends its slice of the tokens to the expert
-    owners through the peer-memory all-to-all-v, inside captured decode graphs when eager is off."""
+    owners through the peer-memory all-to-all-v, inside captured decode graphs when eager is off.
+    With e4m3 experts that run the fp8 tiles (forced here for every batch size) the rows travel as e4m3 + one scale
+    each: the owner skips its own quantisation pass and gets the same bytes it would have produced."""
     from tests.test_e2e_cpu import _save_tiny
     model, _ = _save_tiny(str(tmp_path), "mixtral")
     kw = dict(device="cuda", dtype="bfloat16", gpu_memory_utilization=0.03, enforce_eager=eager, max_num_seqs=8)
-    single, _ = _launch(1, model, str(tmp_path / "one"), kw, {})
-    env = {"VDA_REHEARSE_ON_ONE_GPU": "1", "VLLM_LOGGING_LEVEL": "INFO"}
+    base = {}
+    if quant:
+        kw["quantization"] = quant
+        base = {"VDA_MOE_GROUPED_MAX_PAIRS_FP8": "0"}
+    single, _ = _launch(1, model, str(tmp_path / "one"), kw, base)
+    env = dict(base, VDA_REHEARSE_ON_ONE_GPU="1", VLLM_LOGGING_LEVEL="INFO")
     got, logs = _launch(world, model, str(tmp_path / "ep"),
                         dict(kw, tensor_parallel_size=world, enable_expert_parallel=True), env)
     assert all(g == got[0] for g in got), "expert-parallel ranks disagree"
     assert any("peer-memory all-to-all enabled" in l for l in logs), logs[0][-2000:]
+    assert any("e4m3 rows on the wire" in l for l in logs) == bool(quant), logs[0][-2000:]
     first = [a[0] == b[0] for a, b in zip(got[0], single[0])]
     assert sum(first) >= len(first) - 1
     gap = _teacher_forced_gap(world, model, str(tmp_path / "tf"),

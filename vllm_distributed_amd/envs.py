@@ -103,6 +103,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_EP_DISPATCH": (_bool, True),            # expert parallel without DP attention: route tokens to expert owners (False: replicate + mask + all-reduce)
     "VDA_MOE_GROUPED_MAX_PAIRS": (int, 2048),    # (token, slot) pairs served by the grouped skinny MoE kernel
     "VDA_MOE_GROUPED_MAX_PAIRS_FP8": (int, 192), # the same for e4m3 expert weights (beyond: fp8 MFMA tiles, W8A8)
+    "VDA_EP_FP8_WIRE": (_bool, True),            # expert-parallel dispatch sends e4m3 rows + scale when the owner would quantise them anyway
     "VLLM_FUSED_MOE_CHUNK_SIZE": (int, 32768),
     "VLLM_MOE_DP_CHUNK_SIZE": (int, 256),
     "VLLM_ROCM_FP8_PADDING": (_bool, False),

@@ -20,11 +20,14 @@ from typing import Callable, Optional
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import envs, ops
 from ..config import get_current_vllm_config
+from ..logger import init_logger
 from ..parallel.state import (get_dp_group, get_ep_group, get_tensor_model_parallel_rank,
                               get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce)
 from .linear import set_weight_attrs
+
+logger = init_logger(__name__)
 
 
 def determine_expert_map(ep_size: int, ep_rank: int, global_num_experts: int) -> tuple[int, Optional[torch.Tensor]]:
@@ -76,6 +79,8 @@ class UnquantizedMoEMethod:
 
 
 class FusedMoE(nn.Module):
+    _fp8_wire_logged = False
+
     def __init__(self, num_experts: int, top_k: int, hidden_size: int, intermediate_size: int,
                  params_dtype: Optional[torch.dtype] = None, reduce_results: bool = True, renormalize: bool = True,
                  use_grouped_topk: bool = False, num_expert_group: Optional[int] = None,
@@ -259,9 +264,26 @@ class FusedMoE(nn.Module):
             self.eplb_state.record(self.eplb_layer, topk_ids)
         if self.routed_scaling_factor != 1.0:
             topk_w = topk_w * self.routed_scaling_factor
-        recv, local_ids, st = self._ep_disp.dispatch(xs.contiguous(), topk_ids.to(torch.int32), cap_tokens)
-        ones = torch.ones((recv.shape[0], 1), dtype=torch.float32, device=x.device)
-        y = self.quant_method.apply(self, recv, ones, local_ids)
+        # rows the owner would quantise per token anyway travel as e4m3 + their scale (H + 16 bytes instead of 2 H)
+        cap = min(self._ep_disp.rx.cap, -(-max(cap_tokens, 1) * self.top_k // 16) * 16)
+        fp8_rows = getattr(self.quant_method, "fp8_rows_ok", None)
+        if envs.VDA_EP_FP8_WIRE and fp8_rows is not None and fp8_rows(self, x.dtype, ep.world_size * cap):
+            if not FusedMoE._fp8_wire_logged:
+                FusedMoE._fp8_wire_logged = True
+                logger.info("expert-parallel dispatch: e4m3 rows on the wire (%d instead of %d bytes per row)",
+                            H + 16, H * x.element_size())
+            xq, xsc = ops.per_token_fp8_quant(xs)
+            pack = torch.empty((Tp, H + 16), dtype=torch.uint8, device=x.device)
+            pack[:, :H] = xq.view(torch.uint8)
+            pack[:, H:H + 4] = xsc.reshape(Tp, 1).contiguous().view(torch.uint8)
+            recv, local_ids, st = self._ep_disp.dispatch(pack, topk_ids.to(torch.int32), cap_tokens)
+            ones = torch.ones((recv.shape[0], 1), dtype=torch.float32, device=x.device)
+            y = self.quant_method.apply(self, recv[:, :H].view(torch.float8_e4m3fn), ones, local_ids,
+                                        x_scale=recv[:, H:H + 4].contiguous().view(torch.float32), out_dtype=x.dtype)
+        else:
+            recv, local_ids, st = self._ep_disp.dispatch(xs.contiguous(), topk_ids.to(torch.int32), cap_tokens)
+            ones = torch.ones((recv.shape[0], 1), dtype=torch.float32, device=x.device)
+            y = self.quant_method.apply(self, recv, ones, local_ids)
         part = self._ep_disp.combine(y, topk_w, st)
         if self.dp_size == 1:
             out = self._ep_disp.rx.all_gather_rows(part)[:T]

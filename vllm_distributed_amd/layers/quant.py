@@ -533,13 +533,19 @@ class Fp8MoEMethod:
                     blk.copy_((blk.float() * s[e, half] / mx[e]).clamp(-FP8_MAX, FP8_MAX).to(FP8))
         layer.w13_weight_scale = nn.Parameter(mx.contiguous(), requires_grad=False)
 
-    def apply(self, layer, x: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor) -> torch.Tensor:
+    def fp8_rows_ok(self, layer, dtype: torch.dtype, pairs: int) -> bool:
+        """May rows for ``pairs`` (row, expert) pairs arrive as e4m3 + one scale per row?"""
+        return self.cfg.weight_block_size is None and ops.moe_fp8_rows_ok(layer.w13_weight, layer.w2_weight, dtype, pairs)
+
+    def apply(self, layer, x: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor, x_scale=None,
+              out_dtype=None) -> torch.Tensor:
         if self.cfg.weight_block_size is not None:
             return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids, layer.w13_weight_scale_inv,
                                  layer.w2_weight_scale_inv, block_scales=True,
                                  activation=getattr(layer, "activation", "silu"))
         return ops.fused_moe(x, layer.w13_weight, layer.w2_weight, topk_w, topk_ids, layer.w13_weight_scale,
-                             layer.w2_weight_scale, activation=getattr(layer, "activation", "silu"))
+                             layer.w2_weight_scale, activation=getattr(layer, "activation", "silu"), x_scale=x_scale,
+                             out_dtype=out_dtype)
 
 
 class Fp8KVCacheMethod:

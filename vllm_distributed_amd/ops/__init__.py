@@ -928,10 +928,13 @@ def moe_align_tiles(topk_ids: torch.Tensor, E: int, rows_per_tile: int):
 
 
 def _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales: bool = False,
-               activation: str = "silu"):
+               activation: str = "silu", x_scale=None, out_dtype=None):
     """Compute-bound batches: both expert GEMMs run as LDS-tiled MFMA GEMMs over the expert-sorted pairs
     (ops/csrc/gemm_tile.hip).  e4m3 weights: activations are quantised per token (or per group of 128
-    with block-scaled weights) and the fp8 matrix cores do the products; 16-bit weights: 16-bit MFMA."""
+    with block-scaled weights) and the fp8 matrix cores do the products; 16-bit weights: 16-bit MFMA.
+    ``x_scale`` [T, 1] fp32: x already is e4m3 with one scale per row (rows that arrived quantised from
+    another rank); ``out_dtype`` then names the 16-bit type of the result."""
+    odt = out_dtype or x.dtype
     T, H = x.shape
     k = topk_ids.shape[1]
     E, I2, _ = w13.shape
@@ -944,19 +947,22 @@ def _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales: 
                          tiles[3 * max_tiles:])
     fp8 = w13.dtype == torch.float8_e4m3fn
     st = N.stream()
-    inter = torch.empty((P_, I), dtype=x.dtype, device=dev)
-    out2 = torch.empty((P_, H), dtype=x.dtype, device=dev)
-    out = torch.empty((T, H), dtype=x.dtype, device=dev)
+    inter = torch.empty((P_, I), dtype=odt, device=dev)
+    out2 = torch.empty((P_, H), dtype=odt, device=dev)
+    out = torch.empty((T, H), dtype=odt, device=dev)
     tw = topk_w.contiguous()
     if fp8:
         mode = SC_BLOCK if block_scales else SC_TOKEN
-        xq, xs = per_group_fp8_quant(x) if block_scales else per_token_fp8_quant(x)
+        if x_scale is not None:
+            xq, xs = x, x_scale.float().reshape(T, 1)
+        else:
+            xq, xs = per_group_fp8_quant(x) if block_scales else per_token_fp8_quant(x)
         xs = xs.contiguous()
     else:
         mode, xq, xs = SC_NONE, _contig_last(x), None
     N.call("vda_tile_gemm", inter.data_ptr(), xq.data_ptr(), w13.data_ptr(), N.ptr(xs), N.ptr(w13_scale), None, None,
            sorted_ids.data_ptr(), te.data_ptr(), tb.data_ptr(), tend.data_ptr(), ntl.data_ptr(), 0, I, H, k,
-           max_tiles, xq.stride(0), I, I2 * H, EPI_GATE_UP, mode, rows, N.dt(xq.dtype), N.dt(x.dtype), N.ACT[activation], st)
+           max_tiles, xq.stride(0), I, I2 * H, EPI_GATE_UP, mode, rows, N.dt(xq.dtype), N.dt(odt), N.ACT[activation], st)
     if fp8:
         hq, hs = per_group_fp8_quant(inter) if block_scales else per_token_fp8_quant(inter)
         hs = hs.contiguous()
@@ -965,10 +971,21 @@ def _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, block_scales: 
     N.call("vda_tile_gemm", out2.data_ptr(), hq.data_ptr(), w2.data_ptr(), N.ptr(hs), N.ptr(w2_scale),
            tw.data_ptr(), None, sorted_ids.data_ptr(), te.data_ptr(), tb.data_ptr(), tend.data_ptr(),
            ntl.data_ptr(), 0, H, I, 1, max_tiles, hq.stride(0), H, H * I, EPI_DOWN, mode, rows, N.dt(hq.dtype),
-           N.dt(x.dtype), 0, st)
+           N.dt(odt), 0, st)
     N.call("vda_moe_sum", out.data_ptr(), out2.data_ptr(), topk_ids.contiguous().data_ptr(), T, H, k,
-           out.stride(0), N.dt(x.dtype), st)
+           out.stride(0), N.dt(odt), st)
     return out
+
+
+def moe_fp8_rows_ok(w13: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype, pairs: int) -> bool:
+    """Will ``fused_moe`` quantise these rows per token and run the fp8 tiles?  Then they may as well arrive
+    quantised (expert-parallel dispatch sends e4m3 rows + their scale: half the bytes per xGMI link, and the
+    receiver's quantisation pass disappears)."""
+    probe = torch.empty(0, dtype=dtype)
+    return (w13.dtype == torch.float8_e4m3fn and dtype in (torch.bfloat16, torch.float16) and w13.is_cuda
+            and not envs.VDA_FORCE_TORCH_OPS and moe_tiled_ok(probe, w13, w2) and w13.shape[2] % 16 == 0
+            and (pairs > min(envs.VDA_MOE_GROUPED_MAX_PAIRS, envs.VDA_MOE_GROUPED_MAX_PAIRS_FP8)
+                 or not moe_grouped_ok(probe, w13, w2)))
 
 
 def moe_tiled_ok(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor) -> bool:
@@ -1006,7 +1023,8 @@ MOE_ACTIVATIONS = ("silu", "gelu", "gelu_tanh", "gelu_pytorch_tanh", "relu", "re
 
 def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torch.Tensor, topk_ids: torch.Tensor,
               w13_scale: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None,
-              block_scales: bool = False, activation: str = "silu") -> torch.Tensor:
+              block_scales: bool = False, activation: str = "silu", x_scale: Optional[torch.Tensor] = None,
+              out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """Routed gated expert MLPs, out[t] = sum_j w[t, j] * W2_e(act(Wg_e x_t) * (Wu_e x_t)) with ``activation`` one of
     MOE_ACTIVATIONS (reference: vllm/model_executor/layers/fused_moe/fused_moe.py:1003,1034 ``activation``), fused
     into the first GEMM's epilogue in every kernel form.  x [T,H]; w13 [E,2I,H] (gate rows then up rows); w2 [E,H,I];
@@ -1015,6 +1033,12 @@ def fused_moe(x: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, topk_w: torc
     (w13_scale [E, 2I/128, H/128], w2_scale [E, H/128, I/128])."""
     if activation not in MOE_ACTIVATIONS:
         raise ValueError(f"expert activation {activation!r} is not supported (supported: {', '.join(MOE_ACTIVATIONS)})")
+    if x_scale is not None:
+        # x is e4m3 with one scale per row (see moe_fp8_rows_ok): straight into the fp8 tiles, or widened again
+        odt = out_dtype or torch.bfloat16
+        if _dev(x) and not block_scales and moe_tiled_ok(torch.empty(0, dtype=odt), w13, w2):
+            return _moe_tiled(x, w13, w2, topk_w, topk_ids, w13_scale, w2_scale, False, activation, x_scale, odt)
+        x = (x.float() * x_scale.float().reshape(-1, 1)).to(odt)
     if _dev(x) and block_scales and not moe_tiled_ok(x, w13, w2):
         raise RuntimeError(f"block-scaled expert shapes {tuple(w13.shape)} / {tuple(w2.shape)} are outside the tiled "
                            "fp8 GEMM (hidden and expert width must be multiples of 128)")
