@@ -218,6 +218,24 @@ def test_qwen2_5_vl_matches_hf(tmp_path):
                           mm_token_type_ids=torch.tensor([[1 if t == 300 else 0 for t in ids]], dtype=torch.int32)
                           )[0, len(ids):].tolist()
     assert list(o.outputs[0].token_ids) == ref
+    # a video: frames are positioned by their distance in time (seconds per temporal step x tokens per second)
+    vid = {"pixel_values_videos": torch.randn(3 * 4 * 4, 1176, generator=g), "video_grid_thw": torch.tensor([3, 4, 4]),
+           "second_per_grid_ts": 1.5}
+    pv = [5, 302, 301, 303, 9, 11]
+    o = llm.generate([{"prompt_token_ids": pv, "multi_modal_data": {"video": vid}}],
+                     SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))[0]
+    ids = [5, 302] + [301] * 12 + [303, 9, 11]
+    assert list(o.prompt_token_ids) == ids
+    with torch.no_grad():
+        ref = hf.generate(input_ids=torch.tensor([ids]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                          eos_token_id=None, pixel_values_videos=vid["pixel_values_videos"],
+                          video_grid_thw=vid["video_grid_thw"][None], second_per_grid_ts=torch.tensor([1.5]),
+                          mm_token_type_ids=torch.tensor([[2 if t == 301 else 0 for t in ids]], dtype=torch.int32)
+                          )[0, len(ids):].tolist()
+    assert list(o.outputs[0].token_ids) == ref
+    from vllm_distributed_amd.models.qwen2_vl import mrope_positions
+    pos, delta = mrope_positions(len(ids), [(2, 12)], [(3, 4, 4)], 2, [1.5 * 2])
+    assert pos[0, 2:14].tolist() == [2] * 4 + [5] * 4 + [8] * 4 and pos[0, 14] == 9 and delta == 9 - 14
     llm.shutdown()
 
 

@@ -106,25 +106,27 @@ class Qwen2VisionTransformer(nn.Module):
 
 
 def mrope_positions(prompt_len: int, image_spans: list[tuple[int, int]], grids: list[tuple[int, int, int]],
-                    merge: int) -> tuple[np.ndarray, int]:
+                    merge: int, t_scales: Optional[list[float]] = None) -> tuple[np.ndarray, int]:
     """Three position rows for a prompt whose images occupy ``image_spans`` (offset, length) with patch
     grids ``grids``.  Text continues from the largest position so far on all axes; an image's tokens take
-    (frame, row, column) offsets from where it starts.  Returns ([3, prompt_len], delta) where positions
-    of later tokens are their index + delta."""
+    (frame, row, column) offsets from where it starts.  ``t_scales``: positions per temporal step of every item
+    (Qwen2.5-VL spaces video frames by their distance in time), truncated to integers.  Returns
+    ([3, prompt_len], delta) where positions of later tokens are their index + delta."""
     pos = np.zeros((3, prompt_len), dtype=np.int64)
     cur, nxt = 0, 0            # index into the prompt, next free position
-    for (off, length), (t, h, w) in zip(image_spans, grids):
+    for k, ((off, length), (t, h, w)) in enumerate(zip(image_spans, grids)):
         n = off - cur
         pos[:, cur:off] = nxt + np.arange(n)
         nxt += n
         gh, gw = h // merge, w // merge
         if t * gh * gw != length:
             raise ValueError(f"image placeholder of {length} tokens does not match its grid {(t, h, w)}")
-        ti = np.repeat(np.arange(t), gh * gw)
+        steps = np.arange(t) if t_scales is None else (np.arange(t) * float(t_scales[k])).astype(np.int64)
+        ti = np.repeat(steps, gh * gw)
         hi = np.tile(np.repeat(np.arange(gh), gw), t)
         wi = np.tile(np.arange(gw), t * gh)
         pos[:, off:off + length] = np.stack([ti, hi, wi]) + nxt
-        nxt += max(t, gh, gw)
+        nxt += max(int(steps[-1]) + 1, gh, gw)
         cur = off + length
     pos[:, cur:] = nxt + np.arange(prompt_len - cur)
     nxt += prompt_len - cur
@@ -151,16 +153,19 @@ class Qwen2VLForConditionalGeneration(nn.Module):
     # ---- encoder ----------------------------------------------------------------------------------
     def encode_mm_items(self, items: list) -> list[torch.Tensor]:
         """items: (patches [n_i, C*tps*p*p], grid [3]) per image -> embeddings [n_i / merge^2, H] per image."""
-        grids = [tuple(int(x) for x in g.tolist()) for _, g in items]
+        grids = [tuple(int(x) for x in it[1].tolist()) for it in items]
         dev = self.visual.patch_embed.proj.weight.device
-        out = self.visual(torch.cat([p for p, _ in items], dim=0).to(dev), grids)
+        out = self.visual(torch.cat([it[0] for it in items], dim=0).to(dev), grids)
         sizes = [t * h * w // self.merge ** 2 for t, h, w in grids]
         return list(out.split(sizes, dim=0))
 
     def get_mrope_positions(self, prompt_len: int, mm_positions: list, mm_inputs: list) -> tuple[np.ndarray, int]:
         spans = [(p.offset, p.length) for p in mm_positions]
-        grids = [tuple(int(x) for x in g.tolist()) for _, g in mm_inputs]
-        return mrope_positions(prompt_len, spans, grids, self.merge)
+        grids = [tuple(int(x) for x in it[1].tolist()) for it in mm_inputs]
+        # a third entry: seconds per temporal step of a video (Qwen2.5-VL); images and Qwen2-VL count steps
+        tps = float(getattr(self, "tokens_per_second", 0.0) or 0.0)
+        scales = [float(it[2]) * tps if len(it) > 2 and tps else 1.0 for it in mm_inputs]
+        return mrope_positions(prompt_len, spans, grids, self.merge, scales if any(x != 1.0 for x in scales) else None)
 
     def get_input_embeddings(self, input_ids, mm_embeds: Optional[torch.Tensor] = None,
                              mm_mask: Optional[torch.Tensor] = None):
@@ -344,6 +349,7 @@ class Qwen2_5_VLForConditionalGeneration(Qwen2VLForConditionalGeneration):
         vc = hf.vision_config if isinstance(hf.vision_config, dict) else hf.vision_config.to_dict()
         self.merge = int(vc.get("spatial_merge_size", 2))
         self.image_token_id = int(getattr(hf, "image_token_id", 151655))
+        self.tokens_per_second = float(vc.get("tokens_per_second", 2) or 2)     # video frames are spaced by their time
         self.visual = Qwen25VisionTransformer(vc, int(vc.get("out_hidden_size", None) or hf.hidden_size))
         self.language_model = LlamaForCausalLM(vllm_config, prefix=maybe_prefix(prefix, "language_model"))
         self.rotary = self.language_model.model.layers[self.language_model.model.start_layer].self_attn.rotary_emb

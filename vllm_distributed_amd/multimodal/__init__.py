@@ -197,6 +197,7 @@ class PatchGridProcessor:
         self.image_token_id, self.patch, self.merge, self.tps = image_token_id, patch, merge, tps
         self.video_token_id = video_token_id
         self.min_pixels, self.max_pixels = min_pixels, max_pixels
+        self.video_fps: Optional[float] = None     # set: videos carry seconds per temporal step (tps / fps) as a third entry
 
     def patches(self, img: Any) -> tuple[torch.Tensor, torch.Tensor]:
         if isinstance(img, dict):
@@ -275,7 +276,11 @@ class PatchGridProcessor:
             positions.append(PlaceholderRange(offset=len(out), length=length))
             out.extend([tok] * length)
             cur = start + n
-            inputs.append([px, grid])
+            extra = []
+            if tok == self.video_token_id and self.video_fps:
+                sec = item.get("second_per_grid_ts") if isinstance(item, dict) else None
+                extra = [torch.tensor(float(sec if sec is not None else self.tps / self.video_fps))]
+            inputs.append([px, grid] + extra)
             hashes.append(hash_item(px if isinstance(item, dict) else item))
         out.extend(prompt_token_ids[cur:])
         return out, inputs, hashes, positions
@@ -284,9 +289,13 @@ class PatchGridProcessor:
 def _qwen2_vl_processor(vllm_config):
     hf = vllm_config.model_config.hf_config
     vc = hf.vision_config if isinstance(hf.vision_config, dict) else hf.vision_config.to_dict()
-    return PatchGridProcessor(int(getattr(hf, "image_token_id", 151655)), int(vc.get("patch_size", 14)),
+    proc = PatchGridProcessor(int(getattr(hf, "image_token_id", 151655)), int(vc.get("patch_size", 14)),
                               int(vc.get("spatial_merge_size", 2)), int(vc.get("temporal_patch_size", 2)),
                               56 * 56, 14 * 14 * 4 * 1280, video_token_id=int(getattr(hf, "video_token_id", 151656)))
+    if "Qwen2_5_VL" in (vllm_config.model_config.architectures or [""])[0]:
+        # frames sampled at ``fps`` (mm_processor_kwargs, default 2): a temporal step spans temporal_patch_size / fps s
+        proc.video_fps = float((vllm_config.model_config.mm_processor_kwargs or {}).get("fps", 2.0))
+    return proc
 
 
 MULTIMODAL_REGISTRY.register_processor("Qwen2VLForConditionalGeneration", _qwen2_vl_processor)
