@@ -455,6 +455,15 @@ def test_quark_mxfp4_checkpoint_is_dequantised_while_loading(tmp_path):
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
     llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
               max_num_batched_tokens=64)
+    # linear layers keep the codes as 8-bit integers with power-of-two group scales: exactly the same values
+    model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+    qkv = model.model.layers[0].self_attn.qkv_proj
+    assert qkv.qweight.dtype == torch.uint8 and qkv.scales.shape[1] == qkv.qweight.shape[1] // 32
+    assert not hasattr(qkv, "weight") or qkv.weight is None
+    want = torch.cat([hf.model.layers[0].self_attn.get_submodule(n).weight for n in ("q_proj", "k_proj", "v_proj")])
+    got = (qkv.qweight.float() - qkv.qzeros.repeat_interleave(32, 1)) * qkv.scales.repeat_interleave(32, 1)
+    assert torch.equal(got, want.detach())
+    assert model.lm_head.weight.dtype == torch.float32                      # excluded layers stay as they are
     outs = llm.generate(prompt_token_ids=prompts,
                         sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
     llm.shutdown()

@@ -156,3 +156,24 @@ def test_gguf_blocks_run_packed(tid):
         ref = x.float() @ deq.t()
         y = ops.wq_linear(x, t["qweight"], t["scales"], t["qzeros"], sz, 32, bits)
         assert (y.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2, (name, M)
+
+
+def test_mxfp4_rows_come_back_exactly():
+    """Microscaling fp4 re-coded as 8-bit integers with power-of-two group scales (models/dequant.py::mxfp4_to_packed8):
+    identity activations must return exactly the rows that decoding the fp4 codes gives, in every kernel form."""
+    from vllm_distributed_amd import ops
+    from vllm_distributed_amd.models.dequant import dequantize_mxfp4, mxfp4_to_packed8
+    g = torch.Generator().manual_seed(0)
+    N, K = 320, 256
+    packed = torch.randint(0, 256, (N, K // 2), generator=g, dtype=torch.int32).to(torch.uint8)
+    scale = torch.randint(112, 131, (N, K // 32), generator=g, dtype=torch.int32).to(torch.uint8)     # 2^-15 .. 2^3
+    w = mxfp4_to_packed8(packed, scale, torch.bfloat16)
+    deq = dequantize_mxfp4(packed, scale, torch.float32).cuda()
+    qw, sc, z = (w[k].cuda() for k in ("qweight", "scales", "qzeros"))
+    sz = torch.stack([sc.t(), z.t()], dim=-1).contiguous()
+    for M, variant in ((16, 1), (16, 2), (16, 3), (128, 2), (512, 1)):
+        idx = torch.arange(M, device="cuda")
+        x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+        x[idx, idx % K] = 1
+        got = ops.wq_gemm(x, qw, sz, 32, 8, splits=1, variant=variant).float()
+        assert torch.equal(got, deq.t()[idx % K]), (M, variant)

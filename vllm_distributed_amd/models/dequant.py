@@ -132,6 +132,23 @@ def dequantize_mxfp4(packed: torch.Tensor, scale: torch.Tensor, dtype: torch.dty
     return (lut[codes].view(N, -1, MX_BLOCK) * s.unsqueeze(-1)).view(N, 2 * K2).to(dtype)
 
 
+def mxfp4_to_packed8(packed: torch.Tensor, scale: torch.Tensor, dtype: torch.dtype) -> dict:
+    """Microscaling fp4 as 8-bit integers, EXACTLY: every E2M1 value is a multiple of one half, so
+    value = (q - 128) * 2^(s - 128) with q - 128 in {0, +-1, +-2, +-3, +-4, +-6, +-8, +-12} -- the W8A16 layout of
+    ``PackedIntLinearMethod`` with groups of 32, zero point 128 and a power-of-two scale (exact in bf16; fp16 holds
+    scales down to 2^-24).  Nine bits per weight in memory instead of sixteen, and no table look-up in the GEMM."""
+    if packed.dtype != torch.uint8 or scale.dtype != torch.uint8:
+        raise ValueError("mxfp4: packed weights and scales are uint8")
+    N, K2 = packed.shape
+    if scale.shape != (N, 2 * K2 // MX_BLOCK):
+        raise ValueError(f"mxfp4: scale shape {tuple(scale.shape)} does not match weights {tuple(packed.shape)}")
+    twice = torch.tensor([int(2 * v) for v in _E2M1], dtype=torch.int16, device=packed.device)
+    codes = torch.stack((packed & 15, packed >> 4), dim=-1).reshape(N, 2 * K2).long()
+    q = (twice[codes] + 128).to(torch.uint8)
+    sc = torch.exp2(scale.to(torch.float32) - 128.0).to(dtype)
+    return {"qweight": q.contiguous(), "scales": sc.contiguous(), "qzeros": torch.full_like(sc, 128.0)}
+
+
 def dequantize_nvfp4(packed: torch.Tensor, scale: torch.Tensor, global_scale: torch.Tensor,
                      dtype: torch.dtype) -> torch.Tensor:
     """NVFP4: E2M1 codes two per byte (element 2i in the low nibble) [N, K/2], one fp8-e4m3 scale per 16
@@ -279,13 +296,16 @@ class LoadTimeDequant:
             raise ValueError(f"{method}: {self.bits}-bit weights are not supported (2, 4, 8)")
         from .. import envs
         self.group_size = int(cfg.get("group_size", cfg.get("q_group_size", 128)) or 128)
-        self.skip = list(cfg.get("modules_to_not_convert") or [])
+        self.skip = [str(x).strip("*") for x in (cfg.get("modules_to_not_convert") or cfg.get("exclude") or [])]
         # activation reordering gathers whole-K activations: kept packed only without tensor parallelism (a
         # row-parallel shard would need every group's scales); 8-bit GPTQ stays 8 bit
         self.act_order = bool(cfg.get("desc_act", False)) and method == "gptq"
         self.pack4 = (method in ("gptq", "awq") and (self.bits == 4 or (self.bits == 8 and method == "gptq"))
                       and (not self.act_order or tp_size == 1)
                       and envs.VDA_INT4_WEIGHTS and (self.group_size == -1 or self.group_size % 32 == 0))
+        if method == "mxfp4" and envs.VDA_INT4_WEIGHTS:
+            # linear layers keep their codes as exact 8-bit integers with power-of-two group scales (mxfp4_to_packed8)
+            self.pack4, self.bits, self.group_size = True, 8, MX_BLOCK
 
     def _packed(self, prefix: str) -> bool:
         return self.pack4 and ".experts." not in prefix and not prefix.endswith("lm_head") \
@@ -360,6 +380,8 @@ class LoadTimeDequant:
                 return None
             if mx:
                 if "weight" in d and "weight_scale" in d:
+                    if self._packed(prefix):
+                        return mxfp4_to_packed8(d["weight"], d["weight_scale"], dtype)
                     return dequantize_mxfp4(d["weight"], d["weight_scale"], dtype)
                 return None
             if self.method == "fp8":
