@@ -580,3 +580,44 @@ def test_gpu_florence2_and_phi4mm_follow_hf(tmp_path):
     lp = torch.log_softmax(lg.float(), -1)
     worst = max(abs(float(lp[k, t]) - out.logprobs[k][t].logprob) for k, t in enumerate(gen))
     assert worst < 0.1, ("phi4mm", worst)
+
+
+def test_gpu_in_flight_nf4_follows_hf_with_rounded_weights(tmp_path):
+    """quantization="bitsandbytes" on the GPU: the projections live as NF4 codes + fp32 block scales and run the
+    code-book kernels (skinny for decode, expansion for the prompt); log-probabilities follow transformers holding
+    the NF4-rounded weights, graph replay equals eager decode."""
+    import transformers as tf
+    from vllm_distributed_amd import SamplingParams, ops
+    from vllm_distributed_amd.layers.quant import nf4_dequantize, nf4_quantize
+    path, _ = _save_tiny(str(tmp_path), "llama")
+    sp = SamplingParams(temperature=0, max_tokens=12, ignore_eos=True, logprobs=0)
+    calls = []
+    real = ops.cb4_linear
+    ops.cb4_linear = lambda x, *a, **k: (calls.append(x.shape[0]), real(x, *a, **k))[1]
+    try:
+        a = _llm(path, quantization="bitsandbytes")
+        model = a.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
+        qkv = model.model.layers[0].self_attn.qkv_proj
+        assert qkv.qweight.dtype == torch.uint8 and qkv.qweight.is_cuda and getattr(qkv, "weight", None) is None
+        outs_g = a.generate(prompt_token_ids=PROMPTS, sampling_params=sp)
+        a.shutdown()
+        b = _llm(path, quantization="bitsandbytes", enforce_eager=True)
+        outs_e = b.generate(prompt_token_ids=PROMPTS, sampling_params=sp)
+        b.shutdown()
+    finally:
+        ops.cb4_linear = real
+    assert any(m <= 64 for m in calls) and any(m > 64 for m in calls)
+    assert [list(o.outputs[0].token_ids) for o in outs_g] == [list(o.outputs[0].token_ids) for o in outs_e]
+    hf = tf.AutoModelForCausalLM.from_pretrained(path, torch_dtype=torch.float32).eval()
+    with torch.no_grad():
+        for name, mod in hf.named_modules():
+            if isinstance(mod, torch.nn.Linear) and name != "lm_head":
+                mod.weight.copy_(nf4_dequantize(*nf4_quantize(mod.weight.data), torch.float32))
+    worst = 0.0
+    for p, o in zip(PROMPTS, outs_g):
+        gen = list(o.outputs[0].token_ids)
+        with torch.no_grad():
+            lp = torch.log_softmax(hf(torch.tensor([p + gen])).logits[0].float(), -1)
+        for k, t in enumerate(gen):
+            worst = max(worst, abs(float(lp[len(p) + k - 1, t]) - o.outputs[0].logprobs[k][t].logprob))
+    assert worst < 0.08, worst

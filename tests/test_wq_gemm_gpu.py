@@ -177,3 +177,113 @@ def test_mxfp4_rows_come_back_exactly():
         x[idx, idx % K] = 1
         got = ops.wq_gemm(x, qw, sz, 32, 8, splits=1, variant=variant).float()
         assert torch.equal(got, deq.t()[idx % K]), (M, variant)
+
+
+def _codebook(N, K, G, table):
+    g = torch.Generator().manual_seed(N + K + G)
+    codes = torch.randint(0, 256, (N, K // 2), generator=g, dtype=torch.int32).to(torch.uint8)
+    scales = (torch.rand(N, K // G, generator=g) + 0.5) * K ** -0.5
+    return codes.cuda(), scales.cuda(), torch.tensor(table, dtype=torch.float32).cuda()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("G,hi_first,table", [(64, True, "nf4"), (16, False, "e2m1"), (32, False, "e2m1"),
+                                              (128, True, "nf4"), (256, True, "e2m1")])
+def test_codebook4_kernels_match_fp32(dtype, G, hi_first, table):
+    """4-bit code-book weights (ops/csrc/cb4.hip): the expansion kernel equals table[code] * scale rounded once, the
+    skinny kernel (1 .. 64 rows) and the expand + library path (more rows) equal the fp32 product, bias and strided
+    activations included."""
+    from vllm_distributed_amd import ops
+    from vllm_distributed_amd.layers.quant import NF4_CODE
+    from vllm_distributed_amd.models.dequant import _E2M1
+    from vllm_distributed_amd.ops import reference as R
+    N, K = 528, 1024
+    codes, scales, tab = _codebook(N, K, G, NF4_CODE if table == "nf4" else _E2M1)
+    deq = R.cb4_dequant(codes, scales, tab, G, hi_first, torch.float32)
+    got = ops.cb4_dequant(codes, scales, tab, G, hi_first, dtype)
+    if dtype == torch.bfloat16:
+        assert torch.equal(got, deq.to(dtype))
+    else:       # fp16: the kernel's fused multiply-convert rounds the exact product once, the reference twice
+        torch.testing.assert_close(got.float(), deq, rtol=2 ** -11, atol=2 ** -24)
+    bias = torch.randn(N, device="cuda", dtype=dtype)
+    forms = [(codes, scales, False)]
+    if ops.cb4_chunk_layout_ok(K, G):        # the layout whose kernel scales accumulators instead of weights
+        forms.append((*ops.cb4_to_chunk_layout(codes, scales), True))
+        got = ops.cb4_dequant(forms[1][0], forms[1][1], tab, G, hi_first, dtype, chunked=True)
+        assert torch.equal(got, ops.cb4_dequant(codes, scales, tab, G, hi_first, dtype))
+    else:
+        assert G == 16
+    seen = []
+    real = ops.cb4_dequant
+    ops.cb4_dequant = lambda *a, **k: (seen.append(1), real(*a, **k))[1]
+    try:
+        for c, sc, chunked in forms:
+            for M in (1, 7, 16, 17, 33, 48, 64, 100):
+                x = torch.randn(M, K + 32, device="cuda", dtype=dtype)[:, 32:]
+                ref = x.float() @ deq.t()
+                tol = 2e-2 * ref.abs().max().item() + 2e-2
+                got = ops.cb4_linear(x, c, sc, tab, G, hi_first, chunked=chunked)
+                assert got.shape == (M, N) and (got.float() - ref).abs().max().item() < tol, (M, chunked)
+                got = ops.cb4_linear(x, c, sc, tab, G, hi_first, bias, chunked=chunked)
+                assert (got.float() - ref - bias.float()).abs().max().item() < tol, (M, chunked)
+    finally:
+        ops.cb4_dequant = real
+    assert len(seen) == 2 * len(forms)       # only the 100-row batches expanded the weights
+
+
+@pytest.mark.parametrize("G,hi_first", [(16, False), (64, True)])
+def test_codebook4_rows_come_back_exactly(G, hi_first):
+    """Identity activations return exactly the expanded rows: a misplaced nibble, byte or scale cannot pass."""
+    from vllm_distributed_amd import ops
+    from vllm_distributed_amd.layers.quant import NF4_CODE
+    from vllm_distributed_amd.ops import reference as R
+    N, K = 320, 256
+    codes, scales, tab = _codebook(N, K, G, NF4_CODE)
+    scales = torch.exp2(torch.randint(-6, 3, scales.shape, device="cuda").float())
+    deq = R.cb4_dequant(codes, scales, tab, G, hi_first, torch.bfloat16).float()
+    chunked = ops.cb4_chunk_layout_ok(K, G)
+    if chunked:         # power-of-two scales: scaling the 16-bit table value equals rounding the scaled value
+        for M in (16, 64):
+            idx = torch.arange(M, device="cuda")
+            x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+            x[idx, (idx * 5) % K] = 1
+            got = ops.cb4_linear(x, *ops.cb4_to_chunk_layout(codes, scales), tab, G, hi_first, chunked=True).float()
+            assert torch.equal(got, deq.t()[(idx * 5) % K]), M
+    for M in (16, 40, 64):
+        idx = torch.arange(M, device="cuda")
+        x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+        x[idx, (idx * 5) % K] = 1
+        got = ops.cb4_linear(x, codes, scales, tab, G, hi_first).float()
+        assert torch.equal(got, deq.t()[(idx * 5) % K]), M
+    if chunked:
+        codes, scales = ops.cb4_to_chunk_layout(codes, scales)
+    xs = torch.randn(24, K, device="cuda", dtype=torch.bfloat16)
+    out = ops.cb4_linear(xs, codes, scales, tab, G, hi_first, chunked=chunked)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.cb4_linear(xs, codes, scales, tab, G, hi_first, chunked=chunked)
+    xs.copy_(torch.randn(24, K, device="cuda", dtype=torch.bfloat16))
+    g.replay()
+    torch.cuda.synchronize()
+    ref = xs.float() @ deq.t()
+    assert (out.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2
+
+
+@pytest.mark.parametrize("G", [32, 64, 128])
+def test_codebook4_wide_layers_share_activation_registers(G):
+    """Layers wide enough for 512 workgroups of 32 / 64 rows take the forms whose activation registers serve two / four
+    row sets (ops/csrc/cb4.hip, RW): same results as the fp32 product, bias included."""
+    from vllm_distributed_amd import ops
+    from vllm_distributed_amd.layers.quant import NF4_CODE
+    from vllm_distributed_amd.ops import reference as R
+    N, K = 32768, 384
+    codes, scales, tab = _codebook(N, K, G, NF4_CODE)
+    deq = R.cb4_dequant(codes, scales, tab, G, True, torch.float32)
+    c, st = ops.cb4_to_chunk_layout(codes, scales)
+    bias = torch.randn(N, device="cuda", dtype=torch.bfloat16)
+    for M in (1, 8, 16, 20, 32, 40):                     # four row sets up to 16 rows, two up to 32, one beyond
+        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        ref = x.float() @ deq.t() + bias.float()
+        got = ops.cb4_linear(x, c, st, tab, G, True, bias, chunked=True)
+        assert (got.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2, M

@@ -93,6 +93,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_LORA_KERNEL_MAX_TOKENS": (int, 1024),   # multi-LoRA: batches up to this many rows use the fused shrink/expand kernels
     "VDA_SCAN_CHUNK_MIN_TOKENS": (int, 256),     # state-space scan: sequences of at least this many new tokens run chunk-parallel
     "VDA_W4_SKINNY_MAX_M": (int, 32),            # W4A16: rows served by the packed-weight skinny kernel
+    "VDA_CB4_SKINNY_MAX_M": (int, 64),           # 4-bit code-book weights (NF4 / FP4 / NVFP4): rows served by the skinny kernel
     "VDA_GGUF_PACKED": (_bool, True),            # GGUF: keep 4- / 5- / 8-bit block codes packed (False: expand to 16 bit at load)
     "VDA_WQ_GEMM_MAX_M": (int, 512),             # W4A16 / W8A16: rows served by the packed-weight GEMM kernels
     "VDA_MLA": (_bool, True),                    # DeepSeek: latent KV cache + absorbed projections; 0 = expanded heads

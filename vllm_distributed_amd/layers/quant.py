@@ -249,10 +249,61 @@ def nf4_dequantize(packed: torch.Tensor, absmax: torch.Tensor, dtype: torch.dtyp
     return (code[idx].reshape(N, -1, block) * absmax[..., None]).reshape(N, -1).to(dtype)
 
 
+class CodeBook4LinearMethod:
+    """Linear layer over 4-bit code-book weights: ``qweight`` uint8 [N, K/2] (two codes per byte), ``scales`` fp32
+    [N, K/group], ``code_table`` fp32 [16]; weight = code_table[code] * scale.  The codes stay packed in device memory
+    (4 bits per weight + 32 / group bits of scale): up to 64 rows stream them through the MFMA skinny kernel of
+    ops/csrc/cb4.hip, larger batches expand a transient 16-bit copy in front of the library GEMM.  Serves
+    bitsandbytes NF4 / FP4 (groups of 64, first element in the high nibble; double-quantised scales are decoded to
+    fp32 while loading) and NVFP4 (E2M1 codes, groups of 16, first element in the low nibble; the per-tensor scale
+    is folded into the group scales).  Reference: vllm/model_executor/layers/quantization/bitsandbytes.py
+    (BitsAndBytesLinearMethod._apply_4bit_weight), modelopt.py (ModelOptNvFp4LinearMethod)."""
+
+    def __init__(self, group: int, hi_first: bool, table: Optional[tuple] = None):
+        self.group, self.hi_first, self.table = int(group), bool(hi_first), table
+
+    def _create_packed(self, layer: nn.Module, in_per_rank: int, out_per_rank: int, device=None) -> None:
+        if in_per_rank % self.group:
+            raise ValueError(f"{getattr(layer, 'prefix', '')}: {in_per_rank} input features per rank do not divide "
+                             f"into groups of {self.group}")
+        qw = nn.Parameter(torch.zeros(out_per_rank, in_per_rank // 2, dtype=torch.uint8, device=device),
+                          requires_grad=False)
+        sc = nn.Parameter(torch.zeros(out_per_rank, in_per_rank // self.group, dtype=torch.float32, device=device),
+                          requires_grad=False)
+        for name, p in (("qweight", qw), ("scales", sc)):
+            set_weight_attrs(p, {"input_dim": 1, "output_dim": 0})
+            layer.register_parameter(name, p)
+        tab = torch.tensor(self.table or [0.0] * 16, dtype=torch.float32, device=device)
+        layer.register_parameter("code_table", nn.Parameter(tab, requires_grad=False))     # loaded whole, never cut
+
+    def create_weights(self, layer: nn.Module, in_per_rank: int, out_per_rank: int, dtype: torch.dtype) -> None:
+        self._create_packed(layer, in_per_rank, out_per_rank)
+
+    def process_weights_after_loading(self, layer: nn.Module) -> None:
+        """On the GPU, groups of 32 and more take the chunk layout once (codes: word transpose inside every 64-byte
+        chunk; scales: [K/group, N]), which lets the decode kernel scale accumulators instead of weights."""
+        from .. import ops
+        qw = layer.qweight
+        if getattr(layer, "cb4_chunked", False) or not qw.is_cuda or qw.shape[0] % 16 \
+                or not ops.cb4_chunk_layout_ok(qw.shape[1] * 2, self.group):
+            return
+        codes, scales_t = ops.cb4_to_chunk_layout(qw.data, layer.scales.data)
+        layer.qweight = nn.Parameter(codes, requires_grad=False)
+        layer.scales = nn.Parameter(scales_t, requires_grad=False)
+        layer.cb4_chunked = True
+
+    def apply(self, layer: nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        from .. import ops
+        shape = x.shape
+        y = ops.cb4_linear(x.reshape(-1, shape[-1]), layer.qweight, layer.scales, layer.code_table, self.group,
+                           self.hi_first, bias, getattr(layer, "cb4_chunked", False))
+        return y.view(*shape[:-1], -1)
+
+
 class Bnb4InflightConfig(QuantizationConfig):
     """``quantization="bitsandbytes"`` on an unquantised checkpoint: every linear layer's weight is quantised to
-    NF4 (blocks of 64 values, one fp32 absmax each: 4.5 bits per weight in HBM) right after it is loaded, and
-    expanded to the activation dtype in front of its GEMM.  Reference:
+    NF4 (blocks of 64 values, one fp32 absmax each: 4.5 bits per weight in HBM) right after it is loaded and runs
+    as a code-book layer from then on (``CodeBook4LinearMethod``).  Reference:
     vllm/model_executor/model_loader/bitsandbytes_loader.py (in-flight path :418-520) and
     layers/quantization/bitsandbytes.py; the bitsandbytes package itself is not part of this build, the NF4 code
     book and blocking are its published ones (pre-quantised checkpoints: models/dequant.py)."""
@@ -265,28 +316,32 @@ class Bnb4InflightConfig(QuantizationConfig):
         return None
 
 
-class Bnb4LinearMethod:
+class Bnb4LinearMethod(CodeBook4LinearMethod):
     BLOCK = 64
+
+    def __init__(self):
+        super().__init__(self.BLOCK, True, NF4_CODE)
 
     def create_weights(self, layer: nn.Module, in_per_rank: int, out_per_rank: int, dtype: torch.dtype) -> None:
         w = nn.Parameter(torch.empty(out_per_rank, in_per_rank, dtype=dtype), requires_grad=False)
         set_weight_attrs(w, {"input_dim": 1, "output_dim": 0})
         layer.register_parameter("weight", w)
-        layer.orig_dtype = dtype
 
     def process_weights_after_loading(self, layer: nn.Module) -> None:
-        w = layer.weight.data
-        if w.dtype == torch.uint8 or w.shape[1] % self.BLOCK:
+        w = getattr(layer, "weight", None)
+        if w is None or w.shape[1] % self.BLOCK:
             return                                   # already processed, or a width the blocking does not divide
-        packed, absmax = nf4_quantize(w, self.BLOCK)
-        layer.weight = nn.Parameter(packed, requires_grad=False)
-        layer.absmax = nn.Parameter(absmax, requires_grad=False)
+        packed, absmax = nf4_quantize(w.data, self.BLOCK)
+        self._create_packed(layer, w.shape[1], w.shape[0], device=w.device)
+        layer.qweight.data.copy_(packed)
+        layer.scales.data.copy_(absmax)
+        del layer.weight
+        super().process_weights_after_loading(layer)
 
     def apply(self, layer: nn.Module, x: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-        w = layer.weight
-        if w.dtype == torch.uint8:
-            w = nf4_dequantize(w, layer.absmax, x.dtype, self.BLOCK)
-        return torch.nn.functional.linear(x, w, bias)
+        if getattr(layer, "weight", None) is not None:
+            return torch.nn.functional.linear(x, layer.weight, bias)
+        return super().apply(layer, x, bias)
 
 
 def get_quant_config(vllm_config) -> Optional[QuantizationConfig]:

@@ -206,6 +206,41 @@ def dequantize_bnb4(packed: torch.Tensor, absmax: torch.Tensor, quant_map: torch
     return w.view(shape).to(dtype)
 
 
+BNB_BLOCK = 64
+
+
+def bnb4_to_codebook(packed: torch.Tensor, absmax: torch.Tensor, quant_map: torch.Tensor, state: dict,
+                     nested_absmax: Optional[torch.Tensor], nested_quant_map: Optional[torch.Tensor],
+                     name: str = "") -> dict:
+    """bitsandbytes 4-bit tensors as they are kept in memory by ``CodeBook4LinearMethod``: the byte stream re-shaped
+    to [N, K/2], one fp32 scale per block (double-quantised scales decoded here, once), the 16 code values."""
+    bs = int(state["blocksize"])
+    shape = tuple(int(x) for x in state["shape"])
+    if len(shape) != 2 or bs != BNB_BLOCK or shape[1] % bs:
+        raise ValueError(f"{name}: bitsandbytes blocks of {bs} over a weight of shape {shape} do not line up with "
+                         f"rows in groups of {BNB_BLOCK}; set VDA_INT4_WEIGHTS=0 to expand this checkpoint while loading")
+    if nested_absmax is not None:
+        nbs = int(state.get("nested_blocksize", 256))
+        a = nested_quant_map.float()[absmax.long().view(-1)]
+        a = a * nested_absmax.float().repeat_interleave(nbs)[: a.numel()]
+        absmax = a + float(state.get("nested_offset", 0.0))
+    N, K = shape
+    return {"qweight": packed.reshape(-1).to(torch.uint8)[: N * K // 2].view(N, K // 2).contiguous(),
+            "scales": absmax.float().view(N, K // bs).contiguous(),
+            "code_table": quant_map.float().reshape(16).contiguous()}
+
+
+def nvfp4_to_codebook(packed: torch.Tensor, scale: torch.Tensor, global_scale: torch.Tensor) -> dict:
+    """NVFP4 tensors as ``CodeBook4LinearMethod`` keeps them: the codes untouched, the e4m3 group scales times the
+    per-tensor scale as fp32 (so fused projections with different per-tensor scales share one layer)."""
+    N, K2 = packed.shape
+    if packed.dtype != torch.uint8 or scale.shape != (N, 2 * K2 // 16):
+        raise ValueError(f"nvfp4: weights {tuple(packed.shape)} {packed.dtype} / scales {tuple(scale.shape)} mismatch")
+    s = scale.to(torch.float32) * global_scale.to(torch.float32).max()
+    return {"qweight": packed.contiguous(), "scales": s.contiguous(),
+            "code_table": torch.tensor(_E2M1, dtype=torch.float32)}
+
+
 def dequantize_bnb8(weight: torch.Tensor, scb: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """LLM.int8() weights: int8 rows with one fp scale per output row (value = q * SCB / 127)."""
     return (weight.float() * (scb.float().view(-1, 1) / 127.0)).to(dtype)
@@ -296,7 +331,8 @@ class LoadTimeDequant:
             raise ValueError(f"{method}: {self.bits}-bit weights are not supported (2, 4, 8)")
         from .. import envs
         self.group_size = int(cfg.get("group_size", cfg.get("q_group_size", 128)) or 128)
-        self.skip = [str(x).strip("*") for x in (cfg.get("modules_to_not_convert") or cfg.get("exclude") or [])]
+        self.skip = [str(x).strip("*") for x in (cfg.get("modules_to_not_convert") or cfg.get("exclude")
+                                                 or cfg.get("exclude_modules") or cfg.get("llm_int8_skip_modules") or [])]
         # activation reordering gathers whole-K activations: kept packed only without tensor parallelism (a
         # row-parallel shard would need every group's scales); 8-bit GPTQ stays 8 bit
         self.act_order = bool(cfg.get("desc_act", False)) and method == "gptq"
@@ -306,6 +342,12 @@ class LoadTimeDequant:
         if method == "mxfp4" and envs.VDA_INT4_WEIGHTS:
             # linear layers keep their codes as exact 8-bit integers with power-of-two group scales (mxfp4_to_packed8)
             self.pack4, self.bits, self.group_size = True, 8, MX_BLOCK
+        # 4-bit code-book formats: linear layers keep codes + fp32 group scales (layers/quant.py::CodeBook4LinearMethod)
+        self.codebook = None                     # (group, first element in the high nibble)
+        if envs.VDA_INT4_WEIGHTS and method == "nvfp4":
+            self.pack4, self.codebook = True, (16, False)
+        if envs.VDA_INT4_WEIGHTS and method == "bitsandbytes" and not cfg.get("load_in_8bit"):
+            self.pack4, self.codebook = True, (BNB_BLOCK, True)
 
     def _packed(self, prefix: str) -> bool:
         return self.pack4 and ".experts." not in prefix and not prefix.endswith("lm_head") \
@@ -314,6 +356,9 @@ class LoadTimeDequant:
     def get_quant_method(self, layer, prefix):
         from ..layers.linear import LinearBase
         if isinstance(layer, LinearBase) and self._packed(prefix):
+            if self.codebook is not None:
+                from ..layers.quant import CodeBook4LinearMethod
+                return CodeBook4LinearMethod(*self.codebook)
             return PackedIntLinearMethod(self.group_size, self.bits, self.act_order)
         return None
 
@@ -336,6 +381,9 @@ class LoadTimeDequant:
             nested = "nested_blocksize" in st or "nested_offset" in st
             if nested and not ("nested_absmax" in d and "nested_quant_map" in d):
                 return None
+            if self.codebook is not None and self._packed(base):
+                return bnb4_to_codebook(d["weight"], d["absmax"], d["quant_map"], st, d.get("nested_absmax"),
+                                        d.get("nested_quant_map"), base)
             return dequantize_bnb4(d["weight"], d["absmax"], d["quant_map"], st, d.get("nested_absmax"),
                                    d.get("nested_quant_map"), dtype)
 
@@ -360,7 +408,11 @@ class LoadTimeDequant:
             w = try_finish(base)
             if w is not None:
                 del pending[base]
-                yield f"{base}.weight", w
+                if isinstance(w, dict):
+                    for k, v in w.items():
+                        yield f"{base}.{k}", v
+                else:
+                    yield f"{base}.weight", w
         if pending:
             raise ValueError(f"incomplete bitsandbytes tensors for {sorted(pending)[:4]}")
 
@@ -376,6 +428,8 @@ class LoadTimeDequant:
         def finish(prefix: str, d: dict):
             if nv:
                 if all(k in d for k in ("weight", "weight_scale", "weight_scale_2")):
+                    if self._packed(prefix):
+                        return nvfp4_to_codebook(d["weight"], d["weight_scale"], d["weight_scale_2"])
                     return dequantize_nvfp4(d["weight"], d["weight_scale"], d["weight_scale_2"], dtype)
                 return None
             if mx:

@@ -694,6 +694,71 @@ def w4_linear(x: torch.Tensor, qw: torch.Tensor, scales: torch.Tensor, zeros: to
     return torch.nn.functional.linear(x, w4_dequant(qw, scales, zeros, group, x.dtype), bias)
 
 
+# ---- 4-bit code-book weights (bitsandbytes NF4 / FP4, NVFP4) -------------------------------------
+def cb4_chunk_layout_ok(K: int, group: int) -> bool:
+    """Whether the kernels that scale accumulators instead of weights apply: whole 128-element chunks, and every run of
+    32 consecutive elements inside one scale group."""
+    return K % 128 == 0 and (group in (32, 64) or (group >= 128 and group % 128 == 0)) and K % group == 0
+
+
+def cb4_to_chunk_layout(codes: torch.Tensor, scales: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """codes uint8 [N, K/2] in K order, scales [N, K/group] -> the layout of ``cb4_skinny_post_kernel``: the sixteen
+    4-byte words of every 64-byte chunk re-ordered as a transposed 4 x 4 matrix (stored word 4 g + q = the codes of
+    elements 32 q + 8 g .. + 7), scales transposed to [K/group, N]."""
+    N_, K2 = codes.shape
+    c = codes.view(N_, K2 // 64, 4, 4, 4).transpose(2, 3).contiguous().view(N_, K2)
+    return c, scales.t().contiguous()
+
+
+def cb4_from_chunk_layout(codes: torch.Tensor, scales_t: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    return cb4_to_chunk_layout(codes, scales_t)          # the word transpose is its own inverse, so is ``.t()``
+
+
+def cb4_dequant(codes: torch.Tensor, scales: torch.Tensor, table: torch.Tensor, group: int, hi_first: bool,
+                dtype: torch.dtype, chunked: bool = False) -> torch.Tensor:
+    """Code-book weights -> [N, K] in ``dtype``: ``codes`` uint8 [N, K/2] (two per byte, the first element in the high
+    nibble when ``hi_first``), ``scales`` fp32 [N, K/group], ``table`` fp32 [16]; value = table[code] * scale.
+    ``chunked``: codes and scales are in the layout of ``cb4_to_chunk_layout``."""
+    N_, K = codes.shape[0], codes.shape[1] * 2
+    ok = _dev(codes) and dtype in (torch.bfloat16, torch.float16) and group % 8 == 0 \
+        and codes.is_contiguous() and scales.is_contiguous() and scales.dtype == torch.float32
+    if ok and chunked:
+        out = torch.empty((N_, K), dtype=dtype, device=codes.device)
+        N.call("vda_cb4_dequant_post", out.data_ptr(), codes.data_ptr(), scales.data_ptr(), table.data_ptr(), N_, K,
+               group, int(hi_first), N.dt(dtype), N.stream())
+        return out
+    if chunked:
+        codes, scales = cb4_from_chunk_layout(codes, scales)
+    if ok and K % 8 == 0:
+        out = torch.empty((N_, K), dtype=dtype, device=codes.device)
+        N.call("vda_cb4_dequant", out.data_ptr(), codes.data_ptr(), scales.data_ptr(), table.data_ptr(), N_, K, group,
+               int(hi_first), N.dt(dtype), N.stream())
+        return out
+    return R.cb4_dequant(codes, scales, table, group, hi_first, dtype)
+
+
+def cb4_linear(x: torch.Tensor, codes: torch.Tensor, scales: torch.Tensor, table: torch.Tensor, group: int,
+               hi_first: bool, bias: Optional[torch.Tensor] = None, chunked: bool = False) -> torch.Tensor:
+    """y = x @ (table[codes] * scales).T (+ bias) over weights that stay 4-bit codes in device memory
+    (ops/csrc/cb4.hip).  Decode-sized batches (``VDA_CB4_SKINNY_MAX_M`` rows, 64 at most) stream the codes once
+    through an MFMA skinny kernel -- in the chunk layout (``chunked``) with operands straight out of a byte-indexed
+    table and the scales applied to the accumulators, otherwise scaling every weight; more rows expand the codes into
+    a transient 16-bit copy for the library GEMM."""
+    M, K = x.shape
+    N_ = codes.shape[0]
+    if _dev(x) and M <= min(envs.VDA_CB4_SKINNY_MAX_M, 64) and N_ % 16 == 0 and K % 128 == 0 and K % group == 0 \
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 \
+            and x.dtype in (torch.bfloat16, torch.float16) and scales.dtype == torch.float32 \
+            and codes.is_contiguous() and scales.is_contiguous() and (bias is None or bias.dtype == x.dtype) \
+            and (cb4_chunk_layout_ok(K, group) if chunked else (group == 16 or group % 32 == 0)):
+        y = torch.empty((M, N_), dtype=x.dtype, device=x.device)
+        N.call("vda_cb4_skinny_gemm_post" if chunked else "vda_cb4_skinny_gemm", y.data_ptr(), x.data_ptr(),
+               codes.data_ptr(), scales.data_ptr(), table.data_ptr(), N.ptr(bias), M, N_, K, group, int(hi_first),
+               x.stride(0), y.stride(0), N.dt(x.dtype), N.stream())
+        return y
+    return torch.nn.functional.linear(x, cb4_dequant(codes, scales, table, group, hi_first, x.dtype, chunked), bias)
+
+
 def wq_dequant(qw: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, group: int, bits: int,
                dtype: torch.dtype) -> torch.Tensor:
     """Packed 4- / 8-bit weights -> [N, K] in ``dtype``: (q - zero) * scale per group of ``group`` K elements."""

@@ -72,6 +72,10 @@ _SIGS = {
     "vda_per_group_fp8_quant": [P, P, P, I, I, I, L, L, I, P],
     "vda_w4_skinny_gemm": [P, P, P, P, P, P, I, I, I, I, L, L, I, P],
     "vda_w4_dequant": [P, P, P, P, I, I, I, I, P],
+    "vda_cb4_skinny_gemm": [P, P, P, P, P, P, I, I, I, I, I, L, L, I, P],
+    "vda_cb4_dequant": [P, P, P, P, I, I, I, I, I, P],
+    "vda_cb4_skinny_gemm_post": [P, P, P, P, P, P, I, I, I, I, I, L, L, I, P],
+    "vda_cb4_dequant_post": [P, P, P, P, I, I, I, I, I, P],
     "vda_w8_dequant": [P, P, P, P, I, I, I, I, P],
     "vda_mla_cache_write": [P, P, P, P, P, I, I, I, I, L, L, I, I, F, P],
     "vda_mla_attention": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, L, L, F, I, I, F, P],

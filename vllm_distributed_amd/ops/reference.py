@@ -497,6 +497,14 @@ def w4_unpack(qw: torch.Tensor) -> torch.Tensor:
     return torch.stack(cols, dim=-1).reshape(qw.shape[0], -1)
 
 
+def cb4_dequant(codes, scales, table, group, hi_first, dtype):
+    N_, K2 = codes.shape
+    first, second = (codes >> 4, codes & 15) if hi_first else (codes & 15, codes >> 4)
+    idx = torch.stack((first, second), dim=-1).reshape(N_, 2 * K2).long()
+    vals = table.float()[idx].view(N_, -1, group) * scales.float().unsqueeze(-1)
+    return vals.view(N_, 2 * K2).to(dtype)
+
+
 def w4_dequant(qw, scales, zeros, group, dtype):
     q = w4_unpack(qw).float()
     s = scales.float().repeat_interleave(group, dim=1)
