@@ -43,8 +43,14 @@ def main():
                 t = timed(run)
                 t_lib = timed(lambda: torch.nn.functional.linear(x, w))
                 bytes_ = N * K / 2 + N * (K // G) * 4
+                extra = ""
+                if chunked and M <= 64:
+                    def run1():
+                        i[0] += 1
+                        return ops.cb4_linear(x, codes[i[0] % copies], scales, tab, G, hi, chunked=True, splits=1)
+                    extra = f"   without K splits {timed(run1):8.1f} us"
                 print(f"{fmt:10s} {name:8s} M={M:4d}  code-book {t:8.1f} us ({bytes_ / t / 1e6:5.2f} TB/s of packed bytes)"
-                      f"   bf16 library {t_lib:8.1f} us", flush=True)
+                      f"   bf16 library {t_lib:8.1f} us{extra}", flush=True)
             del codes, w
 
 

@@ -287,3 +287,35 @@ def test_codebook4_wide_layers_share_activation_registers(G):
         ref = x.float() @ deq.t() + bias.float()
         got = ops.cb4_linear(x, c, st, tab, G, True, bias, chunked=True)
         assert (got.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2, M
+
+
+@pytest.mark.parametrize("N,K,G", [(528, 1024, 64), (8192, 4096, 64), (1024, 8192, 128), (16384, 2048, 32)])
+def test_codebook4_k_splits(N, K, G):
+    """K splits of the chunk-layout kernel: every split writes a slab of fp32 partial sums, a second kernel adds the
+    slabs and the bias.  Forced and automatic splits, calls back to back, inside a captured graph too."""
+    from vllm_distributed_amd import ops
+    from vllm_distributed_amd.layers.quant import NF4_CODE
+    from vllm_distributed_amd.ops import reference as R
+    codes, scales, tab = _codebook(N, K, G, NF4_CODE)
+    deq = R.cb4_dequant(codes, scales, tab, G, True, torch.float32)
+    c, st = ops.cb4_to_chunk_layout(codes, scales)
+    bias = torch.randn(N, device="cuda", dtype=torch.bfloat16)
+    for M in (1, 16, 24, 64):
+        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        ref = x.float() @ deq.t() + bias.float()
+        tol = 2e-2 * ref.abs().max().item() + 2e-2
+        for splits in (0, 2, 3, 8, 0):
+            got = ops.cb4_linear(x, c, st, tab, G, True, bias, chunked=True, splits=splits)
+            assert (got.float() - ref).abs().max().item() < tol, (M, splits)
+    x = torch.randn(16, K, device="cuda", dtype=torch.bfloat16)
+    out = ops.cb4_linear(x, c, st, tab, G, True, chunked=True, splits=4)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.cb4_linear(x, c, st, tab, G, True, chunked=True, splits=4)
+    for _ in range(3):
+        x.copy_(torch.randn(16, K, device="cuda", dtype=torch.bfloat16))
+        g.replay()
+        torch.cuda.synchronize()
+        ref = x.float() @ deq.t()
+        assert (out.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2

@@ -695,6 +695,9 @@ def w4_linear(x: torch.Tensor, qw: torch.Tensor, scales: torch.Tensor, zeros: to
 
 
 # ---- 4-bit code-book weights (bitsandbytes NF4 / FP4, NVFP4) -------------------------------------
+_CB4_WS: dict = {}
+
+
 def cb4_chunk_layout_ok(K: int, group: int) -> bool:
     """Whether the kernels that scale accumulators instead of weights apply: whole 128-element chunks, and every run of
     32 consecutive elements inside one scale group."""
@@ -738,7 +741,8 @@ def cb4_dequant(codes: torch.Tensor, scales: torch.Tensor, table: torch.Tensor, 
 
 
 def cb4_linear(x: torch.Tensor, codes: torch.Tensor, scales: torch.Tensor, table: torch.Tensor, group: int,
-               hi_first: bool, bias: Optional[torch.Tensor] = None, chunked: bool = False) -> torch.Tensor:
+               hi_first: bool, bias: Optional[torch.Tensor] = None, chunked: bool = False,
+               splits: int = 0) -> torch.Tensor:
     """y = x @ (table[codes] * scales).T (+ bias) over weights that stay 4-bit codes in device memory
     (ops/csrc/cb4.hip).  Decode-sized batches (``VDA_CB4_SKINNY_MAX_M`` rows, 64 at most) stream the codes once
     through an MFMA skinny kernel -- in the chunk layout (``chunked``) with operands straight out of a byte-indexed
@@ -752,9 +756,18 @@ def cb4_linear(x: torch.Tensor, codes: torch.Tensor, scales: torch.Tensor, table
             and codes.is_contiguous() and scales.is_contiguous() and (bias is None or bias.dtype == x.dtype) \
             and (cb4_chunk_layout_ok(K, group) if chunked else (group == 16 or group % 32 == 0)):
         y = torch.empty((M, N_), dtype=x.dtype, device=x.device)
-        N.call("vda_cb4_skinny_gemm_post" if chunked else "vda_cb4_skinny_gemm", y.data_ptr(), x.data_ptr(),
-               codes.data_ptr(), scales.data_ptr(), table.data_ptr(), N.ptr(bias), M, N_, K, group, int(hi_first),
-               x.stride(0), y.stride(0), N.dt(x.dtype), N.stream())
+        if chunked:
+            # K splits write slabs of fp32 partial sums that a second small kernel adds (fewer splits if they do not fit)
+            ws = _CB4_WS.get(x.device)
+            if ws is None:
+                ws = _CB4_WS[x.device] = torch.empty(1 << 23, dtype=torch.float32, device=x.device)
+            N.call("vda_cb4_skinny_gemm_post", y.data_ptr(), x.data_ptr(), codes.data_ptr(), scales.data_ptr(),
+                   table.data_ptr(), N.ptr(bias), M, N_, K, group, int(hi_first), x.stride(0), y.stride(0),
+                   N.dt(x.dtype), ws.data_ptr(), ws.numel(), splits, N.stream())
+        else:
+            N.call("vda_cb4_skinny_gemm", y.data_ptr(), x.data_ptr(), codes.data_ptr(), scales.data_ptr(),
+                   table.data_ptr(), N.ptr(bias), M, N_, K, group, int(hi_first), x.stride(0), y.stride(0),
+                   N.dt(x.dtype), N.stream())
         return y
     return torch.nn.functional.linear(x, cb4_dequant(codes, scales, table, group, hi_first, x.dtype, chunked), bias)
 

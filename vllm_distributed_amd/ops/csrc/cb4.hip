@@ -169,10 +169,12 @@ __global__ __launch_bounds__(256) void cb4_skinny_post_kernel(T* __restrict__ y,
                                                               const float* __restrict__ scales_t,
                                                               const float* __restrict__ table,
                                                               const T* __restrict__ bias, int M, int N, int K, int G,
-                                                              int hi_first, long x_stride, long y_stride) {
+                                                              int hi_first, long x_stride, long y_stride,
+                                                              float* __restrict__ ws) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   __shared__ uint32_t tab2[256 * 32];
+  __shared__ uint32_t tab1[256];
   __shared__ f32x4 red[3][MT][64];
   {
     const int b = threadIdx.x;
@@ -180,9 +182,13 @@ __global__ __launch_bounds__(256) void cb4_skinny_post_kernel(T* __restrict__ y,
     union { T h[2]; uint32_t u; } pk;
     pk.h[0] = (T)table[first];
     pk.h[1] = (T)table[second];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) tab2[b * 32 + j] = pk.u;
+    tab1[b] = pk.u;
   }
+  __syncthreads();
+  // the 32 copies are written in address order (a wave's 64 stores go to 64 banks; entry by entry they would all
+  // land in two banks)
+#pragma unroll
+  for (int i = 0; i < 32; ++i) tab2[i * 256 + threadIdx.x] = tab1[(i * 256 + threadIdx.x) >> 5];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -205,58 +211,97 @@ __global__ __launch_bounds__(256) void cb4_skinny_post_kernel(T* __restrict__ y,
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[rw][mt] = f32x4{0, 0, 0, 0};
 
-  const int nchunk = K >> 7;
+  // K splits (gridDim.y): workgroup y takes a contiguous run of chunks
+  const int per = ((K >> 7) + gridDim.y - 1) / gridDim.y;
+  const int nchunk = min(K >> 7, (int)(blockIdx.y + 1) * per);
   constexpr int UN = RW >= 4 ? 1 : 4 / RW;                    // UN x RW 16-byte code loads in flight per lane
   constexpr int NS = 4 / GQ;                                  // scale groups per chunk: 4 (G = 32), 2 (64), 1 (>= 128)
-  for (int c = wave; c < nchunk; c += 4 * UN) {
-    u32x4 raw[UN][RW];
-    f32x4 sv[UN][RW][NS];
+  struct Codes { u32x4 raw[UN][RW]; };
+  struct Side { V8 xa[4][MT]; f32x4 sv[RW][NS]; };            // activations and scales of one chunk
+  // codes of UN chunks (first chunk c, stride 4) for all row sets: the HBM stream
+  auto issue = [&](Codes& s, int c) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int cc = c + 4 * u;
       if (cc < nchunk) {
 #pragma unroll
-        for (int rw = 0; rw < RW; ++rw) {
-          raw[u][rw] = *reinterpret_cast<const u32x4*>(wrow + rw * wset + (long)cc * 64);
-#pragma unroll
-          for (int sgi = 0; sgi < NS; ++sgi)
-            sv[u][rw][sgi] = *reinterpret_cast<const f32x4*>(srow + (long)((cc * 128 + sgi * GQ * 32) / G) * N + rw * 16);
-        }
+        for (int rw = 0; rw < RW; ++rw)
+          s.raw[u][rw] = *reinterpret_cast<const u32x4*>(wrow + rw * wset + (long)cc * 64);
       }
     }
+  };
+  // activations and scales of chunk cc: L2 traffic
+  auto load_side = [&](Side& d, int cc) {
+    if (cc >= nchunk) return;
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int cc = c + 4 * u;
-      if (cc >= nchunk) break;
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int sgi = 0; sgi < NS; ++sgi) {
-        V8 xa[GQ][MT];
+      for (int mt = 0; mt < MT; ++mt) d.xa[q][mt] = xv[mt] ? ld16<V8>(xp[mt] + (long)cc * 128 + 32 * q) : V8{};
 #pragma unroll
-        for (int qq = 0; qq < GQ; ++qq)
+    for (int rw = 0; rw < RW; ++rw)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            xa[qq][mt] = xv[mt] ? ld16<V8>(xp[mt] + (long)cc * 128 + 32 * (sgi * GQ + qq)) : V8{};
+      for (int sgi = 0; sgi < NS; ++sgi)
+        d.sv[rw][sgi] = *reinterpret_cast<const f32x4*>(srow + (long)((cc * 128 + sgi * GQ * 32) / G) * N + rw * 16);
+  };
+  auto compute = [&](const u32x4 (&raw)[RW], const Side& d) {
 #pragma unroll
-        for (int rw = 0; rw < RW; ++rw) {
-          f32x4 part[MT];
+    for (int sgi = 0; sgi < NS; ++sgi) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) part[mt] = f32x4{0, 0, 0, 0};
+      for (int rw = 0; rw < RW; ++rw) {
+        f32x4 part[MT];
 #pragma unroll
-          for (int qq = 0; qq < GQ; ++qq) {
-            const uint32_t w = raw[u][rw][sgi * GQ + qq];
-            union { uint32_t d[4]; V8 v; } op;
-            op.d[0] = tl[(w & 0xffu) << 5];
-            op.d[1] = tl[((w >> 8) & 0xffu) << 5];
-            op.d[2] = tl[((w >> 16) & 0xffu) << 5];
-            op.d[3] = tl[(w >> 24) << 5];
+        for (int mt = 0; mt < MT; ++mt) part[mt] = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) part[mt] = mfma16(op.v, xa[qq][mt], part[mt]);
-          }
+        for (int qq = 0; qq < GQ; ++qq) {
+          const uint32_t w = raw[rw][sgi * GQ + qq];
+          union { uint32_t d[4]; V8 v; } op;
+          op.d[0] = tl[(w & 0xffu) << 5];
+          op.d[1] = tl[((w >> 8) & 0xffu) << 5];
+          op.d[2] = tl[((w >> 16) & 0xffu) << 5];
+          op.d[3] = tl[(w >> 24) << 5];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[rw][mt][i] = fmaf(part[mt][i], sv[u][rw][sgi][i], acc[rw][mt][i]);
+          for (int mt = 0; mt < MT; ++mt) part[mt] = mfma16(op.v, d.xa[sgi * GQ + qq][mt], part[mt]);
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[rw][mt][i] = fmaf(part[mt][i], d.sv[rw][sgi][i], acc[rw][mt][i]);
+      }
+    }
+  };
+  constexpr int STEP = 4 * UN;
+  const int c0 = blockIdx.y * per + wave;
+  if constexpr (MT == 1) {
+    // up to 16 rows: the codes of the next step are in flight while this one computes.  Loads return in issue order,
+    // so a step's activations and scales are issued BEFORE the next step's codes: waiting for them then leaves
+    // those codes outstanding.
+    Codes ca, cb;
+    Side d[UN];
+    issue(ca, c0);
+    for (int c = c0; c < nchunk; c += 2 * STEP) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) load_side(d[u], c + 4 * u);
+      issue(cb, c + STEP);
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (c + 4 * u < nchunk) compute(ca.raw[u], d[u]);
+#pragma unroll
+      for (int u = 0; u < UN; ++u) load_side(d[u], c + STEP + 4 * u);
+      issue(ca, c + 2 * STEP);
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (c + STEP + 4 * u < nchunk) compute(cb.raw[u], d[u]);
+    }
+  } else {
+    for (int c = c0; c < nchunk; c += STEP) {
+      Codes cs;
+      issue(cs, c);
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (c + 4 * u >= nchunk) break;
+        Side d;
+        load_side(d, c + 4 * u);
+        compute(cs.raw[u], d);
       }
     }
   }
@@ -276,34 +321,71 @@ __global__ __launch_bounds__(256) void cb4_skinny_post_kernel(T* __restrict__ y,
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const f32x4 sum = acc[rw][mt] + red[0][mt][lane] + red[1][mt][lane] + red[2][mt][lane];
-        if (xv[mt]) {
+        if (!xv[mt]) continue;
+        if (gridDim.y == 1) {
           V4 o;
 #pragma unroll
           for (int i = 0; i < 4; ++i) o[i] = (T)(sum[i] + (float)bv[i]);
           *reinterpret_cast<V4*>(y + (long)(mt * 16 + r) * y_stride + nb) = o;
+        } else {                                 // K splits: this split's slab of fp32 partial sums
+          *reinterpret_cast<f32x4*>(ws + ((long)blockIdx.y * M + mt * 16 + r) * N + nb) = sum;
         }
       }
     }
   }
 }
 
+// y[m, n] = sum over the K splits' slabs (+ bias); one thread per four outputs
+template <typename T>
+__global__ __launch_bounds__(256) void cb4_finish_kernel(T* __restrict__ y, const float* __restrict__ ws,
+                                                         const T* __restrict__ bias, int M, int N, int splits,
+                                                         long y_stride) {
+  using V4 = typename Vec<T>::v4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int nq = N / 4;
+  if (i >= (long)M * nq) return;
+  const int m = (int)(i / nq), n = (int)(i - (long)m * nq) * 4;
+  f32x4 sum = *reinterpret_cast<const f32x4*>(ws + (long)m * N + n);
+  for (int k = 1; k < splits; ++k) sum += *reinterpret_cast<const f32x4*>(ws + ((long)k * M + m) * N + n);
+  V4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (T)(sum[j] + (bias ? (float)bias[n + j] : 0.0f));
+  *reinterpret_cast<V4*>(y + (long)m * y_stride + n) = o;
+}
+
 // codes in the transposed-chunk layout, scales_t [K / G, N]
 VDA_EXPORT int vda_cb4_skinny_gemm_post(void* y, const void* x, const void* codes, const void* scales_t,
                                         const void* table, const void* bias, int M, int N, int K, int G, int hi_first,
-                                        long x_stride, long y_stride, int dtype, hipStream_t st) {
+                                        long x_stride, long y_stride, int dtype, void* ws, size_t ws_floats,
+                                        int splits, hipStream_t st) {
   if (M < 1 || M > 64 || N < 16 || N % 16 || K < 128 || K % 128 || K % G) return -1;
   if (!(G == 32 || G == 64 || (G >= 128 && G % 128 == 0))) return -1;
   const int mt = (M + 15) / 16;
   const int gq = G == 32 ? 1 : G == 64 ? 2 : 4;
   // rows per workgroup: as many as keep two workgroups per CU busy (512 of them) and the accumulators in registers
+  // (from 8 rows on the activations every workgroup re-reads from L2 outweigh its codes unless it owns 64 rows:
+  // narrow layers then take 64-row workgroups too and fill the chip with K splits instead)
   int rw = 1;
-  if (mt == 1 && N % 64 == 0 && N / 64 >= 512) rw = 4;
-  else if (mt <= 2 && N % 32 == 0 && N / 32 >= 512) rw = 2;
-  dim3 grid(N / (16 * rw)), block(256);
+  const bool wide_rows = mt <= 2 && N % (mt == 1 ? 64 : 32) == 0 && splits == 0 && ws;
+  if (mt == 1 && N % 64 == 0 && (N / 64 >= 512 || wide_rows)) rw = 4;
+  else if (mt <= 2 && N % 32 == 0 && (N / 32 >= 512 || wide_rows)) rw = 2;
+  // K splits (splits = 0: chosen here): enough workgroups for four per CU, at least 16 chunks each; every split writes
+  // a slab of fp32 partial sums [M, N] and a second small kernel adds the slabs (no fences, no atomics: an agent-scope
+  // fence writes back the whole L2 of an XCD, which cost more than the splits gained)
+  const int blocks = N / (16 * rw), nchunk = K >> 7;
+  int sk = splits;
+  if (sk <= 0) {
+    sk = 1;
+    if (wide_rows)
+      while (sk < 8 && blocks * sk < 512 && nchunk / (sk * 2) >= 8) sk *= 2;
+  }
+  if (sk > nchunk) sk = nchunk;
+  while (sk > 1 && (!ws || ws_floats < (size_t)sk * M * N)) --sk;
+  dim3 grid(blocks, sk), block(256);
 #define L(TT, MM, GG, RR) hipLaunchKernelGGL((cb4_skinny_post_kernel<TT, MM, GG, RR>), grid, block, 0, st, (TT*)y,      \
                                              (const TT*)x, (const uint8_t*)codes, (const float*)scales_t,             \
                                              (const float*)table, (const TT*)bias, M, N, K, G, hi_first, x_stride,    \
-                                             y_stride)
+                                             y_stride, (float*)ws)
 #define BYM(TT, GG) do { if (mt == 1) { if (rw == 4) L(TT, 1, GG, 4); else if (rw == 2) L(TT, 1, GG, 2);               \
                                         else L(TT, 1, GG, 1); }                                                       \
                          else if (mt == 2) { if (rw == 2) L(TT, 2, GG, 2); else L(TT, 2, GG, 1); }                    \
@@ -315,6 +397,15 @@ VDA_EXPORT int vda_cb4_skinny_gemm_post(void* y, const void* x, const void* code
 #undef BY
 #undef BYM
 #undef L
+  if (sk > 1) {
+    dim3 fgrid((unsigned)(((long)M * (N / 4) + 255) / 256));
+    if (dtype == VDA_BF16)
+      hipLaunchKernelGGL(cb4_finish_kernel<bf16_t>, fgrid, block, 0, st, (bf16_t*)y, (const float*)ws,
+                         (const bf16_t*)bias, M, N, sk, y_stride);
+    else
+      hipLaunchKernelGGL(cb4_finish_kernel<f16_t>, fgrid, block, 0, st, (f16_t*)y, (const float*)ws,
+                         (const f16_t*)bias, M, N, sk, y_stride);
+  }
   VDA_CHECK_LAUNCH();
   return 0;
 }

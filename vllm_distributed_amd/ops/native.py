@@ -74,7 +74,7 @@ _SIGS = {
     "vda_w4_dequant": [P, P, P, P, I, I, I, I, P],
     "vda_cb4_skinny_gemm": [P, P, P, P, P, P, I, I, I, I, I, L, L, I, P],
     "vda_cb4_dequant": [P, P, P, P, I, I, I, I, I, P],
-    "vda_cb4_skinny_gemm_post": [P, P, P, P, P, P, I, I, I, I, I, L, L, I, P],
+    "vda_cb4_skinny_gemm_post": [P, P, P, P, P, P, I, I, I, I, I, L, L, I, P, L, I, P],
     "vda_cb4_dequant_post": [P, P, P, P, I, I, I, I, I, P],
     "vda_w8_dequant": [P, P, P, P, I, I, I, I, P],
     "vda_mla_cache_write": [P, P, P, P, P, I, I, I, I, L, L, I, I, F, P],
