@@ -23,3 +23,18 @@ def test_cpu_model_tests_pass_with_engines_on_the_gpu():
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
     assert r.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
+
+
+@pytest.mark.gpu
+def test_quantised_checkpoint_tests_pass_with_engines_on_the_gpu():
+    """Pre-quantised bitsandbytes / NVFP4 / microscaling-fp4 checkpoints and in-flight NF4 with the engine on the GPU in
+    fp32: loading, sharding into the fused projections, the chunk layout the GPU keeps for code-book layers and its
+    expansion must still give transformers' tokens exactly."""
+    env = dict(os.environ, VDA_TEST_DEVICE="cuda", VDA_FORCE_TORCH_OPS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_quant_cpu.py", "-k",
+                        "bitsandbytes or nvfp4 or mxfp4", "-q", "-x", "-m", "not gpu", "-p", "no:cacheprovider",
+                        "--timeout", "180", "--timeout-method", "thread"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-40:])
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail

@@ -399,12 +399,13 @@ def test_bitsandbytes_checkpoint_is_dequantised_while_loading(tmp_path, kind):
         assert qkv.weight.dtype == torch.float32
     else:
         # the 4-bit codes stay in memory: bytes as the checkpoint holds them, scales decoded to fp32 once
-        from vllm_distributed_amd.ops import reference as R
+        from vllm_distributed_amd import ops
         assert qkv.qweight.dtype == torch.uint8 and qkv.scales.dtype == torch.float32
-        assert qkv.scales.shape[1] * 64 == qkv.qweight.shape[1] * 2 and getattr(qkv, "weight", None) is None
+        assert qkv.scales.numel() * 64 == qkv.qweight.numel() * 2 and getattr(qkv, "weight", None) is None
         want = torch.cat([hf.model.layers[0].self_attn.get_submodule(n).weight for n in ("q_proj", "k_proj", "v_proj")])
-        got = R.cb4_dequant(qkv.qweight, qkv.scales, qkv.code_table, 64, True, torch.float32)
-        torch.testing.assert_close(got, want.detach(), rtol=1e-6, atol=1e-8)
+        got = ops.cb4_dequant(qkv.qweight, qkv.scales, qkv.code_table, 64, True, torch.float32,
+                              getattr(qkv, "cb4_chunked", False))        # (the GPU keeps a chunk layout)
+        torch.testing.assert_close(got.cpu(), want.detach(), rtol=1e-6, atol=1e-8)
     outs = llm.generate(prompt_token_ids=prompts,
                         sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
     llm.shutdown()
@@ -474,7 +475,7 @@ def test_quark_mxfp4_checkpoint_is_dequantised_while_loading(tmp_path):
     assert not hasattr(qkv, "weight") or qkv.weight is None
     want = torch.cat([hf.model.layers[0].self_attn.get_submodule(n).weight for n in ("q_proj", "k_proj", "v_proj")])
     got = (qkv.qweight.float() - qkv.qzeros.repeat_interleave(32, 1)) * qkv.scales.repeat_interleave(32, 1)
-    assert torch.equal(got, want.detach())
+    assert torch.equal(got.cpu(), want.detach())
     assert model.lm_head.weight.dtype == torch.float32                      # excluded layers stay as they are
     outs = llm.generate(prompt_token_ids=prompts,
                         sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
@@ -522,13 +523,13 @@ def test_modelopt_nvfp4_checkpoint_is_dequantised_while_loading(tmp_path):
     llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
               max_num_batched_tokens=64)
     # linear layers keep the E2M1 codes; group scales carry the per-tensor scale of their projection
-    from vllm_distributed_amd.ops import reference as R
+    from vllm_distributed_amd import ops
     model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
     qkv = model.model.layers[0].self_attn.qkv_proj
     assert qkv.qweight.dtype == torch.uint8 and qkv.scales.shape[1] * 16 == qkv.qweight.shape[1] * 2
     want = torch.cat([hf.model.layers[0].self_attn.get_submodule(n).weight for n in ("q_proj", "k_proj", "v_proj")])
-    got = R.cb4_dequant(qkv.qweight, qkv.scales, qkv.code_table, 16, False, torch.float32)
-    torch.testing.assert_close(got, want.detach(), rtol=1e-6, atol=1e-9)
+    got = ops.cb4_dequant(qkv.qweight, qkv.scales, qkv.code_table, 16, False, torch.float32)
+    torch.testing.assert_close(got.cpu(), want.detach(), rtol=1e-6, atol=1e-9)
     assert model.lm_head.weight.dtype == torch.float32
     outs = llm.generate(prompt_token_ids=prompts,
                         sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
@@ -670,7 +671,8 @@ def test_bitsandbytes_in_flight_nf4(tmp_path):
               max_num_batched_tokens=64, quantization="bitsandbytes")
     model = llm.llm_engine.engine_core.engine_core.model_executor.worker.model_runner.model
     qkv = model.model.layers[0].self_attn.qkv_proj
-    assert qkv.qweight.dtype == torch.uint8 and qkv.qweight.shape[1] * 2 == 128 and qkv.scales.shape[1] == 2
+    assert qkv.qweight.dtype == torch.uint8 and qkv.qweight.shape[1] * 2 == 128
+    assert qkv.scales.shape[0 if getattr(qkv, "cb4_chunked", False) else 1] == 2
     assert getattr(qkv, "weight", None) is None and qkv.code_table.tolist() == list(code.tolist())
     outs = llm.generate(prompt_token_ids=prompts,
                         sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
