@@ -366,9 +366,9 @@ VDA_EXPORT int vda_cb4_skinny_gemm_post(void* y, const void* x, const void* code
   // (from 8 rows on the activations every workgroup re-reads from L2 outweigh its codes unless it owns 64 rows:
   // narrow layers then take 64-row workgroups too and fill the chip with K splits instead)
   int rw = 1;
-  const bool wide_rows = mt <= 2 && N % (mt == 1 ? 64 : 32) == 0 && splits == 0 && ws;
-  if (mt == 1 && N % 64 == 0 && (N / 64 >= 512 || wide_rows)) rw = 4;
-  else if (mt <= 2 && N % 32 == 0 && (N / 32 >= 512 || wide_rows)) rw = 2;
+  const bool wide_rows = N % 32 == 0 && splits == 0 && ws;
+  if (N % 64 == 0 && (N / 64 >= 512 || wide_rows)) rw = 4;
+  else if (N % 32 == 0 && (N / 32 >= 512 || wide_rows)) rw = 2;
   // K splits (splits = 0: chosen here): enough workgroups for four per CU, at least 16 chunks each; every split writes
   // a slab of fp32 partial sums [M, N] and a second small kernel adds the slabs (no fences, no atomics: an agent-scope
   // fence writes back the whole L2 of an XCD, which cost more than the splits gained)
@@ -386,15 +386,16 @@ VDA_EXPORT int vda_cb4_skinny_gemm_post(void* y, const void* x, const void* code
                                              (const TT*)x, (const uint8_t*)codes, (const float*)scales_t,             \
                                              (const float*)table, (const TT*)bias, M, N, K, G, hi_first, x_stride,    \
                                              y_stride, (float*)ws)
-#define BYM(TT, GG) do { if (mt == 1) { if (rw == 4) L(TT, 1, GG, 4); else if (rw == 2) L(TT, 1, GG, 2);               \
-                                        else L(TT, 1, GG, 1); }                                                       \
-                         else if (mt == 2) { if (rw == 2) L(TT, 2, GG, 2); else L(TT, 2, GG, 1); }                    \
-                         else if (mt == 3) L(TT, 3, GG, 1); else L(TT, 4, GG, 1); } while (0)
+#define BYR(TT, MM, GG) do { if (rw == 4) L(TT, MM, GG, 4); else if (rw == 2) L(TT, MM, GG, 2);                       \
+                             else L(TT, MM, GG, 1); } while (0)
+#define BYM(TT, GG) do { if (mt == 1) BYR(TT, 1, GG); else if (mt == 2) BYR(TT, 2, GG);                                \
+                         else if (mt == 3) BYR(TT, 3, GG); else BYR(TT, 4, GG); } while (0)
 #define BY(TT) do { if (gq == 1) BYM(TT, 1); else if (gq == 2) BYM(TT, 2); else BYM(TT, 4); } while (0)
   if (dtype == VDA_BF16) BY(bf16_t);
   else if (dtype == VDA_F16) BY(f16_t);
   else return -3;
 #undef BY
+#undef BYR
 #undef BYM
 #undef L
   if (sk > 1) {
