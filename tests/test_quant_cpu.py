@@ -352,18 +352,13 @@ def _bnb4_quantise(w, blocksize=64, nested=True):
     return packed, out, deq
 
 
-@pytest.mark.parametrize("kind", ["nf4_nested", "nf4", "int8"])
-def test_bitsandbytes_checkpoint_is_dequantised_while_loading(tmp_path, kind):
-    """A pre-quantised bitsandbytes checkpoint (tensor names and packing as bitsandbytes writes them; the
-    package itself is not installed, so its own writer is unpinned) decodes to the tokens of the HF model
-    holding the dequantised weights."""
+def _write_bnb_checkpoint(tmp_path, kind):
     import json
     import os
 
     from safetensors.torch import load_file, save_file
 
     from tests.test_e2e_cpu import _save_tiny
-    from vllm_distributed_amd import LLM, SamplingParams
     path, hf = _save_tiny(str(tmp_path), "llama")
     sd = load_file(os.path.join(path, "model.safetensors"))
     out = {}
@@ -390,6 +385,16 @@ def test_bitsandbytes_checkpoint_is_dequantised_while_loading(tmp_path, kind):
     cfg["quantization_config"] = {"quant_method": "bitsandbytes", "load_in_4bit": kind != "int8",
                                   "load_in_8bit": kind == "int8", "bnb_4bit_quant_type": "nf4"}
     json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    return path, hf
+
+
+@pytest.mark.parametrize("kind", ["nf4_nested", "nf4", "int8"])
+def test_bitsandbytes_checkpoint_is_dequantised_while_loading(tmp_path, kind):
+    """A pre-quantised bitsandbytes checkpoint (tensor names and packing as bitsandbytes writes them; the
+    package itself is not installed, so its own writer is unpinned) decodes to the tokens of the HF model
+    holding the dequantised weights."""
+    from vllm_distributed_amd import LLM, SamplingParams
+    path, hf = _write_bnb_checkpoint(tmp_path, kind)
     prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
     llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
               max_num_batched_tokens=64)
@@ -682,3 +687,24 @@ def test_bitsandbytes_in_flight_nf4(tmp_path):
             ref = hf.generate(torch.tensor([pr]), max_new_tokens=8, do_sample=False, pad_token_id=0,
                               eos_token_id=None)[0, len(pr):].tolist()
         assert list(o.outputs[0].token_ids) == ref
+
+
+def test_code_book_layers_shard_over_two_ranks(tmp_path):
+    """Tensor parallel 2 (two worker processes over gloo) on a pre-quantised NF4 checkpoint with double-quantised
+    scales: column-parallel layers take their rows of codes and scales, row-parallel layers their byte and group
+    columns; the tokens are transformers' for the dequantised weights."""
+    from vllm_distributed_amd import LLM, SamplingParams
+    path, hf = _write_bnb_checkpoint(tmp_path, "nf4_nested")
+    prompts = [[5, 17, 99, 3, 250, 11], [7] * 30]
+    llm = LLM(model=path, skip_tokenizer_init=True, dtype="float32", device="cpu", max_model_len=256, max_num_seqs=4,
+              max_num_batched_tokens=64, distributed_executor_backend="mp", tensor_parallel_size=2)
+    try:
+        outs = llm.generate(prompt_token_ids=prompts,
+                            sampling_params=SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    finally:
+        llm.shutdown()
+    for p, o in zip(prompts, outs):
+        with torch.no_grad():
+            ref = hf.generate(torch.tensor([p]), max_new_tokens=8, do_sample=False, pad_token_id=0,
+                              eos_token_id=None)[0, len(p):].tolist()
+        assert list(o.outputs[0].token_ids) == ref, p
