@@ -97,7 +97,7 @@ _REGISTRY: dict[str, tuple[Callable[[str], Any], Any]] = {
     "VDA_GGUF_PACKED": (_bool, True),            # GGUF: keep 4- / 5- / 8-bit block codes packed (False: expand to 16 bit at load)
     "VDA_WQ_GEMM_MAX_M": (int, 512),             # W4A16 / W8A16: rows served by the packed-weight GEMM kernels
     "VDA_MLA": (_bool, True),                    # DeepSeek: latent KV cache + absorbed projections; 0 = expanded heads
-    "VDA_INT4_WEIGHTS": (_bool, True),           # keep 4-bit GPTQ/AWQ linear weights packed (W4A16 kernel); 0 = expand at load
+    "VDA_INT4_WEIGHTS": (_bool, True),           # keep GPTQ / AWQ / fp4 / NF4 linear weights packed in memory; 0 = expand at load
     "VDA_FP8_BLOCK_NATIVE": (_bool, True),       # 128x128 block-scaled fp8 checkpoints: keep weights in fp8 (0: expand to 16 bit at load)
     "VDA_FP8_W8A16_MAX_M": (int, 64),            # fp8 linear: up to this M stream weights, beyond use fp8 MFMA GEMM
     "VDA_DISABLE_PEER_ALL2ALL": (_bool, False),  # expert / token parallel row exchange through torch.distributed instead of peer memory
