@@ -21,7 +21,10 @@ def timed(fn, iters=20):
 
 
 def main():
+    import sys
     shapes = {"qkv": (10240, 8192), "o": (8192, 8192), "gate_up": (57344, 8192), "down": (8192, 28672)}
+    if len(sys.argv) > 1 and sys.argv[1] == "8b":
+        shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (28672, 4096), "down": (4096, 14336)}
     for fmt, G, hi, table in (("nf4 g64", 64, True, NF4_CODE), ("nvfp4 g16", 16, False, _E2M1)):
         tab = torch.tensor(table, dtype=torch.float32, device="cuda")
         for name, (N, K) in shapes.items():
@@ -33,7 +36,7 @@ def main():
             if chunked:
                 scales = scales.t().contiguous()        # random codes: only the scales' layout matters for timing
             w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16)
-            for M in (1, 16, 32, 64, 256):
+            for M in (1, 8, 16, 32, 64, 256):
                 x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
                 i = [0]
 

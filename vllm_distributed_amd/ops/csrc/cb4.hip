@@ -366,7 +366,9 @@ VDA_EXPORT int vda_cb4_skinny_gemm_post(void* y, const void* x, const void* code
   // (from 8 rows on the activations every workgroup re-reads from L2 outweigh its codes unless it owns 64 rows:
   // narrow layers then take 64-row workgroups too and fill the chip with K splits instead)
   int rw = 1;
-  const bool wide_rows = N % 32 == 0 && splits == 0 && ws;
+  // (layers under 16 MiB of codes finish in about ten microseconds either way: the second launch would cost them more
+  // than the wider workgroups gain)
+  const bool wide_rows = N % 32 == 0 && splits == 0 && ws && (size_t)N * K / 2 >= ((size_t)16 << 20);
   if (N % 64 == 0 && (N / 64 >= 512 || wide_rows)) rw = 4;
   else if (N % 32 == 0 && (N / 32 >= 512 || wide_rows)) rw = 2;
   // K splits (splits = 0: chosen here): enough workgroups for four per CU, at least 16 chunks each; every split writes
@@ -376,7 +378,7 @@ VDA_EXPORT int vda_cb4_skinny_gemm_post(void* y, const void* x, const void* code
   int sk = splits;
   if (sk <= 0) {
     sk = 1;
-    if (wide_rows)
+    if (wide_rows && blocks < 256)
       while (sk < 8 && blocks * sk < 512 && nchunk / (sk * 2) >= 8) sk *= 2;
   }
   if (sk > nchunk) sk = nchunk;
