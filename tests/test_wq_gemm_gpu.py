@@ -287,6 +287,15 @@ def test_codebook4_wide_layers_share_activation_registers(G):
         ref = x.float() @ deq.t() + bias.float()
         got = ops.cb4_linear(x, c, st, tab, G, True, bias, chunked=True)
         assert (got.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2, M
+        got = ops.cb4_linear(x, codes, scales, tab, G, True, bias)          # the per-weight form has row sets too
+        assert (got.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2, M
+    codes16, scales16, _ = _codebook(N, K, 16, NF4_CODE)
+    deq = R.cb4_dequant(codes16, scales16, tab, 16, False, torch.float32)
+    for M in (3, 16, 30, 50):
+        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        ref = x.float() @ deq.t()
+        got = ops.cb4_linear(x, codes16, scales16, tab, 16, False)
+        assert (got.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 2e-2, M
 
 
 @pytest.mark.parametrize("N,K,G", [(528, 1024, 64), (8192, 4096, 64), (1024, 8192, 128), (16384, 2048, 32)])

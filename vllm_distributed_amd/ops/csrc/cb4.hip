@@ -30,7 +30,9 @@ __device__ __forceinline__ typename Vec<T>::v8 cb4_expand(uint32_t w, const floa
   return o;
 }
 
-template <typename T, int MT, bool HI_FIRST>
+// RW: row sets of 16 per workgroup -- the activation registers of a chunk serve all of them (see the note on L2
+// traffic at cb4_skinny_post_kernel)
+template <typename T, int MT, bool HI_FIRST, int RW>
 __global__ __launch_bounds__(256) void cb4_skinny_gemm_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                               const uint8_t* __restrict__ codes,
                                                               const float* __restrict__ scales,
@@ -45,10 +47,12 @@ __global__ __launch_bounds__(256) void cb4_skinny_gemm_kernel(T* __restrict__ y,
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * 16 * RW;
   const int ngroups = K / G;
   const uint8_t* wrow = codes + (long)(n0 + r) * (K / 2) + g * 16;       // 16 bytes = 32 elements per chunk
+  const long wset = (long)16 * (K / 2);
   const float* srow = scales + (long)(n0 + r) * ngroups;
+  const long sset = (long)16 * ngroups;
   const T* xp[MT];
   bool xv[MT];
 #pragma unroll
@@ -57,71 +61,73 @@ __global__ __launch_bounds__(256) void cb4_skinny_gemm_kernel(T* __restrict__ y,
     xv[mt] = m < M;
     xp[mt] = x + (long)(xv[mt] ? m : 0) * x_stride + g * 32;
   }
-  f32x4 acc[MT];
+  f32x4 acc[RW][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0, 0, 0, 0};
+  for (int rw = 0; rw < RW; ++rw)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[rw][mt] = f32x4{0, 0, 0, 0};
 
   const int nchunk = K >> 7;
   // UN chunks per trip: all their code and scale loads are issued before the first look-up, so a lane keeps
-  // UN x 16 bytes of codes in flight
-  constexpr int UN = 4;
-  int c = wave;
-  for (; c + 4 * (UN - 1) < nchunk; c += 4 * UN) {
-    u32x4 raw[UN];
-    float sa[UN], sb[UN];
+  // UN x RW x 16 bytes of codes in flight
+  constexpr int UN = RW >= 4 ? 1 : 4 / RW;
+  for (int c = wave; c < nchunk; c += 4 * UN) {
+    u32x4 raw[UN][RW];
+    float sa[UN][RW], sb[UN][RW];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int cc = c + 4 * u;
-      raw[u] = *reinterpret_cast<const u32x4*>(wrow + (long)cc * 64);
-      const int e0 = cc * 128 + g * 32;
-      sa[u] = srow[e0 / G];                     // elements 0 .. 15 of the lane's 32
-      sb[u] = srow[(e0 + 16) / G];              // elements 16 .. 31 (the same group unless G is 16)
+      if (cc < nchunk) {
+        const int e0 = cc * 128 + g * 32;
+#pragma unroll
+        for (int rw = 0; rw < RW; ++rw) {
+          raw[u][rw] = *reinterpret_cast<const u32x4*>(wrow + rw * wset + (long)cc * 64);
+          sa[u][rw] = srow[rw * sset + e0 / G];             // elements 0 .. 15 of the lane's 32
+          sb[u][rw] = srow[rw * sset + (e0 + 16) / G];      // elements 16 .. 31 (the same group unless G is 16)
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int cc = c + 4 * u;
+      if (cc >= nchunk) break;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const V8 wa = cb4_expand<T, HI_FIRST>(raw[u][q], tab, q < 2 ? sa[u] : sb[u]);
+        V8 xa[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)cc * 128 + 8 * q) : V8{};
-          acc[mt] = mfma16(wa, xa, acc[mt]);
+        for (int mt = 0; mt < MT; ++mt) xa[mt] = xv[mt] ? ld16<V8>(xp[mt] + (long)cc * 128 + 8 * q) : V8{};
+#pragma unroll
+        for (int rw = 0; rw < RW; ++rw) {
+          const V8 wa = cb4_expand<T, HI_FIRST>(raw[u][rw][q], tab, q < 2 ? sa[u][rw] : sb[u][rw]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[rw][mt] = mfma16(wa, xa[mt], acc[rw][mt]);
         }
       }
     }
   }
-  for (; c < nchunk; c += 4) {
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(wrow + (long)c * 64);
-    const int e0 = c * 128 + g * 32;
-    const float sa = srow[e0 / G], sb = srow[(e0 + 16) / G];
+
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const V8 wa = cb4_expand<T, HI_FIRST>(raw[q], tab, q < 2 ? sa : sb);
+  for (int rw = 0; rw < RW; ++rw) {
+    if (rw) __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) red[wave - 1][mt][lane] = acc[rw][mt];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int nb = n0 + rw * 16 + 4 * g;
+      V4 bv = V4{};
+      if (bias) bv = *reinterpret_cast<const V4*>(bias + nb);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const V8 xa = xv[mt] ? ld16<V8>(xp[mt] + (long)c * 128 + 8 * q) : V8{};
-        acc[mt] = mfma16(wa, xa, acc[mt]);
+        const f32x4 sum = acc[rw][mt] + red[0][mt][lane] + red[1][mt][lane] + red[2][mt][lane];
+        if (xv[mt]) {
+          V4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (T)(sum[i] + (float)bv[i]);
+          *reinterpret_cast<V4*>(y + (long)(mt * 16 + r) * y_stride + nb) = o;
+        }
       }
-    }
-  }
-
-  if (wave > 0) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) red[wave - 1][mt][lane] = acc[mt];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  V4 bv = V4{};
-  if (bias) bv = *reinterpret_cast<const V4*>(bias + n0 + 4 * g);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const f32x4 sum = acc[mt] + red[0][mt][lane] + red[1][mt][lane] + red[2][mt][lane];
-    if (xv[mt]) {
-      V4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = (T)(sum[i] + (float)bv[i]);
-      *reinterpret_cast<V4*>(y + (long)(mt * 16 + r) * y_stride + n0 + 4 * g) = o;
     }
   }
 }
@@ -131,19 +137,29 @@ VDA_EXPORT int vda_cb4_skinny_gemm(void* y, const void* x, const void* codes, co
                                    long y_stride, int dtype, hipStream_t st) {
   if (M < 1 || M > 64 || N < 16 || N % 16 || K < 128 || K % 128 || G < 16 || G % 16 || K % G) return -1;
   if (G > 16 && G % 32) return -1;          // a lane's 16-element halves must not straddle groups
-  dim3 grid(N / 16), block(256);
   const int mt = (M + 15) / 16;
-#define L(TT, MM, HF) hipLaunchKernelGGL((cb4_skinny_gemm_kernel<TT, MM, HF>), grid, block, 0, st, (TT*)y, (const TT*)x, \
-                                         (const uint8_t*)codes, (const float*)scales, (const float*)table,             \
-                                         (const TT*)bias, M, N, K, G, x_stride, y_stride)
-#define BYM(TT, HF) do { if (mt == 1) L(TT, 1, HF); else if (mt == 2) L(TT, 2, HF); else if (mt == 3) L(TT, 3, HF);    \
-                         else L(TT, 4, HF); } while (0)
+  // rows per workgroup: as many as leave one workgroup per CU and the accumulators in registers
+  // (below 8 rows x is small beside the codes and more, smaller workgroups hide latency better)
+  int rw = 1;
+  const int want = M >= 8 ? 256 : 512;
+  if (mt <= 2 && N % 64 == 0 && N / 64 >= want) rw = 4;
+  else if (N % 32 == 0 && N / 32 >= want) rw = 2;
+  dim3 grid(N / (16 * rw)), block(256);
+#define L(TT, MM, HF, RR) hipLaunchKernelGGL((cb4_skinny_gemm_kernel<TT, MM, HF, RR>), grid, block, 0, st, (TT*)y,      \
+                                             (const TT*)x, (const uint8_t*)codes, (const float*)scales,               \
+                                             (const float*)table, (const TT*)bias, M, N, K, G, x_stride, y_stride)
+#define BYR(TT, MM, HF) do { if (rw == 4) L(TT, MM, HF, 4); else if (rw == 2) L(TT, MM, HF, 2);                        \
+                             else L(TT, MM, HF, 1); } while (0)
+#define BYM(TT, HF) do { if (mt == 1) BYR(TT, 1, HF); else if (mt == 2) BYR(TT, 2, HF);                                \
+                         else if (rw == 2) { if (mt == 3) L(TT, 3, HF, 2); else L(TT, 4, HF, 2); }                    \
+                         else { if (mt == 3) L(TT, 3, HF, 1); else L(TT, 4, HF, 1); } } while (0)
 #define BY(TT) do { if (hi_first) BYM(TT, true); else BYM(TT, false); } while (0)
   if (dtype == VDA_BF16) BY(bf16_t);
   else if (dtype == VDA_F16) BY(f16_t);
   else return -3;
 #undef BY
 #undef BYM
+#undef BYR
 #undef L
   VDA_CHECK_LAUNCH();
   return 0;
