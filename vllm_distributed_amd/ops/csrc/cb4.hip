@@ -6,11 +6,13 @@
 //   scales float [N, K/G]   one fp32 scale per row and group of G input elements (G a multiple of 16)
 //   table  float [16]       value of every code;  weight = table[code] * scale
 //
-// Decode (M <= 64): the skinny scheme of w4.hip -- 16 weight rows per workgroup, a lane streams 32 consecutive K
-// elements (one 16-byte load of codes) per 128-wide chunk, looks the 32 values up in a 16-entry LDS table (lanes that
-// read the same entry are served by one broadcast, different entries sit in different banks), scales them and feeds
-// them to MFMA as the A operand; the activation rows ride on the MFMA column dimension.  HBM traffic is 4 bits per
-// weight plus 32 / G bits of scale.  Larger M: `vda_cb4_dequant` expands the weights to 16 bit once per call and the
+// Decode (M <= 64), two forms.  Per-weight form (any G, the one groups of 16 use): 16 RW weight rows per workgroup, a
+// lane streams 32 consecutive K elements (one 16-byte load of codes) per 128-wide chunk and row set, looks the 32
+// values up in a 16-entry LDS table (lanes that read the same entry are served by one broadcast, different entries
+// sit in different banks), scales them and feeds them to MFMA as the A operand; the activation rows ride on the MFMA
+// column dimension.  Chunk-layout form (G >= 32, further down): operands straight out of a byte-indexed table, scales
+// applied to the accumulators, K splits for narrow layers.  HBM traffic is 4 bits per weight plus 32 / G bits of
+// scale.  Larger M: `vda_cb4_dequant` / `vda_cb4_dequant_post` expand the weights to 16 bit once per call and the
 // library GEMM does the rest.
 // Role of the reference's bitsandbytes matmul_4bit / dequantize_4bit calls
 // (vllm/model_executor/layers/quantization/bitsandbytes.py:_apply_4bit_weight) and of the NVFP4 GEMM
