@@ -155,4 +155,16 @@ class StatelessProcessGroup:
         return out
 
     def barrier(self) -> None:
+        """Every rank has arrived when this returns.  The rank that hosts the store (rank 0) additionally waits until
+        every rank has READ what the barrier published: it may exit right after a final barrier, and the others'
+        pending reads would find the store's socket closed."""
         self.all_gather_obj(self.rank)
+        n = getattr(self, "_barriers", 0)
+        self._barriers = n + 1
+        key = f"barrier_read/{n}"
+        arrived = self.store.add(key, 1)
+        if self.rank == 0:
+            deadline = self._time.time() + 60.0
+            while arrived < self.world_size and self._time.time() < deadline:
+                self._time.sleep(0.002)
+                arrived = self.store.add(key, 0)
